@@ -1,0 +1,150 @@
+/* CPU restatement (C + OpenMP) of watroo's 2-D a-trous hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Used only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, as the
+ * full-size parity checker and the host-CPU baseline ("kind": "port").  The product library
+ * (wavelets_amd/csrc) never links or calls it.
+ *
+ * It is written to be BIT-IDENTICAL to oracle/atrous_numpy.py (which is pinned against the
+ * reference-generated fixtures in tests/golden): same tap order, one fp32 rounding per
+ * multiply and per add (build with -ffp-contract=off), same symmetric border.
+ * Reference lines restated (paths relative to /root/reference):
+ *   orc_smooth      watroo/wavelets.py:35-45 (convolution, 2-D) in the per-tap form of
+ *                   watroo/wavelets.py:74-94 (atrous_convolution, bilateral_variance=None)
+ *   orc_decompose   watroo/wavelets.py:408-444 (atrous_standard, bilateral None)
+ *   orc_plane_sum   np.sum(coefficients, axis=0) - watroo/utils.py:98,205
+ *   orc_abs_median  np.median(np.abs(data[0])) - watroo/wavelets.py:127
+ *   orc_denoise     watroo/wavelets.py:129-149 (scalar noise; NumPy-2 promotion: ratio and
+ *                   erf evaluated in double, product rounded back to float)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static const float TAPS_B3[5] = {1.f / 16, 1.f / 4, 3.f / 8, 1.f / 4, 1.f / 16};
+static const float TAPS_TRI[3] = {1.f / 4, 1.f / 2, 1.f / 4};
+
+static inline long reflect(long i, long n)
+{
+    long p = 2 * n;
+    long m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* family: 0 = triangle (3 taps), 1 = b3spline (5 taps). square_input: smooth in*in. */
+int orc_smooth(const float *in, float *out, long H, long W, int family, int s, int square_input)
+{
+    const int K = family ? 5 : 3, hw = K / 2;
+    const float *t = family ? TAPS_B3 : TAPS_TRI;
+    const long d = 1L << s;
+    float k2[5][5];
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < K; j++) k2[i][j] = (float)((double)t[i] * (double)t[j]);
+    long *cx = (long *)malloc(sizeof(long) * (size_t)W * K);
+    if (!cx) return 1;
+    for (int j = 0; j < K; j++)
+        for (long x = 0; x < W; x++) cx[j * W + x] = reflect(x + (long)(K - 1 - j - hw) * d, W);
+#pragma omp parallel for schedule(static)
+    for (long y = 0; y < H; y++) {
+        float *o = out + y * W;
+        const float *c = in + y * W;
+        const float kc = k2[hw][hw];
+        if (square_input)
+            for (long x = 0; x < W; x++) { float v = c[x] * c[x]; o[x] = kc * v; }
+        else
+            for (long x = 0; x < W; x++) o[x] = kc * c[x];
+        for (int i = 0; i < K; i++) {
+            const float *r = in + reflect(y + (long)(K - 1 - i - hw) * d, H) * W;
+            for (int j = 0; j < K; j++) {
+                if (i == hw && j == hw) continue;
+                const float k = k2[i][j];
+                const long *ix = cx + j * W;
+                const long off = (long)(K - 1 - j - hw) * d;
+                long x0 = off < 0 ? -off : 0, x1 = off > 0 ? W - off : W;
+                if (x0 > W) x0 = W;
+                if (x1 < x0) x1 = x0;
+                if (square_input) {
+                    for (long x = 0; x < W; x++) { float v = r[ix[x]]; v = v * v; float p = v * k; o[x] = o[x] + p; }
+                } else {
+                    for (long x = 0; x < x0; x++) { float p = r[ix[x]] * k; o[x] = o[x] + p; }
+                    const float *rs = r + off;
+                    for (long x = x0; x < x1; x++) { float p = rs[x] * k; o[x] = o[x] + p; }
+                    for (long x = x1; x < W; x++) { float p = r[ix[x]] * k; o[x] = o[x] + p; }
+                }
+            }
+        }
+    }
+    free(cx);
+    return 0;
+}
+
+/* planes: (level+1) contiguous HxW planes; planes[0..level-1] detail, planes[level] smooth. */
+int orc_decompose(const float *in, float *planes, long H, long W, int family, int level)
+{
+    const size_t n = (size_t)H * W;
+    memcpy(planes, in, n * sizeof(float));
+    for (int s = 0; s < level; s++) {
+        float *cs = planes + (size_t)s * n, *cn = planes + (size_t)(s + 1) * n;
+        int rc = orc_smooth(cs, cn, H, W, family, s, 0);
+        if (rc) return rc;
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)n; i++) cs[i] = cs[i] - cn[i];
+    }
+    return 0;
+}
+
+int orc_plane_sum(const float *planes, int nplanes, long npix, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < npix; i++) {
+        float a = planes[i];
+        for (int p = 1; p < nplanes; p++) a = a + planes[(size_t)p * npix + i];
+        out[i] = a;
+    }
+    return 0;
+}
+
+static int cmp_f(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* exact median of |x| (even n: fp32 mean of the two middle values, as np.median on f32) */
+int orc_abs_median(const float *x, long n, float *out)
+{
+    float *t = (float *)malloc(sizeof(float) * (size_t)n);
+    if (!t) return 1;
+    for (long i = 0; i < n; i++) t[i] = fabsf(x[i]);
+    qsort(t, (size_t)n, sizeof(float), cmp_f);
+    if (n & 1) *out = t[n / 2];
+    else { float s = t[n / 2 - 1] + t[n / 2]; *out = s / 2.0f; }
+    free(t);
+    return 0;
+}
+
+/* plane *= wgt * significance; tau = sigma*noise*sigma_e[scale] (double), scalar noise */
+int orc_denoise(float *plane, long npix, double tau, double wgt, int soft)
+{
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < npix; i++) {
+        double sig;
+        if (soft) sig = erf(fabs((double)plane[i] / tau));
+        else sig = fabs((double)plane[i]) > tau ? 1.0 : 0.0;
+        plane[i] = (float)((double)plane[i] * (wgt * sig));
+    }
+    return 0;
+}

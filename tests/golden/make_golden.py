@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference/watroo) in the build container.  Not product code; never runs on the GPU box.
+
+    python tests/golden/make_golden.py            # python3.10 / numpy 2.x (fixtures g*.npz)
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py --real-numexpr
+                                                  # numpy 1.26 + REAL numexpr 2.7.3 -> g5_realne.npz
+
+The reference imports two third-party wheels that are absent from this image
+(requirements.txt:2,4): ``cv2`` (opencv-python) and - under python3.10 - ``numexpr``.
+Stand-ins are registered in ``sys.modules`` *before* importing it:
+
+* ``cv2.filter2D`` -> OpenCV's documented semantics for the only call form watroo uses
+  (wavelets.py:39-45: ddepth=-1, anchor=(-1,-1), delta=0, BORDER_REFLECT): correlation with
+  the kernel, centre anchor, border ``fedcba|abcdefgh|hgfedcb`` == scipy.ndimage 'reflect'.
+  This pins semantics, not OpenCV's rounding.  Fixture groups that depend on it are tagged
+  ``pin = "semantic(cv2 stand-in)"``.
+* ``numexpr.evaluate`` -> evaluates the single expression of wavelets.py:97 with numpy in
+  the caller's frame.  ``--real-numexpr`` regenerates the bilateral group with the real
+  numexpr under /opt/conda's interpreter to show the stand-in is faithful.
+
+Fixture groups that never touch cv2 (the reference's own pure-numpy ``atrous_convolution``,
+``Coefficients`` methods, ``generalized_anscombe``) are tagged ``pin = "hard"``.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy
+from scipy import ndimage
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REAL_NE = "--real-numexpr" in sys.argv
+
+
+def _install_standins():
+    cv2 = types.ModuleType("cv2")
+    cv2.BORDER_REFLECT = 2
+    cv2.BORDER_REFLECT_101 = 4
+
+    def filter2D(src, ddepth, kernel, dst=None, anchor=(-1, -1), delta=0, borderType=4):
+        assert ddepth == -1 and tuple(anchor) == (-1, -1)
+        mode = {2: "reflect", 4: "mirror"}[borderType]
+        k = np.asarray(kernel)
+        k = k[None, :] if k.ndim == 1 else k
+        res = ndimage.correlate(np.asarray(src), k.astype(src.dtype), mode=mode) + delta
+        if dst is not None:
+            dst[...] = res
+            return dst
+        return res
+
+    cv2.filter2D = filter2D
+    sys.modules["cv2"] = cv2
+    try:
+        import numexpr  # noqa: F401  (real one, conda python)
+        return "real numexpr " + numexpr.__version__
+    except ImportError:
+        ne = types.ModuleType("numexpr")
+
+        def evaluate(expr, out=None, **kw):
+            f = sys._getframe(1)
+            ns = {**f.f_globals, **f.f_locals, "exp": np.exp, "sqrt": np.sqrt}
+            r = eval(expr, {}, ns)
+            if out is not None:
+                out[...] = r
+                return out
+            return r
+
+        ne.evaluate = evaluate
+        sys.modules["numexpr"] = ne
+        return "numexpr stand-in (numpy eval)"
+
+
+NE_KIND = _install_standins()
+sys.path.insert(0, "/root/reference")
+import watroo  # noqa: E402
+from watroo import (AtrousTransform, B3spline, Triangle, Coefficients,  # noqa: E402
+                    generalized_anscombe, convolution, denoise, wow)
+from watroo.wavelets import atrous_convolution, sdev_loc  # noqa: E402
+
+FAM = {"b3spline": B3spline, "triangle": Triangle}
+META = dict(numpy=np.__version__, scipy=scipy.__version__, watroo=watroo.__version__,
+            numexpr=NE_KIND)
+
+
+def img(shape, seed, positive=False):
+    a = np.random.default_rng(seed).standard_normal(shape).astype(np.float32)
+    if positive:
+        a = (np.abs(a) * 20 + 5).astype(np.float32)
+    return a
+
+
+def save(name, pin, **arrays):
+    arrays["_meta"] = np.array(repr(dict(META, pin=pin)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  pin={pin}")
+
+
+SHAPES = [((37, 53), 1), ((64, 48), 2), ((16, 16), 3)]
+
+
+def g0_hard():
+    """Reference's own numpy operator + pointwise code: no cv2 anywhere in the arithmetic."""
+    out = {}
+    for shape, seed in SHAPES:
+        a = img(shape, seed)
+        tag = f"{shape[0]}x{shape[1]}"
+        out[f"img_{tag}"] = a
+        for fam, cls in FAM.items():
+            k = cls(2).kernel.astype(a.dtype)
+            for s in range(5):
+                out[f"aconv_{fam}_{tag}_s{s}"] = atrous_convolution(a, k, None, s, "symmetric")
+    # Coefficients methods on a synthetic stack (data need not come from a transform)
+    stack = img((4, 37, 53), 11) * np.array([1, .3, .1, 2], np.float32)[:, None, None]
+    out["stack"] = stack.copy()
+    for fam, cls in FAM.items():
+        c = Coefficients(stack.copy(), cls(2))
+        out[f"noise_{fam}"] = np.float64(c.get_noise())
+        out[f"sig_hard_3_2_{fam}"] = c.significance(3, 2, soft_threshold=False)
+        out[f"sig_soft_3_1_{fam}"] = c.significance(3, 1)
+        c = Coefficients(stack.copy(), cls(2)); c.denoise([5, 3])
+        out[f"den_53_{fam}"] = c.data
+        c = Coefficients(stack.copy(), cls(2)); c.denoise([5, 3, 2], weights=[.5, 2, 1])
+        out[f"den_532_w_{fam}"] = c.data
+        c = Coefficients(stack.copy(), cls(2)); c.denoise([5, 3], soft_threshold=False)
+        out[f"den_53_hard_{fam}"] = c.data
+        c = Coefficients(stack.copy(), cls(2)); c.noise = 0.7; c.denoise([3, 2])
+        out[f"den_32_noise07_{fam}"] = c.data
+        nmap = (np.abs(img((37, 53), 12)) + .5).astype(np.float32)
+        out["noise_map"] = nmap
+        c = Coefficients(stack.copy(), cls(2)); c.noise = nmap; c.denoise([3, 2])
+        out[f"den_32_noisemap_{fam}"] = c.data
+        c = Coefficients(stack.copy(), cls(2), bilateral=[1, 1]); c.denoise([5, 3])
+        out[f"den_53_bilat_{fam}"] = c.data
+    cz = Coefficients(np.zeros((3, 8, 8), np.float32), B3spline(2)); cz.denoise([5, 3])
+    out["den_zero_noise_branch"] = cz.data
+    out["noise_zero"] = np.float64(cz.noise)
+    p = img((37, 53), 13, positive=True)
+    out["ans_in"] = p
+    out["ans_fwd"] = generalized_anscombe(p)
+    out["ans_fwd_params"] = generalized_anscombe(p, alpha=2., g=1., sigma=.5)
+    out["ans_inv"] = generalized_anscombe(generalized_anscombe(p), inverse=True)
+    save("g0_hard", "hard", **out)
+
+
+def g1_transform():
+    out = {}
+    for shape, seed in SHAPES:
+        a = img(shape, seed)
+        tag = f"{shape[0]}x{shape[1]}"
+        out[f"img_{tag}"] = a
+        for fam, cls in FAM.items():
+            for L in (1, 2, 3, 4, 5):
+                out[f"coef_{fam}_{tag}_L{L}"] = AtrousTransform(cls)(a, L).data
+            out[f"conv_{fam}_{tag}_s2"] = convolution(a, cls(2), s=2)
+    save("g1_transform", "semantic(cv2 stand-in)", **out)
+
+
+def g2_g3_denoise():
+    out = {}
+    a = img((64, 48), 2)
+    out["img"] = a
+    for fam, cls in FAM.items():
+        c = AtrousTransform(cls)(a, 4)
+        out[f"noise_{fam}"] = np.float64(c.get_noise())
+        c.denoise([5, 3])
+        out[f"coef_den_53_{fam}"] = c.data
+        out[f"denoise_53_{fam}"] = denoise(a, [5, 3], cls)
+        out[f"denoise_532_hard_{fam}"] = denoise(a, [5, 3, 2], cls, soft_threshold=False)
+        out[f"denoise_53_noise_{fam}"] = denoise(a, [5, 3], cls, noise=0.9)
+    p = img((64, 48), 5, positive=True)
+    out["img_pos"] = p
+    out["denoise_53_anscombe"] = denoise(p, [5, 3], Triangle, anscombe=True)
+    save("g2_denoise", "semantic(cv2 stand-in)", **out)
+
+
+def g4_wow():
+    out = {}
+    a = (img((64, 64), 4) + 3 * np.sin(np.arange(64) / 5.)[None, :]).astype(np.float32)
+    out["img"] = a
+    cases = {
+        "default": dict(),
+        "triangle": dict(scaling_function=Triangle),
+        "dc52": dict(denoise_coefficients=[5, 2]),
+        "n3_w_dc": dict(n_scales=3, weights=[.5], denoise_coefficients=[5, 2]),
+        "h05_g2": dict(h=.5, gamma=2, denoise_coefficients=[5, 2]),
+        "h1": dict(h=1, denoise_coefficients=[5, 2]),
+        "pv": dict(preserve_variance=True, denoise_coefficients=[5, 2]),
+        "nowhite": dict(whitening=False, denoise_coefficients=[5, 2]),
+        "hard": dict(denoise_coefficients=[5, 2], soft_threshold=False),
+        "bilat1": dict(bilateral=1),
+        "bilat1_dc52": dict(bilateral=1, denoise_coefficients=[5, 2]),
+        "bilat_list_scaling": dict(bilateral=[1.5, 1.], bilateral_scaling=True,
+                                   denoise_coefficients=[4]),
+    }
+    for name, kw in cases.items():
+        recon, coef = wow(a.copy(), **kw)
+        out[f"recon_{name}"] = recon
+        out[f"coef_{name}"] = coef.data
+        out[f"noise_{name}"] = np.float64(np.nan if coef.noise is None else coef.noise)
+    # Coefficients input (utils.py:128-131, 152-153): same object returned
+    c = AtrousTransform()(a.copy(), 3)
+    recon, c2 = wow(c, denoise_coefficients=[5, 2])
+    assert c2 is c
+    out["recon_from_coeffs"] = recon
+    out["coef_from_coeffs"] = c.data
+    save("g4_wow", "semantic(cv2 stand-in)", **out)
+
+
+def g5_bilateral(name="g5_bilateral"):
+    out = {}
+    a = img((37, 53), 6)
+    out["img"] = a
+    for fam, cls in FAM.items():
+        sf = cls(2)
+        for s in (0, 1, 2):
+            var = sdev_loc(a, sf, s=s, variance=True)
+            out[f"var_{fam}_s{s}"] = var
+            out[f"sdev_{fam}_s{s}"] = sdev_loc(a, sf, s=s)
+            out[f"bconv_{fam}_s{s}"] = atrous_convolution(a, sf.kernel.astype(a.dtype), var, s,
+                                                          "symmetric")
+        out[f"coef_b1_{fam}"] = AtrousTransform(cls, bilateral=1)(a, 3).data
+        out[f"coef_blist_scaling_{fam}"] = AtrousTransform(
+            cls, bilateral=[2., .5], bilateral_scaling=True)(a, 3).data
+    save(name, "semantic(cv2 stand-in); numexpr: " + NE_KIND, **out)
+
+
+def g7_recursive_g8_tests():
+    out = {}
+    a = img((64, 48), 2)
+    out["img"] = a
+    out["recursive_b3_L3"] = AtrousTransform()(a, 3, recursive=True).data
+    ones = np.ones((128, 128))
+    out["ones_L4"] = AtrousTransform()(ones, 4).data          # tests/test_wavelets.py:8-13
+    r, c = wow(ones)                                            # tests/test_utils.py:7-9
+    out["wow_ones"] = r
+    r, c = wow(ones, bilateral=True)
+    out["wow_ones_bilateral"] = r
+    # integer input recast (wavelets.py:297,319-320)
+    ai = (img((16, 16), 9) * 100).astype(np.int32)
+    out["img_int32"] = ai
+    out["coef_int32_L2"] = AtrousTransform()(ai, 2).data
+    save("g7_misc", "semantic(cv2 stand-in)", **out)
+
+
+if __name__ == "__main__":
+    if REAL_NE:
+        assert NE_KIND.startswith("real"), "run with /opt/conda/bin/python3.9"
+        g5_bilateral("g5_realne")
+    else:
+        g0_hard()
+        g1_transform()
+        g2_g3_denoise()
+        g4_wow()
+        g5_bilateral()
+        g7_recursive_g8_tests()

@@ -1,0 +1,213 @@
+"""Pin the numpy oracle (oracle/atrous_numpy.py) against fixtures generated from the
+unmodified reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerances (fp32, stated per SURVEY.md section 7 "Tolerance statement"):
+  coefficients      atol = 1e-5 * max|input|   (sum-order / FMA / direct-vs-DFT rounding)
+  hard pins         the oracle follows the reference's numpy op order -> exact or 1 ulp
+"""
+import numpy as np
+import pytest
+
+from oracle import atrous_numpy as O
+from conftest import load_golden
+
+FAMS = ("b3spline", "triangle")
+SHAPES = ("37x53", "64x48", "16x16")
+
+
+def close(a, b, atol, rtol=0.0):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64),
+                               rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------- hard pins (no cv2 involved)
+def test_hard_atrous_convolution_exact():
+    g = load_golden("g0_hard")
+    for tag in SHAPES:
+        a = g[f"img_{tag}"]
+        for fam in FAMS:
+            for s in range(5):
+                got = O.convolution(a, fam, s)
+                ref = g[f"aconv_{fam}_{tag}_s{s}"]
+                assert got.dtype == ref.dtype == np.float32
+                np.testing.assert_array_equal(got, ref)     # same op order -> bit exact
+
+
+def test_hard_coefficients_methods():
+    g = load_golden("g0_hard")
+    stack = g["stack"]
+    for fam in FAMS:
+        c = O.Coeffs(stack.copy(), fam)
+        assert c.get_noise() == g[f"noise_{fam}"]
+        np.testing.assert_array_equal(c.significance(3, 2, soft_threshold=False),
+                                      g[f"sig_hard_3_2_{fam}"])
+        np.testing.assert_array_equal(c.significance(3, 1), g[f"sig_soft_3_1_{fam}"])
+        for key, sig, kw, pre in [
+            ("den_53", [5, 3], {}, None),
+            ("den_532_w", [5, 3, 2], dict(weights=[.5, 2, 1]), None),
+            ("den_53_hard", [5, 3], dict(soft_threshold=False), None),
+            ("den_32_noise07", [3, 2], {}, 0.7),
+            ("den_32_noisemap", [3, 2], {}, g["noise_map"]),
+        ]:
+            c = O.Coeffs(stack.copy(), fam)
+            if pre is not None:
+                c.noise = pre
+            c.denoise(sig, **kw)
+            np.testing.assert_array_equal(c.data, g[f"{key}_{fam}"])
+        c = O.Coeffs(stack.copy(), fam, bilateral=[1, 1])
+        c.denoise([5, 3])
+        np.testing.assert_array_equal(c.data, g[f"den_53_bilat_{fam}"])
+    cz = O.Coeffs(np.zeros((3, 8, 8), np.float32), "b3spline")
+    cz.denoise([5, 3])
+    np.testing.assert_array_equal(cz.data, g["den_zero_noise_branch"])
+    assert cz.noise == g["noise_zero"] == 0
+
+
+def test_hard_anscombe():
+    g = load_golden("g0_hard")
+    p = g["ans_in"]
+    np.testing.assert_array_equal(O.generalized_anscombe(p), g["ans_fwd"])
+    np.testing.assert_array_equal(O.generalized_anscombe(p, alpha=2., g=1., sigma=.5),
+                                  g["ans_fwd_params"])
+    np.testing.assert_array_equal(
+        O.generalized_anscombe(O.generalized_anscombe(p), inverse=True), g["ans_inv"])
+
+
+# ------------------------------------------------- semantic pins (full API, cv2 stand-in)
+def test_transform_vs_reference_api():
+    g = load_golden("g1_transform")
+    for tag in SHAPES:
+        a = g[f"img_{tag}"]
+        tol = 1e-5 * np.abs(a).max()
+        for fam in FAMS:
+            for L in (1, 2, 3, 4, 5):
+                got = O.atrous_standard(a, L, fam)
+                ref = g[f"coef_{fam}_{tag}_L{L}"]
+                assert got.shape == ref.shape == (L + 1,) + a.shape and got.dtype == ref.dtype
+                close(got, ref, tol)
+            close(O.convolution(a, fam, 2), g[f"conv_{fam}_{tag}_s2"], tol)
+
+
+def test_denoise_vs_reference_api():
+    g = load_golden("g2_denoise")
+    a = g["img"]
+    tol = 1e-5 * np.abs(a).max()
+    for fam in FAMS:
+        c = O.Coeffs(O.atrous_standard(a, 4, fam), fam)
+        np.testing.assert_allclose(c.get_noise(), g[f"noise_{fam}"], rtol=1e-6)
+        c.denoise([5, 3])
+        close(c.data, g[f"coef_den_53_{fam}"], tol)
+        close(O.denoise(a, [5, 3], fam), g[f"denoise_53_{fam}"], tol)
+        close(O.denoise(a, [5, 3], fam, noise=0.9), g[f"denoise_53_noise_{fam}"], tol)
+        # hard threshold: a pixel within rounding of tau may flip; allow a handful
+        got = O.denoise(a, [5, 3, 2], fam, soft_threshold=False)
+        ref = g[f"denoise_532_hard_{fam}"]
+        assert (np.abs(got - ref) > tol).sum() <= 2
+    p = g["img_pos"]
+    close(O.denoise(p, [5, 3], "triangle", anscombe=True), g["denoise_53_anscombe"],
+          1e-5 * np.abs(p).max())
+
+
+WOW_CASES = {
+    "default": dict(),
+    "triangle": dict(family="triangle"),
+    "dc52": dict(denoise_coefficients=[5, 2]),
+    "n3_w_dc": dict(n_scales=3, weights=[.5], denoise_coefficients=[5, 2]),
+    "h05_g2": dict(h=.5, gamma=2, denoise_coefficients=[5, 2]),
+    "h1": dict(h=1, denoise_coefficients=[5, 2]),
+    "pv": dict(preserve_variance=True, denoise_coefficients=[5, 2]),
+    "nowhite": dict(whitening=False, denoise_coefficients=[5, 2]),
+    "hard": dict(denoise_coefficients=[5, 2], soft_threshold=False),
+    "bilat1": dict(bilateral=1),
+    "bilat1_dc52": dict(bilateral=1, denoise_coefficients=[5, 2]),
+    "bilat_list_scaling": dict(bilateral=[1.5, 1.], bilateral_scaling=True,
+                               denoise_coefficients=[4]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WOW_CASES))
+def test_wow_vs_reference_api(name):
+    g = load_golden("g4_wow")
+    a = g["img"]
+    recon, coef = O.wow(a.copy(), **WOW_CASES[name])
+    ref_c, ref_r = g[f"coef_{name}"], g[f"recon_{name}"]
+    assert coef.data.shape == ref_c.shape          # n_scales logic (utils.py:121-138)
+    # whitening divides by local power -> relative tolerance (rtol 1e-4)
+    scale = np.abs(ref_c).max()
+    close(coef.data, ref_c, atol=1e-4 * scale, rtol=1e-4)
+    close(recon, ref_r, atol=1e-4 * max(1.0, np.abs(ref_r).max()), rtol=1e-4)
+    if not np.isnan(g[f"noise_{name}"]):
+        np.testing.assert_allclose(coef.noise, g[f"noise_{name}"], rtol=1e-5)
+
+
+def test_wow_from_coefficients():
+    g = load_golden("g4_wow")
+    a = g["img"]
+    c = O.Coeffs(O.atrous_standard(a.copy(), 3), "b3spline")
+    recon, c2 = O.wow(c, denoise_coefficients=[5, 2])
+    assert c2 is c
+    close(c.data, g["coef_from_coeffs"], atol=1e-4 * np.abs(g["coef_from_coeffs"]).max(),
+          rtol=1e-4)
+    close(recon, g["recon_from_coeffs"], atol=1e-4 * np.abs(g["recon_from_coeffs"]).max(),
+          rtol=1e-4)
+
+
+@pytest.mark.parametrize("fixture", ["g5_bilateral", "g5_realne"])
+def test_bilateral_vs_reference(fixture):
+    """g5_realne was generated with the REAL numexpr (conda python3.9, numpy 1.26)."""
+    g = load_golden(fixture)
+    a = g["img"]
+    tol = 2e-5 * np.abs(a).max()
+    for fam in FAMS:
+        k = O.kernel_2d(fam, a.dtype)
+        for s in (0, 1, 2):
+            var = O.sdev_loc(a, fam, s, variance=True)
+            close(var, g[f"var_{fam}_s{s}"], tol)
+            close(O.sdev_loc(a, fam, s), g[f"sdev_{fam}_s{s}"], tol)
+            # feed the reference's variance so only the bilateral operator is compared
+            close(O.atrous_convolution(a, k, g[f"var_{fam}_s{s}"], s),
+                  g[f"bconv_{fam}_s{s}"], tol)
+        close(O.atrous_standard(a, 3, fam, bilateral=1), g[f"coef_b1_{fam}"], 5 * tol)
+        close(O.atrous_standard(a, 3, fam, bilateral=[2., .5], bilateral_scaling=True),
+              g[f"coef_blist_scaling_{fam}"], 5 * tol)
+
+
+def test_reference_own_tests_and_recast():
+    g = load_golden("g7_misc")
+    ones = np.ones((128, 128))
+    got = O.atrous_standard(ones, 4)
+    expected = np.zeros(got.shape)
+    expected[-1] = 1                                    # tests/test_wavelets.py:8-13
+    assert np.isclose(got, expected).all()
+    close(got, g["ones_L4"], 1e-12)
+    r, _ = O.wow(ones)                                   # tests/test_utils.py:7-9 (smoke)
+    close(r, g["wow_ones"], 1e-9)
+    r, _ = O.wow(ones, bilateral=True)
+    close(r, g["wow_ones_bilateral"], 1e-9)
+    ai = g["img_int32"]
+    got = O.atrous_standard(ai, 2)
+    assert got.dtype == np.float64
+    close(got, g["coef_int32_L2"], 1e-9)
+
+
+def test_known_answers_no_fixture():
+    """impulse response reproduces sigma_e tables; perfect reconstruction."""
+    imp = np.zeros((257, 257), np.float32)
+    imp[128, 128] = 1
+    for fam in FAMS:
+        c = O.atrous_standard(imp, 5, fam)
+        got = np.sqrt((c[:-1].astype(np.float64) ** 2).sum(axis=(1, 2)))
+        np.testing.assert_allclose(got, O.SIGMA_E_2D[fam][:5], rtol=1e-2)  # tables are Monte-Carlo
+    a = np.random.default_rng(0).standard_normal((96, 80)).astype(np.float32)
+    for fam in FAMS:
+        c = O.atrous_standard(a, 5, fam)
+        close(c.sum(axis=0), a, 2e-6)
+
+
+def test_reflect_index_matches_np_pad():
+    for n in (1, 2, 5, 16):
+        base = np.arange(n)
+        pad = 3 * n + 2
+        ref = np.pad(base, pad, mode="symmetric")
+        got = O.reflect_index(np.arange(-pad, n + pad), n)
+        np.testing.assert_array_equal(got, ref)
