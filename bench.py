@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s of a-trous decompose + plane sum (B3spline, 6 scales, float32).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1 : the BASELINE.json headline workload - 8192 x 8192 float32, B3spline, 6 scales,
+        decompose (7 planes materialised in HBM) followed by the plane sum; input already
+        resident in HBM when the timed region starts.
+N > 1 : launched by torch.distributed.run, one rank per GPU.  BASELINE config 4: one
+        32768 x 32768 image split into N row strips, halo rows exchanged with the strip
+        neighbours over RCCL (ncclSend/ncclRecv on the compute stream) before every pass.
+        torch.distributed (gloo) is only the launcher plumbing: rendezvous, broadcast of the
+        RCCL unique id, barrier and the MAX over ranks of the timed region.
+
+One step = one pass of the hot path over the image.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LEVEL = 6
+FAMILY = "b3spline"
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy
+
+
+def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
+    """Compulsory HBM bytes per pixel of one launch of `kernel`."""
+    if kernel.startswith("wt_plane_sum"):
+        return 4.0 * (level + 2)                 # read level+1 planes, write one
+    if kernel.startswith("wt_chain_kernel<decomp>"):
+        return 12.0                              # read c_s, write w_s and c_{s+1}
+    if kernel.startswith("wt_fused"):
+        ns = int(kernel.rstrip(">").split("x")[-1]) if "x" in kernel else 3
+        return 4.0 * (ns + 2)                    # read c_s0, write ns detail planes + c_{s0+ns}
+    return None
+
+
+def make_strip(nrows, W, seed):
+    """Synthetic N(0,1) float32 strip; tall strips repeat a 2048-row block (generation time)."""
+    rng = np.random.default_rng(seed)
+    block = rng.standard_normal((min(nrows, 2048), W), dtype=np.float32)
+    if nrows <= 2048:
+        return block
+    reps = (nrows + 2047) // 2048
+    return np.ascontiguousarray(np.tile(block, (reps, 1))[:nrows])
+
+
+def cpu_baseline():
+    """The C/OpenMP oracle (a port of the reference algorithm, oracle/atrous_ref.c) timed on
+    this host on a bounded sample of the same workload."""
+    from oracle import cref
+    cref.build()
+    cores = len(os.sched_getaffinity(0))
+    threads = cref.num_threads()
+    probe = np.random.default_rng(0).standard_normal((1024, 1024), dtype=np.float32)
+    t = time.perf_counter()
+    cref.plane_sum(cref.decompose(probe, LEVEL, FAMILY))
+    per_pix = (time.perf_counter() - t) / probe.size
+    side = 8192
+    while side > 1024 and per_pix * side * side > 15.0:
+        side //= 2
+    img = np.random.default_rng(0).standard_normal((side, side), dtype=np.float32)
+    reps, t_tot = 0, 0.0
+    while reps < 5 and t_tot < 10.0:
+        t = time.perf_counter()
+        cref.plane_sum(cref.decompose(img, LEVEL, FAMILY))
+        t_tot += time.perf_counter() - t
+        reps += 1
+    return {"value": round(img.size * reps / t_tot / 1e6, 2), "unit": "Mpix/s",
+            "cores": min(threads, cores), "kind": "port",
+            "sample": f"{reps} x decompose+sum of {side}x{side} f32 {FAMILY} L={LEVEL} "
+                      f"(oracle/atrous_ref.c, gcc -O3 -fopenmp, {threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=0, help="override image side (testing)")
+    ap.add_argument("--unfused", action="store_true", help="one kernel per scale")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(one rank per GPU)")
+        args.gpus = world
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    from wavelets_amd import _lib
+    from wavelets_amd._lib import PLANE_INPUT, PLANE_OUT
+
+    ctx = _lib.Context(local_rank)
+    if world > 1:
+        ids = [_lib.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(rank, world, ids[0])
+
+    side = args.size or (8192 if world == 1 else 32768)
+    H = W = side
+    nrows = H // world
+    row0 = rank * nrows
+    if rank == world - 1:
+        nrows = H - row0
+    fam = _lib.B3SPLINE
+    plan = _lib.Plan(ctx, H, W, fam, LEVEL, row0=row0, nrows=nrows, rank=rank, nranks=world)
+    plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
+    flags = 0 if args.unfused else _lib.FLAG_FUSED
+
+    def step():
+        plan.decompose(PLANE_INPUT, LEVEL, flags)
+        plan.plane_sum(0, LEVEL + 1, PLANE_OUT)
+
+    def fence():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    dev_ms = ctx.timer_stop()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = H * W * args.steps / elapsed / 1e6
+
+    # ---- live per-kernel timing (HIP events on the launch stream) for the roofline figure
+    ctx.profile(True)
+    ctx.profile_reset()
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+    prof = ctx.profile_entries()
+    ctx.profile(False)
+    roofline = None
+    kernels = {}
+    my_pix = float(nrows) * W
+    for name, (calls, ms) in prof.items():
+        bpp = algorithmic_bytes_per_pixel(name)
+        avg_ms = ms / calls
+        kernels[name] = {"calls_per_step": calls // max(3, min(args.steps, 10)),
+                         "avg_ms": round(avg_ms, 4),
+                         "algorithmic_GBs": None if bpp is None else
+                         round(bpp * my_pix / (avg_ms * 1e-3) / 1e9, 1)}
+    cand = [(ms, n) for n, (c, ms) in prof.items() if algorithmic_bytes_per_pixel(n)]
+    if cand:
+        _, dom = max(cand)
+        calls, ms = prof[dom]
+        achieved = algorithmic_bytes_per_pixel(dom) * my_pix / (ms / calls * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{dom}@{side}", None)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
+
+    if rank == 0:
+        whole_job_GBs = 8.0 * (LEVEL + 2) * H * W * args.steps / elapsed / 1e9
+        out = {
+            "metric": "Mpix/s decompose+sum, 8192^2 f32 B3spline 6 scales; %HBM roofline",
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{H}x{W} float32 N(0,1), {FAMILY} L={LEVEL}, decompose "
+                                   f"({LEVEL + 1} planes in HBM) + plane sum; device-resident"
+                                   + ("" if world == 1 else f"; {world} row strips, RCCL halo "
+                                      "exchange per pass"),
+                       "image": [H, W], "levels": LEVEL, "family": FAMILY,
+                       "fused": not args.unfused,
+                       "schedule": _lib.schedule(fam, LEVEL, not args.unfused),
+                       "parallelism": f"strips{world}"},
+            "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "whole_path": {"algorithmic_GBs": round(whole_job_GBs, 1),
+                           "frac_of_hbm_peak": round(whole_job_GBs / (HBM_PEAK_GBS * world), 4),
+                           "bytes_per_pixel": 8 * (LEVEL + 2)},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1:
+            # PCIe-inclusive rate (host numpy in, reconstruction out) - never `value`
+            img = make_strip(nrows, W, seed=0)
+            recon = np.empty((nrows, W), np.float32)
+            t = time.perf_counter()
+            plan.upload(PLANE_INPUT, img)
+            step()
+            plan.download(PLANE_OUT, recon)
+            out["pcie_inclusive_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
+            if not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/* watroo_hip.h - C ABI of libwatroo_hip.so, the MI355X (gfx950) a-trous wavelet engine.
+ *
+ * The reference (frederic-auchere/wavelets, "watroo" 0.0.4) is pure Python and has no
+ * FFI/plugin interface of its own: its boundary to native code is the handful of calls it
+ * makes into OpenCV / numexpr / scipy / numpy.  Each entry point below replaces one of those
+ * call sites (cited as file:line relative to /root/reference) for 2-D float32 images, plus
+ * the plan/buffer plumbing a device-resident engine needs.  Host Python
+ * (wavelets_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the stub a watroo
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; wt_last_error() returns a
+ *    thread-local message (argument errors, HIP errors, RCCL errors).
+ *  - plain pointers and sizes only; host pointers are borrowed for the duration of a call.
+ *  - one HIP stream per context; calls on a context are serialised on that stream and are
+ *    asynchronous unless they return a host value (upload/download/median/reduce sync).
+ *  - images are row-major float32.  A plan describes ONE row strip [row0,row0+nrows) of a
+ *    global H x W image (the whole image when nranks == 1).  Planes live in HBM with a row
+ *    pitch of round_up(W,4) floats and `halo` margin rows above and below the strip that are
+ *    filled by the RCCL halo exchange (nranks > 1) - borders of the GLOBAL image are always
+ *    handled by symmetric reflection (cv2.BORDER_REFLECT == np.pad 'symmetric').
+ *  - plane ids: 0..max_level are the coefficient planes (plane s = detail w_s, plane
+ *    `level` = final smooth); WT_PLANE_INPUT holds the image handed to the transform;
+ *    WT_PLANE_OUT the reconstruction; WT_PLANE_SCRATCH(i), i in [0,WT_NUM_SCRATCH), are
+ *    general purpose (allocated on first use).
+ */
+#ifndef WATROO_HIP_H
+#define WATROO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WT_ABI_VERSION 1
+
+typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
+typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */
+
+enum { WT_TRIANGLE = 0, WT_B3SPLINE = 1 };      /* watroo/wavelets.py:232-287 */
+
+#define WT_PLANE_INPUT (-1)
+#define WT_PLANE_OUT (-2)
+#define WT_NUM_SCRATCH 6
+#define WT_PLANE_SCRATCH(i) (-3 - (i))
+#define WT_PLANE_NONE (-1000)
+
+/* ---- library / device ------------------------------------------------------------- */
+int wt_abi_version(void);
+const char *wt_last_error(void);
+int wt_device_count(int *count);
+
+/* ---- context ---------------------------------------------------------------------- */
+int wt_ctx_create(int device, wt_ctx **out);
+int wt_ctx_destroy(wt_ctx *ctx);
+int wt_ctx_sync(wt_ctx *ctx);
+/* hipEvent stopwatch on the context's stream (the stream every kernel is launched on). */
+int wt_timer_start(wt_ctx *ctx);
+int wt_timer_stop(wt_ctx *ctx, float *elapsed_ms);
+/* Per-kernel HIP-event profile: when enabled every kernel launch is bracketed by events.
+ * wt_profile_entry copies the i-th kernel name (<= 63 chars) and its call count and total
+ * device milliseconds.  Used by bench.py for the live roofline figure. */
+int wt_profile_enable(wt_ctx *ctx, int on);
+int wt_profile_reset(wt_ctx *ctx);
+int wt_profile_count(wt_ctx *ctx, int *n);
+int wt_profile_entry(wt_ctx *ctx, int i, char *name64, int64_t *calls, double *total_ms);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) --------------------------------- */
+/* 128-byte ncclUniqueId; rank 0 creates it, the launcher broadcasts it out of band. */
+int wt_comm_unique_id(void *id128);
+int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *id128);
+/* test hook: nranks==1 periodic self exchange through RCCL send/recv (plumbing check). */
+int wt_comm_selftest(wt_ctx *ctx, int64_t nfloats, int *ok);
+
+/* ---- plan --------------------------------------------------------------------------- */
+/* Whole image on one GPU. */
+int wt_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level,
+                   wt_plan **out);
+/* Row strip [row0,row0+nrows) of a global H x W image.  halo_rows = margin rows to allocate
+ * above/below (>= the largest halo any requested op needs; 0 lets the library size it from
+ * max_level).  rank/nranks give the strip's position: neighbours are rank-1 / rank+1. */
+int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level,
+                         int64_t row0, int64_t nrows, int64_t halo_rows, int rank,
+                         int nranks, wt_plan **out);
+int wt_plan_destroy(wt_plan *plan);
+/* geometry query: out[0..7] = H, W, pitch, row0, nrows, halo, max_level, family */
+int wt_plan_info(wt_plan *plan, int64_t out[8]);
+/* Decomposition schedule (host logic, needs no GPU): for `level` scales of `family`, writes
+ * up to `cap` passes as triples {first_scale, n_scales, halo_rows_of_input}.  The same
+ * schedule drives the kernels and the halo exchange; tests use it for the gloo CPU model. */
+int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int *n_passes);
+/* device pointer of a plane's local row 0 (for zero-copy interop / virtual-strip tests) */
+int wt_plane_ptr(wt_plan *plan, int plane, void **dev_ptr);
+
+/* ---- host <-> device ---------------------------------------------------------------- */
+/* host image = this strip's rows, `host_stride` floats between rows (>= W). */
+int wt_upload(wt_plan *plan, int plane, const float *host, int64_t host_stride);
+int wt_download(wt_plan *plan, int plane, float *host, int64_t host_stride);
+int wt_copy_plane(wt_plan *plan, int src, int dst);
+int wt_fill_plane(wt_plan *plan, int plane, float value);
+/* In-process stand-in for the RCCL halo exchange between two plans on the SAME device
+ * ("virtual strips"): copies upper's top rows into lower... see tests. `upper` owns the rows
+ * just above `lower`.  Copies `rows` rows each way for `plane`. */
+int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane, int64_t rows);
+/* RCCL halo exchange of `rows` margin rows of `plane` with the strip neighbours. */
+int wt_halo_exchange(wt_plan *plan, int plane, int64_t rows);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* AtrousTransform.atrous_standard, bilateral=None  (watroo/wavelets.py:408-444):
+ * planes[0..level-1] <- detail, planes[level] <- smooth, from plane `src` (left intact).
+ * flags: bit0 = allow fused multi-scale passes (default path), bit1 = skip halo exchange
+ * (caller did it / virtual strips). */
+int wt_decompose(wt_plan *plan, int src, int level, int flags);
+/* one scale of the above on explicit planes (per-scale operator; virtual-strip tests):
+ * dst_c <- h_s (*) src ; dst_w <- src - dst_c (dst_w may be WT_PLANE_NONE). */
+int wt_atrous_scale(wt_plan *plan, int src, int dst_c, int dst_w, int s, int flags);
+/* convolution(arr, scaling_function, s)  (watroo/wavelets.py:35-45; cv2.filter2D with the
+ * zero-stuffed kernel of :191-197, BORDER_REFLECT).  square_input: smooth src*src
+ * (utils.py:177,194). */
+int wt_smooth(wt_plan *plan, int src, int dst, int s, int square_input, int flags);
+/* sdev_loc(image, sf, s, variance)  (watroo/wavelets.py:24-32), times f1 then f2
+ * (the sigma_bilateral**2 and (s+1) factors of :434-436). */
+int wt_local_variance(wt_plan *plan, int src, int dst, int s, float f1, float f2,
+                      int take_sqrt, int flags);
+/* atrous_convolution(image, kernel, bilateral_variance, s, 'symmetric')
+ * (watroo/wavelets.py:74-105; numexpr expression :97). */
+int wt_bilateral_conv(wt_plan *plan, int src, int var, int dst, int s, int flags);
+/* atrous_standard with bilateral (watroo/wavelets.py:421-442): sigma_b[level] */
+int wt_decompose_bilateral(wt_plan *plan, int src, int level, const double *sigma_b,
+                           int bilateral_scaling, int flags);
+/* np.sum(coefficients, axis=0) (watroo/utils.py:98,205): dst <- sum planes[first..first+n) */
+int wt_plane_sum(wt_plan *plan, int first, int count, int dst);
+/* np.median(np.abs(data[0])) (watroo/wavelets.py:127): exact radix select, fp32 result */
+int wt_abs_median(wt_plan *plan, int plane, float *median);
+/* Coefficients.significance (watroo/wavelets.py:129-143): dst <- erf(|c|/tau) (soft) or
+ * |c| > tau (hard, 1.0/0.0).  tau = sigma*noise*sigma_e[scale]; with noise_plane !=
+ * WT_PLANE_NONE tau is multiplied per pixel by that plane (ndarray noise map, :133). */
+int wt_significance(wt_plan *plan, int plane, int dst, double tau, int soft, int noise_plane);
+/* Coefficients.denoise body (watroo/wavelets.py:149): plane *= wgt * significance */
+int wt_denoise(wt_plan *plan, int plane, double tau, double wgt, int soft, int noise_plane);
+/* wow per-scale update (watroo/utils.py:193-203) fused:
+ *   c <- c * significance(tau)            (skipped when tau <= 0)
+ *   gamma_plane += c                      (skipped when gamma_plane == WT_PLANE_NONE)
+ *   c <- c * (factor / sqrt(clip(P)))     P = power_plane (conv of c^2), clip <=0 -> 1e-15;
+ *                                         power_plane == WT_PLANE_NONE: c <- c * factor */
+int wt_wow_update(wt_plan *plan, int plane, int power_plane, double tau, int soft,
+                  int noise_plane, float factor, int gamma_plane);
+/* global reductions for wow (watroo/utils.py:180-187,209-211): out = {sum, sumsq, min, max} */
+int wt_reduce(wt_plan *plan, int plane, double out[4]);
+/* gamma blend (watroo/utils.py:212-217):
+ *   g <- clip((g-gmin)/(gmax-gmin),0,1)**(1/gamma); recon <- (1-h)*recon + h*g */
+int wt_gamma_blend(wt_plan *plan, int recon, int gamma_plane, float gmin, float gmax,
+                   float inv_gamma, float h);
+/* generalized_anscombe (watroo/wavelets.py:14-21) */
+int wt_anscombe(wt_plan *plan, int src, int dst, float alpha, float g, float sigma,
+                int inverse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WATROO_HIP_H */

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports
+every symbol include/watroo_hip.h declares, the host-logic entry points work, and the product
+package fails loudly (no CPU fallback) when no device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from wavelets_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    entry.build()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "watroo_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"libwatroo_hip.so lacks {n}"
+    assert sorted(_lib.SIGNATURES) == names       # python binding covers the whole header
+    assert _lib.load().wt_abi_version() == 1
+
+
+def test_schedule_host_logic():
+    # B3 (hw=2): 6 scales fuse into two 3-scale passes with cumulative halos 14 and 112 rows
+    assert _lib.schedule(_lib.B3SPLINE, 6, True) == [(0, 3, 14), (3, 3, 112)]
+    assert _lib.schedule(_lib.B3SPLINE, 4, True) == [(0, 3, 14), (3, 1, 16)]
+    # unfused: one pass per scale, halo hw * 2^s
+    assert _lib.schedule(_lib.TRIANGLE, 4, False) == [(0, 1, 1), (1, 1, 2), (2, 1, 4), (3, 1, 8)]
+    sch = _lib.schedule(_lib.B3SPLINE, 11, True)
+    assert sum(n for _, n, _ in sch) == 11 and [s for s, _, _ in sch][:3] == [0, 3, 6]
+    total = sum(h for _, _, h in _lib.schedule(_lib.B3SPLINE, 6, False))
+    assert total == 2 * 63 == sum(h for _, _, h in _lib.schedule(_lib.B3SPLINE, 6, True))
+    with pytest.raises(_lib.WatrooHipError):
+        _lib.schedule(7, 3)
+
+
+def test_fails_loudly_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import wavelets_amd as W
+    with pytest.raises(_lib.WatrooHipError, match="no CPU fallback"):
+        W.AtrousTransform()(np.ones((8, 8), np.float32), 2)
+    with pytest.raises(_lib.WatrooHipError):
+        W.denoise(np.ones((8, 8), np.float32), [3])
+
+
+def test_argument_errors_match_reference():
+    import wavelets_amd as W
+    with pytest.raises(ValueError, match="Unsupported number of dimensions"):
+        W.AtrousTransform()(np.ones((2, 2, 2, 2)), 1)          # ref wavelets.py:316-317
+    with pytest.raises(ValueError, match="Unknown input type"):
+        W.wow([1, 2, 3])                                        # ref utils.py:133
+    with pytest.raises(ValueError, match="Unsupported number of dimensions"):
+        W.B3spline(4)                                           # ref wavelets.py:189
+    with pytest.raises(NotImplementedError):
+        W.AtrousTransform()(np.ones(16), 1)                     # 1-D: out of scope, loud
+
+
+def test_scaling_function_objects_match_oracle_constants():
+    import wavelets_amd as W
+    from oracle import atrous_numpy as O
+    for cls, fam in ((W.B3spline, "b3spline"), (W.Triangle, "triangle")):
+        sf = cls(2)
+        assert sf.name == fam and sf.n_dim == 2
+        np.testing.assert_array_equal(sf.coefficients_1d, O.TAPS[fam])
+        np.testing.assert_array_equal(sf.kernel, O.kernel_2d(fam, np.float64))
+        np.testing.assert_array_equal(sf.sigma_e(), O.SIGMA_E_2D[fam])
+        np.testing.assert_array_equal(sf.sigma_e(bilateral=1), O.SIGMA_E_2D_BILATERAL[fam])
+        k = sf.atrous_kernel(2)
+        assert k.shape == ((len(O.TAPS[fam]) - 1) * 4 + 1,) * 2
+        np.testing.assert_array_equal(k[::4, ::4], sf.kernel)
+        assert k.sum() == pytest.approx(1.0)
+        assert cls(3).kernel.shape == (len(O.TAPS[fam]),) * 3
+        assert cls(1).sigma_e(bilateral=1) is None              # ref: 1-D bilateral table absent

@@ -1,0 +1,392 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every check goes through the C ABI
+(wavelets_amd._lib -> libwatroo_hip.so) and compares with the pinned oracle / golden fixtures.
+
+Tolerances (fp32; SURVEY.md section 7 "Tolerance statement"):
+  TOL_COEF  = 1e-5 * max|input|   coefficients, smoothing, reconstruction
+  wow       rtol 1e-4 (+ atol 1e-4 * max|ref|)   whitening divides by local power
+  bit-exact: plane sum, Anscombe, exact median, hard threshold given identical planes
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+FAMS = ("b3spline", "triangle")
+SHAPES = ("37x53", "64x48", "16x16")
+
+
+@pytest.fixture(scope="module")
+def W():
+    import __graft_entry__ as entry
+    entry.build()
+    import wavelets_amd
+    return wavelets_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import atrous_numpy
+    return atrous_numpy
+
+
+@pytest.fixture(scope="module")
+def C():
+    from oracle import cref
+    cref.build()
+    return cref
+
+
+def cls_of(W, fam):
+    return {"b3spline": W.B3spline, "triangle": W.Triangle}[fam]
+
+
+def close(a, b, atol, rtol=0.0):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64),
+                               rtol=rtol, atol=atol)
+
+
+def rnd(shape, seed=0):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------- transform
+def test_transform_vs_golden(W):
+    g = load_golden("g1_transform")
+    for tag in SHAPES:
+        a = g[f"img_{tag}"]
+        tol = 1e-5 * np.abs(a).max()
+        for fam in FAMS:
+            for L in (1, 2, 3, 4, 5):
+                c = W.AtrousTransform(cls_of(W, fam))(a, L)
+                ref = g[f"coef_{fam}_{tag}_L{L}"]
+                assert len(c) == L + 1 and c.data.shape == ref.shape
+                assert c.data.dtype == np.float32
+                close(c.data, ref, tol)
+                close(np.sum(c, axis=0), a, 2 * tol)     # __array__ protocol + reconstruction
+            close(W.convolution(a, cls_of(W, fam)(2), s=2), g[f"conv_{fam}_{tag}_s2"], tol)
+
+
+def test_hard_pin_operator_all_scales(W):
+    """reference's own numpy atrous_convolution (no cv2) vs the HIP smooth, s = 0..4"""
+    g = load_golden("g0_hard")
+    for tag in SHAPES:
+        a = g[f"img_{tag}"]
+        tol = 1e-5 * np.abs(a).max()
+        for fam in FAMS:
+            sf = cls_of(W, fam)(2)
+            for s in range(5):
+                close(W.convolution(a, sf, s=s), g[f"aconv_{fam}_{tag}_s{s}"], tol)
+                close(W.atrous_convolution(a, sf.kernel.astype(np.float32), None, s),
+                      g[f"aconv_{fam}_{tag}_s{s}"], tol)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (5, 3), (3, 129), (130, 2), (257, 255),
+                                   (64, 1028)])
+def test_ragged_shapes_and_multibounce(W, O, shape):
+    a = rnd(shape, 3)
+    tol = 1e-5 * max(1.0, np.abs(a).max())
+    for fam in FAMS:
+        for L in (1, 4, 7):
+            c = W.AtrousTransform(cls_of(W, fam))(a, L)
+            close(c.data, O.atrous_standard(a, L, fam), tol)
+
+
+def test_output_param_and_input_untouched(W):
+    a = rnd((40, 44), 4)
+    keep = a.copy()
+    out = np.empty_like(a)
+    r = W.convolution(a, W.B3spline(2), s=1, output=out)
+    assert r is out
+    W.AtrousTransform()(a, 3)
+    np.testing.assert_array_equal(a, keep)
+
+
+def test_dtype_policy(W, O):
+    g = load_golden("g7_misc")
+    ai = g["img_int32"]
+    c = W.AtrousTransform()(ai, 2)
+    assert c.data.dtype == np.float32                  # engine computes in fp32
+    close(c.data, g["coef_int32_L2"], 1e-5 * np.abs(ai).max())
+    ones = np.ones((128, 128))                         # reference tests/test_wavelets.py:8-13
+    regular = W.AtrousTransform()(ones, 4)
+    expected = np.zeros(regular.data.shape)
+    expected[-1] = 1
+    assert np.isclose(regular, expected).all()
+    with pytest.raises(NotImplementedError):
+        W.AtrousTransform()(ones, 4, recursive=True)
+
+
+def test_reference_wow_smoke_tests(W):
+    g = load_golden("g7_misc")
+    ones = np.ones((128, 128))                         # reference tests/test_utils.py:7-9
+    r, _ = W.wow(ones)
+    close(r, g["wow_ones"], 1e-5)
+    r, _ = W.wow(ones, bilateral=True)
+    close(r, g["wow_ones_bilateral"], 1e-5)
+
+
+# --------------------------------------------------------------------------- pointwise / select
+def test_plane_sum_bit_exact(W):
+    a = rnd((123, 77), 5)
+    c = W.AtrousTransform()(a, 6)
+    np.testing.assert_array_equal(c.sum(), c.data.sum(axis=0))
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (64, 48), (1, 1), (2, 1), (300, 333), (512, 512)])
+def test_exact_median(W, shape):
+    a = rnd(shape, 6)
+    c = W.Coefficients(np.stack([a, a]), W.B3spline(2))
+    med = c._device().abs_median(0)
+    assert med == np.median(np.abs(a))
+    assert c.get_noise() == np.median(np.abs(a)) / 0.6745 / c.sigma_e[0]
+    # heavy ties and zeros
+    b = np.round(a * 2) / 2
+    c = W.Coefficients(np.stack([b, b]), W.B3spline(2))
+    assert c._device().abs_median(0) == np.median(np.abs(b))
+
+
+def test_coefficients_methods_vs_hard_pins(W):
+    g = load_golden("g0_hard")
+    stack = g["stack"]
+    for fam in FAMS:
+        sf = cls_of(W, fam)(2)
+        c = W.Coefficients(stack.copy(), sf)
+        assert c.get_noise() == g[f"noise_{fam}"]
+        np.testing.assert_array_equal(c.significance(3, 2, soft_threshold=False),
+                                      g[f"sig_hard_3_2_{fam}"])
+        close(c.significance(3, 1), g[f"sig_soft_3_1_{fam}"], 1e-6)
+        scale = np.abs(stack).max()
+        for key, sig, kw, pre in [
+            ("den_53", [5, 3], {}, None),
+            ("den_532_w", [5, 3, 2], dict(weights=[.5, 2, 1]), None),
+            ("den_53_hard", [5, 3], dict(soft_threshold=False), None),
+            ("den_32_noise07", [3, 2], {}, 0.7),
+            ("den_32_noisemap", [3, 2], {}, g["noise_map"]),
+        ]:
+            c = W.Coefficients(stack.copy(), sf)
+            if pre is not None:
+                c.noise = pre
+            held = c.data                       # reference idiom: user keeps a view of .data
+            c.denoise(sig, **kw)
+            assert c.data is held               # mirror refreshed in place
+            close(c.data, g[f"{key}_{fam}"], 1e-6 * scale)
+        c = W.Coefficients(stack.copy(), sf, bilateral=[1, 1])
+        c.denoise([5, 3])
+        close(c.data, g[f"den_53_bilat_{fam}"], 1e-6 * scale)
+    cz = W.Coefficients(np.zeros((3, 8, 8), np.float32), W.B3spline(2))
+    cz.denoise([5, 3])                           # noise == 0 short-circuit (ref :133-135)
+    np.testing.assert_array_equal(cz.data, g["den_zero_noise_branch"])
+    assert cz.noise == 0
+
+
+def test_host_mirror_edits_are_honoured(W, O):
+    a = rnd((48, 40), 8)
+    c = W.AtrousTransform()(a, 3)
+    c.data[0] *= 0.0                             # user edit on the host mirror
+    close(c.sum(), O.atrous_standard(a, 3)[1:].sum(axis=0), 1e-5 * np.abs(a).max())
+
+
+def test_anscombe_bit_exact(W):
+    g = load_golden("g0_hard")
+    p = g["ans_in"]
+    np.testing.assert_array_equal(W.generalized_anscombe(p), g["ans_fwd"])
+    np.testing.assert_array_equal(W.generalized_anscombe(p, alpha=2., g=1., sigma=.5),
+                                  g["ans_fwd_params"])
+    np.testing.assert_array_equal(
+        W.generalized_anscombe(W.generalized_anscombe(p), inverse=True), g["ans_inv"])
+
+
+# --------------------------------------------------------------------------- denoise / wow
+def test_denoise_vs_golden(W):
+    g = load_golden("g2_denoise")
+    a = g["img"]
+    tol = 1e-5 * np.abs(a).max()
+    for fam in FAMS:
+        cls = cls_of(W, fam)
+        c = W.AtrousTransform(cls)(a, 4)
+        np.testing.assert_allclose(c.get_noise(), g[f"noise_{fam}"], rtol=1e-5)
+        c.denoise([5, 3])
+        close(c.data, g[f"coef_den_53_{fam}"], tol)
+        close(W.denoise(a, [5, 3], cls), g[f"denoise_53_{fam}"], tol)
+        close(W.denoise(a, [5, 3], cls, noise=0.9), g[f"denoise_53_noise_{fam}"], tol)
+        got = W.denoise(a, [5, 3, 2], cls, soft_threshold=False)
+        assert (np.abs(got - g[f"denoise_532_hard_{fam}"]) > tol).sum() <= 2
+    p = g["img_pos"]
+    close(W.denoise(p, [5, 3], W.Triangle, anscombe=True), g["denoise_53_anscombe"],
+          1e-5 * np.abs(p).max())
+
+
+WOW_CASES = {
+    "default": dict(),
+    "triangle": dict(scaling_function="triangle"),
+    "dc52": dict(denoise_coefficients=[5, 2]),
+    "n3_w_dc": dict(n_scales=3, weights=[.5], denoise_coefficients=[5, 2]),
+    "h05_g2": dict(h=.5, gamma=2, denoise_coefficients=[5, 2]),
+    "h1": dict(h=1, denoise_coefficients=[5, 2]),
+    "pv": dict(preserve_variance=True, denoise_coefficients=[5, 2]),
+    "nowhite": dict(whitening=False, denoise_coefficients=[5, 2]),
+    "hard": dict(denoise_coefficients=[5, 2], soft_threshold=False),
+    "bilat1": dict(bilateral=1),
+    "bilat1_dc52": dict(bilateral=1, denoise_coefficients=[5, 2]),
+    "bilat_list_scaling": dict(bilateral=[1.5, 1.], bilateral_scaling=True,
+                               denoise_coefficients=[4]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WOW_CASES))
+def test_wow_vs_golden(W, name):
+    g = load_golden("g4_wow")
+    a = g["img"]
+    kw = dict(WOW_CASES[name])
+    if "scaling_function" in kw:
+        kw["scaling_function"] = cls_of(W, kw["scaling_function"])
+    recon, coef = W.wow(a.copy(), **kw)
+    ref_c, ref_r = g[f"coef_{name}"], g[f"recon_{name}"]
+    assert coef.data.shape == ref_c.shape                # n_scales logic (utils.py:121-138)
+    close(coef.data, ref_c, atol=1e-4 * np.abs(ref_c).max(), rtol=1e-4)
+    close(recon, ref_r, atol=1e-4 * max(1.0, np.abs(ref_r).max()), rtol=1e-4)
+    if not np.isnan(g[f"noise_{name}"]):
+        np.testing.assert_allclose(coef.noise, g[f"noise_{name}"], rtol=1e-4)
+
+
+def test_wow_from_coefficients(W):
+    g = load_golden("g4_wow")
+    a = g["img"]
+    c = W.AtrousTransform()(a.copy(), 3)
+    recon, c2 = W.wow(c, denoise_coefficients=[5, 2])
+    assert c2 is c
+    close(c.data, g["coef_from_coeffs"], atol=1e-4 * np.abs(g["coef_from_coeffs"]).max(),
+          rtol=1e-4)
+    close(recon, g["recon_from_coeffs"], atol=1e-4 * np.abs(g["recon_from_coeffs"]).max(),
+          rtol=1e-4)
+
+
+@pytest.mark.parametrize("fixture", ["g5_bilateral", "g5_realne"])
+def test_bilateral_vs_golden(W, fixture):
+    g = load_golden(fixture)
+    a = g["img"]
+    tol = 2e-5 * np.abs(a).max()
+    for fam in FAMS:
+        cls = cls_of(W, fam)
+        sf = cls(2)
+        k = sf.kernel.astype(np.float32)
+        for s in (0, 1, 2):
+            close(W.sdev_loc(a, sf, s=s, variance=True), g[f"var_{fam}_s{s}"], tol)
+            close(W.sdev_loc(a, sf, s=s), g[f"sdev_{fam}_s{s}"], tol)
+            close(W.atrous_convolution(a, k, g[f"var_{fam}_s{s}"], s), g[f"bconv_{fam}_s{s}"], tol)
+        close(W.AtrousTransform(cls, bilateral=1)(a, 3).data, g[f"coef_b1_{fam}"], 5 * tol)
+        close(W.AtrousTransform(cls, bilateral=[2., .5], bilateral_scaling=True)(a, 3).data,
+              g[f"coef_blist_scaling_{fam}"], 5 * tol)
+
+
+# --------------------------------------------------------------------------- BASELINE configs
+def test_cfg1_readme_512(W, O):
+    """BASELINE cfg 1: 512x512, B3spline 4 scales, denoise([5,3])."""
+    a = rnd((512, 512), 0)
+    c = W.AtrousTransform(W.B3spline)(a, 4)
+    ref = O.Coeffs(O.atrous_standard(a, 4), "b3spline")
+    close(c.data, ref.data, 1e-5 * np.abs(a).max())
+    c.denoise([5, 3])
+    ref.denoise([5, 3])
+    np.testing.assert_allclose(c.noise, ref.noise, rtol=1e-5)
+    close(c.data, ref.data, 1e-5 * np.abs(a).max())
+    close(np.sum(c, axis=0), ref.data.sum(axis=0), 1e-5 * np.abs(a).max())
+
+
+def test_cfg2_4096_b3_l6_vs_c_oracle(W, C):
+    """BASELINE cfg 2: 4096x4096 B3spline 6 scales decompose + reconstruct vs the C oracle."""
+    a = rnd((4096, 4096), 0)
+    tol = 1e-5 * np.abs(a).max()
+    c = W.AtrousTransform(W.B3spline)(a, 6)
+    ref = C.decompose(a, 6, "b3spline")
+    for s in range(7):
+        close(c.data[s], ref[s], tol)
+    recon = c.sum()
+    np.testing.assert_array_equal(recon, C.plane_sum(c.data))     # same planes -> bit exact
+    close(recon, a, 2e-6 * np.abs(a).max() * 4)                  # perfect reconstruction
+
+
+def test_cfg3_8192_triangle_l8_denoise(W, C):
+    """BASELINE cfg 3: 8192x8192 Triangle 8 scales + denoise([5,3,2]) soft threshold."""
+    from oracle import atrous_numpy as O
+    a = rnd((8192, 8192), 0)
+    amax = np.abs(a).max()
+    c = W.AtrousTransform(W.Triangle)(a, 8)
+    ref = C.decompose(a, 8, "triangle")
+    for s in range(9):
+        close(c.data[s], ref[s], 1e-5 * amax)
+    noise = c.get_noise()
+    assert noise == np.median(np.abs(c.data[0])) / 0.6745 / c.sigma_e[0]   # exact select
+    ref_noise = C.abs_median(ref[0]) / 0.6745 / O.SIGMA_E_2D["triangle"][0]
+    np.testing.assert_allclose(noise, ref_noise, rtol=1e-5)
+    got = W.denoise(a, [5, 3, 2], W.Triangle)
+    for s, sig in enumerate([5, 3, 2]):
+        C.denoise_plane(ref[s], sig * ref_noise * O.SIGMA_E_2D["triangle"][s], 1.0, True)
+    close(got, C.plane_sum(ref), 1e-5 * amax)
+
+
+def test_8192_b3_l6_properties(W):
+    """Headline size: size-independent properties (no CPU pass needed)."""
+    a = rnd((8192, 8192), 1)
+    amax = np.abs(a).max()
+    T = W.AtrousTransform(W.B3spline)
+    c = T(a, 6)
+    plan = c._device()
+    recon = c.sum()
+    close(recon, a, 1e-5 * amax)                                   # sum of planes == input
+    # linearity: T(2a + b) == 2 T(a) + T(b) on the last (smooth) and a detail plane
+    b = rnd((8192, 8192), 2)
+    cb = T(b, 6)
+    cab = T(2 * a + b, 6)
+    for s in (0, 3, 6):
+        pa, pb, pab = plan.download(s), cb._device().download(s), cab._device().download(s)
+        close(pab, 2 * pa + pb, 4e-5 * amax)
+    # DC gain 1 / mass preservation of the symmetric border: mean(smooth) == mean(input)
+    tot = plan.reduce(6)[0]
+    np.testing.assert_allclose(tot / a.size, a.astype(np.float64).mean(), atol=1e-5)
+    # detail planes of a constant image vanish, smooth plane is the constant
+    k = T(np.full((8192, 8192), 3.25, np.float32), 6)
+    for s in range(6):
+        assert k._device().reduce(s)[2:] == (0.0, 0.0)
+    assert k._device().reduce(6)[2:] == (3.25, 3.25)
+
+
+def test_large_dilation_scales(W, C):
+    """wow-sized dilations (d up to 512) on a 2048x1024 image vs the C oracle."""
+    a = rnd((2048, 1024), 9)
+    c = W.AtrousTransform(W.B3spline)(a, 10)
+    ref = C.decompose(a, 10, "b3spline")
+    close(c.data, ref, 1e-5 * np.abs(a).max())
+
+
+# --------------------------------------------------------------------------- C-ABI behaviour
+def test_abi_errors_and_profile(W):
+    from wavelets_amd import _lib
+    ctx = _lib.default_context()
+    plan = _lib.Plan(ctx, 32, 32, _lib.B3SPLINE, 2)
+    with pytest.raises(_lib.WatrooHipError, match="invalid plane id"):
+        plan.copy(7, 0)
+    with pytest.raises(_lib.WatrooHipError, match="exceeds plan max_level"):
+        plan.decompose(_lib.PLANE_INPUT, 5)
+    with pytest.raises(_lib.WatrooHipError, match="tau must be positive"):
+        plan.denoise(0, 0.0)
+    plan.upload(_lib.PLANE_INPUT, rnd((32, 32)))
+    ctx.profile(True)
+    ctx.profile_reset()
+    plan.decompose(_lib.PLANE_INPUT, 2)
+    plan.plane_sum(0, 3)
+    ent = ctx.profile_entries()
+    ctx.profile(False)
+    assert any("chain" in k or "fused" in k for k in ent) and "wt_plane_sum_kernel" in ent
+    assert all(calls >= 1 and ms > 0 for calls, ms in ent.values())
+
+
+def test_rccl_single_rank_selftest(W):
+    """RCCL plumbing (dlopen, unique id, comm init, grouped send/recv, all-reduce) on 1 GPU."""
+    from wavelets_amd import _lib
+    ctx = _lib.Context(0)
+    ctx.comm_init(0, 1, _lib.Context.unique_id())
+    assert ctx.comm_selftest(1 << 18)
+    ctx.close()

@@ -1,0 +1,334 @@
+"""ctypes binding of libwatroo_hip.so (C ABI: include/watroo_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible the
+import of the binding (or the first device call) raises.  numpy is the only dependency.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwatroo_hip.so")
+
+TRIANGLE, B3SPLINE = 0, 1
+PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
+NUM_SCRATCH = 6
+FLAG_FUSED, FLAG_NO_EXCHANGE = 1, 2
+
+
+def PLANE_SCRATCH(i):
+    assert 0 <= i < NUM_SCRATCH
+    return -3 - i
+
+
+class WatrooHipError(RuntimeError):
+    pass
+
+
+_c = ctypes
+_fp = _c.POINTER(_c.c_float)
+_vp = _c.c_void_p
+_i64 = _c.c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/watroo_hip.h
+SIGNATURES = {
+    "wt_abi_version": (_c.c_int, []),
+    "wt_last_error": (_c.c_char_p, []),
+    "wt_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "wt_ctx_create": (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
+    "wt_ctx_destroy": (_c.c_int, [_vp]),
+    "wt_ctx_sync": (_c.c_int, [_vp]),
+    "wt_timer_start": (_c.c_int, [_vp]),
+    "wt_timer_stop": (_c.c_int, [_vp, _c.POINTER(_c.c_float)]),
+    "wt_profile_enable": (_c.c_int, [_vp, _c.c_int]),
+    "wt_profile_reset": (_c.c_int, [_vp]),
+    "wt_profile_count": (_c.c_int, [_vp, _c.POINTER(_c.c_int)]),
+    "wt_profile_entry": (_c.c_int, [_vp, _c.c_int, _c.c_char_p, _c.POINTER(_i64),
+                                    _c.POINTER(_c.c_double)]),
+    "wt_comm_unique_id": (_c.c_int, [_vp]),
+    "wt_ctx_comm_init": (_c.c_int, [_vp, _c.c_int, _c.c_int, _vp]),
+    "wt_comm_selftest": (_c.c_int, [_vp, _i64, _c.POINTER(_c.c_int)]),
+    "wt_plan_create": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _c.POINTER(_vp)]),
+    "wt_plan_create_strip": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _i64, _i64, _i64,
+                                        _c.c_int, _c.c_int, _c.POINTER(_vp)]),
+    "wt_plan_destroy": (_c.c_int, [_vp]),
+    "wt_plan_info": (_c.c_int, [_vp, _c.POINTER(_i64)]),
+    "wt_schedule": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.c_int,
+                               _c.POINTER(_c.c_int)]),
+    "wt_plane_ptr": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_vp)]),
+    "wt_upload": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
+    "wt_download": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
+    "wt_copy_plane": (_c.c_int, [_vp, _c.c_int, _c.c_int]),
+    "wt_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_float]),
+    "wt_halo_exchange_local": (_c.c_int, [_vp, _vp, _c.c_int, _i64]),
+    "wt_halo_exchange": (_c.c_int, [_vp, _c.c_int, _i64]),
+    "wt_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_atrous_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float,
+                                     _c.c_int, _c.c_int]),
+    "wt_bilateral_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_decompose_bilateral": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_double),
+                                          _c.c_int, _c.c_int]),
+    "wt_plane_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_abs_median": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_float)]),
+    "wt_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int]),
+    "wt_denoise": (_c.c_int, [_vp, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_int]),
+    "wt_wow_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
+                                 _c.c_float, _c.c_int]),
+    "wt_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
+    "wt_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
+                                  _c.c_float]),
+    "wt_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
+                               _c.c_int]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libwatroo_hip.so (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise WatrooHipError(
+                    f"{LIB_PATH} not found - the HIP engine is not built "
+                    "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+            L = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+                fn.restype, fn.argtypes = res, args
+            if L.wt_abi_version() != 1:
+                raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
+            _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WatrooHipError(load().wt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = _c.c_int(0)
+    check(load().wt_device_count(_c.byref(n)))
+    return n.value
+
+
+class Context:
+    """One GPU + one HIP stream (+ optional RCCL communicator).  wt_ctx."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        self.device = device
+        self.rank, self.nranks = 0, 1
+        L = load()
+        if device_count() == 0:
+            raise WatrooHipError("no HIP device visible: the a-trous engine needs an MI355X "
+                                 "(there is no CPU fallback)")
+        check(L.wt_ctx_create(device, _c.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().wt_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(load().wt_ctx_sync(self._h))
+
+    def timer_start(self):
+        check(load().wt_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = _c.c_float(0)
+        check(load().wt_timer_stop(self._h, _c.byref(ms)))
+        return ms.value
+
+    def profile(self, on):
+        check(load().wt_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        check(load().wt_profile_reset(self._h))
+
+    def profile_entries(self):
+        """{kernel name: (calls, total_ms)} measured with HIP events on the launch stream."""
+        L = load()
+        n = _c.c_int(0)
+        check(L.wt_profile_count(self._h, _c.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = _c.create_string_buffer(64)
+            calls, ms = _i64(0), _c.c_double(0)
+            check(L.wt_profile_entry(self._h, i, name, _c.byref(calls), _c.byref(ms)))
+            out[name.value.decode()] = (calls.value, ms.value)
+        return out
+
+    # ---- RCCL
+    @staticmethod
+    def unique_id():
+        buf = _c.create_string_buffer(128)
+        check(load().wt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        assert len(unique_id) == 128
+        buf = _c.create_string_buffer(unique_id, 128)
+        check(load().wt_ctx_comm_init(self._h, rank, nranks, buf))
+        self.rank, self.nranks = rank, nranks
+
+    def comm_selftest(self, nfloats=1 << 20):
+        ok = _c.c_int(0)
+        check(load().wt_comm_selftest(self._h, nfloats, _c.byref(ok)))
+        return bool(ok.value)
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context (device from WATROO_HIP_DEVICE, default 0)."""
+    if device is None:
+        device = int(os.environ.get("WATROO_HIP_DEVICE", "0"))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def schedule(family, level, fused=True):
+    """Pass schedule [(first_scale, n_scales, halo_rows)] - host logic, needs no GPU."""
+    tr = (_c.c_int32 * (3 * 32))()
+    n = _c.c_int(0)
+    check(load().wt_schedule(family, level, int(fused), tr, 32, _c.byref(n)))
+    return [(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]) for i in range(n.value)]
+
+
+def _as_f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D image")
+    return a
+
+
+class Plan:
+    """Device planes of one image (or one row strip of it).  wt_plan."""
+
+    def __init__(self, ctx, H, W, family, max_level, row0=0, nrows=None, halo_rows=0,
+                 rank=0, nranks=1):
+        self._h = _vp()
+        self.ctx = ctx
+        nrows = H if nrows is None else nrows
+        check(load().wt_plan_create_strip(ctx._h, H, W, family, max_level, row0, nrows,
+                                          halo_rows, rank, nranks, _c.byref(self._h)))
+        info = (_i64 * 8)()
+        check(load().wt_plan_info(self._h, info))
+        (self.H, self.W, self.pitch, self.row0, self.nrows, self.halo, self.max_level,
+         self.family) = [int(v) for v in info]
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if self._h:
+            load().wt_plan_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def shape(self):
+        return (self.nrows, self.W)
+
+    # ---- transfers
+    def upload(self, plane, host):
+        host = _as_f32(host)
+        if host.shape != self.shape:
+            raise ValueError(f"image shape {host.shape} != plan strip shape {self.shape}")
+        check(load().wt_upload(self._h, plane, host.ctypes.data_as(_fp), host.shape[1]))
+
+    def download(self, plane, out=None):
+        if out is None:
+            out = np.empty(self.shape, np.float32)
+        assert out.dtype == np.float32 and out.shape == self.shape and out.strides[1] == 4
+        check(load().wt_download(self._h, plane, out.ctypes.data_as(_fp), out.strides[0] // 4))
+        return out
+
+    def copy(self, src, dst):
+        check(load().wt_copy_plane(self._h, src, dst))
+
+    def fill(self, plane, value):
+        check(load().wt_fill_plane(self._h, plane, value))
+
+    def plane_ptr(self, plane):
+        p = _vp()
+        check(load().wt_plane_ptr(self._h, plane, _c.byref(p)))
+        return p.value
+
+    def halo_exchange(self, plane, rows):
+        check(load().wt_halo_exchange(self._h, plane, rows))
+
+    @staticmethod
+    def halo_exchange_local(upper, lower, plane, rows):
+        check(load().wt_halo_exchange_local(upper._h, lower._h, plane, rows))
+
+    # ---- hot path
+    def decompose(self, src, level, flags=FLAG_FUSED):
+        check(load().wt_decompose(self._h, src, level, flags))
+
+    def atrous_scale(self, src, dst_c, dst_w, s, flags=0):
+        check(load().wt_atrous_scale(self._h, src, dst_c, dst_w, s, flags))
+
+    def smooth(self, src, dst, s, square_input=False, flags=0):
+        check(load().wt_smooth(self._h, src, dst, s, int(square_input), flags))
+
+    def local_variance(self, src, dst, s, f1=1.0, f2=1.0, take_sqrt=False, flags=0):
+        check(load().wt_local_variance(self._h, src, dst, s, f1, f2, int(take_sqrt), flags))
+
+    def bilateral_conv(self, src, var, dst, s, flags=0):
+        check(load().wt_bilateral_conv(self._h, src, var, dst, s, flags))
+
+    def decompose_bilateral(self, src, level, sigma_b, bilateral_scaling=False, flags=0):
+        arr = (_c.c_double * max(level, 1))(*[float(v) for v in sigma_b[:level]])
+        check(load().wt_decompose_bilateral(self._h, src, level, arr, int(bilateral_scaling),
+                                            flags))
+
+    def plane_sum(self, first, count, dst=PLANE_OUT):
+        check(load().wt_plane_sum(self._h, first, count, dst))
+
+    def abs_median(self, plane):
+        m = _c.c_float(0)
+        check(load().wt_abs_median(self._h, plane, _c.byref(m)))
+        return np.float32(m.value)
+
+    def significance(self, plane, dst, tau, soft=True, noise_plane=PLANE_NONE):
+        check(load().wt_significance(self._h, plane, dst, float(tau), int(soft), noise_plane))
+
+    def denoise(self, plane, tau, wgt=1.0, soft=True, noise_plane=PLANE_NONE):
+        check(load().wt_denoise(self._h, plane, float(tau), float(wgt), int(soft), noise_plane))
+
+    def wow_update(self, plane, power_plane, tau, soft, noise_plane, factor, gamma_plane):
+        check(load().wt_wow_update(self._h, plane, power_plane, float(tau), int(soft),
+                                   noise_plane, float(factor), gamma_plane))
+
+    def reduce(self, plane):
+        """(sum, sumsq, min, max) over the GLOBAL image, fp64."""
+        out = (_c.c_double * 4)()
+        check(load().wt_reduce(self._h, plane, out))
+        return tuple(out)
+
+    def gamma_blend(self, recon, gamma_plane, gmin, gmax, inv_gamma, h):
+        check(load().wt_gamma_blend(self._h, recon, gamma_plane, gmin, gmax, inv_gamma, h))
+
+    def anscombe(self, src, dst, alpha=1.0, g=0.0, sigma=0.0, inverse=False):
+        check(load().wt_anscombe(self._h, src, dst, alpha, g, sigma, int(inverse)))

@@ -1,0 +1,946 @@
+// libwatroo_hip.so - host side of the C ABI declared in include/watroo_hip.h.
+// Plan / buffer management, kernel dispatch, RCCL halo exchange.  gfx950 only.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdlib>
+
+#include "wt_internal.h"
+#include "wt_kernels.h"
+#include "wt_fused.h"
+
+// =============================================================================================
+// errors
+// =============================================================================================
+static thread_local char g_err[512] = "";
+
+void wt_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *wt_last_error(void) { return g_err; }
+extern "C" int wt_abi_version(void) { return WT_ABI_VERSION; }
+
+extern "C" int wt_device_count(int *count)
+{
+    if (!count) WT_FAIL("wt_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return 0;
+}
+
+// =============================================================================================
+// profiling scope
+// =============================================================================================
+static hipEvent_t take_event(wt_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(wt_ctx *c, const char *n) : ctx(c), name(n)
+{
+    if (!ctx->profiling) return;
+    a = take_event(ctx);
+    b = take_event(ctx);
+    (void)hipEventRecord(a, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!ctx->profiling || !a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({name, a, b});
+}
+
+static int prof_resolve(wt_ctx *c)
+{
+    if (c->pending.empty()) return 0;
+    WT_HIP(hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        WT_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        auto it = c->prof.find(p.name);
+        if (it == c->prof.end()) {
+            c->prof_order.push_back(p.name);
+            it = c->prof.emplace(p.name, ProfEntry{}).first;
+        }
+        it->second.calls += 1;
+        it->second.ms += ms;
+        c->event_pool.push_back(p.a);
+        c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+    return 0;
+}
+
+// =============================================================================================
+// RCCL, loaded on demand
+// =============================================================================================
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    void *CommInitRank = nullptr;  // ncclCommInitRank(comm*, nranks, ncclUniqueId by value, rank)
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct UniqueId128 {
+    char b[128];
+};
+typedef int (*CommInitRank_t)(void **, int, UniqueId128, int);
+
+static RcclApi g_rccl;
+enum { NCCL_UINT32 = 3, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8 };
+enum { NCCL_SUM = 0, NCCL_MAX = 2, NCCL_MIN = 3 };
+
+static int rccl_load()
+{
+    if (g_rccl.h) return 0;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) WT_FAIL("cannot load librccl.so: %s", dlerror());
+#define SYM(field, name)                                              \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                      \
+    if (!g_rccl.field) WT_FAIL("librccl.so lacks symbol %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return 0;
+}
+
+#define WT_NCCL(expr)                                                                         \
+    do {                                                                                      \
+        int r_ = (expr);                                                                      \
+        if (r_ != 0) {                                                                        \
+            wt_set_error("RCCL error %d (%s) at %s:%d: %s", r_,                               \
+                         g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__,   \
+                         __LINE__, #expr);                                                    \
+            return 3;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+extern "C" int wt_comm_unique_id(void *id128)
+{
+    if (!id128) WT_FAIL("wt_comm_unique_id: null pointer");
+    WT_TRY(rccl_load());
+    WT_NCCL(g_rccl.GetUniqueId(id128));
+    return 0;
+}
+
+extern "C" int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *id128)
+{
+    if (!ctx || !id128) WT_FAIL("wt_ctx_comm_init: null pointer");
+    if (nranks < 1 || rank < 0 || rank >= nranks) WT_FAIL("wt_ctx_comm_init: bad rank %d/%d", rank, nranks);
+    if (ctx->comm) WT_FAIL("wt_ctx_comm_init: communicator already initialised");
+    WT_TRY(rccl_load());
+    WT_HIP(hipSetDevice(ctx->device));
+    UniqueId128 id;
+    memcpy(&id, id128, sizeof(id));
+    void *comm = nullptr;
+    WT_NCCL(((CommInitRank_t)g_rccl.CommInitRank)(&comm, nranks, id, rank));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return 0;
+}
+
+// =============================================================================================
+// context
+// =============================================================================================
+static const int kPartialBlocks = 1024;
+
+extern "C" int wt_ctx_create(int device, wt_ctx **out)
+{
+    if (!out) WT_FAIL("wt_ctx_create: null pointer");
+    int n = 0;
+    WT_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) WT_FAIL("wt_ctx_create: device %d out of range (%d devices)", device, n);
+    WT_HIP(hipSetDevice(device));
+    wt_ctx *c = new wt_ctx();
+    c->device = device;
+    WT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    WT_HIP(hipEventCreate(&c->t0));
+    WT_HIP(hipEventCreate(&c->t1));
+    WT_HIP(hipMalloc(&c->d_hist, (WT_HIST_BINS + 16) * sizeof(uint32_t)));
+    WT_HIP(hipMalloc(&c->d_partials, (kPartialBlocks * 4 + 8) * sizeof(double)));
+    c->partial_blocks = kPartialBlocks;
+    WT_HIP(hipHostMalloc(&c->h_pinned, 65536, hipHostMallocDefault));
+    *out = c;
+    return 0;
+}
+
+extern "C" int wt_ctx_destroy(wt_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (auto &p : c->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->t0);
+    (void)hipEventDestroy(c->t1);
+    (void)hipFree(c->d_hist);
+    (void)hipFree(c->d_partials);
+    (void)hipHostFree(c->h_pinned);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int wt_ctx_sync(wt_ctx *c)
+{
+    if (!c) WT_FAIL("wt_ctx_sync: null context");
+    WT_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int wt_timer_start(wt_ctx *c)
+{
+    if (!c) WT_FAIL("wt_timer_start: null context");
+    WT_HIP(hipEventRecord(c->t0, c->stream));
+    return 0;
+}
+
+extern "C" int wt_timer_stop(wt_ctx *c, float *ms)
+{
+    if (!c || !ms) WT_FAIL("wt_timer_stop: null pointer");
+    WT_HIP(hipEventRecord(c->t1, c->stream));
+    WT_HIP(hipEventSynchronize(c->t1));
+    WT_HIP(hipEventElapsedTime(ms, c->t0, c->t1));
+    return 0;
+}
+
+extern "C" int wt_profile_enable(wt_ctx *c, int on)
+{
+    if (!c) WT_FAIL("wt_profile_enable: null context");
+    WT_TRY(prof_resolve(c));
+    c->profiling = on != 0;
+    return 0;
+}
+
+extern "C" int wt_profile_reset(wt_ctx *c)
+{
+    if (!c) WT_FAIL("wt_profile_reset: null context");
+    WT_TRY(prof_resolve(c));
+    c->prof.clear();
+    c->prof_order.clear();
+    return 0;
+}
+
+extern "C" int wt_profile_count(wt_ctx *c, int *n)
+{
+    if (!c || !n) WT_FAIL("wt_profile_count: null pointer");
+    WT_TRY(prof_resolve(c));
+    *n = (int)c->prof_order.size();
+    return 0;
+}
+
+extern "C" int wt_profile_entry(wt_ctx *c, int i, char *name64, int64_t *calls, double *total_ms)
+{
+    if (!c || !name64 || !calls || !total_ms) WT_FAIL("wt_profile_entry: null pointer");
+    WT_TRY(prof_resolve(c));
+    if (i < 0 || i >= (int)c->prof_order.size()) WT_FAIL("wt_profile_entry: index %d out of range", i);
+    const std::string &nm = c->prof_order[i];
+    snprintf(name64, 64, "%s", nm.c_str());
+    *calls = c->prof[nm].calls;
+    *total_ms = c->prof[nm].ms;
+    return 0;
+}
+
+// =============================================================================================
+// plan
+// =============================================================================================
+static inline int family_taps(int family) { return family == WT_B3SPLINE ? 5 : 3; }
+
+extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int *n_passes)
+{
+    if (!triples || !n_passes) WT_FAIL("wt_schedule: null pointer");
+    if (family != WT_TRIANGLE && family != WT_B3SPLINE) WT_FAIL("wt_schedule: unknown family %d", family);
+    if (level < 0 || level > 30) WT_FAIL("wt_schedule: level %d out of range", level);
+    const int hw = family_taps(family) / 2;
+    int n = 0, s = 0;
+    while (s < level) {
+        int ns = 1;
+        if (fused && s <= WT_FUSED_MAX_FIRST_SCALE) ns = std::min(WT_FUSED_MAX_SCALES, level - s);
+        if (n >= cap) WT_FAIL("wt_schedule: capacity %d too small", cap);
+        triples[3 * n + 0] = s;
+        triples[3 * n + 1] = ns;
+        triples[3 * n + 2] = hw * ((1 << (s + ns)) - (1 << s));
+        ++n;
+        s += ns;
+    }
+    *n_passes = n;
+    return 0;
+}
+
+static int plan_alloc(wt_plan *p, float **slot)
+{
+    if (*slot) return 0;
+    WT_HIP(hipSetDevice(p->ctx->device));
+    WT_HIP(hipMalloc(slot, p->plane_floats * sizeof(float)));
+    return 0;
+}
+
+// pointer to LOCAL ROW 0 of a plane (allocating scratch/out planes on first use)
+static int plane_base(wt_plan *p, int id, float **base)
+{
+    float **slot = nullptr;
+    if (id >= 0 && id <= p->max_level) slot = &p->coef[id];
+    else if (id == WT_PLANE_INPUT) slot = &p->input;
+    else if (id == WT_PLANE_OUT) slot = &p->out;
+    else if (id <= WT_PLANE_SCRATCH(0) && id > WT_PLANE_SCRATCH(WT_NUM_SCRATCH)) slot = &p->scratch[-3 - id];
+    else WT_FAIL("invalid plane id %d (max_level %d)", id, p->max_level);
+    WT_TRY(plan_alloc(p, slot));
+    *base = *slot + (size_t)p->g.halo * p->g.P;
+    return 0;
+}
+
+extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level,
+                                    int64_t row0, int64_t nrows, int64_t halo_rows, int rank,
+                                    int nranks, wt_plan **out)
+{
+    if (!ctx || !out) WT_FAIL("wt_plan_create: null pointer");
+    if (family != WT_TRIANGLE && family != WT_B3SPLINE) WT_FAIL("wt_plan_create: unknown family %d", family);
+    if (H < 1 || W < 1 || H > (1 << 30) || W > (1 << 30)) WT_FAIL("wt_plan_create: bad image size %lld x %lld", (long long)H, (long long)W);
+    if (max_level < 0 || max_level > 30) WT_FAIL("wt_plan_create: max_level %d out of range", max_level);
+    if (row0 < 0 || nrows < 1 || row0 + nrows > H) WT_FAIL("wt_plan_create: strip [%lld,+%lld) outside image of %lld rows", (long long)row0, (long long)nrows, (long long)H);
+    if (nranks < 1 || rank < 0 || rank >= nranks) WT_FAIL("wt_plan_create: bad rank %d/%d", rank, nranks);
+    if (nranks == 1 && (row0 != 0 || nrows != H)) WT_FAIL("wt_plan_create: a single strip must cover the whole image");
+    const int hw = family_taps(family) / 2;
+    int64_t halo = 0;
+    if (nranks > 1) {
+        halo = halo_rows > 0 ? halo_rows : (max_level > 0 ? (int64_t)hw << (max_level - 1) : 0);
+        // the fused schedule needs the cumulative halo of its widest pass
+        int32_t tr[3 * 32];
+        int np = 0;
+        WT_TRY(wt_schedule(family, max_level, 1, tr, 32, &np));
+        for (int i = 0; i < np; ++i) halo = std::max<int64_t>(halo, tr[3 * i + 2]);
+    }
+    const int64_t P = (W + 3) / 4 * 4;
+    if ((nrows + 2 * halo) * P >= ((int64_t)1 << 31)) {
+        // kernels index pixels with 64-bit offsets but rows/cols with int32
+        if (nrows + 2 * halo >= ((int64_t)1 << 30)) WT_FAIL("wt_plan_create: strip too tall");
+    }
+    wt_plan *p = new wt_plan();
+    p->ctx = ctx;
+    p->g = Geo{(int)W, (int)P, (int)H, (int)row0, (int)nrows, (int)halo};
+    p->family = family;
+    p->max_level = max_level;
+    p->rank = rank;
+    p->nranks = nranks;
+    p->plane_floats = (size_t)(nrows + 2 * halo) * (size_t)P;
+    p->coef.assign(max_level + 1, nullptr);
+    for (int i = 0; i <= max_level; ++i) {
+        int rc = plan_alloc(p, &p->coef[i]);
+        if (rc) {
+            wt_plan_destroy(p);
+            return rc;
+        }
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int wt_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level, wt_plan **out)
+{
+    return wt_plan_create_strip(ctx, H, W, family, max_level, 0, H, 0, 0, 1, out);
+}
+
+extern "C" int wt_plan_destroy(wt_plan *p)
+{
+    if (!p) return 0;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (float *q : p->coef) (void)hipFree(q);
+    (void)hipFree(p->input);
+    (void)hipFree(p->out);
+    for (float *q : p->scratch) (void)hipFree(q);
+    delete p;
+    return 0;
+}
+
+extern "C" int wt_plan_info(wt_plan *p, int64_t out[8])
+{
+    if (!p || !out) WT_FAIL("wt_plan_info: null pointer");
+    out[0] = p->g.H; out[1] = p->g.W; out[2] = p->g.P; out[3] = p->g.row0;
+    out[4] = p->g.nrows; out[5] = p->g.halo; out[6] = p->max_level; out[7] = p->family;
+    return 0;
+}
+
+extern "C" int wt_plane_ptr(wt_plan *p, int plane, void **dev_ptr)
+{
+    if (!p || !dev_ptr) WT_FAIL("wt_plane_ptr: null pointer");
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    *dev_ptr = b;
+    return 0;
+}
+
+// =============================================================================================
+// host <-> device, copies
+// =============================================================================================
+extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_stride)
+{
+    if (!p || !host) WT_FAIL("wt_upload: null pointer");
+    if (host_stride < p->g.W) WT_FAIL("wt_upload: host stride %lld < width %d", (long long)host_stride, p->g.W);
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    WT_HIP(hipMemcpy2DAsync(b, (size_t)p->g.P * 4, host, (size_t)host_stride * 4, (size_t)p->g.W * 4,
+                            (size_t)p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream));
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+}
+
+extern "C" int wt_download(wt_plan *p, int plane, float *host, int64_t host_stride)
+{
+    if (!p || !host) WT_FAIL("wt_download: null pointer");
+    if (host_stride < p->g.W) WT_FAIL("wt_download: host stride %lld < width %d", (long long)host_stride, p->g.W);
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    WT_HIP(hipMemcpy2DAsync(host, (size_t)host_stride * 4, b, (size_t)p->g.P * 4, (size_t)p->g.W * 4,
+                            (size_t)p->g.nrows, hipMemcpyDeviceToHost, p->ctx->stream));
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+}
+
+static inline int64_t plan_n4(const wt_plan *p) { return (int64_t)p->g.nrows * p->g.P / 4; }
+static inline int flat_grid(int64_t n4) { return (int)std::min<int64_t>((n4 + 255) / 256, 256 * 8); }
+
+extern "C" int wt_copy_plane(wt_plan *p, int src, int dst)
+{
+    if (!p) WT_FAIL("wt_copy_plane: null plan");
+    float *s = nullptr, *d = nullptr;
+    WT_TRY(plane_base(p, src, &s));
+    WT_TRY(plane_base(p, dst, &d));
+    if (s == d) return 0;
+    WT_HIP(hipMemcpyAsync(d, s, (size_t)p->g.nrows * p->g.P * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
+    return 0;
+}
+
+extern "C" int wt_fill_plane(wt_plan *p, int plane, float value)
+{
+    if (!p) WT_FAIL("wt_fill_plane: null plan");
+    float *d = nullptr;
+    WT_TRY(plane_base(p, plane, &d));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_fill_kernel");
+    hipLaunchKernelGGL(wt_fill_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, d, n4, value);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================================
+// halo exchange
+// =============================================================================================
+extern "C" int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane, int64_t rows)
+{
+    if (!upper || !lower) WT_FAIL("wt_halo_exchange_local: null plan");
+    if (rows == 0) return 0;
+    if (upper->g.P != lower->g.P || upper->g.row0 + upper->g.nrows != lower->g.row0)
+        WT_FAIL("wt_halo_exchange_local: plans are not vertically adjacent strips of one image");
+    if (rows < 0 || rows > upper->g.halo || rows > lower->g.halo || rows > upper->g.nrows || rows > lower->g.nrows)
+        WT_FAIL("wt_halo_exchange_local: %lld rows exceed halo/strip size", (long long)rows);
+    float *u = nullptr, *l = nullptr;
+    WT_TRY(plane_base(upper, plane, &u));
+    WT_TRY(plane_base(lower, plane, &l));
+    const size_t P = (size_t)upper->g.P, bytes = (size_t)rows * P * 4;
+    hipStream_t st = upper->ctx->stream;
+    // upper's last rows -> lower's top margin ; lower's first rows -> upper's bottom margin
+    WT_HIP(hipMemcpyAsync(l - (size_t)rows * P, u + (size_t)(upper->g.nrows - rows) * P, bytes, hipMemcpyDeviceToDevice, st));
+    WT_HIP(hipMemcpyAsync(u + (size_t)upper->g.nrows * P, l, bytes, hipMemcpyDeviceToDevice, st));
+    if (lower->ctx->stream != st) WT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int wt_halo_exchange(wt_plan *p, int plane, int64_t rows)
+{
+    if (!p) WT_FAIL("wt_halo_exchange: null plan");
+    if (p->nranks == 1 || rows == 0) return 0;
+    wt_ctx *c = p->ctx;
+    if (!c->comm) WT_FAIL("wt_halo_exchange: context has no RCCL communicator (wt_ctx_comm_init)");
+    if (c->nranks != p->nranks || c->rank != p->rank) WT_FAIL("wt_halo_exchange: plan rank %d/%d != communicator rank %d/%d", p->rank, p->nranks, c->rank, c->nranks);
+    if (rows < 0 || rows > p->g.halo) WT_FAIL("wt_halo_exchange: %lld rows exceed the plan's halo margin %d", (long long)rows, p->g.halo);
+    if (rows > p->g.nrows) WT_FAIL("wt_halo_exchange: halo of %lld rows spans more than one neighbour (strip has %d rows)", (long long)rows, p->g.nrows);
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    const size_t P = (size_t)p->g.P, cnt = (size_t)rows * P;
+    const int up = p->rank - 1, dn = p->rank + 1;
+    ProfScope ps(c, "rccl_halo_exchange");
+    WT_NCCL(g_rccl.GroupStart());
+    if (up >= 0) {
+        WT_NCCL(g_rccl.Send(b, cnt, NCCL_FLOAT32, up, c->comm, c->stream));
+        WT_NCCL(g_rccl.Recv(b - cnt, cnt, NCCL_FLOAT32, up, c->comm, c->stream));
+    }
+    if (dn < p->nranks) {
+        WT_NCCL(g_rccl.Send(b + (size_t)(p->g.nrows - rows) * P, cnt, NCCL_FLOAT32, dn, c->comm, c->stream));
+        WT_NCCL(g_rccl.Recv(b + (size_t)p->g.nrows * P, cnt, NCCL_FLOAT32, dn, c->comm, c->stream));
+    }
+    WT_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
+extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
+{
+    if (!c || !ok) WT_FAIL("wt_comm_selftest: null pointer");
+    if (!c->comm) WT_FAIL("wt_comm_selftest: no communicator");
+    if (nfloats < 1) WT_FAIL("wt_comm_selftest: nfloats must be positive");
+    *ok = 0;
+    WT_HIP(hipSetDevice(c->device));
+    float *a = nullptr, *b = nullptr;
+    WT_HIP(hipMalloc(&a, nfloats * 4));
+    WT_HIP(hipMalloc(&b, nfloats * 4));
+    std::vector<float> h(nfloats), r(nfloats, 0.f);
+    for (int64_t i = 0; i < nfloats; ++i) h[i] = (float)(i % 977) * 0.5f + (float)c->rank;
+    WT_HIP(hipMemcpy(a, h.data(), nfloats * 4, hipMemcpyHostToDevice));
+    WT_HIP(hipMemset(b, 0, nfloats * 4));
+    // ring: send to (rank+1)%n, receive from (rank-1+n)%n  (self when n == 1)
+    const int to = (c->rank + 1) % c->nranks, from = (c->rank + c->nranks - 1) % c->nranks;
+    WT_NCCL(g_rccl.GroupStart());
+    WT_NCCL(g_rccl.Send(a, nfloats, NCCL_FLOAT32, to, c->comm, c->stream));
+    WT_NCCL(g_rccl.Recv(b, nfloats, NCCL_FLOAT32, from, c->comm, c->stream));
+    WT_NCCL(g_rccl.GroupEnd());
+    // all-reduce of a tiny vector
+    WT_HIP(hipMemsetAsync(c->d_hist, 0, 16, c->stream));
+    WT_NCCL(g_rccl.AllReduce(c->d_hist, c->d_hist, 4, NCCL_UINT32, NCCL_SUM, c->comm, c->stream));
+    WT_HIP(hipStreamSynchronize(c->stream));
+    WT_HIP(hipMemcpy(r.data(), b, nfloats * 4, hipMemcpyDeviceToHost));
+    int good = 1;
+    for (int64_t i = 0; i < nfloats; ++i)
+        if (r[i] != (float)(i % 977) * 0.5f + (float)from) { good = 0; break; }
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *ok = good;
+    return 0;
+}
+
+// =============================================================================================
+// chain-march launches (generic per-scale operator)
+// =============================================================================================
+static int check_scale(const wt_plan *p, int s, const char *who)
+{
+    if (s < 0 || s > 24) WT_FAIL("%s: scale %d out of range", who, s);
+    const int hw = family_taps(p->family) / 2;
+    const int64_t halo = (int64_t)hw << s;
+    if (p->nranks > 1) {
+        if (halo > p->g.halo) WT_FAIL("%s: scale %d needs %lld halo rows, plan has %d", who, s, (long long)halo, p->g.halo);
+    }
+    return 0;
+}
+
+template <int MODE>
+static int launch_chain(wt_plan *p, const float *in, float *out_c, float *out_w, int s, float f1,
+                        float f2, int take_sqrt, const char *name)
+{
+    const Geo &g = p->g;
+    const int d = 1 << s;
+    const int X = (g.W + 3) / 4;                 // float4 columns
+    const int gx = (X + 63) / 64;
+    const int n_max = (g.nrows + d - 1) / d;     // longest chain
+    const int64_t want_items = std::max<int64_t>(1, (int64_t)524288 / std::max(1, gx * 64));
+    int chunks_target = (int)std::max<int64_t>(1, want_items / std::min(d, g.nrows));
+    int S = (n_max + chunks_target - 1) / chunks_target;
+    S = std::max(S, std::min(n_max, 8));
+    S = std::min(S, 64);
+    int chunks = (n_max + S - 1) / S;
+    const int dd = std::min(d, g.nrows);          // phases >= nrows own no rows
+    (void)dd;
+    int64_t items = (int64_t)d * chunks;
+    while ((items + 3) / 4 > 65535) {             // grid.y limit
+        S *= 2;
+        chunks = (n_max + S - 1) / S;
+        items = (int64_t)d * chunks;
+    }
+    ChainArgs a{in, out_c, out_w, g, d, S, chunks, f1, f2, take_sqrt};
+    dim3 grid(gx, (unsigned)((items + 3) / 4)), block(64, 4);
+    ProfScope ps(p->ctx, name);
+    if (p->family == WT_B3SPLINE)
+        hipLaunchKernelGGL((wt_chain_kernel<5, MODE>), grid, block, 0, p->ctx->stream, a);
+    else
+        hipLaunchKernelGGL((wt_chain_kernel<3, MODE>), grid, block, 0, p->ctx->stream, a);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+static int maybe_exchange(wt_plan *p, int plane, int64_t rows, int flags)
+{
+    if (p->nranks == 1 || (flags & 2)) return 0;
+    return wt_halo_exchange(p, plane, rows);
+}
+
+static inline int64_t scale_halo(const wt_plan *p, int s) { return (int64_t)(family_taps(p->family) / 2) << s; }
+
+extern "C" int wt_atrous_scale(wt_plan *p, int src, int dst_c, int dst_w, int s, int flags)
+{
+    if (!p) WT_FAIL("wt_atrous_scale: null plan");
+    WT_TRY(check_scale(p, s, "wt_atrous_scale"));
+    if (src == dst_c || src == dst_w || dst_c == dst_w) WT_FAIL("wt_atrous_scale: planes must be distinct");
+    float *in = nullptr, *oc = nullptr, *ow = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, dst_c, &oc));
+    if (dst_w != WT_PLANE_NONE) WT_TRY(plane_base(p, dst_w, &ow));
+    WT_TRY(maybe_exchange(p, src, scale_halo(p, s), flags));
+    return launch_chain<MODE_DECOMP>(p, in, oc, ow, s, 1.f, 1.f, 0, "wt_chain_kernel<decomp>");
+}
+
+extern "C" int wt_smooth(wt_plan *p, int src, int dst, int s, int square_input, int flags)
+{
+    if (!p) WT_FAIL("wt_smooth: null plan");
+    WT_TRY(check_scale(p, s, "wt_smooth"));
+    if (src == dst) WT_FAIL("wt_smooth: src and dst must differ");
+    float *in = nullptr, *o = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, dst, &o));
+    WT_TRY(maybe_exchange(p, src, scale_halo(p, s), flags));
+    if (square_input) return launch_chain<MODE_SMOOTH_SQ>(p, in, o, nullptr, s, 1.f, 1.f, 0, "wt_chain_kernel<smooth_sq>");
+    return launch_chain<MODE_SMOOTH>(p, in, o, nullptr, s, 1.f, 1.f, 0, "wt_chain_kernel<smooth>");
+}
+
+extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, float f2, int take_sqrt, int flags)
+{
+    if (!p) WT_FAIL("wt_local_variance: null plan");
+    WT_TRY(check_scale(p, s, "wt_local_variance"));
+    if (src == dst) WT_FAIL("wt_local_variance: src and dst must differ");
+    float *in = nullptr, *o = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, dst, &o));
+    WT_TRY(maybe_exchange(p, src, scale_halo(p, s), flags));
+    return launch_chain<MODE_VAR>(p, in, o, nullptr, s, f1, f2, take_sqrt, "wt_chain_kernel<variance>");
+}
+
+static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s)
+{
+    const Geo &g = p->g;
+    dim3 grid((g.W + 63) / 64, (g.nrows + 3) / 4), block(64, 4);
+    if (grid.y > 65535u) WT_FAIL("bilateral: strip of %d rows too tall for one launch", g.nrows);
+    ProfScope ps(p->ctx, "wt_bilateral_kernel");
+    if (p->family == WT_B3SPLINE)
+        hipLaunchKernelGGL((wt_bilateral_kernel<5>), grid, block, 0, p->ctx->stream, in, var, out, out_w, g, 1 << s);
+    else
+        hipLaunchKernelGGL((wt_bilateral_kernel<3>), grid, block, 0, p->ctx->stream, in, var, out, out_w, g, 1 << s);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, int flags)
+{
+    if (!p) WT_FAIL("wt_bilateral_conv: null plan");
+    WT_TRY(check_scale(p, s, "wt_bilateral_conv"));
+    if (src == dst || var == dst) WT_FAIL("wt_bilateral_conv: dst must differ from src and var");
+    float *in = nullptr, *v = nullptr, *o = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, var, &v));
+    WT_TRY(plane_base(p, dst, &o));
+    WT_TRY(maybe_exchange(p, src, scale_halo(p, s), flags));
+    return launch_bilateral(p, in, v, o, nullptr, s);
+}
+
+// =============================================================================================
+// decomposition drivers
+// =============================================================================================
+extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
+{
+    if (!p) WT_FAIL("wt_decompose: null plan");
+    if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose: level %d exceeds plan max_level %d", level, p->max_level);
+    if (src >= 0 && src <= level) WT_FAIL("wt_decompose: src plane %d is one of the output planes", src);
+    if (src == WT_PLANE_SCRATCH(0) || src == WT_PLANE_SCRATCH(1)) WT_FAIL("wt_decompose: scratch planes 0/1 are used internally");
+    if (level == 0) return wt_copy_plane(p, src, 0);
+    int32_t tr[3 * 32];
+    int np = 0;
+    WT_TRY(wt_schedule(p->family, level, (flags & 1) && wt_fused_supported(p), tr, 32, &np));
+    int cur = src;  // plane holding c_s
+    for (int i = 0; i < np; ++i) {
+        const int s0 = tr[3 * i], ns = tr[3 * i + 1], halo = tr[3 * i + 2];
+        const bool last = (s0 + ns == level);
+        const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+        if (p->nranks > 1 && halo > p->g.halo) WT_FAIL("wt_decompose: pass %d needs %d halo rows, plan has %d", i, halo, p->g.halo);
+        WT_TRY(maybe_exchange(p, cur, halo, flags));
+        float *in = nullptr, *oc = nullptr;
+        WT_TRY(plane_base(p, cur, &in));
+        WT_TRY(plane_base(p, nxt, &oc));
+        if (ns == 1) {
+            float *ow = nullptr;
+            WT_TRY(plane_base(p, s0, &ow));
+            WT_TRY(launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>"));
+        } else {
+            float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
+            for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
+            WT_TRY(wt_fused_launch(p, in, oc, ow, s0, ns));
+        }
+        cur = nxt;
+    }
+    return 0;
+}
+
+extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const double *sigma_b, int bilateral_scaling, int flags)
+{
+    if (!p || !sigma_b) WT_FAIL("wt_decompose_bilateral: null pointer");
+    if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose_bilateral: level %d exceeds plan max_level %d", level, p->max_level);
+    if (src >= 0 && src <= level) WT_FAIL("wt_decompose_bilateral: src plane %d is one of the output planes", src);
+    if (src <= WT_PLANE_SCRATCH(0) && src >= WT_PLANE_SCRATCH(2)) WT_FAIL("wt_decompose_bilateral: scratch planes 0..2 are used internally");
+    if (level == 0) return wt_copy_plane(p, src, 0);
+    int cur = src;
+    for (int s = 0; s < level; ++s) {
+        WT_TRY(check_scale(p, s, "wt_decompose_bilateral"));
+        const int nxt = (s == level - 1) ? level : WT_PLANE_SCRATCH(s & 1);
+        float *in = nullptr, *oc = nullptr, *ow = nullptr, *var = nullptr;
+        WT_TRY(plane_base(p, cur, &in));
+        WT_TRY(plane_base(p, nxt, &oc));
+        WT_TRY(plane_base(p, s, &ow));
+        WT_TRY(plane_base(p, WT_PLANE_SCRATCH(2), &var));
+        WT_TRY(maybe_exchange(p, cur, scale_halo(p, s), flags));
+        // variance = sdev_loc(c_s)^2-form * sigma_b[s]**2 (* (s+1))   watroo/wavelets.py:434-436
+        const float f1 = (float)(sigma_b[s] * sigma_b[s]);
+        const float f2 = bilateral_scaling ? (float)(s + 1) : 1.f;
+        WT_TRY(launch_chain<MODE_VAR>(p, in, var, nullptr, s, f1, f2, 0, "wt_chain_kernel<variance>"));
+        WT_TRY(launch_bilateral(p, in, var, oc, ow, s));
+        cur = nxt;
+    }
+    return 0;
+}
+
+// =============================================================================================
+// pointwise ops
+// =============================================================================================
+extern "C" int wt_plane_sum(wt_plan *p, int first, int count, int dst)
+{
+    if (!p) WT_FAIL("wt_plane_sum: null plan");
+    if (count < 1 || count > WT_MAX_SUM_PLANES) WT_FAIL("wt_plane_sum: count %d out of range [1,%d]", count, WT_MAX_SUM_PLANES);
+    if (first < 0 || first + count - 1 > p->max_level) WT_FAIL("wt_plane_sum: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
+    SumArgs a{};
+    a.n = count;
+    for (int i = 0; i < count; ++i) {
+        float *b = nullptr;
+        WT_TRY(plane_base(p, first + i, &b));
+        a.p[i] = b;
+    }
+    float *o = nullptr;
+    WT_TRY(plane_base(p, dst, &o));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_plane_sum_kernel");
+    hipLaunchKernelGGL(wt_plane_sum_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, a, o, n4);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+static int noise_ptr(wt_plan *p, int noise_plane, float **np_)
+{
+    *np_ = nullptr;
+    if (noise_plane == WT_PLANE_NONE) return 0;
+    return plane_base(p, noise_plane, np_);
+}
+
+extern "C" int wt_significance(wt_plan *p, int plane, int dst, double tau, int soft, int noise_plane)
+{
+    if (!p) WT_FAIL("wt_significance: null plan");
+    if (!(tau > 0.0)) WT_FAIL("wt_significance: tau must be positive (the sigma==0 / noise==0 short-circuits of wavelets.py:130-143 are host-side)");
+    float *c = nullptr, *d = nullptr, *nz = nullptr;
+    WT_TRY(plane_base(p, plane, &c));
+    WT_TRY(plane_base(p, dst, &d));
+    WT_TRY(noise_ptr(p, noise_plane, &nz));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_signif_kernel");
+    hipLaunchKernelGGL(wt_signif_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, c, nz, d, n4, tau, 1.f, soft, 0);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_denoise(wt_plan *p, int plane, double tau, double wgt, int soft, int noise_plane)
+{
+    if (!p) WT_FAIL("wt_denoise: null plan");
+    if (!(tau > 0.0)) WT_FAIL("wt_denoise: tau must be positive");
+    float *c = nullptr, *nz = nullptr;
+    WT_TRY(plane_base(p, plane, &c));
+    WT_TRY(noise_ptr(p, noise_plane, &nz));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_signif_kernel");
+    hipLaunchKernelGGL(wt_signif_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, c, nz, c, n4, tau, (float)wgt, soft, 1);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_wow_update(wt_plan *p, int plane, int power_plane, double tau, int soft, int noise_plane, float factor, int gamma_plane)
+{
+    if (!p) WT_FAIL("wt_wow_update: null plan");
+    float *c = nullptr, *pw = nullptr, *nz = nullptr, *gm = nullptr;
+    WT_TRY(plane_base(p, plane, &c));
+    if (power_plane != WT_PLANE_NONE) WT_TRY(plane_base(p, power_plane, &pw));
+    if (gamma_plane != WT_PLANE_NONE) WT_TRY(plane_base(p, gamma_plane, &gm));
+    WT_TRY(noise_ptr(p, noise_plane, &nz));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_wow_kernel");
+    hipLaunchKernelGGL(wt_wow_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, c, pw, nz, gm, n4, tau, soft, factor);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_gamma_blend(wt_plan *p, int recon, int gamma_plane, float gmin, float gmax, float inv_gamma, float h)
+{
+    if (!p) WT_FAIL("wt_gamma_blend: null plan");
+    float *r = nullptr, *g = nullptr;
+    WT_TRY(plane_base(p, recon, &r));
+    WT_TRY(plane_base(p, gamma_plane, &g));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_gamma_kernel");
+    hipLaunchKernelGGL(wt_gamma_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, r, g, n4, gmin, gmax - gmin, inv_gamma, h);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_anscombe(wt_plan *p, int src, int dst, float alpha, float g, float sigma, int inverse)
+{
+    if (!p) WT_FAIL("wt_anscombe: null plan");
+    if (alpha == 0.f) WT_FAIL("wt_anscombe: alpha must be non-zero");
+    float *s = nullptr, *d = nullptr;
+    WT_TRY(plane_base(p, src, &s));
+    WT_TRY(plane_base(p, dst, &d));
+    // scalar terms are formed in double like the python floats of wavelets.py:17,19
+    const double a = alpha, gg = g, sg = sigma;
+    float c1, c2, c3;
+    if (inverse) { c1 = (float)(a * gg); c2 = (float)(sg * sg); c3 = (float)(3.0 * a / 8.0); }
+    else { c1 = (float)(3.0 * a * a / 8.0); c2 = (float)(sg * sg); c3 = (float)(a * gg); }
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_anscombe_kernel");
+    hipLaunchKernelGGL(wt_anscombe_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, s, d, n4, alpha, c1, c2, c3, inverse);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================================
+// reductions / selection (host-synchronous: they return values)
+// =============================================================================================
+extern "C" int wt_reduce(wt_plan *p, int plane, double out[4])
+{
+    if (!p || !out) WT_FAIL("wt_reduce: null pointer");
+    wt_ctx *c = p->ctx;
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    const int64_t n4 = plan_n4(p);
+    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, c->partial_blocks);
+    double *dout = c->d_partials + (size_t)c->partial_blocks * 4;
+    {
+        ProfScope ps(c, "wt_reduce_kernel");
+        hipLaunchKernelGGL(wt_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, b, n4, p->g.P / 4, p->g.W, c->d_partials);
+        hipLaunchKernelGGL(wt_reduce_final_kernel, dim3(1), dim3(64), 0, c->stream, c->d_partials, blocks, dout);
+    }
+    WT_HIP(hipGetLastError());
+    if (p->nranks > 1) {
+        if (!c->comm) WT_FAIL("wt_reduce: multi-rank plan without communicator");
+        WT_NCCL(g_rccl.AllReduce(dout, dout, 2, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));
+        WT_NCCL(g_rccl.AllReduce(dout + 2, dout + 2, 1, NCCL_FLOAT64, NCCL_MIN, c->comm, c->stream));
+        WT_NCCL(g_rccl.AllReduce(dout + 3, dout + 3, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, c->stream));
+    }
+    WT_HIP(hipMemcpyAsync(c->h_pinned, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    WT_HIP(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_pinned, 4 * sizeof(double));
+    return 0;
+}
+
+// one histogram pass; returns the bin holding rank k (0-based among the elements matching the
+// prefix), the number of matching elements below that bin, and the bin's population
+static int select_pass(wt_plan *p, const float *b, uint32_t prefix_mask, uint32_t prefix_val, int shift,
+                       uint32_t bin_mask, int64_t k, uint32_t *bin, int64_t *below, int64_t *in_bin)
+{
+    wt_ctx *c = p->ctx;
+    const int64_t n4 = plan_n4(p);
+    WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+    {
+        ProfScope ps(c, "wt_hist_kernel");
+        hipLaunchKernelGGL(wt_hist_kernel, dim3(flat_grid(n4)), dim3(256), 0, c->stream, b, n4, p->g.P / 4, p->g.W,
+                           prefix_mask, prefix_val, shift, bin_mask, c->d_hist);
+    }
+    WT_HIP(hipGetLastError());
+    if (p->nranks > 1) {
+        if (!c->comm) WT_FAIL("wt_abs_median: multi-rank plan without communicator");
+        WT_NCCL(g_rccl.AllReduce(c->d_hist, c->d_hist, WT_HIST_BINS, NCCL_UINT32, NCCL_SUM, c->comm, c->stream));
+    }
+    WT_HIP(hipMemcpyAsync(c->h_pinned, c->d_hist, WT_HIST_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    WT_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t *h = (const uint32_t *)c->h_pinned;
+    int64_t cum = 0;
+    for (uint32_t i = 0; i <= bin_mask; ++i) {
+        if (k < cum + (int64_t)h[i]) {
+            *bin = i;
+            *below = cum;
+            *in_bin = h[i];
+            return 0;
+        }
+        cum += h[i];
+    }
+    WT_FAIL("wt_abs_median: rank %lld not found (NaN input?)", (long long)k);
+}
+
+extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
+{
+    if (!p || !median) WT_FAIL("wt_abs_median: null pointer");
+    wt_ctx *c = p->ctx;
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    const int64_t N = (int64_t)p->g.H * p->g.W;   // global element count
+    const int64_t klo = (N - 1) / 2;
+    uint32_t b1, b2, b3;
+    int64_t below, inb, k = klo, cum_le = 0;
+    WT_TRY(select_pass(p, b, 0u, 0u, 20, 0x7ffu, k, &b1, &below, &inb));
+    k -= below; cum_le += below;
+    WT_TRY(select_pass(p, b, 0x7ff00000u, b1 << 20, 10, 0x3ffu, k, &b2, &below, &inb));
+    k -= below; cum_le += below;
+    const uint32_t pre21 = (b1 << 20) | (b2 << 10);
+    WT_TRY(select_pass(p, b, 0x7ffffc00u, pre21, 0, 0x3ffu, k, &b3, &below, &inb));
+    cum_le += below + inb;                        // elements <= v_lo
+    const uint32_t ulo = pre21 | b3;
+    uint32_t uhi = ulo;
+    if ((N & 1) == 0 && cum_le < klo + 2) {
+        // the upper median is the smallest element strictly greater than v_lo
+        uint32_t *res = c->d_hist + WT_HIST_BINS;
+        WT_HIP(hipMemsetAsync(res, 0xff, sizeof(uint32_t), c->stream));
+        const int64_t n4 = plan_n4(p);
+        {
+            ProfScope ps(c, "wt_min_greater_kernel");
+            hipLaunchKernelGGL(wt_min_greater_kernel, dim3(flat_grid(n4)), dim3(256), 0, c->stream, b, n4, p->g.P / 4, p->g.W, ulo, res);
+        }
+        WT_HIP(hipGetLastError());
+        if (p->nranks > 1) WT_NCCL(g_rccl.AllReduce(res, res, 1, NCCL_UINT32, NCCL_MIN, c->comm, c->stream));
+        WT_HIP(hipMemcpyAsync(c->h_pinned, res, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        WT_HIP(hipStreamSynchronize(c->stream));
+        uhi = *(const uint32_t *)c->h_pinned;
+        if (uhi == 0xffffffffu) WT_FAIL("wt_abs_median: upper median not found");
+    }
+    float lo, hi;
+    memcpy(&lo, &ulo, 4);
+    memcpy(&hi, &uhi, 4);
+    // np.median on float32: mean of the two middle values in float32
+    *median = (N & 1) ? lo : (lo + hi) / 2.0f;
+    return 0;
+}

@@ -1,0 +1,104 @@
+// Internal host-side structures of libwatroo_hip.so (gfx950 only; no compatibility layers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/watroo_hip.h"
+
+// ------------------------------------------------------------------ error plumbing
+void wt_set_error(const char *fmt, ...);
+
+#define WT_FAIL(...)               \
+    do {                           \
+        wt_set_error(__VA_ARGS__); \
+        return 1;                  \
+    } while (0)
+
+#define WT_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            wt_set_error("HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_), \
+                         __FILE__, __LINE__, #expr);                                   \
+            return 2;                                                                  \
+        }                                                                              \
+    } while (0)
+
+#define WT_TRY(expr)          \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_) return rc_;  \
+    } while (0)
+
+// ------------------------------------------------------------------ geometry shared with kernels
+// One row strip of a global H x W image resident on this GPU.  `base` pointers handed to
+// kernels point at LOCAL row 0 (global row row0); rows [-halo, nrows+halo) are addressable.
+struct Geo {
+    int W;      // valid pixels per row
+    int P;      // row pitch in floats (multiple of 4)
+    int H;      // global image height
+    int row0;   // global row index of local row 0
+    int nrows;  // rows owned by this strip
+    int halo;   // margin rows allocated above and below
+};
+
+// ------------------------------------------------------------------ RCCL (dlopen'ed lazily: the
+// library is 570 MB; single-GPU users never page it in)
+struct RcclApi;
+
+struct ProfEntry {
+    int64_t calls = 0;
+    double ms = 0.0;
+};
+
+struct PendingEvent {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+struct wt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::string> prof_order;
+    // comm
+    int rank = 0, nranks = 1;
+    void *comm = nullptr;  // ncclComm_t
+    // small device/host scratch for selects & reductions
+    uint32_t *d_hist = nullptr;   // 2048 bins + extras
+    double *d_partials = nullptr; // reduction partials
+    int partial_blocks = 0;
+    void *h_pinned = nullptr;     // 64 KiB pinned host scratch
+};
+
+struct wt_plan {
+    wt_ctx *ctx = nullptr;
+    Geo g{};
+    int family = WT_B3SPLINE;
+    int max_level = 0;
+    int rank = 0, nranks = 1;
+    size_t plane_floats = 0;                // (nrows + 2*halo) * P
+    std::vector<float *> coef;              // max_level+1 allocations (alloc base, incl. margin)
+    float *input = nullptr, *out = nullptr;
+    float *scratch[WT_NUM_SCRATCH] = {nullptr};
+};
+
+// Profiling bracket: records events around a kernel launch when ctx->profiling.
+struct ProfScope {
+    wt_ctx *ctx;
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(wt_ctx *c, const char *n);
+    ~ProfScope();
+};

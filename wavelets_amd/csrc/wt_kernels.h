@@ -1,0 +1,536 @@
+// CDNA4 (gfx950) kernels of the a-trous engine.  Wave = 64 lanes; every kernel moves 16 B per
+// lane per access (float4) so a wave touches 1 KiB of a row per instruction.
+//
+// Reference semantics restated by each kernel are cited as file:line under /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wt_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+// Symmetric reflection with edge duplication and any number of bounces:
+// cv2.BORDER_REFLECT (watroo/wavelets.py:45) == np.pad 'symmetric' (watroo/wavelets.py:77).
+__device__ __forceinline__ int wt_refl(int i, int n)
+{
+    if ((unsigned)i < (unsigned)n) return i;
+    const int p = 2 * n;
+    int m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+}
+
+template <int K>
+__device__ __forceinline__ constexpr float wt_tap(int i)
+{
+    // Triangle (watroo/wavelets.py:239) and B3spline (watroo/wavelets.py:268) 1-D taps:
+    // dyadic rationals, exact in fp32.
+    if (K == 3) return i == 1 ? 0.5f : 0.25f;
+    return (i == 2) ? 0.375f : ((i == 1 || i == 3) ? 0.25f : 0.0625f);
+}
+
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b)
+{
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 f4_scale(float k, float4 a)
+{
+    return make_float4(k * a.x, k * a.y, k * a.z, k * a.w);
+}
+__device__ __forceinline__ float4 f4_fma(float k, float4 a, float4 c)
+{
+    return make_float4(fmaf(k, a.x, c.x), fmaf(k, a.y, c.y), fmaf(k, a.z, c.z), fmaf(k, a.w, c.w));
+}
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b)
+{
+    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// Row pointer for GLOBAL row gy (any integer): reflect on the global image, then map into
+// this strip's buffer (rows outside the strip live in the halo margins).
+__device__ __forceinline__ const float *wt_row(const float *base, const Geo &g, int gy)
+{
+    const int ry = wt_refl(gy, g.H);
+    return base + (int64_t)(ry - g.row0) * g.P;
+}
+
+// 4 consecutive pixels starting at pixel xo (xo % 4 == 0) of a row, reflected at the image
+// border.  Interior: one 16-byte load.
+__device__ __forceinline__ float4 wt_load4(const float *row, int xo, int W)
+{
+    if (xo >= 0 && xo + 3 < W) return *reinterpret_cast<const float4 *>(row + xo);
+    return make_float4(row[wt_refl(xo, W)], row[wt_refl(xo + 1, W)], row[wt_refl(xo + 2, W)],
+                       row[wt_refl(xo + 3, W)]);
+}
+
+__device__ __forceinline__ void wt_store4(float *row, int x, int W, float4 v)
+{
+    if (x + 3 < W) {
+        *reinterpret_cast<float4 *>(row + x) = v;
+    } else {
+        if (x < W) row[x] = v.x;
+        if (x + 1 < W) row[x + 1] = v.y;
+        if (x + 2 < W) row[x + 2] = v.z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1  generic per-scale separable dilated convolution ("chain march")
+//
+//   c_{s+1} = h^(s) (*) c_s ,  w_s = c_s - c_{s+1}          watroo/wavelets.py:432,442
+//   h^(s) = zero-stuffed outer product of the 1-D taps         watroo/wavelets.py:191-197
+//
+// A thread owns 4 adjacent columns and one POLYPHASE ROW CHAIN  y = q, q+d, q+2d, ...  (d = 2^s):
+// along a chain the dilated vertical filter is an ordinary K-tap sliding window that lives in
+// registers, so every input row is fetched once per chain (plus K-1 warm-up rows per chunk of
+// S chain steps).  The horizontal taps are K coalesced 16-byte row loads at x + j*d (served by
+// L1/L2 after the first touch; for d < 4 three aligned loads are recombined in registers).
+// Works for any dilation and any image size (multi-bounce reflection), which is what the large
+// scales of wow() (d up to 1024) need; the fused kernels in wt_fused.h take over for the
+// small dilations of the headline path.
+// ---------------------------------------------------------------------------------------------
+enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3 };
+
+// Horizontal K-tap filter of one row at the thread's 4 pixels.
+//   h   = sum_j k_j v(x + (j-hw) d)                  (v squared first for MODE_SMOOTH_SQ)
+//   h2  = sum_j k_j v^2                              (MODE_VAR only)
+//   cen = v(x)                                       (centre pixels, for the detail plane)
+template <int K, int MODE>
+__device__ __forceinline__ void wt_hrow(const float *row, int x, int d, int W, float4 &h,
+                                        float4 &h2, float4 &cen)
+{
+    constexpr int hw = K / 2;
+    if (d >= 4) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float4 v = wt_load4(row, x + (j - hw) * d, W);
+            if (j == hw) cen = v;
+            float4 vv = f4_mul(v, v);
+            if (MODE == MODE_SMOOTH_SQ) v = vv;
+            h = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, h);
+            if (MODE == MODE_VAR)
+                h2 = (j == 0) ? f4_scale(wt_tap<K>(0), vv) : f4_fma(wt_tap<K>(j), vv, h2);
+        }
+    } else {
+        // d = 1 or 2: pixels x-4 .. x+7 cover every tap (2*d <= 4)
+        const float4 L = wt_load4(row, x - 4, W), C = wt_load4(row, x, W),
+                     R = wt_load4(row, x + 4, W);
+        float e[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
+        float e2[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            e2[i] = e[i] * e[i];
+            if (MODE == MODE_SMOOTH_SQ) e[i] = e2[i];
+        }
+        cen = C;
+        float o[4], o2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // d is 1 or 2 at run time; index arithmetic stays in registers after unrolling
+            float a = wt_tap<K>(0) * (d == 1 ? e[4 + k - hw] : e[4 + k - 2 * hw]);
+            float a2 = wt_tap<K>(0) * (d == 1 ? e2[4 + k - hw] : e2[4 + k - 2 * hw]);
+#pragma unroll
+            for (int j = 1; j < K; ++j) {
+                const float v = d == 1 ? e[4 + k + (j - hw)] : e[4 + k + 2 * (j - hw)];
+                const float v2 = d == 1 ? e2[4 + k + (j - hw)] : e2[4 + k + 2 * (j - hw)];
+                a = fmaf(wt_tap<K>(j), v, a);
+                a2 = fmaf(wt_tap<K>(j), v2, a2);
+            }
+            o[k] = a;
+            o2[k] = a2;
+        }
+        h = make_float4(o[0], o[1], o[2], o[3]);
+        if (MODE == MODE_VAR) h2 = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    }
+}
+
+struct ChainArgs {
+    const float *in;  // local row 0 of the input plane
+    float *out_c;     // smooth / variance output (local row 0)
+    float *out_w;     // detail output or nullptr
+    Geo g;
+    int d;        // dilation 2^s
+    int S;        // chain steps per thread
+    int chunks;   // chunks per chain
+    float f1, f2; // MODE_VAR: factors applied to the clipped variance (wavelets.py:434-436)
+    int take_sqrt;
+};
+
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
+{
+    constexpr int hw = K / 2;
+    const Geo g = a.g;
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (x >= g.W) return;
+    const int item = blockIdx.y * blockDim.y + threadIdx.y;
+    const int d = a.d;
+    const int q = item % d;   // chain phase (local row offset)
+    const int c = item / d;   // chunk along the chain
+    if (c >= a.chunks || q >= g.nrows) return;
+    const int n_q = (g.nrows - q + d - 1) / d;  // chain length
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+
+    float4 hwin[K], h2win[K], cen[hw + 1];
+    float4 dummy = make_float4(0, 0, 0, 0);
+    const int gy0 = g.row0 + q;  // global row of chain element 0
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        float4 ct;
+        hwin[j] = dummy;
+        h2win[j] = dummy;
+        wt_hrow<K, MODE>(wt_row(a.in, g, gy0 + d * (r0 - hw + j)), x, d, g.W, hwin[j], h2win[j], ct);
+        if (j >= hw) cen[j - hw] = ct;
+    }
+    for (int r = r0; r < r1; ++r) {
+        hwin[K - 1] = dummy;
+        h2win[K - 1] = dummy;
+        wt_hrow<K, MODE>(wt_row(a.in, g, gy0 + d * (r + hw)), x, d, g.W, hwin[K - 1], h2win[K - 1],
+                         cen[hw]);
+        float4 o = f4_scale(wt_tap<K>(0), hwin[0]);
+#pragma unroll
+        for (int j = 1; j < K; ++j) o = f4_fma(wt_tap<K>(j), hwin[j], o);
+        const int64_t off = (int64_t)(q + d * r) * g.P;
+        if (MODE == MODE_VAR) {
+            float4 p = f4_scale(wt_tap<K>(0), h2win[0]);
+#pragma unroll
+            for (int j = 1; j < K; ++j) p = f4_fma(wt_tap<K>(j), h2win[j], p);
+            // sdev_loc: vari = conv(I^2) - conv(I)^2 ; <=0 -> 1e-20   (wavelets.py:25-28)
+            float v[4] = {p.x - o.x * o.x, p.y - o.y * o.y, p.z - o.z * o.z, p.w - o.w * o.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = v[k] <= 0.f ? 1e-20f : v[k];
+                if (a.take_sqrt) t = sqrtf(t);
+                v[k] = (t * a.f1) * a.f2;
+            }
+            wt_store4(a.out_c + off, x, g.W, make_float4(v[0], v[1], v[2], v[3]));
+        } else {
+            wt_store4(a.out_c + off, x, g.W, o);
+            if (MODE == MODE_DECOMP && a.out_w)
+                wt_store4(a.out_w + off, x, g.W, f4_sub(cen[0], o));
+        }
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) {
+            hwin[j] = hwin[j + 1];
+            h2win[j] = h2win[j + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < hw; ++j) cen[j] = cen[j + 1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10  bilateral (range-weighted) dilated convolution - watroo/wavelets.py:74-105
+//   out = (k_c I + sum_t k_t e_t I_t) / (k_c + sum_t k_t e_t),
+//   e_t = exp(-((I - I_t)^2) / var / 2)                        (numexpr expression, :97)
+// Full K x K tap set (not separable).  One pixel per lane, 64 x 4 tiles; taps are L1/L2-served
+// gathers.  Transcendental-bound (K*K-1 v_exp_f32 per pixel), not HBM-bound.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void wt_bilateral_kernel(const float *in, const float *var,
+                                                           float *out, float *out_w, Geo g, int d)
+{
+    constexpr int hw = K / 2;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int ly = blockIdx.y * 4 + threadIdx.y;
+    if (x >= g.W || ly >= g.nrows) return;
+    const int gy = g.row0 + ly;
+    const float I = in[(int64_t)ly * g.P + x];
+    const float v = var[(int64_t)ly * g.P + x];
+    const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
+    float norm = kc;
+    float acc = kc * I;
+    int xs[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) xs[j] = wt_refl(x + (K - 1 - j - hw) * d, g.W);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const float *row = wt_row(in, g, gy + (K - 1 - i - hw) * d);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (i == hw && j == hw) continue;
+            const float k = wt_tap<K>(i) * wt_tap<K>(j);
+            const float It = row[xs[j]];
+            const float diff = I - It;
+            const float w = k * expf((-(diff * diff)) / v * 0.5f);
+            norm += w;
+            acc += It * w;
+        }
+    }
+    const float res = acc / norm;
+    out[(int64_t)ly * g.P + x] = res;
+    if (out_w) out_w[(int64_t)ly * g.P + x] = I - res;   // detail plane, wavelets.py:442
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise kernels over the strip's owned rows: rows are contiguous (pitch P), so they are a
+// flat float4 range of nrows*P/4 elements.  Grid-stride, 16 B per lane.
+// ---------------------------------------------------------------------------------------------
+#define WT_MAX_SUM_PLANES 16
+struct SumArgs {
+    const float *p[WT_MAX_SUM_PLANES];
+    int n;
+};
+
+// K5  np.sum(planes, axis=0): sequential fp32 accumulation in plane order (bit-exact vs numpy)
+__global__ __launch_bounds__(256) void wt_plane_sum_kernel(SumArgs a, float *out, int64_t n4)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc = reinterpret_cast<const float4 *>(a.p[0])[i];
+        for (int k = 1; k < a.n; ++k) {
+            const float4 v = reinterpret_cast<const float4 *>(a.p[k])[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = acc;
+    }
+}
+
+__device__ __forceinline__ float wt_sig(float c, float tau, double taud, int soft)
+{
+    // Coefficients.significance - watroo/wavelets.py:137-141
+    if (soft) return erff(fabsf(c / tau));
+    return ((double)fabsf(c) > taud) ? 1.f : 0.f;
+}
+
+// K3/K4  significance / denoise.  mode 0: dst = sig ; mode 1: dst = c * (wgt*sig)
+__global__ __launch_bounds__(256) void wt_signif_kernel(const float *c, const float *noise,
+                                                        float *dst, int64_t n4, double tau,
+                                                        float wgt, int soft, int mode)
+{
+    const float tauf = (float)tau;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(c)[i];
+        float4 nz = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (noise) nz = reinterpret_cast<const float4 *>(noise)[i];
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float s = wt_sig(in[k], tauf * nn[k], tau * (double)nn[k], soft);
+            o[k] = mode ? in[k] * (wgt * s) : s;
+        }
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// K6  wow per-scale update - watroo/utils.py:193-203 (see wt_wow_update in the header)
+__global__ __launch_bounds__(256) void wt_wow_kernel(float *c, const float *power,
+                                                     const float *noise, float *gamma,
+                                                     int64_t n4, double tau, int soft,
+                                                     float factor)
+{
+    const float tauf = (float)tau;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(c)[i];
+        float4 nz = make_float4(1.f, 1.f, 1.f, 1.f), pw = nz, gm = make_float4(0, 0, 0, 0);
+        if (noise) nz = reinterpret_cast<const float4 *>(noise)[i];
+        if (power) pw = reinterpret_cast<const float4 *>(power)[i];
+        if (gamma) gm = reinterpret_cast<const float4 *>(gamma)[i];
+        float in[4] = {v.x, v.y, v.z, v.w};
+        const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
+        const float pp[4] = {pw.x, pw.y, pw.z, pw.w};
+        float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = in[k];
+            if (tau > 0.0) t *= wt_sig(t, tauf * nn[k], tau * (double)nn[k], soft);
+            gg[k] += t;
+            float q = factor;
+            if (power) {
+                float lp = pp[k] <= 0.f ? 1e-15f : pp[k];   // utils.py:195
+                q = factor / sqrtf(lp);                      // utils.py:196,203
+            }
+            in[k] = t * q;
+        }
+        reinterpret_cast<float4 *>(c)[i] = make_float4(in[0], in[1], in[2], in[3]);
+        if (gamma) reinterpret_cast<float4 *>(gamma)[i] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    }
+}
+
+// K8  gamma blend - watroo/utils.py:212-217
+__global__ __launch_bounds__(256) void wt_gamma_kernel(float *recon, float *gamma, int64_t n4,
+                                                       float gmin, float range, float inv_gamma,
+                                                       float h)
+{
+#pragma clang fp contract(off)
+    const float omh = 1.f - h;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 r = reinterpret_cast<const float4 *>(recon)[i];
+        const float4 gq = reinterpret_cast<const float4 *>(gamma)[i];
+        const float rr[4] = {r.x, r.y, r.z, r.w};
+        float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = (gg[k] - gmin) / range;
+            t = t < 0.f ? 0.f : t;
+            t = t > 1.f ? 1.f : t;
+            t = powf(t, inv_gamma);
+            gg[k] = t;
+            o[k] = omh * rr[k] + h * t;
+        }
+        reinterpret_cast<float4 *>(recon)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<float4 *>(gamma)[i] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    }
+}
+
+// K11  generalized Anscombe - watroo/wavelets.py:14-21.  Host precomputes the scalar terms:
+// forward: c1 = 3 alpha^2/8, c2 = sigma^2, c3 = alpha g ; inverse: c1 = alpha g, c2 = sigma^2,
+// c3 = 3 alpha / 8.  Contraction is off so each numpy op rounds exactly as on the host.
+__global__ __launch_bounds__(256) void wt_anscombe_kernel(const float *src, float *dst,
+                                                          int64_t n4, float alpha, float c1,
+                                                          float c2, float c3, int inverse)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(src)[i];
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (inverse) {
+                float t = alpha * in[k];
+                t = t / 2.f;
+                t = t * t;
+                t = t + c1;
+                t = t - c2;
+                t = t - c3;
+                o[k] = t / alpha;
+            } else {
+                float t = alpha * in[k];
+                t = t + c1;
+                t = t + c2;
+                t = t - c3;
+                t = t <= 0.f ? 0.f : t;
+                o[k] = (2.f * sqrtf(t)) / alpha;
+            }
+        }
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void wt_fill_kernel(float *dst, int64_t n4, float value)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(value, value, value, value);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  exact median of |x| by radix select on the fp32 bit pattern (non-negative floats order
+// like their uint32 bits) - np.median(np.abs(data[0])), watroo/wavelets.py:127.
+// One histogram pass per digit (11 + 10 + 10 bits); LDS-privatised bins, one global atomic per
+// non-empty bin per block.  Pixels in the pitch padding (x >= W) are masked.
+// ---------------------------------------------------------------------------------------------
+#define WT_HIST_BINS 2048
+__global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int64_t n4, int P4, int W,
+                                                      uint32_t prefix_mask, uint32_t prefix_val,
+                                                      int shift, uint32_t bin_mask,
+                                                      uint32_t *hist)
+{
+    __shared__ uint32_t lh[WT_HIST_BINS];
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+        const int x = (int)(i % P4) * 4;
+        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = b[k] & 0x7fffffffu;
+            if (x + k < W && (u & prefix_mask) == prefix_val)
+                atomicAdd(&lh[(u >> shift) & bin_mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// smallest |x| bit pattern strictly greater than `than` (for the upper median when N is even)
+__global__ __launch_bounds__(256) void wt_min_greater_kernel(const float *p, int64_t n4, int P4,
+                                                             int W, uint32_t than,
+                                                             uint32_t *result)
+{
+    uint32_t best = 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+        const int x = (int)(i % P4) * 4;
+        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = b[k] & 0x7fffffffu;
+            if (x + k < W && u > than) best = min(best, u);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_down((int)best, off));
+    if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(result, best);
+}
+
+// K7  {sum, sumsq, min, max} in fp64, deterministic two-stage reduction (per-block partials,
+// then one block folds them in index order).
+__global__ __launch_bounds__(256) void wt_reduce_kernel(const float *p, int64_t n4, int P4, int W,
+                                                        double *partials)
+{
+    double s = 0.0, s2 = 0.0, mn = 1e300, mx = -1e300;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(p)[i];
+        const int x = (int)(i % P4) * 4;
+        const float b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x + k < W) {
+                const double t = (double)b[k];
+                s += t;
+                s2 += t * t;
+                mn = fmin(mn, t);
+                mx = fmax(mx, t);
+            }
+    }
+    __shared__ double red[4][4];
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        s2 += __shfl_down(s2, off);
+        mn = fmin(mn, __shfl_down(mn, off));
+        mx = fmax(mx, __shfl_down(mx, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave][0] = s; red[wave][1] = s2; red[wave][2] = mn; red[wave][3] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            s += red[w][0]; s2 += red[w][1];
+            mn = fmin(mn, red[w][2]); mx = fmax(mx, red[w][3]);
+        }
+        double *o = partials + (int64_t)blockIdx.x * 4;
+        o[0] = s; o[1] = s2; o[2] = mn; o[3] = mx;
+    }
+}
+
+__global__ void wt_reduce_final_kernel(const double *partials, int nblocks, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, s2 = 0.0, mn = 1e300, mx = -1e300;
+    for (int b = 0; b < nblocks; ++b) {
+        s += partials[b * 4 + 0];
+        s2 += partials[b * 4 + 1];
+        mn = fmin(mn, partials[b * 4 + 2]);
+        mx = fmax(mx, partials[b * 4 + 3]);
+    }
+    out[0] = s; out[1] = s2; out[2] = mn; out[3] = mx;
+}

@@ -1,0 +1,179 @@
+"""Host-side mirror of ``watroo.utils``: ``denoise`` and ``wow`` on the MI355X engine.
+
+Same signatures and plumbing as /root/reference/watroo/utils.py (cited ``ref:LINE``); the
+planes never leave HBM between the transform and the final reconstruction download.
+``richardson_lucy`` (ref:222-290) is a consumer of this path and is listed as "next" in
+SURVEY.md section 8(f); calling it raises NotImplementedError.
+"""
+import copy
+import warnings
+
+import numpy as np
+
+from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, Plan, default_context
+from .wavelets import (AtrousTransform, B3spline, Coefficients, _family_of, _to_f32_image,
+                       PLANE_INPUT)
+
+__all__ = ['denoise', 'wow', 'richardson_lucy']
+
+_POWER_PLANE = PLANE_SCRATCH(3)
+_GAMMA_PLANE = PLANE_SCRATCH(4)
+
+
+def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None,
+            soft_threshold=True, anscombe=False):
+    """Denoise ``data``: transform over ``len(weights)`` scales, threshold each scale at
+    ``weights[s]`` sigma, sum the planes (ref:83-102).  Optional Anscombe pre/post transform.
+    Everything between the upload of ``data`` and the download of the result runs on the GPU.
+    """
+    img = _to_f32_image(data, "data")
+    level = len(weights)
+    transform = AtrousTransform(scaling_function, bilateral=bilateral)
+    sf = scaling_function(2)
+    plan = Plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
+    plan.upload(PLANE_INPUT, img)
+    if anscombe:
+        plan.anscombe(PLANE_INPUT, PLANE_INPUT)                           # ref:93-94
+    transform._run(plan, level)                                           # ref:95
+    coefficients = Coefficients(plan, sf, bilateral)
+    coefficients.noise = noise                                            # ref:96
+    coefficients.denoise(weights, soft_threshold=soft_threshold)          # ref:97
+    plan.plane_sum(0, level + 1, PLANE_OUT)                               # ref:98
+    if anscombe:
+        plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)                 # ref:99-100
+    return plan.download(PLANE_OUT)
+
+
+def _pad_list(values, n, fill):
+    out = copy.copy(values)
+    if len(out) <= n:
+        out.extend([fill, ] * (n - len(out) + 1))
+    return out
+
+
+def wow(data,
+        scaling_function=B3spline,
+        n_scales=None,
+        weights=[],
+        whitening=True,
+        denoise_coefficients=[],
+        noise=None,
+        bilateral=None,
+        bilateral_scaling=False,
+        soft_threshold=True,
+        preserve_variance=False,
+        gamma=3.2,
+        gamma_min=None,
+        gamma_max=None,
+        h=0):
+    """Wavelets Optimized Whitening (ref:105-219; Auchere et al. 2023).
+
+    ``data`` is a 2-D ndarray or a ``Coefficients`` object (which is then mutated and
+    returned, ref:128-131,152-153).  Returns ``(image, coefficients)``; the coefficients are
+    the whitened ones, exactly as in the reference.
+    """
+    if type(data) is np.ndarray:                                          # ref:121-127
+        if data.ndim != 2:
+            _to_f32_image(data, "data")
+        max_scales = int(np.round(np.log2(min(data.shape))
+                                  - np.log2(len(scaling_function.coefficients_1d))))
+        if n_scales is None:
+            n_scales = max_scales if h < 1 else len(denoise_coefficients)
+        elif n_scales > max_scales:
+            n_scales = max_scales
+        n_dims = data.ndim
+    elif type(data) is Coefficients:                                      # ref:128-131
+        n_scales = len(data) - 1
+        n_dims = 2
+        scaling_function = data.scaling_function.__class__
+    else:
+        raise ValueError('Unknown input type')                            # ref:133
+
+    max_scales = len(scaling_function(n_dims).sigma_e(bilateral=bilateral))
+    if len(denoise_coefficients) >= max_scales:                           # ref:136-138
+        warnings.warn('Required number of scales lager then the maximum for scaling '
+                      f'function. Using {max_scales}.')
+        n_scales = max_scales
+
+    if bilateral is None:                                                 # ref:140-146
+        sigma_bilateral = None
+    else:
+        sigma_bilateral = copy.copy(bilateral) if type(bilateral) is list \
+            else [bilateral, ] * (n_scales + 1)
+        if len(sigma_bilateral) <= n_scales:
+            sigma_bilateral.extend([1, ] * (n_scales - len(sigma_bilateral) + 1))
+
+    if type(data) is np.ndarray:                                          # ref:148-151
+        transform = AtrousTransform(scaling_function, bilateral=sigma_bilateral,
+                                    bilateral_scaling=bilateral_scaling)
+        coefficients = transform(data, n_scales)
+        coefficients.noise = noise
+    else:
+        coefficients = data
+
+    plan = coefficients._device()
+    npix = float(plan.H) * float(plan.W)
+
+    use_gamma = h > 0
+    if use_gamma:
+        plan.fill(_GAMMA_PLANE, 0.0)                                      # ref:157-158
+
+    recomposition_weights = _pad_list(weights, n_scales, 1)               # ref:160-163
+    sdc = copy.copy(denoise_coefficients)                                 # ref:165-170
+    if len(sdc) < n_scales:
+        sdc.extend([0, ] * (n_scales - len(sdc)))
+    if len(sdc) == n_scales:
+        sdc.extend([1, ])
+
+    nplanes = len(coefficients)
+    gplane = _GAMMA_PLANE if use_gamma else PLANE_NONE
+    for s, (_, w, d) in enumerate(zip(range(nplanes), recomposition_weights, sdc)):  # ref:174
+        need_moments = preserve_variance or (s == n_scales and whitening and h < 1)
+        if need_moments:
+            tot, tot2, _, _ = plan.reduce(s)
+            mean = tot / npix
+            std = np.float32(np.sqrt(max(tot2 / npix - mean * mean, 0.0)))
+            rms = np.float32(np.sqrt(tot2 / npix))
+        if preserve_variance:                                             # ref:178-184
+            power_norm = std if s == n_scales else rms
+        else:
+            power_norm = 1
+        if s == n_scales:                                                 # ref:185-191
+            if whitening and h < 1:
+                local_power = std
+                if local_power <= 0:
+                    local_power = 1e-15
+            else:
+                local_power = 1
+            factor = np.float32(w * power_norm / local_power)             # ref:203
+            plan.wow_update(s, PLANE_NONE, 0.0, soft_threshold, PLANE_NONE, factor, gplane)
+        else:
+            power_plane = PLANE_NONE
+            if whitening and h < 1:                                       # ref:193-196
+                plan.smooth(s, _POWER_PLANE, s, square_input=True)
+                power_plane = _POWER_PLANE
+            t = coefficients._tau(d, s)                                   # ref:199
+            tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
+            factor = np.float32(w * power_norm)
+            plan.wow_update(s, power_plane, tau, soft_threshold, noise_plane, factor, gplane)
+
+    plan.plane_sum(0, nplanes, PLANE_OUT)                                 # ref:205
+
+    if use_gamma:                                                         # ref:207-217
+        if gamma_min is None or gamma_max is None:
+            _, _, lo, hi = plan.reduce(_GAMMA_PLANE)
+            if gamma_min is None:
+                gamma_min = lo
+            if gamma_max is None:
+                gamma_max = hi
+        plan.gamma_blend(PLANE_OUT, _GAMMA_PLANE, gamma_min, gamma_max, 1 / gamma, h)
+
+    recon = plan.download(PLANE_OUT)
+    coefficients._refresh_host(range(nplanes))
+    return recon, coefficients
+
+
+def richardson_lucy(*args, **kwargs):
+    """Wavelet-regularised Richardson-Lucy deconvolution (ref:222-290) - a consumer of the
+    transform, ranked "next" in SURVEY.md section 8(f); not part of this engine yet."""
+    raise NotImplementedError("richardson_lucy is out of scope for the HIP engine (SURVEY 8f)")

@@ -1,0 +1,395 @@
+"""Host-side mirror of ``watroo.wavelets`` for the MI355X engine.
+
+Same public names, argument meaning and error behaviour as the reference module
+(/root/reference/watroo/wavelets.py, cited as ``ref:LINE``), but the arithmetic runs in
+``libwatroo_hip.so`` on the GPU and coefficient planes stay resident in HBM.
+
+Scope: 2-D images, float32 compute.  float64 / integer inputs are
+converted to float32 (the reference keeps float64, ref:297,319-320); 1-D / 3-D arrays and
+``recursive=True`` raise ``NotImplementedError`` - there is deliberately no CPU fallback.
+"""
+import copy
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PLANE_INPUT, PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, FLAG_FUSED, Plan,
+                   default_context)
+
+__all__ = ['AtrousTransform', 'B3spline', 'Triangle', 'Coefficients', 'generalized_anscombe',
+           'convolution']
+
+_NOISE_PLANE = PLANE_SCRATCH(5)   # ndarray noise maps live here (ref:133)
+_TMP_PLANE = PLANE_SCRATCH(4)
+
+
+# ------------------------------------------------------------------------------------------
+# scaling functions (ref:152-287): host constants; the tables are data and part of the
+# numerical contract (thresholds scale with sigma_e).
+# ------------------------------------------------------------------------------------------
+class AbstractScalingFunction:
+    """Base class: 1-D taps -> separable N-D kernel, dilated kernel, noise tables."""
+
+    coefficients_1d = None
+    sigma_e_1d = sigma_e_2d = sigma_e_3d = None
+    sigma_e_1d_bilateral = sigma_e_2d_bilateral = sigma_e_3d_bilateral = None
+    _family = None   # engine enum; None for user-defined taps
+
+    def __init__(self, name, n_dim):
+        self.name = name
+        self.n_dim = n_dim
+        self.kernel = self.make_kernel()
+
+    @property
+    def coefficients_2d(self):
+        return np.outer(self.coefficients_1d, self.coefficients_1d)
+
+    @property
+    def coefficients_3d(self):
+        t = self.coefficients_1d
+        return np.einsum('i,j,k->ijk', t, t, t)
+
+    def make_kernel(self):
+        by_dim = {1: lambda: self.coefficients_1d, 2: lambda: self.coefficients_2d,
+                  3: lambda: self.coefficients_3d}
+        if self.n_dim not in by_dim:
+            raise ValueError("Unsupported number of dimensions")          # ref:189
+        return by_dim[self.n_dim]()
+
+    def atrous_kernel(self, scale):
+        """Zero-stuffed ('a trous') kernel at dilation 2**scale (ref:191-197)."""
+        step = 2 ** scale
+        out = np.zeros([(n - 1) * step + 1 for n in self.kernel.shape])
+        out[(slice(None, None, step),) * self.n_dim] = self.kernel
+        return out
+
+    def sigma_e(self, bilateral=None):
+        """Per-scale std of the coefficients of unit white noise (ref:199-219)."""
+        suffix = "" if bilateral is None else "_bilateral"
+        if self.n_dim not in (1, 2, 3):
+            raise ValueError("Unsupported number of dimensions")          # ref:208,218
+        return getattr(self, f"sigma_e_{self.n_dim}d{suffix}")
+
+    def compute_noise_weights(self, n_scales, n_trials=100, bilateral=None):
+        """Monte-Carlo calibration of sigma_e (ref:221-229) on top of the GPU transform."""
+        transform = AtrousTransform(self.__class__, bilateral=bilateral)
+        std = np.zeros(n_scales)
+        for _ in range(n_trials):
+            size = (len(self.sigma_e_1d) * 2 ** n_scales,) * self.n_dim
+            data = np.random.normal(size=size).astype(np.float32)
+            coefficients = transform(data, n_scales)
+            std += coefficients.data[:-1].std(axis=tuple(range(1, self.n_dim + 1)))
+        return std / n_trials
+
+
+class Triangle(AbstractScalingFunction):
+    """Triangle scaling function, 3 taps (ref:232-258; Starck & Murtagh, appendix A)."""
+
+    _family = _lib.TRIANGLE
+    coefficients_1d = np.array([1 / 4, 1 / 2, 1 / 4])
+    sigma_e_1d = np.array([0.60840933, 0.33000059, 0.21157957, 0.145824, 0.10158388,
+                           0.07155912, 0.04902655, 0.03529812, 0.02409187, 0.01722846,
+                           0.01144442])
+    sigma_e_2d = np.array([0.7999247, 0.27308452, 0.11998217, 0.05793947, 0.0288104,
+                           0.01447795, 0.00733832, 0.0037203, 0.00192882, 0.00098568,
+                           0.00048533])
+    sigma_e_3d = np.array([0.89736751, 0.19514386, 0.06239262, 0.02311278, 0.00939645])
+    sigma_e_2d_bilateral = np.array([0.31063172, 0.34575647, 0.23712331, 0.13559906,
+                                     0.07172004, 0.03665405, 0.01850046, 0.00928768,
+                                     0.00465967, 0.00234445, 0.00119249])
+    sigma_e_3d_bilateral = np.array([0.3828863, 0.36182913, 0.19520299, 0.08498861,
+                                     0.03363142])
+
+    def __init__(self, *args, **kwargs):
+        super().__init__('triangle', *args, **kwargs)
+
+
+class B3spline(AbstractScalingFunction):
+    """B3-spline scaling function, 5 taps (ref:261-287; Starck & Murtagh, appendix A)."""
+
+    _family = _lib.B3SPLINE
+    coefficients_1d = np.array([1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16])
+    sigma_e_1d = np.array([0.72514976, 0.28538683, 0.17901161, 0.12222841, 0.08469601,
+                           0.06027006, 0.04242257, 0.02919823, 0.01805671, 0.01383672,
+                           0.00943623])
+    sigma_e_2d = np.array([8.907e-01, 2.0072e-01, 8.5551e-02, 4.1261e-02, 2.0470e-02,
+                           1.0232e-02, 5.1435e-03, 2.6008e-03, 1.3161e-03, 6.7359e-04,
+                           4.0040e-04])
+    sigma_e_3d = np.array([0.95633954, 0.12491933, 0.03933029, 0.01489642, 0.0064108])
+    sigma_e_2d_bilateral = np.array([0.38234752, 0.24305799, 0.16012153, 0.10633541,
+                                     0.07083733, 0.04728659, 0.03163678, 0.02122341,
+                                     0.01429102, 0.00952376])
+    sigma_e_3d_bilateral = np.array([0.44111772, 0.3552894, 0.16137159, 0.05769064,
+                                     0.01932497])
+
+    def __init__(self, *args, **kwargs):
+        super().__init__('b3spline', *args, **kwargs)
+
+
+def _family_of(scaling_function):
+    """Engine family enum of a scaling-function class or instance."""
+    fam = getattr(scaling_function, "_family", None)
+    if fam is None:
+        raise NotImplementedError(
+            "the HIP engine implements the Triangle and B3spline scaling functions only")
+    return fam
+
+
+def _to_f32_image(arr, what="arr"):
+    arr = np.asarray(arr)
+    if arr.ndim > 3:
+        raise ValueError("Unsupported number of dimensions")              # ref:317
+    if arr.ndim != 2:
+        raise NotImplementedError(
+            f"{what}: the HIP engine covers the 2-D path only ({arr.ndim}-D arrays are out of "
+            "scope, SURVEY.md section 8)")
+    return np.ascontiguousarray(arr, dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------------------
+# pointwise / single-operator entry points
+# ------------------------------------------------------------------------------------------
+def generalized_anscombe(signal, alpha=1, g=0, sigma=0, inverse=False):
+    """Generalised Anscombe variance-stabilising transform and its algebraic inverse
+    (ref:14-21), evaluated on the GPU in float32."""
+    img = _to_f32_image(signal, "signal")
+    plan = Plan(default_context(), img.shape[0], img.shape[1], _lib.B3SPLINE, 0)
+    plan.upload(PLANE_INPUT, img)
+    plan.anscombe(PLANE_INPUT, PLANE_OUT, alpha, g, sigma, inverse)
+    return plan.download(PLANE_OUT)
+
+
+def convolution(arr, scaling_function, s=0, output=None):
+    """Dilated smoothing with ``scaling_function`` at scale ``s``; symmetric borders.
+    Mirrors ref:35-45 (2-D branch: cv2.filter2D with the zero-stuffed kernel,
+    BORDER_REFLECT).  ``output`` is written in place and returned, as in the reference."""
+    img = _to_f32_image(arr)
+    plan = Plan(default_context(), img.shape[0], img.shape[1], _family_of(scaling_function), 0)
+    plan.upload(PLANE_INPUT, img)
+    plan.smooth(PLANE_INPUT, PLANE_OUT, s)
+    res = plan.download(PLANE_OUT)
+    if output is None:
+        return res
+    output[...] = res
+    return output
+
+
+def sdev_loc(image, scaling_function, s=0, variance=False):
+    """Local standard deviation (or variance) at scale ``s`` (ref:24-32)."""
+    img = _to_f32_image(image, "image")
+    plan = Plan(default_context(), img.shape[0], img.shape[1], _family_of(scaling_function), 0)
+    plan.upload(PLANE_INPUT, img)
+    plan.local_variance(PLANE_INPUT, PLANE_OUT, s, 1.0, 1.0, take_sqrt=not variance)
+    return plan.download(PLANE_OUT)
+
+
+def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmetric",
+                       output=None):
+    """Dilated convolution, optionally range-weighted by ``bilateral_variance`` (ref:74-105).
+    ``kernel`` must be the 2-D Triangle or B3spline kernel; ``mode`` must be 'symmetric'."""
+    if mode != "symmetric":
+        raise NotImplementedError("the HIP engine implements mode='symmetric' only")
+    img = _to_f32_image(image, "image")
+    kernel = np.asarray(kernel)
+    fam = None
+    for cls in (Triangle, B3spline):
+        k = cls(2).kernel
+        if kernel.shape == k.shape and np.allclose(kernel, k, rtol=1e-6, atol=0):
+            fam = cls._family
+    if fam is None:
+        raise NotImplementedError("kernel must be the 2-D Triangle or B3spline kernel")
+    plan = Plan(default_context(), img.shape[0], img.shape[1], fam, 0)
+    plan.upload(PLANE_INPUT, img)
+    if bilateral_variance is None:
+        plan.smooth(PLANE_INPUT, PLANE_OUT, s)
+    else:
+        var = np.broadcast_to(np.asarray(bilateral_variance, np.float32), img.shape)
+        plan.upload(_TMP_PLANE, var)
+        plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s)
+    res = plan.download(PLANE_OUT)
+    if output is None:
+        return res
+    output[...] = res
+    return output
+
+
+# ------------------------------------------------------------------------------------------
+# Coefficients (ref:108-149) - device-resident planes with a lazily materialised host mirror
+# ------------------------------------------------------------------------------------------
+class Coefficients:
+    """``level+1`` coefficient planes: 0..level-1 detail, ``level`` the final smooth.
+
+    Planes live in HBM.  ``.data`` materialises a float32 ndarray mirror on first access;
+    from then on the mirror is treated as user-owned (the reference's idiom is in-place
+    edits such as ``coefficients.data[s] *= ...``): every device operation first re-uploads
+    it and afterwards refreshes it in place, so references held by the caller stay valid.
+    """
+
+    def __init__(self, data, scaling_function, bilateral=None):
+        self.scaling_function = scaling_function
+        self.bilateral = bilateral
+        self.noise = None
+        self._plan = None
+        self._host = None
+        self._noise_uploaded = None
+        if isinstance(data, Plan):
+            self._plan = data
+            self._nplanes = data.max_level + 1
+        else:
+            data = np.asarray(data)
+            if data.ndim != 3:
+                raise NotImplementedError("Coefficients: the HIP engine covers 2-D images "
+                                          "(a (level+1, H, W) stack)")
+            self._host = np.ascontiguousarray(data, dtype=np.float32)
+            self._nplanes = self._host.shape[0]
+
+    # -- host mirror -------------------------------------------------------------------
+    @property
+    def data(self):
+        if self._host is None:
+            host = np.empty((self._nplanes,) + self._plan.shape, np.float32)
+            for s in range(self._nplanes):
+                self._plan.download(s, host[s])
+            self._host = host
+        return self._host
+
+    @data.setter
+    def data(self, value):
+        value = np.ascontiguousarray(value, dtype=np.float32)
+        if value.ndim != 3 or value.shape[0] != self._nplanes:
+            raise ValueError("Coefficients.data must keep its (level+1, H, W) shape")
+        self._host = value
+
+    def _device(self):
+        """Plan with planes up to date (re-uploading a user-owned mirror)."""
+        if self._plan is None:
+            _, H, W = self._host.shape
+            self._plan = Plan(default_context(), H, W, _family_of(self.scaling_function),
+                              self._nplanes - 1)
+        if self._host is not None:
+            for s in range(self._nplanes):
+                self._plan.upload(s, self._host[s])
+        return self._plan
+
+    def _refresh_host(self, planes):
+        if self._host is not None:
+            for s in planes:
+                self._plan.download(s, self._host[s])
+
+    # -- reference interface -----------------------------------------------------------
+    def __len__(self):
+        return self._nplanes                                              # ref:116
+
+    def __array__(self, dtype=None, copy=None):
+        d = self.data                                                     # ref:119
+        return d if dtype is None else d.astype(dtype, copy=False)
+
+    @property
+    def shape(self):
+        return (self._nplanes,) + (self._plan.shape if self._plan is not None
+                                   else self._host.shape[1:])
+
+    @property
+    def sigma_e(self):
+        return self.scaling_function.sigma_e(bilateral=self.bilateral)    # ref:122-124
+
+    def get_noise(self):
+        """MAD noise estimate: median(|w_0|) / 0.6745 / sigma_e[0] (ref:126-127).  The exact
+        median is a radix select on the GPU; the scalar divisions follow numpy's promotion."""
+        med = self._device().abs_median(0)
+        return med / 0.6745 / self.sigma_e[0]
+
+    def _tau(self, sigma, scale):
+        """(tau, noise_plane) or None when the significance is identically one
+        (sigma == 0, ref:142-143; scalar noise == 0, ref:133-135)."""
+        if sigma == 0:
+            return None
+        if self.noise is None:
+            self.noise = self.get_noise()                                 # ref:131-132 (lazy)
+        if type(self.noise) is not np.ndarray:
+            if self.noise == 0:
+                return None
+            return float(sigma * self.noise * self.sigma_e[scale]), PLANE_NONE
+        plan = self._device()
+        if self._noise_uploaded is not self.noise:
+            plan.upload(_NOISE_PLANE, np.broadcast_to(
+                np.asarray(self.noise, np.float32), plan.shape))
+            self._noise_uploaded = self.noise
+        return float(sigma * self.sigma_e[scale]), _NOISE_PLANE
+
+    def significance(self, sigma, scale, soft_threshold=True):
+        """erf(|w|/tau) (soft) or |w| > tau (hard, bool), tau = sigma*noise*sigma_e[scale]
+        (ref:129-143).  Returns a host ndarray like the reference."""
+        t = self._tau(sigma, scale)
+        plan = self._device()
+        if t is None:
+            return np.ones(plan.shape, np.float32)
+        plan.significance(scale, _TMP_PLANE, t[0], soft_threshold, t[1])
+        sig = plan.download(_TMP_PLANE)
+        return sig if soft_threshold else sig.astype(bool)
+
+    def denoise(self, sigma, weights=None, soft_threshold=True):
+        """In-place ``w_s *= weights[s] * significance(sigma[s], s)`` for the first
+        ``len(sigma)`` planes (ref:145-149)."""
+        if weights is None:
+            weights = (1,) * len(sigma)
+        plan = self._device()
+        touched = []
+        for scl, (_, sig, wgt) in enumerate(zip(range(self._nplanes), sigma, weights)):
+            t = self._tau(sig, scl)
+            if t is None:
+                if wgt != 1:
+                    plan.wow_update(scl, PLANE_NONE, 0.0, True, PLANE_NONE, wgt, PLANE_NONE)
+                    touched.append(scl)
+                continue
+            plan.denoise(scl, t[0], wgt, soft_threshold, t[1])
+            touched.append(scl)
+        self._refresh_host(touched)
+
+    # -- device-side helpers used by utils (not in the reference API) --------------------
+    def sum(self):
+        """Reconstruction ``np.sum(coefficients, axis=0)`` computed on the GPU."""
+        plan = self._device()
+        plan.plane_sum(0, self._nplanes, PLANE_OUT)
+        return plan.download(PLANE_OUT)
+
+
+# ------------------------------------------------------------------------------------------
+# AtrousTransform (ref:290-328, 408-444)
+# ------------------------------------------------------------------------------------------
+class AtrousTransform:
+    """Dyadic 'a trous' (stationary) wavelet transform, Starck & Murtagh appendix A."""
+
+    def __init__(self, scaling_function_class=B3spline, bilateral=None, bilateral_scaling=False):
+        self.scaling_function_class = scaling_function_class
+        self.bilateral = bilateral
+        self.bilateral_scaling = bilateral_scaling
+
+    def __call__(self, arr, level, recursive=False):
+        """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328)."""
+        img = _to_f32_image(arr)
+        if recursive:
+            raise NotImplementedError(
+                "recursive=True (ref:330-406) is out of scope for the HIP engine; use the "
+                "standard algorithm")
+        scaling_function = self.scaling_function_class(img.ndim)
+        plan = Plan(default_context(), img.shape[0], img.shape[1],
+                    _family_of(scaling_function), level)
+        plan.upload(PLANE_INPUT, img)
+        self._run(plan, level)
+        return Coefficients(plan, scaling_function, self.bilateral)
+
+    def _run(self, plan, level, src=PLANE_INPUT, flags=FLAG_FUSED):
+        if self.bilateral is None:
+            plan.decompose(src, level, flags)                              # ref:432,442
+        else:
+            sb = self._sigma_bilateral(level)
+            plan.decompose_bilateral(src, level, sb, self.bilateral_scaling, flags & ~FLAG_FUSED)
+
+    def _sigma_bilateral(self, level):
+        """Per-scale sigma_bilateral list (ref:421-424)."""
+        sb = copy.copy(self.bilateral) if type(self.bilateral) is list \
+            else [self.bilateral, ] * (level + 1)
+        if len(sb) <= level:
+            sb.extend([1, ] * (level - len(sb) + 1))
+        return sb
