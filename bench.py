@@ -58,9 +58,11 @@ def cpu_baseline():
     this host on a bounded sample of the same workload."""
     from oracle import cref
     cref.build()
-    cores = len(os.sched_getaffinity(0))
-    threads = cref.num_threads()
+    cores = cref.usable_cpus()
+    threads = min(cores, cref.num_threads())
+    cref.set_threads(threads)
     probe = np.random.default_rng(0).standard_normal((1024, 1024), dtype=np.float32)
+    cref.plane_sum(cref.decompose(probe, LEVEL, FAMILY))      # spawn the OpenMP team
     t = time.perf_counter()
     cref.plane_sum(cref.decompose(probe, LEVEL, FAMILY))
     per_pix = (time.perf_counter() - t) / probe.size
@@ -75,7 +77,7 @@ def cpu_baseline():
         t_tot += time.perf_counter() - t
         reps += 1
     return {"value": round(img.size * reps / t_tot / 1e6, 2), "unit": "Mpix/s",
-            "cores": min(threads, cores), "kind": "port",
+            "cores": threads, "kind": "port",
             "sample": f"{reps} x decompose+sum of {side}x{side} f32 {FAMILY} L={LEVEL} "
                       f"(oracle/atrous_ref.c, gcc -O3 -fopenmp, {threads} threads)"}
 

@@ -35,6 +35,15 @@ static inline long reflect(long i, long n)
     return m < n ? m : p - 1 - m;
 }
 
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
@@ -45,7 +54,7 @@ int orc_num_threads(void)
 }
 
 /* family: 0 = triangle (3 taps), 1 = b3spline (5 taps). square_input: smooth in*in. */
-int orc_smooth(const float *in, float *out, long H, long W, int family, int s, int square_input)
+int orc_smooth(const float *restrict in, float *restrict out, long H, long W, int family, int s, int square_input)
 {
     const int K = family ? 5 : 3, hw = K / 2;
     const float *t = family ? TAPS_B3 : TAPS_TRI;
@@ -57,17 +66,17 @@ int orc_smooth(const float *in, float *out, long H, long W, int family, int s, i
     if (!cx) return 1;
     for (int j = 0; j < K; j++)
         for (long x = 0; x < W; x++) cx[j * W + x] = reflect(x + (long)(K - 1 - j - hw) * d, W);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 8)
     for (long y = 0; y < H; y++) {
-        float *o = out + y * W;
-        const float *c = in + y * W;
+        float *restrict o = out + y * W;
+        const float *restrict c = in + y * W;
         const float kc = k2[hw][hw];
         if (square_input)
             for (long x = 0; x < W; x++) { float v = c[x] * c[x]; o[x] = kc * v; }
         else
             for (long x = 0; x < W; x++) o[x] = kc * c[x];
         for (int i = 0; i < K; i++) {
-            const float *r = in + reflect(y + (long)(K - 1 - i - hw) * d, H) * W;
+            const float *restrict r = in + reflect(y + (long)(K - 1 - i - hw) * d, H) * W;
             for (int j = 0; j < K; j++) {
                 if (i == hw && j == hw) continue;
                 const float k = k2[i][j];
@@ -80,7 +89,7 @@ int orc_smooth(const float *in, float *out, long H, long W, int family, int s, i
                     for (long x = 0; x < W; x++) { float v = r[ix[x]]; v = v * v; float p = v * k; o[x] = o[x] + p; }
                 } else {
                     for (long x = 0; x < x0; x++) { float p = r[ix[x]] * k; o[x] = o[x] + p; }
-                    const float *rs = r + off;
+                    const float *restrict rs = r + off;
                     for (long x = x0; x < x1; x++) { float p = rs[x] * k; o[x] = o[x] + p; }
                     for (long x = x1; x < W; x++) { float p = r[ix[x]] * k; o[x] = o[x] + p; }
                 }
@@ -100,7 +109,7 @@ int orc_decompose(const float *in, float *planes, long H, long W, int family, in
         float *cs = planes + (size_t)s * n, *cn = planes + (size_t)(s + 1) * n;
         int rc = orc_smooth(cs, cn, H, W, family, s, 0);
         if (rc) return rc;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 65536)
         for (long i = 0; i < (long)n; i++) cs[i] = cs[i] - cn[i];
     }
     return 0;
@@ -108,7 +117,7 @@ int orc_decompose(const float *in, float *planes, long H, long W, int family, in
 
 int orc_plane_sum(const float *planes, int nplanes, long npix, float *out)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 65536)
     for (long i = 0; i < npix; i++) {
         float a = planes[i];
         for (int p = 1; p < nplanes; p++) a = a + planes[(size_t)p * npix + i];
@@ -139,7 +148,7 @@ int orc_abs_median(const float *x, long n, float *out)
 /* plane *= wgt * significance; tau = sigma*noise*sigma_e[scale] (double), scalar noise */
 int orc_denoise(float *plane, long npix, double tau, double wgt, int soft)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 65536)
     for (long i = 0; i < npix; i++) {
         double sig;
         if (soft) sig = erf(fabs((double)plane[i] / tau));

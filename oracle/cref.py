@@ -51,6 +51,22 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
 def smooth(img, family, s, square_input=False):
     img = _c32(img)
     out = np.empty_like(img)

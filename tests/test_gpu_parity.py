@@ -131,7 +131,7 @@ def test_reference_wow_smoke_tests(W):
 def test_plane_sum_bit_exact(W):
     a = rnd((123, 77), 5)
     c = W.AtrousTransform()(a, 6)
-    np.testing.assert_array_equal(c.sum(), c.data.sum(axis=0))
+    np.testing.assert_array_equal(c.sum(axis=0), c.data.sum(axis=0))
 
 
 @pytest.mark.parametrize("shape", [(37, 53), (64, 48), (1, 1), (2, 1), (300, 333), (512, 512)])
@@ -185,7 +185,7 @@ def test_host_mirror_edits_are_honoured(W, O):
     a = rnd((48, 40), 8)
     c = W.AtrousTransform()(a, 3)
     c.data[0] *= 0.0                             # user edit on the host mirror
-    close(c.sum(), O.atrous_standard(a, 3)[1:].sum(axis=0), 1e-5 * np.abs(a).max())
+    close(c.sum(axis=0), O.atrous_standard(a, 3)[1:].sum(axis=0), 1e-5 * np.abs(a).max())
 
 
 def test_anscombe_bit_exact(W):
@@ -303,7 +303,7 @@ def test_cfg2_4096_b3_l6_vs_c_oracle(W, C):
     ref = C.decompose(a, 6, "b3spline")
     for s in range(7):
         close(c.data[s], ref[s], tol)
-    recon = c.sum()
+    recon = c.sum(axis=0)
     np.testing.assert_array_equal(recon, C.plane_sum(c.data))     # same planes -> bit exact
     close(recon, a, 2e-6 * np.abs(a).max() * 4)                  # perfect reconstruction
 
@@ -334,7 +334,7 @@ def test_8192_b3_l6_properties(W):
     T = W.AtrousTransform(W.B3spline)
     c = T(a, 6)
     plan = c._device()
-    recon = c.sum()
+    recon = c.sum(axis=0)
     close(recon, a, 1e-5 * amax)                                   # sum of planes == input
     # linearity: T(2a + b) == 2 T(a) + T(b) on the last (smooth) and a detail plane
     b = rnd((8192, 8192), 2)

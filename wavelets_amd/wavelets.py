@@ -346,12 +346,20 @@ class Coefficients:
             touched.append(scl)
         self._refresh_host(touched)
 
-    # -- device-side helpers used by utils (not in the reference API) --------------------
-    def sum(self):
-        """Reconstruction ``np.sum(coefficients, axis=0)`` computed on the GPU."""
-        plan = self._device()
-        plan.plane_sum(0, self._nplanes, PLANE_OUT)
-        return plan.download(PLANE_OUT)
+    # -- numpy reduction hook ------------------------------------------------------------
+    def sum(self, axis=None, dtype=None, out=None, **kwargs):
+        """``np.sum(coefficients, axis=0)`` (ref utils.py:98,205; README) dispatches here:
+        the plane sum runs on the GPU in plane order (bit-identical to numpy's float32
+        reduction over axis 0).  Any other reduction falls back to numpy on the mirror."""
+        if axis == 0 and dtype is None and not kwargs:
+            plan = self._device()
+            plan.plane_sum(0, self._nplanes, PLANE_OUT)
+            res = plan.download(PLANE_OUT)
+            if out is None:
+                return res
+            out[...] = res
+            return out
+        return np.sum(self.data, axis=axis, dtype=dtype, out=out, **kwargs)
 
 
 # ------------------------------------------------------------------------------------------
