@@ -261,7 +261,9 @@ class Coefficients:
         self._host = value
 
     def _device(self):
-        """Plan with planes up to date (re-uploading a user-owned mirror)."""
+        """Entry point of every device operation: the plan with planes up to date
+        (re-uploading a user-owned mirror).  Call ONCE per public operation; helpers that
+        run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
             _, H, W = self._host.shape
             self._plan = Plan(default_context(), H, W, _family_of(self.scaling_function),
@@ -296,21 +298,25 @@ class Coefficients:
     def get_noise(self):
         """MAD noise estimate: median(|w_0|) / 0.6745 / sigma_e[0] (ref:126-127).  The exact
         median is a radix select on the GPU; the scalar divisions follow numpy's promotion."""
-        med = self._device().abs_median(0)
-        return med / 0.6745 / self.sigma_e[0]
+        self._device()
+        return self._noise_from_device()
+
+    def _noise_from_device(self):
+        return self._plan.abs_median(0) / 0.6745 / self.sigma_e[0]
 
     def _tau(self, sigma, scale):
         """(tau, noise_plane) or None when the significance is identically one
-        (sigma == 0, ref:142-143; scalar noise == 0, ref:133-135)."""
+        (sigma == 0, ref:142-143; scalar noise == 0, ref:133-135).  Runs inside a device
+        operation (planes already in sync)."""
         if sigma == 0:
             return None
         if self.noise is None:
-            self.noise = self.get_noise()                                 # ref:131-132 (lazy)
+            self.noise = self._noise_from_device()                        # ref:131-132 (lazy)
         if type(self.noise) is not np.ndarray:
             if self.noise == 0:
                 return None
             return float(sigma * self.noise * self.sigma_e[scale]), PLANE_NONE
-        plan = self._device()
+        plan = self._plan
         if self._noise_uploaded is not self.noise:
             plan.upload(_NOISE_PLANE, np.broadcast_to(
                 np.asarray(self.noise, np.float32), plan.shape))
@@ -320,8 +326,8 @@ class Coefficients:
     def significance(self, sigma, scale, soft_threshold=True):
         """erf(|w|/tau) (soft) or |w| > tau (hard, bool), tau = sigma*noise*sigma_e[scale]
         (ref:129-143).  Returns a host ndarray like the reference."""
-        t = self._tau(sigma, scale)
         plan = self._device()
+        t = self._tau(sigma, scale)
         if t is None:
             return np.ones(plan.shape, np.float32)
         plan.significance(scale, _TMP_PLANE, t[0], soft_threshold, t[1])
