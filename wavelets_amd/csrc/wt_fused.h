@@ -1,13 +1,294 @@
-// Fused multi-scale passes (several consecutive scales per HBM round trip).
+// Fused multi-scale a-trous passes: NS consecutive scales per HBM round trip.
+//
+//   pass(s0, NS):  read c_{s0} once  ->  write w_{s0} .. w_{s0+NS-1} and c_{s0+NS}
+//                  (watroo/wavelets.py:429-442 for NS consecutive iterations of the loop)
+//
+// Algorithmic traffic 4*(NS+2) B/pixel instead of 12*NS for one kernel per scale.
+//
+// Geometry (D = 2^s0 is the base dilation of the pass):
+//  * y: the image rows split into D POLYPHASE CHAINS  y = q, q+D, q+2D, ...; on a chain the
+//    scales s0+a have dilation 2^a chain steps.  A workgroup marches down one chunk of one
+//    chain, one row per step, so the vertical filters are sliding windows held in REGISTERS
+//    (per lane: (K-1)*(2^NS-1) float4 = 28 for B3/NS=3), never re-read from memory.
+//  * x: a workgroup of NW waves covers NW*256 contiguous pixels of the row (lane = 4 adjacent
+//    pixels = one 16-byte coalesced access), including the cumulative halo
+//    hw*(2^NS-1)*D pixels on each side whose results are discarded.  The horizontal filter
+//    needs the vertically-filtered row of the neighbouring lanes: it is staged through a
+//    per-scale LDS row (one ds_write_b128 + K-1 ds_read_b128 per lane per scale) - for D >= 4
+//    the dilated taps are whole-lane offsets, for D = 1 the taps of dilation 1 and 2 are
+//    recombined from the two adjacent lanes' float4.
+//  * borders: the chain simply continues through reflected rows / columns; symmetric
+//    extension commutes with the symmetric filters, so every intermediate scale is the exact
+//    symmetric extension too.  In a multi-GPU strip the rows beyond the strip come from the
+//    halo margins (RCCL exchange of the pass input) instead.
+//  * latency of the cascade: output row of scale a lags the input row by hw*(2^(a+1)-1)
+//    chain steps, so a chunk of S rows reads S + 2*hw*(2^NS-1) rows (warm-up).
+//    The host sizes chunks so that the whole grid is resident at once (one round).
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include "wt_internal.h"
+#include "wt_kernels.h"
 
 #define WT_FUSED_MAX_SCALES 3
 #define WT_FUSED_MAX_FIRST_SCALE 3
 
-static inline bool wt_fused_supported(const wt_plan *) { return false; }
+struct FusedArgs {
+    const float *in;                       // c_{s0}, local row 0
+    float *out_c;                          // c_{s0+NS}
+    float *out_w[WT_FUSED_MAX_SCALES];     // w_{s0+a}
+    Geo g;
+    int Vx;       // valid (stored) pixels per x-strip, multiple of 4
+    int S;        // chain steps stored per chunk
+    int chunks;   // chunks per chain
+};
 
-static inline int wt_fused_launch(wt_plan *, const float *, float *, float **, int, int)
+template <int K, int SHIFT_PX, int NLANES>
+__device__ __forceinline__ float4 wt_hfilter_lds(const float4 *vrow, int gl, float4 own)
 {
-    WT_FAIL("fused passes not built");
+    // horizontal K-tap filter with taps SHIFT_PX pixels apart; vrow = the WG's LDS row of
+    // vertically filtered values (float4 per lane), gl = this lane's index in the row.
+    constexpr int hw = K / 2;
+    if constexpr (SHIFT_PX % 4 == 0) {
+        constexpr int LO = SHIFT_PX / 4;
+        float4 acc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float4 v;
+            if (j == hw) v = own;
+            else {
+                int idx = gl + (j - hw) * LO;
+                idx = idx < 0 ? 0 : (idx > NLANES - 1 ? NLANES - 1 : idx);
+                v = vrow[idx];
+            }
+            acc = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, acc);
+        }
+        return acc;
+    } else {
+        static_assert(SHIFT_PX == 1 || SHIFT_PX == 2, "sub-float4 shifts are 1 or 2 px");
+        const float4 L = vrow[gl > 0 ? gl - 1 : 0];
+        const float4 R = vrow[gl < NLANES - 1 ? gl + 1 : NLANES - 1];
+        const float e[12] = {L.x, L.y, L.z, L.w, own.x, own.y, own.z, own.w, R.x, R.y, R.z, R.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float acc = wt_tap<K>(0) * e[4 + k - hw * SHIFT_PX];
+#pragma unroll
+            for (int j = 1; j < K; ++j) acc = fmaf(wt_tap<K>(j), e[4 + k + (j - hw) * SHIFT_PX], acc);
+            o[k] = acc;
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// vertical window of scale A: 2^A interleaved sub-chains, K-1 stored rows each
+template <int K, int A>
+struct VWin {
+    float4 w[1 << A][K - 1];
+};
+
+template <int K, int NS, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
+{
+    constexpr int hw = K / 2;
+    constexpr int KM = K - 1;
+    constexpr int LAT = hw * ((1 << NS) - 1);            // cascade latency in chain steps
+    constexpr int HX = (hw * ((1 << NS) - 1) * D + 3) / 4 * 4;  // x halo, rounded to float4
+    constexpr int U = KM << (NS - 1);                    // register-rotation period
+    constexpr int PD = 4;                                // rows prefetched ahead
+    constexpr int NL = NW * 64;                          // lanes (float4 columns) per WG
+    static_assert(U % PD == 0, "prefetch depth must divide the unroll period");
+
+    __shared__ float4 vbuf[NS][NL];
+
+    const Geo g = a.g;
+    const int gl = threadIdx.x;                          // lane index within the WG row
+    const int X0 = blockIdx.x * a.Vx;                    // first valid pixel of this x-strip
+    const int x = X0 - HX + 4 * gl;                      // this lane's first pixel (may be < 0)
+    const int item = blockIdx.y;
+    const int q = item % D;                              // chain phase
+    const int chunk = item / D;
+    if (q >= g.nrows) return;                            // whole WG exits together
+    const int n_q = (g.nrows - q + D - 1) / D;           // chain length
+    const int r0 = chunk * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+
+    const bool lane_store = (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
+    // Every lane issues ONE aligned in-bounds dwordx4 per row; lanes whose 4 pixels are not
+    // all inside the image (reflected halo at the image border, ragged right edge) patch the
+    // value with a reflected gather under a wave-uniform branch (border waves only).
+    const bool lane_interior = (x >= 0) && (x + 3 < g.W);
+    const bool wave_has_edge = !__all(lane_interior);
+    const int xc = min(max(x, 0), g.P - 4);
+    const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + 2, g.W),
+              xi3 = wt_refl(x + 3, g.W);
+    const int gy0 = g.row0 + q;                          // global row of chain element 0
+
+    const int t_last = r1 - 1 + hw * ((1 << NS) - 1);   // last input row any stored output needs
+    auto load_row = [&](int t) -> float4 {
+        // steps past t_last only flush the unroll/prefetch padding: keep the address in range
+        const float *row = wt_row(a.in, g, gy0 + D * min(t, t_last));
+        float4 v = *reinterpret_cast<const float4 *>(row + xc);
+        if (wave_has_edge) {
+            if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
+        }
+        return v;
+    };
+
+    constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0;
+    VWin<K, 0> w0;
+    VWin<K, A1> w1;
+    VWin<K, A2> w2;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+        w0.w[0][j] = zero;
+#pragma unroll
+        for (int r = 0; r < (1 << A1); ++r) w1.w[r][j] = zero;
+#pragma unroll
+        for (int r = 0; r < (1 << A2); ++r) w2.w[r][j] = zero;
+    }
+
+    const int t0 = r0 - LAT;                             // first input chain index
+    const int nsteps = ((r1 - r0) + 2 * LAT + U - 1) / U * U;
+    float4 pf[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
+
+    for (int kb = 0; kb < nsteps; kb += U) {
+#pragma unroll
+        for (int kk = 0; kk < U; ++kk) {
+            const int t = t0 + kb + kk;
+            float4 cur = pf[kk % PD];
+            pf[kk % PD] = load_row(t + PD);
+
+            // ---------------- scale 0
+            {
+                constexpr int A = 0;
+                const int p = kk % KM;
+                float4 *w = w0.w[0];
+                float4 v = f4_scale(wt_tap<K>(0), w[p]);
+#pragma unroll
+                for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
+                v = f4_fma(wt_tap<K>(KM), cur, v);
+                const float4 cen = w[(p + hw) % KM];
+                w[p] = cur;
+                vbuf[A][gl] = v;
+                __syncthreads();
+                const float4 nxt = wt_hfilter_lds<K, D << A, NL>(vbuf[A], gl, v);
+                const int ro = t - hw * ((2 << A) - 1);
+                if (ro >= r0 && ro < r1 && lane_store) {
+                    const int64_t off = (int64_t)(q + D * ro) * g.P;
+                    wt_store4(a.out_w[A] + off, x, g.W, f4_sub(cen, nxt));
+                    if (NS == 1) wt_store4(a.out_c + off, x, g.W, nxt);
+                }
+                cur = nxt;
+            }
+            // ---------------- scale 1
+            if constexpr (NS > 1) {
+                constexpr int A = 1;
+                const int rho = kk % 2;
+                const int p = (kk / 2) % KM;
+                float4 *w = w1.w[rho];
+                float4 v = f4_scale(wt_tap<K>(0), w[p]);
+#pragma unroll
+                for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
+                v = f4_fma(wt_tap<K>(KM), cur, v);
+                const float4 cen = w[(p + hw) % KM];
+                w[p] = cur;
+                vbuf[A][gl] = v;
+                __syncthreads();
+                const float4 nxt = wt_hfilter_lds<K, D << A, NL>(vbuf[A], gl, v);
+                const int ro = t - hw * ((2 << A) - 1);
+                if (ro >= r0 && ro < r1 && lane_store) {
+                    const int64_t off = (int64_t)(q + D * ro) * g.P;
+                    wt_store4(a.out_w[A] + off, x, g.W, f4_sub(cen, nxt));
+                    if (NS == 2) wt_store4(a.out_c + off, x, g.W, nxt);
+                }
+                cur = nxt;
+            }
+            // ---------------- scale 2
+            if constexpr (NS > 2) {
+                constexpr int A = 2;
+                const int rho = kk % 4;
+                const int p = (kk / 4) % KM;
+                float4 *w = w2.w[rho];
+                float4 v = f4_scale(wt_tap<K>(0), w[p]);
+#pragma unroll
+                for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
+                v = f4_fma(wt_tap<K>(KM), cur, v);
+                const float4 cen = w[(p + hw) % KM];
+                w[p] = cur;
+                vbuf[A][gl] = v;
+                __syncthreads();
+                const float4 nxt = wt_hfilter_lds<K, D << A, NL>(vbuf[A], gl, v);
+                const int ro = t - hw * ((2 << A) - 1);
+                if (ro >= r0 && ro < r1 && lane_store) {
+                    const int64_t off = (int64_t)(q + D * ro) * g.P;
+                    wt_store4(a.out_w[A] + off, x, g.W, f4_sub(cen, nxt));
+                    wt_store4(a.out_c + off, x, g.W, nxt);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline bool wt_fused_supported(const wt_plan *) { return true; }
+
+template <int K, int NS, int D, int NW>
+static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name)
+{
+    constexpr int hw = K / 2;
+    constexpr int LAT = hw * ((1 << NS) - 1);
+    constexpr int HX = (hw * ((1 << NS) - 1) * D + 3) / 4 * 4;
+    constexpr int NL = NW * 64;
+    constexpr int VXMAX = NL * 4 - 2 * HX;               // widest valid strip per WG
+    static_assert(VXMAX >= 64, "workgroup too narrow for this halo");
+    const Geo &g = p->g;
+    FusedArgs a = base;
+    const int W4 = (g.W + 3) / 4 * 4;
+    const int nx = (W4 + VXMAX - 1) / VXMAX;
+    a.Vx = ((W4 + nx - 1) / nx + 3) / 4 * 4;             // balanced strips, multiple of 4
+    const int phases = std::min(D, g.nrows);
+    const int n_max = (g.nrows + D - 1) / D;             // longest chain
+    // one round: as many workgroups as the chip holds at once (256 CUs x resident WGs/CU)
+    const int wg_per_cu = std::max(1, 8 / NW);
+    const int slots = 256 * wg_per_cu;
+    int chunks = std::max(1, slots / std::max(1, nx * phases));
+    int S = (n_max + chunks - 1) / chunks;
+    S = std::max(S, std::min(n_max, 2 * LAT));           // keep warm-up <= ~50 % of a chunk
+    chunks = (n_max + S - 1) / S;
+    a.S = S;
+    a.chunks = chunks;
+    const int64_t gy = (int64_t)D * chunks;
+    if (gy > 65535) WT_FAIL("fused pass: grid too large");
+    dim3 grid(nx, (unsigned)gy), block(NL);
+    ProfScope ps(p->ctx, name);
+    hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW>), grid, block, 0, p->ctx->stream, a);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+#ifndef WT_FUSED_NW
+#define WT_FUSED_NW 4
+#endif
+
+static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns)
+{
+    FusedArgs a{};
+    a.in = in;
+    a.out_c = out_c;
+    for (int i = 0; i < ns; ++i) a.out_w[i] = out_w[i];
+    a.g = p->g;
+    constexpr int NW = WT_FUSED_NW;
+    const bool b3 = p->family == WT_B3SPLINE;
+    if (s0 == 0 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 1, NW>(p, a, "wt_fused<d1x3>") : wt_fused_launch_t<3, 3, 1, NW>(p, a, "wt_fused<d1x3>");
+    if (s0 == 0 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 1, NW>(p, a, "wt_fused<d1x2>") : wt_fused_launch_t<3, 2, 1, NW>(p, a, "wt_fused<d1x2>");
+    if (s0 == 3 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 8, NW>(p, a, "wt_fused<d8x3>") : wt_fused_launch_t<3, 3, 8, NW>(p, a, "wt_fused<d8x3>");
+    if (s0 == 3 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 8, NW>(p, a, "wt_fused<d8x2>") : wt_fused_launch_t<3, 2, 8, NW>(p, a, "wt_fused<d8x2>");
+    WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
