@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override image side (testing)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per scale")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--brief", action="store_true", help="one short line (tuning sweeps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,9 +222,13 @@ def main():
             step()
             plan.download(PLANE_OUT, recon)
             out["pcie_inclusive_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
-            if not args.no_cpu:
+            if not args.no_cpu and not args.brief:
                 out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        if args.brief:
+            print(f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
+                f"{k}={v['avg_ms']}" for k, v in kernels.items()), flush=True)
+        else:
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -112,6 +112,9 @@ int wt_halo_exchange(wt_plan *plan, int plane, int64_t rows);
  * flags: bit0 = allow fused multi-scale passes (default path), bit1 = skip halo exchange
  * (caller did it / virtual strips). */
 int wt_decompose(wt_plan *plan, int src, int level, int flags);
+/* one pass of the schedule (wt_schedule): scales [s0,s0+ns) from plane `cur` (c_{s0}) into
+ * detail planes s0..s0+ns-1 and plane `nxt` (c_{s0+ns}); exchanges the pass halo first. */
+int wt_decompose_pass(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags);
 /* one scale of the above on explicit planes (per-scale operator; virtual-strip tests):
  * dst_c <- h_s (*) src ; dst_w <- src - dst_c (dst_w may be WT_PLANE_NONE). */
 int wt_atrous_scale(wt_plan *plan, int src, int dst_c, int dst_w, int s, int flags);

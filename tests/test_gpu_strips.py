@@ -1,0 +1,133 @@
+"""GPU: the sharded path must equal the unsharded path BIT FOR BIT.
+
+"Virtual strips": k strip plans (rank i of k) live on the one GPU the test box has; the RCCL
+send/recv group of wt_halo_exchange is replaced by wt_halo_exchange_local (device-to-device
+copies of exactly the same rows into exactly the same margins) and every kernel runs with
+FLAG_NO_EXCHANGE.  Everything else - strip geometry, margins, global-border reflection,
+chain/fused kernels reading neighbour rows from the margins - is the production path.
+The RCCL transport itself is covered by test_rccl_single_rank_selftest and, on CPU, the
+schedule/partition logic by tests/test_strips_gloo_cpu.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as entry
+    entry.build()
+    from wavelets_amd import _lib
+    return _lib
+
+
+def rnd(shape, seed=0):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def make_strips(L, ctx, img, fam, level, k, halo=0):
+    from wavelets_amd.parallel import partition_rows
+    H, W = img.shape
+    plans = []
+    for r, (row0, n) in enumerate(partition_rows(H, k)):
+        p = L.Plan(ctx, H, W, fam, level, row0=row0, nrows=n, halo_rows=halo, rank=r, nranks=k)
+        p.upload(L.PLANE_INPUT, img[row0:row0 + n])
+        plans.append(p)
+    return plans
+
+
+def exchange_all(L, plans, plane, rows):
+    for up, lo in zip(plans[:-1], plans[1:]):
+        L.Plan.halo_exchange_local(up, lo, plane, rows)
+
+
+def gather(plans, plane):
+    return np.concatenate([p.download(plane) for p in plans])
+
+
+@pytest.mark.parametrize("fam_name,level,fused,k,shape", [
+    ("b3spline", 6, True, 2, (512, 300)),
+    ("b3spline", 6, True, 4, (1024, 1030)),
+    ("b3spline", 5, True, 3, (700, 257)),
+    ("triangle", 8, True, 2, (1024, 192)),
+    ("b3spline", 4, False, 3, (200, 130)),
+    ("triangle", 3, False, 5, (170, 64)),
+])
+def test_sharded_decompose_equals_unsharded_bitwise(L, fam_name, level, fused, k, shape):
+    fam = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam_name]
+    ctx = L.default_context()
+    img = rnd(shape, 11)
+    flags = L.FLAG_FUSED if fused else 0
+    whole = L.Plan(ctx, shape[0], shape[1], fam, level)
+    whole.upload(L.PLANE_INPUT, img)
+    whole.decompose(L.PLANE_INPUT, level, flags)
+
+    plans = make_strips(L, ctx, img, fam, level, k)
+    cur = L.PLANE_INPUT
+    for i, (s0, ns, halo) in enumerate(L.schedule(fam, level, fused)):
+        nxt = level if s0 + ns == level else L.PLANE_SCRATCH(i & 1)
+        exchange_all(L, plans, cur, halo)
+        for p in plans:
+            p.decompose_pass(cur, nxt, s0, ns, flags | L.FLAG_NO_EXCHANGE)
+        cur = nxt
+    for s in range(level + 1):
+        np.testing.assert_array_equal(gather(plans, s), whole.download(s), err_msg=f"plane {s}")
+    # plane sum is pointwise: trivially shards
+    for p in plans:
+        p.plane_sum(0, level + 1)
+    whole.plane_sum(0, level + 1)
+    np.testing.assert_array_equal(gather(plans, L.PLANE_OUT), whole.download(L.PLANE_OUT))
+
+
+def test_sharded_operators_equal_unsharded(L):
+    """smooth / smooth of squares / local variance / bilateral conv on strips with halos"""
+    fam = L.B3SPLINE
+    ctx = L.default_context()
+    img = rnd((640, 200), 12)
+    whole = L.Plan(ctx, 640, 200, fam, 0)
+    whole.upload(L.PLANE_INPUT, img)
+    plans = make_strips(L, ctx, img, fam, 0, 4, halo=64)
+    S0, S1 = L.PLANE_SCRATCH(3), L.PLANE_SCRATCH(4)
+    for s in (0, 2, 5):
+        exchange_all(L, plans, L.PLANE_INPUT, 2 << s)
+        for sq in (False, True):
+            whole.smooth(L.PLANE_INPUT, S0, s, sq)
+            for p in plans:
+                p.smooth(L.PLANE_INPUT, S0, s, sq, flags=L.FLAG_NO_EXCHANGE)
+            np.testing.assert_array_equal(gather(plans, S0), whole.download(S0))
+        whole.local_variance(L.PLANE_INPUT, S0, s, 1.5, 2.0)
+        whole.bilateral_conv(L.PLANE_INPUT, S0, S1, s)
+        for p in plans:
+            p.local_variance(L.PLANE_INPUT, S0, s, 1.5, 2.0, flags=L.FLAG_NO_EXCHANGE)
+            p.bilateral_conv(L.PLANE_INPUT, S0, S1, s, flags=L.FLAG_NO_EXCHANGE)
+        np.testing.assert_array_equal(gather(plans, S0), whole.download(S0))
+        np.testing.assert_array_equal(gather(plans, S1), whole.download(S1))
+
+
+def test_strip_errors(L):
+    ctx = L.default_context()
+    with pytest.raises(L.WatrooHipError, match="single strip must cover"):
+        L.Plan(ctx, 64, 64, L.B3SPLINE, 2, row0=0, nrows=32)
+    p = L.Plan(ctx, 256, 64, L.B3SPLINE, 6, row0=0, nrows=128, rank=0, nranks=2)
+    assert p.halo == 112                           # cumulative halo of the (3,3) fused pass
+    with pytest.raises(L.WatrooHipError, match="no RCCL communicator"):
+        p.decompose(L.PLANE_INPUT, 6)              # multi-rank plan needs wt_ctx_comm_init
+    q = L.Plan(ctx, 256, 64, L.B3SPLINE, 2, row0=0, nrows=128, halo_rows=4, rank=0, nranks=2)
+    with pytest.raises(L.WatrooHipError, match="halo"):
+        q.smooth(L.PLANE_INPUT, L.PLANE_OUT, 4, flags=L.FLAG_NO_EXCHANGE)   # needs 32 rows
+
+
+def test_strip_transform_single_rank(L):
+    """StripTransform with nranks == 1 is the plain engine (what bench.py runs at N=1)."""
+    from oracle import atrous_numpy as O
+    from wavelets_amd.parallel import StripTransform
+    img = rnd((256, 192), 13)
+    st = StripTransform(L.default_context(), 256, 192, 4)
+    st.upload(img)
+    st.decompose()
+    ref = O.Coeffs(O.atrous_standard(img, 4), "b3spline")
+    np.testing.assert_allclose(st.get_noise(), ref.get_noise(), rtol=1e-5)
+    st.denoise([5, 3])
+    ref.denoise([5, 3])
+    np.testing.assert_allclose(st.sum(), ref.data.sum(axis=0), atol=1e-5 * np.abs(img).max())

@@ -1,0 +1,100 @@
+// HBM streaming microbenchmark: ceilings for the read/write mixes of the a-trous kernels.
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/membench tools/membench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+struct Ptrs { float4 *p[12]; };
+__device__ __forceinline__ float4 ntload(const float4 *p) { vf4 v = __builtin_nontemporal_load((const vf4 *)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void ntstore(float4 o, float4 *p) { vf4 v = {o.x, o.y, o.z, o.w}; __builtin_nontemporal_store(v, (vf4 *)p); }
+
+template <int NR, int NWR, int UNROLL, int NT>
+__global__ __launch_bounds__(256) void stream_kernel(Ptrs in, Ptrs out, long n4)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride * UNROLL) {
+        float4 acc[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc[u] = make_float4(0, 0, 0, 0);
+            const long j = i + u * stride;
+            if (j < n4) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    float4 v = (NT & 1) ? ntload(&in.p[r][j]) : in.p[r][j];
+                    acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long j = i + u * stride;
+            if (j < n4) {
+#pragma unroll
+                for (int w = 0; w < NWR; ++w) {
+                    float4 o = acc[u]; o.x += w;
+                    if (NT & 2) ntstore(o, &out.p[w][j]); else out.p[w][j] = o;
+                }
+            }
+        }
+    }
+}
+
+// block-contiguous variant: each block streams a contiguous tile of `tile` float4
+template <int NR, int NWR>
+__global__ __launch_bounds__(256) void tile_kernel(Ptrs in, Ptrs out, long n4, long tile)
+{
+    const long b0 = (long)blockIdx.x * tile;
+    const long b1 = min(b0 + tile, n4);
+    for (long i = b0 + threadIdx.x; i < b1; i += 256) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { float4 v = in.p[r][i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+#pragma unroll
+        for (int w = 0; w < NWR; ++w) { float4 o = acc; o.x += w; out.p[w][i] = o; }
+    }
+}
+
+template <typename F>
+static double timeit(F f, int reps = 20)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+    const long side = argc > 1 ? atol(argv[1]) : 8192;
+    const long n4 = side * side / 4;
+    const size_t bytes = (size_t)n4 * 16;
+    Ptrs in{}, out{};
+    for (int i = 0; i < 8; ++i) { CK(hipMalloc(&in.p[i], bytes)); CK(hipMemset(in.p[i], 0, bytes)); }
+    for (int i = 0; i < 5; ++i) { CK(hipMalloc(&out.p[i], bytes)); }
+    printf("plane %ld x %ld (%.0f MiB)\n", side, side, bytes / 1048576.0);
+#define RUN(NR, NWR, UN, NT, GRID)                                                              \
+    {                                                                                           \
+        double ms = timeit([&] { hipLaunchKernelGGL((stream_kernel<NR, NWR, UN, NT>), dim3(GRID), dim3(256), 0, 0, in, out, n4); }); \
+        printf("R%d W%d unroll%d nt%d grid%-6d : %.4f ms  %.0f GB/s\n", NR, NWR, UN, NT, GRID, ms, (NR + NWR) * (double)bytes / ms / 1e6); \
+    }
+    RUN(7, 1, 1, 0, 2048) RUN(7, 1, 1, 1, 2048) RUN(7, 1, 1, 2, 2048) RUN(7, 1, 1, 3, 2048)
+    RUN(7, 1, 1, 1, 8192) RUN(7, 1, 1, 1, 16384) RUN(7, 1, 1, 1, 65536) RUN(7, 1, 1, 3, 16384) RUN(7, 1, 1, 3, 65536) RUN(7, 1, 1, 3, 262144)
+    RUN(7, 1, 1, 1, 512) RUN(7, 1, 1, 1, 1024) RUN(7, 1, 1, 3, 1024)
+    RUN(1, 4, 1, 0, 2048) RUN(1, 4, 1, 1, 2048) RUN(1, 4, 1, 0, 16384) RUN(1, 4, 1, 0, 65536) RUN(1, 4, 1, 1, 65536)
+    RUN(1, 1, 1, 0, 65536) RUN(1, 1, 1, 1, 65536) RUN(1, 1, 1, 3, 65536) RUN(1, 1, 1, 0, 262144)
+    for (long tile : {4096L, 16384L, 65536L}) {
+        long grid = (n4 + tile - 1) / tile;
+        double ms = timeit([&] { hipLaunchKernelGGL((tile_kernel<7, 1>), dim3(grid), dim3(256), 0, 0, in, out, n4, tile); });
+        printf("tile R7 W1 tile%ld grid%ld : %.4f ms %.0f GB/s\n", tile, grid, ms, 8 * (double)bytes / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((tile_kernel<1, 4>), dim3(grid), dim3(256), 0, 0, in, out, n4, tile); });
+        printf("tile R1 W4 tile%ld grid%ld : %.4f ms %.0f GB/s\n", tile, grid, ms, 5 * (double)bytes / ms / 1e6);
+    }
+    return 0;
+}

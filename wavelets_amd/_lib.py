@@ -65,6 +65,7 @@ SIGNATURES = {
     "wt_halo_exchange_local": (_c.c_int, [_vp, _vp, _c.c_int, _i64]),
     "wt_halo_exchange": (_c.c_int, [_vp, _c.c_int, _i64]),
     "wt_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_decompose_pass": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_atrous_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float,
@@ -285,6 +286,9 @@ class Plan:
     # ---- hot path
     def decompose(self, src, level, flags=FLAG_FUSED):
         check(load().wt_decompose(self._h, src, level, flags))
+
+    def decompose_pass(self, cur, nxt, s0, ns, flags=FLAG_FUSED):
+        check(load().wt_decompose_pass(self._h, cur, nxt, s0, ns, flags))
 
     def atrous_scale(self, src, dst_c, dst_w, s, flags=0):
         check(load().wt_atrous_scale(self._h, src, dst_c, dst_w, s, flags))

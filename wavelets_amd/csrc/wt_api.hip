@@ -310,7 +310,12 @@ static int plan_alloc(wt_plan *p, float **slot)
 {
     if (*slot) return 0;
     WT_HIP(hipSetDevice(p->ctx->device));
-    WT_HIP(hipMalloc(slot, p->plane_floats * sizeof(float)));
+    void *raw = nullptr;
+    const size_t skew_max = p->skew_floats * 16;
+    WT_HIP(hipMalloc(&raw, (p->plane_floats + skew_max) * sizeof(float)));
+    p->raw_allocs.push_back(raw);
+    *slot = (float *)raw + p->skew_floats * (size_t)(p->n_allocs % 16);
+    p->n_allocs++;
     return 0;
 }
 
@@ -362,6 +367,13 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
     p->rank = rank;
     p->nranks = nranks;
     p->plane_floats = (size_t)(nrows + 2 * halo) * (size_t)P;
+    {
+        // default skew: 4 KiB + 256 B per plane index (keeps 16-byte alignment); WT_PLANE_SKEW
+        // (bytes, multiple of 16) overrides it for experiments
+        const char *e = getenv("WT_PLANE_SKEW");
+        size_t skew_bytes = e ? (size_t)atoll(e) : 4352;
+        p->skew_floats = (skew_bytes / 16 * 16) / 4;
+    }
     p->coef.assign(max_level + 1, nullptr);
     for (int i = 0; i <= max_level; ++i) {
         int rc = plan_alloc(p, &p->coef[i]);
@@ -384,10 +396,7 @@ extern "C" int wt_plan_destroy(wt_plan *p)
     if (!p) return 0;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    for (float *q : p->coef) (void)hipFree(q);
-    (void)hipFree(p->input);
-    (void)hipFree(p->out);
-    for (float *q : p->scratch) (void)hipFree(q);
+    for (void *q : p->raw_allocs) (void)hipFree(q);
     delete p;
     return 0;
 }
@@ -670,6 +679,34 @@ extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, i
 // =============================================================================================
 // decomposition drivers
 // =============================================================================================
+// One pass of the schedule: scales [s0, s0+ns) from plane `cur` (= c_{s0}) into the detail
+// planes s0..s0+ns-1 and plane `nxt` (= c_{s0+ns}).
+extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, int flags)
+{
+    if (!p) WT_FAIL("wt_decompose_pass: null plan");
+    if (ns < 1 || ns > WT_FUSED_MAX_SCALES || s0 < 0 || s0 + ns - 1 > p->max_level)
+        WT_FAIL("wt_decompose_pass: scales [%d,%d) outside the plan (max_level %d)", s0, s0 + ns, p->max_level);
+    if (cur == nxt || (cur >= s0 && cur < s0 + ns) || (nxt >= s0 && nxt < s0 + ns))
+        WT_FAIL("wt_decompose_pass: input/output planes alias the detail planes of the pass");
+    const int hw = family_taps(p->family) / 2;
+    const int halo = hw * ((1 << (s0 + ns)) - (1 << s0));
+    if (p->nranks > 1 && halo > p->g.halo) WT_FAIL("wt_decompose_pass: pass needs %d halo rows, plan has %d", halo, p->g.halo);
+    WT_TRY(maybe_exchange(p, cur, halo, flags));
+    float *in = nullptr, *oc = nullptr;
+    WT_TRY(plane_base(p, cur, &in));
+    WT_TRY(plane_base(p, nxt, &oc));
+    if (ns == 1) {
+        WT_TRY(check_scale(p, s0, "wt_decompose_pass"));
+        float *ow = nullptr;
+        WT_TRY(plane_base(p, s0, &ow));
+        return launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>");
+    }
+    if (!(s0 == 0 || s0 == 3) || ns < 2) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
+    float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
+    for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
+    return wt_fused_launch(p, in, oc, ow, s0, ns);
+}
+
 extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
 {
     if (!p) WT_FAIL("wt_decompose: null plan");
@@ -682,23 +719,9 @@ extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
     WT_TRY(wt_schedule(p->family, level, (flags & 1) && wt_fused_supported(p), tr, 32, &np));
     int cur = src;  // plane holding c_s
     for (int i = 0; i < np; ++i) {
-        const int s0 = tr[3 * i], ns = tr[3 * i + 1], halo = tr[3 * i + 2];
-        const bool last = (s0 + ns == level);
-        const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
-        if (p->nranks > 1 && halo > p->g.halo) WT_FAIL("wt_decompose: pass %d needs %d halo rows, plan has %d", i, halo, p->g.halo);
-        WT_TRY(maybe_exchange(p, cur, halo, flags));
-        float *in = nullptr, *oc = nullptr;
-        WT_TRY(plane_base(p, cur, &in));
-        WT_TRY(plane_base(p, nxt, &oc));
-        if (ns == 1) {
-            float *ow = nullptr;
-            WT_TRY(plane_base(p, s0, &ow));
-            WT_TRY(launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>"));
-        } else {
-            float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
-            for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
-            WT_TRY(wt_fused_launch(p, in, oc, ow, s0, ns));
-        }
+        const int s0 = tr[3 * i], ns = tr[3 * i + 1];
+        const int nxt = (s0 + ns == level) ? level : WT_PLANE_SCRATCH(i & 1);
+        WT_TRY(wt_decompose_pass(p, cur, nxt, s0, ns, flags));
         cur = nxt;
     }
     return 0;
@@ -750,7 +773,9 @@ extern "C" int wt_plane_sum(wt_plan *p, int first, int count, int dst)
     WT_TRY(plane_base(p, dst, &o));
     const int64_t n4 = plan_n4(p);
     ProfScope ps(p->ctx, "wt_plane_sum_kernel");
-    hipLaunchKernelGGL(wt_plane_sum_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, a, o, n4);
+    static const int64_t sum_grid = getenv("WT_SUM_GRID") ? atoll(getenv("WT_SUM_GRID")) : ((int64_t)1 << 30);
+    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, sum_grid);
+    hipLaunchKernelGGL(wt_plane_sum_kernel, dim3(grid), dim3(256), 0, p->ctx->stream, a, o, n4);
     WT_HIP(hipGetLastError());
     return 0;
 }

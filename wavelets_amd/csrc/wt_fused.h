@@ -87,6 +87,44 @@ struct VWin {
     float4 w[1 << A][K - 1];
 };
 
+typedef unsigned int wt_v4u __attribute__((ext_vector_type(4)));
+typedef float wt_v4f __attribute__((ext_vector_type(4)));
+
+// Branch-free predicated 16-byte store through a raw buffer descriptor built from wave-uniform
+// values: a row that must not be written gets a zero-length descriptor, a lane that must not
+// write gets an out-of-range offset; the hardware range check drops those stores.  Control
+// flow stays uniform, so the compiler's vmcnt bookkeeping is exact (loads stay in flight
+// across the stores and barriers of several steps).
+__device__ __forceinline__ void wt_bstore4(float *row, bool row_ok, int row_bytes, unsigned voff, float4 v)
+{
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_ok ? row_bytes : 0, 0x00020000);
+    wt_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, 0);
+}
+
+// One scale of one step: push `cur` (row t of c_{s0+A}) into the vertical window, form the
+// vertically filtered row (centred hw*2^A steps back), exchange it through LDS, filter
+// horizontally -> row of c_{s0+A+1}; `cen` returns the matching row of c_{s0+A}.
+template <int K, int A, int D, int NL>
+__device__ __forceinline__ float4 wt_fused_stage(VWin<K, A> &win, const int kk, const float4 cur,
+                                                 float4 *vrow, const int gl, float4 &cen)
+{
+    constexpr int hw = K / 2;
+    constexpr int KM = K - 1;
+    const int rho = kk % (1 << A);
+    const int p = (kk >> A) % KM;
+    float4 *w = win.w[rho];
+    float4 v = f4_scale(wt_tap<K>(0), w[p]);
+#pragma unroll
+    for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
+    v = f4_fma(wt_tap<K>(KM), cur, v);
+    cen = w[(p + hw) % KM];
+    w[p] = cur;
+    vrow[gl] = v;
+    __syncthreads();
+    return wt_hfilter_lds<K, (D << A), NL>(vrow, gl, v);
+}
+
 template <int K, int NS, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
 {
@@ -114,7 +152,11 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
     const int r1 = min(r0 + a.S, n_q);
     if (r0 >= r1) return;
 
+    // lanes that own stored pixels; a float4 that straddles W writes into the row's pitch
+    // padding (allocated, never read as image data)
     const bool lane_store = (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
+    const unsigned voff = lane_store ? (unsigned)x * 4u : 0xfffffff0u;
+    const int row_bytes = g.P * 4;
     // Every lane issues ONE aligned in-bounds dwordx4 per row; lanes whose 4 pixels are not
     // all inside the image (reflected halo at the image border, ragged right edge) patch the
     // value with a reflected gather under a wave-uniform branch (border waves only).
@@ -125,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
               xi3 = wt_refl(x + 3, g.W);
     const int gy0 = g.row0 + q;                          // global row of chain element 0
 
-    const int t_last = r1 - 1 + hw * ((1 << NS) - 1);   // last input row any stored output needs
+    const int t_last = r1 - 1 + LAT;                     // last input row any stored output needs
     auto load_row = [&](int t) -> float4 {
         // steps past t_last only flush the unroll/prefetch padding: keep the address in range
         const float *row = wt_row(a.in, g, gy0 + D * min(t, t_last));
@@ -134,6 +176,12 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
             if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
         }
         return v;
+    };
+    // predicated store of chain row `ro` of plane `base`
+    auto store_row = [&](float *base, int ro, float4 v) {
+        const bool ok = (ro >= r0) && (ro < r1);
+        const int rc = min(max(ro, r0), r1 - 1);
+        wt_bstore4(base + (int64_t)(q + D * rc) * g.P, ok, row_bytes, voff, v);
     };
 
     constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0;
@@ -162,73 +210,22 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
             const int t = t0 + kb + kk;
             float4 cur = pf[kk % PD];
             pf[kk % PD] = load_row(t + PD);
-
-            // ---------------- scale 0
-            {
-                constexpr int A = 0;
-                const int p = kk % KM;
-                float4 *w = w0.w[0];
-                float4 v = f4_scale(wt_tap<K>(0), w[p]);
-#pragma unroll
-                for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
-                v = f4_fma(wt_tap<K>(KM), cur, v);
-                const float4 cen = w[(p + hw) % KM];
-                w[p] = cur;
-                vbuf[A][gl] = v;
-                __syncthreads();
-                const float4 nxt = wt_hfilter_lds<K, D << A, NL>(vbuf[A], gl, v);
-                const int ro = t - hw * ((2 << A) - 1);
-                if (ro >= r0 && ro < r1 && lane_store) {
-                    const int64_t off = (int64_t)(q + D * ro) * g.P;
-                    wt_store4(a.out_w[A] + off, x, g.W, f4_sub(cen, nxt));
-                    if (NS == 1) wt_store4(a.out_c + off, x, g.W, nxt);
-                }
-                cur = nxt;
-            }
-            // ---------------- scale 1
+            float4 cen, nxt;
+            // scale s0: row t in -> rows t - hw of w_{s0} / c_{s0+1}
+            nxt = wt_fused_stage<K, 0, D, NL>(w0, kk, cur, vbuf[0], gl, cen);
+            store_row(a.out_w[0], t - hw, f4_sub(cen, nxt));
+            if constexpr (NS == 1) store_row(a.out_c, t - hw, nxt);
             if constexpr (NS > 1) {
-                constexpr int A = 1;
-                const int rho = kk % 2;
-                const int p = (kk / 2) % KM;
-                float4 *w = w1.w[rho];
-                float4 v = f4_scale(wt_tap<K>(0), w[p]);
-#pragma unroll
-                for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
-                v = f4_fma(wt_tap<K>(KM), cur, v);
-                const float4 cen = w[(p + hw) % KM];
-                w[p] = cur;
-                vbuf[A][gl] = v;
-                __syncthreads();
-                const float4 nxt = wt_hfilter_lds<K, D << A, NL>(vbuf[A], gl, v);
-                const int ro = t - hw * ((2 << A) - 1);
-                if (ro >= r0 && ro < r1 && lane_store) {
-                    const int64_t off = (int64_t)(q + D * ro) * g.P;
-                    wt_store4(a.out_w[A] + off, x, g.W, f4_sub(cen, nxt));
-                    if (NS == 2) wt_store4(a.out_c + off, x, g.W, nxt);
-                }
                 cur = nxt;
+                nxt = wt_fused_stage<K, A1, D, NL>(w1, kk, cur, vbuf[A1], gl, cen);
+                store_row(a.out_w[A1], t - 3 * hw, f4_sub(cen, nxt));
+                if constexpr (NS == 2) store_row(a.out_c, t - 3 * hw, nxt);
             }
-            // ---------------- scale 2
             if constexpr (NS > 2) {
-                constexpr int A = 2;
-                const int rho = kk % 4;
-                const int p = (kk / 4) % KM;
-                float4 *w = w2.w[rho];
-                float4 v = f4_scale(wt_tap<K>(0), w[p]);
-#pragma unroll
-                for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
-                v = f4_fma(wt_tap<K>(KM), cur, v);
-                const float4 cen = w[(p + hw) % KM];
-                w[p] = cur;
-                vbuf[A][gl] = v;
-                __syncthreads();
-                const float4 nxt = wt_hfilter_lds<K, D << A, NL>(vbuf[A], gl, v);
-                const int ro = t - hw * ((2 << A) - 1);
-                if (ro >= r0 && ro < r1 && lane_store) {
-                    const int64_t off = (int64_t)(q + D * ro) * g.P;
-                    wt_store4(a.out_w[A] + off, x, g.W, f4_sub(cen, nxt));
-                    wt_store4(a.out_c + off, x, g.W, nxt);
-                }
+                cur = nxt;
+                nxt = wt_fused_stage<K, A2, D, NL>(w2, kk, cur, vbuf[A2], gl, cen);
+                store_row(a.out_w[A2], t - 7 * hw, f4_sub(cen, nxt));
+                store_row(a.out_c, t - 7 * hw, nxt);
             }
         }
     }
@@ -257,7 +254,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     const int n_max = (g.nrows + D - 1) / D;             // longest chain
     // one round: as many workgroups as the chip holds at once (256 CUs x resident WGs/CU)
     const int wg_per_cu = std::max(1, 8 / NW);
-    const int slots = 256 * wg_per_cu;
+    static const int rounds = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 1;
+    const int slots = 256 * wg_per_cu * rounds;
     int chunks = std::max(1, slots / std::max(1, nx * phases));
     int S = (n_max + chunks - 1) / chunks;
     S = std::max(S, std::min(n_max, 2 * LAT));           // keep warm-up <= ~50 % of a chunk
@@ -273,9 +271,16 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     return 0;
 }
 
-#ifndef WT_FUSED_NW
-#define WT_FUSED_NW 4
-#endif
+template <int NW>
+static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
+{
+    const bool b3 = p->family == WT_B3SPLINE;
+    if (s0 == 0 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 1, NW>(p, a, "wt_fused<d1x3>") : wt_fused_launch_t<3, 3, 1, NW>(p, a, "wt_fused<d1x3>");
+    if (s0 == 0 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 1, NW>(p, a, "wt_fused<d1x2>") : wt_fused_launch_t<3, 2, 1, NW>(p, a, "wt_fused<d1x2>");
+    if (s0 == 3 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 8, NW>(p, a, "wt_fused<d8x3>") : wt_fused_launch_t<3, 3, 8, NW>(p, a, "wt_fused<d8x3>");
+    if (s0 == 3 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 8, NW>(p, a, "wt_fused<d8x2>") : wt_fused_launch_t<3, 2, 8, NW>(p, a, "wt_fused<d8x2>");
+    WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
+}
 
 static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns)
 {
@@ -284,11 +289,7 @@ static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **ou
     a.out_c = out_c;
     for (int i = 0; i < ns; ++i) a.out_w[i] = out_w[i];
     a.g = p->g;
-    constexpr int NW = WT_FUSED_NW;
-    const bool b3 = p->family == WT_B3SPLINE;
-    if (s0 == 0 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 1, NW>(p, a, "wt_fused<d1x3>") : wt_fused_launch_t<3, 3, 1, NW>(p, a, "wt_fused<d1x3>");
-    if (s0 == 0 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 1, NW>(p, a, "wt_fused<d1x2>") : wt_fused_launch_t<3, 2, 1, NW>(p, a, "wt_fused<d1x2>");
-    if (s0 == 3 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 8, NW>(p, a, "wt_fused<d8x3>") : wt_fused_launch_t<3, 3, 8, NW>(p, a, "wt_fused<d8x3>");
-    if (s0 == 3 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 8, NW>(p, a, "wt_fused<d8x2>") : wt_fused_launch_t<3, 2, 8, NW>(p, a, "wt_fused<d8x2>");
-    WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
+    static const int nw = getenv("WT_FUSED_NW") ? atoi(getenv("WT_FUSED_NW")) : 4;
+    if (nw == 8) return wt_fused_dispatch<8>(p, a, s0, ns);
+    return wt_fused_dispatch<4>(p, a, s0, ns);
 }

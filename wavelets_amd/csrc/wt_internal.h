@@ -89,9 +89,15 @@ struct wt_plan {
     int max_level = 0;
     int rank = 0, nranks = 1;
     size_t plane_floats = 0;                // (nrows + 2*halo) * P
-    std::vector<float *> coef;              // max_level+1 allocations (alloc base, incl. margin)
+    // Plane buffers (first margin row).  Each plane is its own allocation, skewed by a
+    // different multiple of `skew_floats` so that the same pixel of different planes does not
+    // map to the same HBM channel/bank (planes are otherwise exactly 2^k bytes apart).
+    std::vector<float *> coef;              // max_level+1 planes
     float *input = nullptr, *out = nullptr;
     float *scratch[WT_NUM_SCRATCH] = {nullptr};
+    std::vector<void *> raw_allocs;         // what hipFree gets
+    size_t skew_floats = 0;
+    int n_allocs = 0;
 };
 
 // Profiling bracket: records events around a kernel launch when ctx->profiling.
