@@ -102,12 +102,12 @@ __device__ __forceinline__ void wt_bstore4(float *row, bool row_ok, int row_byte
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, 0);
 }
 
-// One scale of one step: push `cur` (row t of c_{s0+A}) into the vertical window, form the
-// vertically filtered row (centred hw*2^A steps back), exchange it through LDS, filter
-// horizontally -> row of c_{s0+A+1}; `cen` returns the matching row of c_{s0+A}.
-template <int K, int A, int D, int NL>
-__device__ __forceinline__ float4 wt_fused_stage(VWin<K, A> &win, const int kk, const float4 cur,
-                                                 float4 *vrow, const int gl, float4 &cen)
+// Vertical half of one scale of one step: push `cur` (a row of c_{s0+A}) into the window and
+// return the vertically filtered row (centred hw*2^A steps back); `cen` = matching row of
+// c_{s0+A} (for the detail plane).
+template <int K, int A>
+__device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk, const float4 cur,
+                                                  float4 &cen)
 {
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
@@ -120,24 +120,27 @@ __device__ __forceinline__ float4 wt_fused_stage(VWin<K, A> &win, const int kk, 
     v = f4_fma(wt_tap<K>(KM), cur, v);
     cen = w[(p + hw) % KM];
     w[p] = cur;
-    vrow[gl] = v;
-    __syncthreads();
-    return wt_hfilter_lds<K, (D << A), NL>(vrow, gl, v);
+    return v;
 }
 
-template <int K, int NS, int D, int NW>
+// The NS scales are SOFTWARE-PIPELINED across steps: in step j scale a works on the row scale
+// a-1 produced in step j-1, so the NS vertical filters, the NS LDS row writes, ONE barrier and
+// the NS horizontal filters of a step are mutually independent (one s_barrier per row instead
+// of NS, 4*NS LDS reads in flight together).  LDS rows are double-buffered by step parity.
+template <int K, int NS, int D, int NW, int PDREQ>
 __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
 {
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
-    constexpr int LAT = hw * ((1 << NS) - 1);            // cascade latency in chain steps
+    constexpr int LAT_IN = hw * ((1 << NS) - 1);         // rows of input beyond a stored row
+    constexpr int LAT = LAT_IN + (NS - 1);               // + pipeline skew between the scales
     constexpr int HX = (hw * ((1 << NS) - 1) * D + 3) / 4 * 4;  // x halo, rounded to float4
     constexpr int U = KM << (NS - 1);                    // register-rotation period
-    constexpr int PD = 4;                                // rows prefetched ahead
+    constexpr int PD = (U % PDREQ == 0) ? PDREQ : 4;     // rows prefetched ahead
     constexpr int NL = NW * 64;                          // lanes (float4 columns) per WG
-    static_assert(U % PD == 0, "prefetch depth must divide the unroll period");
+    static_assert(U % PD == 0 && U % 2 == 0, "prefetch depth / LDS parity must divide the unroll period");
 
-    __shared__ float4 vbuf[NS][NL];
+    __shared__ float4 vbuf[2][NS][NL];
 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
               xi3 = wt_refl(x + 3, g.W);
     const int gy0 = g.row0 + q;                          // global row of chain element 0
 
-    const int t_last = r1 - 1 + LAT;                     // last input row any stored output needs
+    const int t_last = r1 - 1 + LAT_IN;                  // last input row any stored output needs
     auto load_row = [&](int t) -> float4 {
-        // steps past t_last only flush the unroll/prefetch padding: keep the address in range
+        // steps past t_last only flush the pipeline / unroll padding: keep the address in range
         const float *row = wt_row(a.in, g, gy0 + D * min(t, t_last));
         float4 v = *reinterpret_cast<const float4 *>(row + xc);
         if (wave_has_edge) {
@@ -198,35 +201,49 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
         for (int r = 0; r < (1 << A2); ++r) w2.w[r][j] = zero;
     }
 
-    const int t0 = r0 - LAT;                             // first input chain index
-    const int nsteps = ((r1 - r0) + 2 * LAT + U - 1) / U * U;
+    const int t0 = r0 - LAT_IN;                          // first input chain index
+    const int nsteps = ((r1 - r0) + LAT + LAT_IN + U - 1) / U * U;
     float4 pf[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
+    float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
 
     for (int kb = 0; kb < nsteps; kb += U) {
 #pragma unroll
         for (int kk = 0; kk < U; ++kk) {
             const int t = t0 + kb + kk;
-            float4 cur = pf[kk % PD];
+            const float4 cur = pf[kk % PD];
             pf[kk % PD] = load_row(t + PD);
-            float4 cen, nxt;
-            // scale s0: row t in -> rows t - hw of w_{s0} / c_{s0+1}
-            nxt = wt_fused_stage<K, 0, D, NL>(w0, kk, cur, vbuf[0], gl, cen);
-            store_row(a.out_w[0], t - hw, f4_sub(cen, nxt));
-            if constexpr (NS == 1) store_row(a.out_c, t - hw, nxt);
+            float4 (*buf)[NL] = vbuf[kk & 1];
+            float4 cen0, cen1, cen2, v0, v1, v2;
+            v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
+            buf[0][gl] = v0;
             if constexpr (NS > 1) {
-                cur = nxt;
-                nxt = wt_fused_stage<K, A1, D, NL>(w1, kk, cur, vbuf[A1], gl, cen);
-                store_row(a.out_w[A1], t - 3 * hw, f4_sub(cen, nxt));
-                if constexpr (NS == 2) store_row(a.out_c, t - 3 * hw, nxt);
+                v1 = wt_fused_vstage<K, A1>(w1, kk, c1, cen1);
+                buf[A1][gl] = v1;
             }
             if constexpr (NS > 2) {
-                cur = nxt;
-                nxt = wt_fused_stage<K, A2, D, NL>(w2, kk, cur, vbuf[A2], gl, cen);
-                store_row(a.out_w[A2], t - 7 * hw, f4_sub(cen, nxt));
-                store_row(a.out_c, t - 7 * hw, nxt);
+                v2 = wt_fused_vstage<K, A2>(w2, kk, c2, cen2);
+                buf[A2][gl] = v2;
             }
+            __syncthreads();
+            // scale s0: input row t -> row t - hw of w_{s0} / c_{s0+1}
+            const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
+            store_row(a.out_w[0], t - hw, f4_sub(cen0, n0));
+            if constexpr (NS == 1) store_row(a.out_c, t - hw, n0);
+            if constexpr (NS > 1) {
+                // scale s0+1 consumed row (t-1) - hw of c_{s0+1} -> row t - 1 - 3 hw
+                const float4 n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
+                store_row(a.out_w[A1], t - 1 - 3 * hw, f4_sub(cen1, n1));
+                if constexpr (NS == 2) store_row(a.out_c, t - 1 - 3 * hw, n1);
+                if constexpr (NS > 2) {
+                    const float4 n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
+                    store_row(a.out_w[A2], t - 2 - 7 * hw, f4_sub(cen2, n2));
+                    store_row(a.out_c, t - 2 - 7 * hw, n2);
+                }
+                c2 = n1;
+            }
+            c1 = n0;
         }
     }
 }
@@ -236,11 +253,11 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
 // ---------------------------------------------------------------------------------------------
 static inline bool wt_fused_supported(const wt_plan *) { return true; }
 
-template <int K, int NS, int D, int NW>
+template <int K, int NS, int D, int NW, int PD>
 static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name)
 {
     constexpr int hw = K / 2;
-    constexpr int LAT = hw * ((1 << NS) - 1);
+    constexpr int LAT = hw * ((1 << NS) - 1) + (NS - 1);
     constexpr int HX = (hw * ((1 << NS) - 1) * D + 3) / 4 * 4;
     constexpr int NL = NW * 64;
     constexpr int VXMAX = NL * 4 - 2 * HX;               // widest valid strip per WG
@@ -266,19 +283,33 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     if (gy > 65535) WT_FAIL("fused pass: grid too large");
     dim3 grid(nx, (unsigned)gy), block(NL);
     ProfScope ps(p->ctx, name);
-    hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW>), grid, block, 0, p->ctx->stream, a);
+    hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }
 
-template <int NW>
+// Tuned on MI355X (8192^2, B3): the D = 1 pass prefers 4-wave workgroups (2 resident per CU)
+// with 8 rows of prefetch; the D = 8 pass prefers 8-wave workgroups (x halo 224 of 2048 px
+// instead of 224 of 1024).  WT_FUSED_NW / WT_FUSED_PD override both (tuning sweeps).
+template <int K>
 static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
 {
-    const bool b3 = p->family == WT_B3SPLINE;
-    if (s0 == 0 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 1, NW>(p, a, "wt_fused<d1x3>") : wt_fused_launch_t<3, 3, 1, NW>(p, a, "wt_fused<d1x3>");
-    if (s0 == 0 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 1, NW>(p, a, "wt_fused<d1x2>") : wt_fused_launch_t<3, 2, 1, NW>(p, a, "wt_fused<d1x2>");
-    if (s0 == 3 && ns == 3) return b3 ? wt_fused_launch_t<5, 3, 8, NW>(p, a, "wt_fused<d8x3>") : wt_fused_launch_t<3, 3, 8, NW>(p, a, "wt_fused<d8x3>");
-    if (s0 == 3 && ns == 2) return b3 ? wt_fused_launch_t<5, 2, 8, NW>(p, a, "wt_fused<d8x2>") : wt_fused_launch_t<3, 2, 8, NW>(p, a, "wt_fused<d8x2>");
+    static const int nw_env = getenv("WT_FUSED_NW") ? atoi(getenv("WT_FUSED_NW")) : 0;
+    static const int pd_env = getenv("WT_FUSED_PD") ? atoi(getenv("WT_FUSED_PD")) : 0;
+    const int nw = nw_env ? nw_env : (s0 == 0 ? 4 : 8);
+    const int pd = pd_env ? pd_env : (s0 == 0 ? 8 : 4);
+#define WT_FUSED_CASE(S0, NS_, D_, NAME)                                                          \
+    if (s0 == S0 && ns == NS_) {                                                                  \
+        if (nw == 8) return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 8, 8>(p, a, NAME)             \
+                                    : wt_fused_launch_t<K, NS_, D_, 8, 4>(p, a, NAME);            \
+        return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 4, 8>(p, a, NAME)                          \
+                       : wt_fused_launch_t<K, NS_, D_, 4, 4>(p, a, NAME);                         \
+    }
+    WT_FUSED_CASE(0, 3, 1, "wt_fused<d1x3>")
+    WT_FUSED_CASE(0, 2, 1, "wt_fused<d1x2>")
+    WT_FUSED_CASE(3, 3, 8, "wt_fused<d8x3>")
+    WT_FUSED_CASE(3, 2, 8, "wt_fused<d8x2>")
+#undef WT_FUSED_CASE
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
@@ -289,7 +320,5 @@ static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **ou
     a.out_c = out_c;
     for (int i = 0; i < ns; ++i) a.out_w[i] = out_w[i];
     a.g = p->g;
-    static const int nw = getenv("WT_FUSED_NW") ? atoi(getenv("WT_FUSED_NW")) : 4;
-    if (nw == 8) return wt_fused_dispatch<8>(p, a, s0, ns);
-    return wt_fused_dispatch<4>(p, a, s0, ns);
+    return p->family == WT_B3SPLINE ? wt_fused_dispatch<5>(p, a, s0, ns) : wt_fused_dispatch<3>(p, a, s0, ns);
 }
