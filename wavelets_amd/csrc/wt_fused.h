@@ -41,6 +41,7 @@ struct FusedArgs {
     int Vx;       // valid (stored) pixels per x-strip, multiple of 4
     int S;        // chain steps stored per chunk
     int chunks;   // chunks per chain
+    int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores, 2 = loads re-read one row
 };
 
 template <int K, int SHIFT_PX, int NLANES>
@@ -95,9 +96,9 @@ typedef float wt_v4f __attribute__((ext_vector_type(4)));
 // write gets an out-of-range offset; the hardware range check drops those stores.  Control
 // flow stays uniform, so the compiler's vmcnt bookkeeping is exact (loads stay in flight
 // across the stores and barriers of several steps).
-__device__ __forceinline__ void wt_bstore4(float *row, bool row_ok, int row_bytes, unsigned voff, float4 v)
+__device__ __forceinline__ void wt_bstore4(uint64_t row_addr, bool row_ok, int row_bytes, unsigned voff, float4 v)
 {
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_ok ? row_bytes : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)row_addr, 0, row_ok ? row_bytes : 0, 0x00020000);
     wt_v4f t = {v.x, v.y, v.z, v.w};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, 0);
 }
@@ -173,18 +174,24 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
     const int t_last = r1 - 1 + LAT_IN;                  // last input row any stored output needs
     auto load_row = [&](int t) -> float4 {
         // steps past t_last only flush the pipeline / unroll padding: keep the address in range
-        const float *row = wt_row(a.in, g, gy0 + D * min(t, t_last));
+        const float *row = wt_row(a.in, g, gy0 + D * ((a.debug & 2) ? r0 : min(t, t_last)));
         float4 v = *reinterpret_cast<const float4 *>(row + xc);
         if (wave_has_edge) {
             if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
         }
         return v;
     };
-    // predicated store of chain row `ro` of plane `base`
-    auto store_row = [&](float *base, int ro, float4 v) {
-        const bool ok = (ro >= r0) && (ro < r1);
-        const int rc = min(max(ro, r0), r1 - 1);
-        wt_bstore4(base + (int64_t)(q + D * rc) * g.P, ok, row_bytes, voff, v);
+    // Output rows advance by one chain step (D image rows) per iteration: the row addresses are
+    // carried incrementally in SGPRs (2 SALU per plane per step); a row outside [r0, r1) gets a
+    // zero-length descriptor instead of a branch.
+    const unsigned span = (unsigned)(r1 - r0);
+    const uint64_t step_bytes = (uint64_t)D * (uint64_t)row_bytes;
+    auto row_addr0 = [&](float *base, int ro) -> uint64_t {
+        return (uint64_t)base + (uint64_t)((int64_t)(q + (int64_t)D * ro) * (int64_t)row_bytes);
+    };
+    auto store_at = [&](uint64_t addr, int ro, float4 v) {
+        const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
+        wt_bstore4(addr, ok, row_bytes, voff, v);
     };
 
     constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0;
@@ -207,6 +214,13 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
     float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
+    // output row of scale a at step t: t - a - hw*(2^(a+1)-1)
+    constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw;
+    constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : LAG2);
+    uint64_t aw0 = row_addr0(a.out_w[0], t0 - LAG0);
+    uint64_t aw1 = NS > 1 ? row_addr0(a.out_w[A1], t0 - LAG1) : 0;
+    uint64_t aw2 = NS > 2 ? row_addr0(a.out_w[A2], t0 - LAG2) : 0;
+    uint64_t ac = row_addr0(a.out_c, t0 - LAGC);
 
     for (int kb = 0; kb < nsteps; kb += U) {
 #pragma unroll
@@ -227,23 +241,25 @@ __global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
                 buf[A2][gl] = v2;
             }
             __syncthreads();
-            // scale s0: input row t -> row t - hw of w_{s0} / c_{s0+1}
             const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
-            store_row(a.out_w[0], t - hw, f4_sub(cen0, n0));
-            if constexpr (NS == 1) store_row(a.out_c, t - hw, n0);
+            store_at(aw0, t - LAG0, f4_sub(cen0, n0));
+            if constexpr (NS == 1) store_at(ac, t - LAGC, n0);
             if constexpr (NS > 1) {
-                // scale s0+1 consumed row (t-1) - hw of c_{s0+1} -> row t - 1 - 3 hw
                 const float4 n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
-                store_row(a.out_w[A1], t - 1 - 3 * hw, f4_sub(cen1, n1));
-                if constexpr (NS == 2) store_row(a.out_c, t - 1 - 3 * hw, n1);
+                store_at(aw1, t - LAG1, f4_sub(cen1, n1));
+                if constexpr (NS == 2) store_at(ac, t - LAGC, n1);
                 if constexpr (NS > 2) {
                     const float4 n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
-                    store_row(a.out_w[A2], t - 2 - 7 * hw, f4_sub(cen2, n2));
-                    store_row(a.out_c, t - 2 - 7 * hw, n2);
+                    store_at(aw2, t - LAG2, f4_sub(cen2, n2));
+                    store_at(ac, t - LAGC, n2);
                 }
                 c2 = n1;
             }
             c1 = n0;
+            aw0 += step_bytes;
+            aw1 += step_bytes;
+            aw2 += step_bytes;
+            ac += step_bytes;
         }
     }
 }
@@ -279,6 +295,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     chunks = (n_max + S - 1) / S;
     a.S = S;
     a.chunks = chunks;
+    static const int dbg = getenv("WT_FUSED_DEBUG") ? atoi(getenv("WT_FUSED_DEBUG")) : 0;
+    a.debug = dbg;
     const int64_t gy = (int64_t)D * chunks;
     if (gy > 65535) WT_FAIL("fused pass: grid too large");
     dim3 grid(nx, (unsigned)gy), block(NL);
@@ -302,6 +320,8 @@ static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
     if (s0 == S0 && ns == NS_) {                                                                  \
         if (nw == 8) return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 8, 8>(p, a, NAME)             \
                                     : wt_fused_launch_t<K, NS_, D_, 8, 4>(p, a, NAME);            \
+        if (nw == 2 && D_ == 1) return wt_fused_launch_t<K, NS_, 1, 2, 8>(p, a, NAME);            \
+        if (nw == 1 && D_ == 1) return wt_fused_launch_t<K, NS_, 1, 1, 8>(p, a, NAME);            \
         return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 4, 8>(p, a, NAME)                          \
                        : wt_fused_launch_t<K, NS_, D_, 4, 4>(p, a, NAME);                         \
     }
