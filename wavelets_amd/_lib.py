@@ -3,9 +3,11 @@
 There is no CPU fallback: if the shared library is missing or no MI355X is visible the
 import of the binding (or the first device call) raises.  numpy is the only dependency.
 """
+import atexit
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -132,6 +134,7 @@ class Context:
             raise WatrooHipError("no HIP device visible: the a-trous engine needs an MI355X "
                                  "(there is no CPU fallback)")
         check(L.wt_ctx_create(device, _c.byref(self._h)))
+        _live.add(self)
 
     def close(self):
         if self._h:
@@ -194,6 +197,21 @@ class Context:
 
 
 _default_ctx = {}
+_live = weakref.WeakSet()        # Plans and Contexts still holding device resources
+
+
+@atexit.register
+def _shutdown():
+    """Release device resources while the HIP runtime is still alive (interpreter teardown
+    otherwise destroys planes after the runtime's own static destructors ran)."""
+    objs = list(_live)
+    for o in objs:
+        if isinstance(o, Plan):
+            o.close()
+    for o in objs:
+        if isinstance(o, Context):
+            o.close()
+    _default_ctx.clear()
 
 
 def default_context(device=None):
@@ -235,6 +253,7 @@ class Plan:
         (self.H, self.W, self.pitch, self.row0, self.nrows, self.halo, self.max_level,
          self.family) = [int(v) for v in info]
         self.rank, self.nranks = rank, nranks
+        _live.add(self)
 
     def close(self):
         if self._h:

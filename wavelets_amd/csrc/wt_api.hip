@@ -569,9 +569,9 @@ static int check_scale(const wt_plan *p, int s, const char *who)
     return 0;
 }
 
-template <int MODE>
-static int launch_chain(wt_plan *p, const float *in, float *out_c, float *out_w, int s, float f1,
-                        float f2, int take_sqrt, const char *name)
+// chunking of the polyphase chains: enough (phase, chunk) items to fill the chip, chunks long
+// enough that the K-1 warm-up rows stay a small fraction
+static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim3 &block)
 {
     const Geo &g = p->g;
     const int d = 1 << s;
@@ -584,21 +584,36 @@ static int launch_chain(wt_plan *p, const float *in, float *out_c, float *out_w,
     S = std::max(S, std::min(n_max, 8));
     S = std::min(S, 64);
     int chunks = (n_max + S - 1) / S;
-    const int dd = std::min(d, g.nrows);          // phases >= nrows own no rows
-    (void)dd;
     int64_t items = (int64_t)d * chunks;
-    while ((items + 3) / 4 > 65535) {             // grid.y limit
+    while ((items + 3) / 4 > 65528) {             // grid.y limit
         S *= 2;
         chunks = (n_max + S - 1) / S;
         items = (int64_t)d * chunks;
     }
-    ChainArgs a{in, out_c, out_w, g, d, S, chunks, f1, f2, take_sqrt};
-    dim3 grid(gx, (unsigned)((items + 3) / 4)), block(64, 4);
+    a.g = g;
+    a.d = d;
+    a.S = S;
+    a.chunks = chunks;
+    grid = dim3(gx, (unsigned)(((items + 3) / 4 + 7) / 8 * 8));   // multiple of 8: wt_xcd_remap
+    block = dim3(64, 4);
+    return 0;
+}
+
+template <int MODE>
+static int launch_chain(wt_plan *p, const float *in, float *out_c, float *out_w, int s, float f1,
+                        float f2, int take_sqrt, const char *name)
+{
+    ChainArgs a{};
+    a.in = in; a.out_c = out_c; a.out_w = out_w; a.aux = nullptr;
+    a.f1 = f1; a.f2 = f2; a.take_sqrt = take_sqrt;
+    dim3 grid, block;
+    WT_TRY(chain_geometry(p, s, a, grid, block));
     ProfScope ps(p->ctx, name);
-    if (p->family == WT_B3SPLINE)
-        hipLaunchKernelGGL((wt_chain_kernel<5, MODE>), grid, block, 0, p->ctx->stream, a);
-    else
-        hipLaunchKernelGGL((wt_chain_kernel<3, MODE>), grid, block, 0, p->ctx->stream, a);
+    const bool small = a.d < 4, b3 = p->family == WT_B3SPLINE;
+    if (b3 && small) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, true>), grid, block, 0, p->ctx->stream, a);
+    else if (b3) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, false>), grid, block, 0, p->ctx->stream, a);
+    else if (small) hipLaunchKernelGGL((wt_chain_kernel<3, MODE, true>), grid, block, 0, p->ctx->stream, a);
+    else hipLaunchKernelGGL((wt_chain_kernel<3, MODE, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }
@@ -651,14 +666,16 @@ extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, 
 
 static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s)
 {
-    const Geo &g = p->g;
-    dim3 grid((g.W + 63) / 64, (g.nrows + 3) / 4), block(64, 4);
-    if (grid.y > 65535u) WT_FAIL("bilateral: strip of %d rows too tall for one launch", g.nrows);
+    ChainArgs a{};
+    a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
+    dim3 grid, block;
+    WT_TRY(chain_geometry(p, s, a, grid, block));
     ProfScope ps(p->ctx, "wt_bilateral_kernel");
-    if (p->family == WT_B3SPLINE)
-        hipLaunchKernelGGL((wt_bilateral_kernel<5>), grid, block, 0, p->ctx->stream, in, var, out, out_w, g, 1 << s);
-    else
-        hipLaunchKernelGGL((wt_bilateral_kernel<3>), grid, block, 0, p->ctx->stream, in, var, out, out_w, g, 1 << s);
+    const bool small = a.d < 4, b3 = p->family == WT_B3SPLINE;
+    if (b3 && small) hipLaunchKernelGGL((wt_bilateral_kernel<5, true>), grid, block, 0, p->ctx->stream, a);
+    else if (b3) hipLaunchKernelGGL((wt_bilateral_kernel<5, false>), grid, block, 0, p->ctx->stream, a);
+    else if (small) hipLaunchKernelGGL((wt_bilateral_kernel<3, true>), grid, block, 0, p->ctx->stream, a);
+    else hipLaunchKernelGGL((wt_bilateral_kernel<3, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }

@@ -30,6 +30,14 @@ __device__ __forceinline__ constexpr float wt_tap(int i)
     return (i == 2) ? 0.375f : ((i == 1 || i == 3) ? 0.25f : 0.0625f);
 }
 
+template <int K>
+__device__ __forceinline__ constexpr float wt_tap_log2(int i)
+{
+    // log2 of the taps: 1/4, 1/2 (Triangle); 1/16, 1/4, 3/8 (B3spline)
+    if (K == 3) return i == 1 ? -1.f : -2.f;
+    return (i == 2) ? -1.4150374992788438f : ((i == 1 || i == 3) ? -2.f : -4.f);
+}
+
 __device__ __forceinline__ float4 f4_mul(float4 a, float4 b)
 {
     return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
@@ -92,19 +100,34 @@ __device__ __forceinline__ void wt_store4(float *row, int x, int W, float4 v)
 // ---------------------------------------------------------------------------------------------
 enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3 };
 
-// Horizontal K-tap filter of one row at the thread's 4 pixels.
+// Raw operands of the horizontal K-tap filter of one row at the thread's 4 pixels:
+//   d >= 4: K float4 at x + (j-hw) d      d < 4: 3 float4 covering x-4 .. x+7
+template <int K, bool SMALL_D>
+__device__ __forceinline__ void wt_hrow_load(const float *row, int x, int d, int W, float4 (&raw)[K])
+{
+    constexpr int hw = K / 2;
+    if constexpr (!SMALL_D) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) raw[j] = wt_load4(row, x + (j - hw) * d, W);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) raw[j] = wt_load4(row, x - 4 + 4 * j, W);
+    }
+}
+
+// Horizontal K-tap filter from the raw operands.
 //   h   = sum_j k_j v(x + (j-hw) d)                  (v squared first for MODE_SMOOTH_SQ)
 //   h2  = sum_j k_j v^2                              (MODE_VAR only)
 //   cen = v(x)                                       (centre pixels, for the detail plane)
-template <int K, int MODE>
-__device__ __forceinline__ void wt_hrow(const float *row, int x, int d, int W, float4 &h,
-                                        float4 &h2, float4 &cen)
+template <int K, int MODE, bool SMALL_D>
+__device__ __forceinline__ void wt_hrow_filter(const float4 (&raw)[K], int d, float4 &h,
+                                               float4 &h2, float4 &cen)
 {
     constexpr int hw = K / 2;
-    if (d >= 4) {
+    if constexpr (!SMALL_D) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            float4 v = wt_load4(row, x + (j - hw) * d, W);
+            float4 v = raw[j];
             if (j == hw) cen = v;
             float4 vv = f4_mul(v, v);
             if (MODE == MODE_SMOOTH_SQ) v = vv;
@@ -114,8 +137,7 @@ __device__ __forceinline__ void wt_hrow(const float *row, int x, int d, int W, f
         }
     } else {
         // d = 1 or 2: pixels x-4 .. x+7 cover every tap (2*d <= 4)
-        const float4 L = wt_load4(row, x - 4, W), C = wt_load4(row, x, W),
-                     R = wt_load4(row, x + 4, W);
+        const float4 L = raw[0], C = raw[1], R = raw[2];
         float e[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
         float e2[12];
 #pragma unroll
@@ -145,10 +167,27 @@ __device__ __forceinline__ void wt_hrow(const float *row, int x, int d, int W, f
     }
 }
 
+// XCD-aware block remap for the chain-march kernels.  Hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs (each with a private 4 MiB L2).  The horizontal taps of a
+// dilated filter re-read the SAME image rows at x +- d, x +- 2d, i.e. from the x-blocks next
+// to this one; with the default order those neighbours sit on other XCDs and every XCD
+// fetches the row segment again through the fabric.  Remapped, all x-blocks of one group of
+// rows run on one XCD and the re-reads are L2 hits.  Pure speed: any placement is correct.
+// Requires gridDim.y % 8 == 0 (the host rounds up; surplus blocks find no work and exit).
+__device__ __forceinline__ void wt_xcd_remap(int &bx, int &by)
+{
+    const int gx = gridDim.x;
+    const int b = blockIdx.y * gx + blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    bx = j % gx;
+    by = (j / gx) * 8 + xcd;
+}
+
 struct ChainArgs {
     const float *in;  // local row 0 of the input plane
     float *out_c;     // smooth / variance output (local row 0)
     float *out_w;     // detail output or nullptr
+    const float *aux; // bilateral: per-pixel variance plane
     Geo g;
     int d;        // dilation 2^s
     int S;        // chain steps per thread
@@ -157,14 +196,16 @@ struct ChainArgs {
     int take_sqrt;
 };
 
-template <int K, int MODE>
+template <int K, int MODE, bool SMALL_D>
 __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
 {
     constexpr int hw = K / 2;
     const Geo g = a.g;
-    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    int bx, by;
+    wt_xcd_remap(bx, by);
+    const int x = (bx * 64 + threadIdx.x) * 4;
     if (x >= g.W) return;
-    const int item = blockIdx.y * blockDim.y + threadIdx.y;
+    const int item = by * blockDim.y + threadIdx.y;
     const int d = a.d;
     const int q = item % d;   // chain phase (local row offset)
     const int c = item / d;   // chunk along the chain
@@ -177,19 +218,26 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
     float4 hwin[K], h2win[K], cen[hw + 1];
     float4 dummy = make_float4(0, 0, 0, 0);
     const int gy0 = g.row0 + q;  // global row of chain element 0
+    float4 raw[K], nxt[K];
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
         float4 ct;
         hwin[j] = dummy;
         h2win[j] = dummy;
-        wt_hrow<K, MODE>(wt_row(a.in, g, gy0 + d * (r0 - hw + j)), x, d, g.W, hwin[j], h2win[j], ct);
+        wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * (r0 - hw + j)), x, d, g.W, raw);
+        wt_hrow_filter<K, MODE, SMALL_D>(raw, d, hwin[j], h2win[j], ct);
         if (j >= hw) cen[j - hw] = ct;
     }
+    // software prefetch: the operands of the NEXT chain row are in flight while this row is
+    // filtered (the kernel is latency-bound at 3-4 waves/SIMD otherwise)
+    wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * (r0 + hw)), x, d, g.W, nxt);
     for (int r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) raw[j] = nxt[j];
+        wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * min(r + 1, r1 - 1) + d * hw), x, d, g.W, nxt);
         hwin[K - 1] = dummy;
         h2win[K - 1] = dummy;
-        wt_hrow<K, MODE>(wt_row(a.in, g, gy0 + d * (r + hw)), x, d, g.W, hwin[K - 1], h2win[K - 1],
-                         cen[hw]);
+        wt_hrow_filter<K, MODE, SMALL_D>(raw, d, hwin[K - 1], h2win[K - 1], cen[hw]);
         float4 o = f4_scale(wt_tap<K>(0), hwin[0]);
 #pragma unroll
         for (int j = 1; j < K; ++j) o = f4_fma(wt_tap<K>(j), hwin[j], o);
@@ -226,43 +274,120 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
 // K10  bilateral (range-weighted) dilated convolution - watroo/wavelets.py:74-105
 //   out = (k_c I + sum_t k_t e_t I_t) / (k_c + sum_t k_t e_t),
 //   e_t = exp(-((I - I_t)^2) / var / 2)                        (numexpr expression, :97)
-// Full K x K tap set (not separable).  One pixel per lane, 64 x 4 tiles; taps are L1/L2-served
-// gathers.  Transcendental-bound (K*K-1 v_exp_f32 per pixel), not HBM-bound.
+// Full K x K tap set (not separable), so this kernel is transcendental/VALU-bound, not
+// HBM-bound: K*K-1 exponentials per pixel.  A lane owns 4 adjacent pixels (16-byte row loads,
+// like every other kernel); per tap the weight is ONE v_exp_f32:
+//   k_t * exp(-d^2/(2 var)) = 2^( d^2 * (-log2(e)/(2 var)) + log2(k_t) )
+// with the per-pixel factor -log2(e)/(2 var) formed once (one division per pixel instead of
+// one per tap).  fp32 rounding differs from the reference's exp()/divide sequence by a few
+// ulp of the weight - inside the stated bilateral tolerance (2e-5 * max|input|).
 // ---------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void wt_bilateral_kernel(const float *in, const float *var,
-                                                           float *out, float *out_w, Geo g, int d)
+// Work decomposition is the chain march of K1: a thread owns 4 columns and one polyphase row
+// chain, and keeps the K x K (dilated) neighbourhood rows in a register window that slides one
+// chain step per iteration - every input row is fetched once per chain (K coalesced 16-byte
+// loads at x + j*d, L2-served) instead of once per output row, which is what makes the large
+// dilations of wow() (d up to 1024, where a tile has no spatial reuse) HBM-neutral.
+template <int K, bool SMALL_D>
+__global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
 {
     constexpr int hw = K / 2;
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int ly = blockIdx.y * 4 + threadIdx.y;
-    if (x >= g.W || ly >= g.nrows) return;
-    const int gy = g.row0 + ly;
-    const float I = in[(int64_t)ly * g.P + x];
-    const float v = var[(int64_t)ly * g.P + x];
+    constexpr int NX = SMALL_D ? 3 : K;   // float4 per window row
+    const Geo g = a.g;
+    int bx, by;
+    wt_xcd_remap(bx, by);
+    const int x = (bx * 64 + threadIdx.x) * 4;
+    if (x >= g.W) return;
+    const int item = by * blockDim.y + threadIdx.y;
+    const int d = a.d;
+    const int q = item % d;
+    const int c = item / d;
+    if (c >= a.chunks || q >= g.nrows) return;
+    const int n_q = (g.nrows - q + d - 1) / d;
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+    const int gy0 = g.row0 + q;
+    constexpr bool small_d = SMALL_D;    // d < 4: taps are sub-float4 shifts
+
+    // win[i][j]: row (r - hw + i) of the chain; j-th float4 of that row:
+    //   d >= 4: pixels x + (j - hw) d .. +3     (K float4 per row)
+    //   d <  4: pixels x - 4 + 4 j .. +3        (3 float4 per row: e[12] of wt_hrow)
+    float4 win[K][NX];
+    auto load_win_row = [&](int r, float4 (&dst)[NX]) {
+        const float *row = wt_row(a.in, g, gy0 + d * r);
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            dst[j] = wt_load4(row, SMALL_D ? x - 4 + 4 * j : x + (j - hw) * d, g.W);
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
+    float4 nxt[NX];
+
     const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
-    float norm = kc;
-    float acc = kc * I;
-    int xs[K];
+    for (int r = r0; r < r1; ++r) {
+        // software prefetch of the row that enters the window in the next iteration
+        load_win_row(min(r + 1, r1 - 1) + hw, nxt);
+        const int64_t off = (int64_t)(q + d * r) * g.P + x;
+        const float4 v4 = *reinterpret_cast<const float4 *>(a.aux + off);
+        const float4 Ic4 = win[hw][SMALL_D ? 1 : hw];
+        const float I[4] = {Ic4.x, Ic4.y, Ic4.z, Ic4.w};
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float norm[4], acc[4], s2[4];
 #pragma unroll
-    for (int j = 0; j < K; ++j) xs[j] = wt_refl(x + (K - 1 - j - hw) * d, g.W);
+        for (int k = 0; k < 4; ++k) {
+            norm[k] = kc;
+            acc[k] = kc * I[k];
+            s2[k] = -0.72134752044448170368f / vv[k];      // -log2(e) / (2 var)
+        }
+        // taps in the reference order (watroo/wavelets.py:89-91): kernel index (i, j) pairs with
+        // the shift (K-1-i-hw, K-1-j-hw) * d
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const float *row = wt_row(in, g, gy + (K - 1 - i - hw) * d);
+        for (int i = 0; i < K; ++i) {
+            const float4 (&wr)[NX] = win[K - 1 - i];
+            float e[12] = {0.f};
+            if constexpr (small_d) {
+                e[0] = wr[0].x; e[1] = wr[0].y; e[2] = wr[0].z; e[3] = wr[0].w;
+                e[4] = wr[1].x; e[5] = wr[1].y; e[6] = wr[1].z; e[7] = wr[1].w;
+                e[8] = wr[2].x; e[9] = wr[2].y; e[10] = wr[2].z; e[11] = wr[2].w;
+            }
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (i == hw && j == hw) continue;
-            const float k = wt_tap<K>(i) * wt_tap<K>(j);
-            const float It = row[xs[j]];
-            const float diff = I - It;
-            const float w = k * expf((-(diff * diff)) / v * 0.5f);
-            norm += w;
-            acc += It * w;
+            for (int j = 0; j < K; ++j) {
+                if (i == hw && j == hw) continue;
+                const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
+                float It[4];
+                if constexpr (small_d) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        It[k] = d == 1 ? e[4 + k + (K - 1 - j - hw)] : e[4 + k + 2 * (K - 1 - j - hw)];
+                } else {
+                    const float4 t = wr[SMALL_D ? 0 : K - 1 - j];
+                    It[0] = t.x; It[1] = t.y; It[2] = t.z; It[3] = t.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float diff = I[k] - It[k];
+                    const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, s2[k], lk));
+                    norm[k] += w;
+                    acc[k] = fmaf(It[k], w, acc[k]);
+                }
+            }
+        }
+        float o[4], ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = acc[k] / norm[k];
+            ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
+        }
+        const int64_t roff = (int64_t)(q + d * r) * g.P;
+        wt_store4(a.out_c + roff, x, g.W, make_float4(o[0], o[1], o[2], o[3]));
+        if (a.out_w) wt_store4(a.out_w + roff, x, g.W, make_float4(ow[0], ow[1], ow[2], ow[3]));
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) win[i][j] = win[i + 1][j];
+            win[K - 1][j] = nxt[j];
         }
     }
-    const float res = acc / norm;
-    out[(int64_t)ly * g.P + x] = res;
-    if (out_w) out_w[(int64_t)ly * g.P + x] = I - res;   // detail plane, wavelets.py:442
 }
 
 // ---------------------------------------------------------------------------------------------
