@@ -142,6 +142,13 @@ int wt_abs_median(wt_plan *plan, int plane, float *median);
 int wt_significance(wt_plan *plan, int plane, int dst, double tau, int soft, int noise_plane);
 /* Coefficients.denoise body (watroo/wavelets.py:149): plane *= wgt * significance */
 int wt_denoise(wt_plan *plan, int plane, double tau, double wgt, int soft, int noise_plane);
+/* Coefficients.denoise (watroo/wavelets.py:145-149) of the first n_den planes fused with the
+ * plane sum (watroo/utils.py:98): dst <- sum_k plane[first+k] * (wgt[k]*significance_k) for
+ * k < n_den, plain planes after.  tau[k] <= 0: significance one.  write_back != 0 also stores
+ * the thresholded planes (exactly denoise-then-sum); 0 leaves the planes untouched
+ * (utils.denoise discards them).  Bit-identical to wt_denoise + wt_plane_sum. */
+int wt_denoise_sum(wt_plan *plan, int first, int count, int dst, int n_den, const double *tau,
+                   const double *wgt, int soft, int noise_plane, int write_back);
 /* wow per-scale update (watroo/utils.py:193-203) fused:
  *   c <- c * significance(tau)            (skipped when tau <= 0)
  *   gamma_plane += c                      (skipped when gamma_plane == WT_PLANE_NONE)

@@ -188,6 +188,32 @@ def test_host_mirror_edits_are_honoured(W, O):
     close(c.sum(axis=0), O.atrous_standard(a, 3)[1:].sum(axis=0), 1e-5 * np.abs(a).max())
 
 
+def test_fused_denoise_sum_is_bit_identical(W):
+    """wt_denoise_sum == wt_denoise followed by wt_plane_sum, with and without write-back."""
+    a = rnd((301, 203), 21)
+    for kw in (dict(), dict(soft_threshold=False), dict(weights=[.5, 2, 1])):
+        sig = [5, 3, 2]
+        c1 = W.AtrousTransform(W.Triangle)(a, 5)
+        c1.denoise(sig, **kw)
+        ref_planes, ref_sum = c1.data.copy(), c1.sum(axis=0)
+        c2 = W.AtrousTransform(W.Triangle)(a, 5)
+        before = c2.data.copy()
+        plan = c2._denoise_sum(sig, write_back=False, **kw)
+        np.testing.assert_array_equal(plan.download(-2), ref_sum)
+        np.testing.assert_array_equal(np.stack([plan.download(s) for s in range(6)]), before)
+        c3 = W.AtrousTransform(W.Triangle)(a, 5)
+        plan = c3._denoise_sum(sig, write_back=True, **kw)
+        np.testing.assert_array_equal(plan.download(-2), ref_sum)
+        np.testing.assert_array_equal(c3.data, ref_planes)
+        assert c3.noise == c1.noise
+    nm = (np.abs(rnd((301, 203), 22)) + .5).astype(np.float32)        # ndarray noise map
+    c1 = W.AtrousTransform()(a, 3); c1.noise = nm; c1.denoise([3, 2])
+    c2 = W.AtrousTransform()(a, 3); c2.noise = nm
+    plan = c2._denoise_sum([3, 2], write_back=True)
+    np.testing.assert_array_equal(plan.download(-2), c1.sum(axis=0))
+    np.testing.assert_array_equal(c2.data, c1.data)
+
+
 def test_anscombe_bit_exact(W):
     g = load_golden("g0_hard")
     p = g["ans_in"]

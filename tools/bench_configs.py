@@ -40,7 +40,17 @@ def main():
         profile("cfg2 4096^2 B3 L=6 decompose+sum", lambda: W.AtrousTransform(W.B3spline)(a, 6).sum(axis=0), a.size)
     if "3" in which:
         a = rng.standard_normal((8192, 8192), dtype=np.float32)
-        profile("cfg3 8192^2 Triangle L=8 + denoise([5,3,2])", lambda: W.denoise(a, [5, 3, 2], W.Triangle), a.size)
+        def cfg3_api():
+            c = W.AtrousTransform(W.Triangle)(a, 8)
+            c.denoise([5, 3, 2])
+            return np.sum(c, axis=0)
+
+        def cfg3_fused():
+            c = W.AtrousTransform(W.Triangle)(a, 8)
+            return c._denoise_sum([5, 3, 2], write_back=True).download(-2)
+        profile("cfg3 8192^2 Triangle L=8 + denoise([5,3,2]) + sum (reference call sequence)", cfg3_api, a.size)
+        profile("cfg3 same, denoise fused into the plane sum (wt_denoise_sum)", cfg3_fused, a.size)
+        profile("denoise(a,[5,3,2],Triangle) convenience (3 scales)", lambda: W.denoise(a, [5, 3, 2], W.Triangle), a.size)
     if "5" in which:
         side = int(os.environ.get("CFG5_SIDE", "8192"))
         a = (rng.standard_normal((side, side), dtype=np.float32)

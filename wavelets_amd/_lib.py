@@ -79,6 +79,9 @@ SIGNATURES = {
     "wt_abs_median": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_float)]),
     "wt_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int]),
     "wt_denoise": (_c.c_int, [_vp, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_int]),
+    "wt_denoise_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                  _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.c_int,
+                                  _c.c_int, _c.c_int]),
     "wt_wow_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
                                  _c.c_float, _c.c_int]),
     "wt_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
@@ -212,6 +215,7 @@ def _shutdown():
         if isinstance(o, Context):
             o.close()
     _default_ctx.clear()
+    del _pool[:]
 
 
 def default_context(device=None):
@@ -340,6 +344,14 @@ class Plan:
     def denoise(self, plane, tau, wgt=1.0, soft=True, noise_plane=PLANE_NONE):
         check(load().wt_denoise(self._h, plane, float(tau), float(wgt), int(soft), noise_plane))
 
+    def denoise_sum(self, count, taus, wgts, soft=True, noise_plane=PLANE_NONE, write_back=False,
+                    dst=PLANE_OUT, first=0):
+        n = len(taus)
+        ta = (_c.c_double * max(n, 1))(*[float(t) for t in taus])
+        wa = (_c.c_double * max(n, 1))(*[float(w) for w in wgts])
+        check(load().wt_denoise_sum(self._h, first, count, dst, n, ta, wa, int(soft), noise_plane,
+                                    int(write_back)))
+
     def wow_update(self, plane, power_plane, tau, soft, noise_plane, factor, gamma_plane):
         check(load().wt_wow_update(self._h, plane, power_plane, float(tau), int(soft),
                                    noise_plane, float(factor), gamma_plane))
@@ -355,3 +367,36 @@ class Plan:
 
     def anscombe(self, src, dst, alpha=1.0, g=0.0, sigma=0.0, inverse=False):
         check(load().wt_anscombe(self._h, src, dst, alpha, g, sigma, int(inverse)))
+
+
+# ------------------------------------------------------------------------------------------
+# plan pool: hipMalloc/hipFree of a dozen multi-hundred-MiB planes costs milliseconds, far more
+# than the transform itself; plans of recently used geometries are kept for reuse.
+# ------------------------------------------------------------------------------------------
+_POOL_MAX_BYTES = int(os.environ.get("WATROO_HIP_POOL_BYTES", str(16 << 30)))
+_pool = []            # [(key, plan)] most recently released last
+
+
+def _plan_bytes(plan):
+    return (plan.nrows + 2 * plan.halo) * plan.pitch * 4 * (plan.max_level + 1 + 2 + NUM_SCRATCH)
+
+
+def acquire_plan(ctx, H, W, family, max_level):
+    """A whole-image plan for (H, W, family, max_level): pooled if available, else new."""
+    key = (id(ctx), H, W, family, max_level)
+    for i in range(len(_pool) - 1, -1, -1):
+        if _pool[i][0] == key:
+            return _pool.pop(i)[1]
+    return Plan(ctx, H, W, family, max_level)
+
+
+def release_plan(plan):
+    """Hand a plan back for reuse (its planes keep stale data; callers re-upload)."""
+    if plan is None or not plan._h or plan.nranks != 1:
+        return
+    _pool.append(((id(plan.ctx), plan.H, plan.W, plan.family, plan.max_level), plan))
+    total = sum(_plan_bytes(p) for _, p in _pool)
+    while _pool and (total > _POOL_MAX_BYTES or len(_pool) > 8):
+        _, old = _pool.pop(0)
+        total -= _plan_bytes(old)
+        old.close()

@@ -797,6 +797,35 @@ extern "C" int wt_plane_sum(wt_plan *p, int first, int count, int dst)
     return 0;
 }
 
+static int noise_ptr(wt_plan *p, int noise_plane, float **np_);
+
+extern "C" int wt_denoise_sum(wt_plan *p, int first, int count, int dst, int n_den, const double *tau,
+                              const double *wgt, int soft, int noise_plane, int write_back)
+{
+    if (!p) WT_FAIL("wt_denoise_sum: null plan");
+    if (count < 1 || count > WT_MAX_SUM_PLANES) WT_FAIL("wt_denoise_sum: count %d out of range [1,%d]", count, WT_MAX_SUM_PLANES);
+    if (first < 0 || first + count - 1 > p->max_level) WT_FAIL("wt_denoise_sum: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
+    if (n_den < 0 || n_den > count) WT_FAIL("wt_denoise_sum: n_den %d outside [0,%d]", n_den, count);
+    if (n_den > 0 && (!tau || !wgt)) WT_FAIL("wt_denoise_sum: null tau/wgt");
+    DenoiseSumArgs a{};
+    a.n = count; a.n_den = n_den; a.soft = soft; a.write_back = write_back;
+    for (int i = 0; i < count; ++i) {
+        float *b = nullptr;
+        WT_TRY(plane_base(p, first + i, &b));
+        a.p[i] = b;
+        a.tau[i] = i < n_den ? tau[i] : 0.0;
+        a.wgt[i] = i < n_den ? (float)wgt[i] : 1.f;
+    }
+    float *o = nullptr, *nz = nullptr;
+    WT_TRY(plane_base(p, dst, &o));
+    WT_TRY(noise_ptr(p, noise_plane, &nz));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_denoise_sum_kernel");
+    hipLaunchKernelGGL(wt_denoise_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, p->ctx->stream, a, nz, o, n4);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
 static int noise_ptr(wt_plan *p, int noise_plane, float **np_)
 {
     *np_ = nullptr;

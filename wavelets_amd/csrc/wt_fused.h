@@ -320,8 +320,6 @@ static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
     if (s0 == S0 && ns == NS_) {                                                                  \
         if (nw == 8) return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 8, 8>(p, a, NAME)             \
                                     : wt_fused_launch_t<K, NS_, D_, 8, 4>(p, a, NAME);            \
-        if (nw == 2 && D_ == 1) return wt_fused_launch_t<K, NS_, 1, 2, 8>(p, a, NAME);            \
-        if (nw == 1 && D_ == 1) return wt_fused_launch_t<K, NS_, 1, 1, 8>(p, a, NAME);            \
         return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 4, 8>(p, a, NAME)                          \
                        : wt_fused_launch_t<K, NS_, D_, 4, 4>(p, a, NAME);                         \
     }

@@ -433,6 +433,48 @@ __device__ __forceinline__ float wt_sig(float c, float tau, double taud, int sof
     return ((double)fabsf(c) > taud) ? 1.f : 0.f;
 }
 
+// K4+K5 fused: dst = sum_k plane_k with the first n_den planes thresholded on the fly
+// (plane_k * (wgt_k * significance_k)); optionally writes the thresholded planes back so the
+// result is exactly Coefficients.denoise (wavelets.py:145-149) followed by np.sum (utils.py:98)
+// in one pass over the planes: saves the read-modify-write of the separate denoise kernel.
+struct DenoiseSumArgs {
+    float *p[WT_MAX_SUM_PLANES];
+    double tau[WT_MAX_SUM_PLANES];   // <= 0: significance identically one
+    float wgt[WT_MAX_SUM_PLANES];
+    int n, n_den, soft, write_back;
+};
+
+__global__ __launch_bounds__(256) void wt_denoise_sum_kernel(DenoiseSumArgs a, const float *noise,
+                                                             float *out, int64_t n4)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 nz = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (noise) nz = reinterpret_cast<const float4 *>(noise)[i];
+        const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < a.n; ++k) {
+            const float4 v = wt_ldnt4(a.p[k] + 4 * i);
+            float c[4] = {v.x, v.y, v.z, v.w};
+            if (k < a.n_den) {
+                const double tau = a.tau[k];
+                const float tauf = (float)tau;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sgn = tau > 0.0 ? wt_sig(c[j], tauf * nn[j], tau * (double)nn[j], a.soft) : 1.f;
+                    c[j] = c[j] * (a.wgt[k] * sgn);
+                }
+                if (a.write_back)
+                    reinterpret_cast<float4 *>(a.p[k])[i] = make_float4(c[0], c[1], c[2], c[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = k == 0 ? c[j] : acc[j] + c[j];
+        }
+        reinterpret_cast<float4 *>(out)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // K3/K4  significance / denoise.  mode 0: dst = sig ; mode 1: dst = c * (wgt*sig)
 __global__ __launch_bounds__(256) void wt_signif_kernel(const float *c, const float *noise,
                                                         float *dst, int64_t n4, double tau,

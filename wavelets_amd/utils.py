@@ -10,7 +10,7 @@ import warnings
 
 import numpy as np
 
-from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, Plan, default_context
+from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _family_of, _to_f32_image,
                        PLANE_INPUT)
 
@@ -30,15 +30,16 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     level = len(weights)
     transform = AtrousTransform(scaling_function, bilateral=bilateral)
     sf = scaling_function(2)
-    plan = Plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
     plan.upload(PLANE_INPUT, img)
     if anscombe:
         plan.anscombe(PLANE_INPUT, PLANE_INPUT)                           # ref:93-94
     transform._run(plan, level)                                           # ref:95
     coefficients = Coefficients(plan, sf, bilateral)
     coefficients.noise = noise                                            # ref:96
-    coefficients.denoise(weights, soft_threshold=soft_threshold)          # ref:97
-    plan.plane_sum(0, level + 1, PLANE_OUT)                               # ref:98
+    # ref:97-98 in one pass over the planes; the thresholded planes themselves are not
+    # returned by denoise(), so they are not written back
+    coefficients._denoise_sum(weights, soft_threshold=soft_threshold, write_back=False)
     if anscombe:
         plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)                 # ref:99-100
     return plan.download(PLANE_OUT)

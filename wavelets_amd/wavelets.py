@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (PLANE_INPUT, PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, FLAG_FUSED, Plan,
-                   default_context)
+                   default_context, acquire_plan, release_plan)
 
 __all__ = ['AtrousTransform', 'B3spline', 'Triangle', 'Coefficients', 'generalized_anscombe',
            'convolution']
@@ -153,10 +153,13 @@ def generalized_anscombe(signal, alpha=1, g=0, sigma=0, inverse=False):
     """Generalised Anscombe variance-stabilising transform and its algebraic inverse
     (ref:14-21), evaluated on the GPU in float32."""
     img = _to_f32_image(signal, "signal")
-    plan = Plan(default_context(), img.shape[0], img.shape[1], _lib.B3SPLINE, 0)
-    plan.upload(PLANE_INPUT, img)
-    plan.anscombe(PLANE_INPUT, PLANE_OUT, alpha, g, sigma, inverse)
-    return plan.download(PLANE_OUT)
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _lib.B3SPLINE, 0)
+    try:
+        plan.upload(PLANE_INPUT, img)
+        plan.anscombe(PLANE_INPUT, PLANE_OUT, alpha, g, sigma, inverse)
+        return plan.download(PLANE_OUT)
+    finally:
+        release_plan(plan)
 
 
 def convolution(arr, scaling_function, s=0, output=None):
@@ -164,10 +167,14 @@ def convolution(arr, scaling_function, s=0, output=None):
     Mirrors ref:35-45 (2-D branch: cv2.filter2D with the zero-stuffed kernel,
     BORDER_REFLECT).  ``output`` is written in place and returned, as in the reference."""
     img = _to_f32_image(arr)
-    plan = Plan(default_context(), img.shape[0], img.shape[1], _family_of(scaling_function), 0)
-    plan.upload(PLANE_INPUT, img)
-    plan.smooth(PLANE_INPUT, PLANE_OUT, s)
-    res = plan.download(PLANE_OUT)
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
+                        _family_of(scaling_function), 0)
+    try:
+        plan.upload(PLANE_INPUT, img)
+        plan.smooth(PLANE_INPUT, PLANE_OUT, s)
+        res = plan.download(PLANE_OUT)
+    finally:
+        release_plan(plan)
     if output is None:
         return res
     output[...] = res
@@ -177,10 +184,14 @@ def convolution(arr, scaling_function, s=0, output=None):
 def sdev_loc(image, scaling_function, s=0, variance=False):
     """Local standard deviation (or variance) at scale ``s`` (ref:24-32)."""
     img = _to_f32_image(image, "image")
-    plan = Plan(default_context(), img.shape[0], img.shape[1], _family_of(scaling_function), 0)
-    plan.upload(PLANE_INPUT, img)
-    plan.local_variance(PLANE_INPUT, PLANE_OUT, s, 1.0, 1.0, take_sqrt=not variance)
-    return plan.download(PLANE_OUT)
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
+                        _family_of(scaling_function), 0)
+    try:
+        plan.upload(PLANE_INPUT, img)
+        plan.local_variance(PLANE_INPUT, PLANE_OUT, s, 1.0, 1.0, take_sqrt=not variance)
+        return plan.download(PLANE_OUT)
+    finally:
+        release_plan(plan)
 
 
 def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmetric",
@@ -198,15 +209,18 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
             fam = cls._family
     if fam is None:
         raise NotImplementedError("kernel must be the 2-D Triangle or B3spline kernel")
-    plan = Plan(default_context(), img.shape[0], img.shape[1], fam, 0)
-    plan.upload(PLANE_INPUT, img)
-    if bilateral_variance is None:
-        plan.smooth(PLANE_INPUT, PLANE_OUT, s)
-    else:
-        var = np.broadcast_to(np.asarray(bilateral_variance, np.float32), img.shape)
-        plan.upload(_TMP_PLANE, var)
-        plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s)
-    res = plan.download(PLANE_OUT)
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
+    try:
+        plan.upload(PLANE_INPUT, img)
+        if bilateral_variance is None:
+            plan.smooth(PLANE_INPUT, PLANE_OUT, s)
+        else:
+            var = np.broadcast_to(np.asarray(bilateral_variance, np.float32), img.shape)
+            plan.upload(_TMP_PLANE, var)
+            plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s)
+        res = plan.download(PLANE_OUT)
+    finally:
+        release_plan(plan)
     if output is None:
         return res
     output[...] = res
@@ -243,6 +257,12 @@ class Coefficients:
             self._host = np.ascontiguousarray(data, dtype=np.float32)
             self._nplanes = self._host.shape[0]
 
+    def __del__(self):
+        try:
+            release_plan(self._plan)     # planes go back to the pool
+        except Exception:
+            pass
+
     # -- host mirror -------------------------------------------------------------------
     @property
     def data(self):
@@ -266,8 +286,8 @@ class Coefficients:
         run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
             _, H, W = self._host.shape
-            self._plan = Plan(default_context(), H, W, _family_of(self.scaling_function),
-                              self._nplanes - 1)
+            self._plan = acquire_plan(default_context(), H, W,
+                                      _family_of(self.scaling_function), self._nplanes - 1)
         if self._host is not None:
             for s in range(self._nplanes):
                 self._plan.upload(s, self._host[s])
@@ -352,6 +372,24 @@ class Coefficients:
             touched.append(scl)
         self._refresh_host(touched)
 
+    def _denoise_sum(self, sigma, weights=None, soft_threshold=True, write_back=True):
+        """denoise(sigma, weights) fused with the plane sum: one pass over the planes
+        (wt_denoise_sum).  Same lazy-noise / truncation rules as ``denoise``."""
+        if weights is None:
+            weights = (1,) * len(sigma)
+        plan = self._device()
+        taus, wgts, noise_plane = [], [], PLANE_NONE
+        for scl, (_, sig, wgt) in enumerate(zip(range(self._nplanes), sigma, weights)):
+            t = self._tau(sig, scl)
+            taus.append(0.0 if t is None else t[0])
+            wgts.append(wgt)
+            if t is not None and t[1] != PLANE_NONE:
+                noise_plane = t[1]
+        plan.denoise_sum(self._nplanes, taus, wgts, soft_threshold, noise_plane, write_back)
+        if write_back:
+            self._refresh_host(range(len(taus)))
+        return plan
+
     # -- numpy reduction hook ------------------------------------------------------------
     def sum(self, axis=None, dtype=None, out=None, **kwargs):
         """``np.sum(coefficients, axis=0)`` (ref utils.py:98,205; README) dispatches here:
@@ -387,8 +425,8 @@ class AtrousTransform:
                 "recursive=True (ref:330-406) is out of scope for the HIP engine; use the "
                 "standard algorithm")
         scaling_function = self.scaling_function_class(img.ndim)
-        plan = Plan(default_context(), img.shape[0], img.shape[1],
-                    _family_of(scaling_function), level)
+        plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
+                            _family_of(scaling_function), level)
         plan.upload(PLANE_INPUT, img)
         self._run(plan, level)
         return Coefficients(plan, scaling_function, self.bilateral)
