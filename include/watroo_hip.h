@@ -110,7 +110,8 @@ int wt_halo_exchange(wt_plan *plan, int plane, int64_t rows);
 /* AtrousTransform.atrous_standard, bilateral=None  (watroo/wavelets.py:408-444):
  * planes[0..level-1] <- detail, planes[level] <- smooth, from plane `src` (left intact).
  * flags: bit0 = allow fused multi-scale passes (default path), bit1 = skip halo exchange
- * (caller did it / virtual strips). */
+ * (caller did it / virtual strips), bit2 (bilateral only) = materialise the variance plane
+ * with a separate kernel instead of forming it inside the bilateral kernel. */
 int wt_decompose(wt_plan *plan, int src, int level, int flags);
 /* one pass of the schedule (wt_schedule): scales [s0,s0+ns) from plane `cur` (c_{s0}) into
  * detail planes s0..s0+ns-1 and plane `nxt` (c_{s0+ns}); exchanges the pass halo first. */
@@ -156,6 +157,12 @@ int wt_denoise_sum(wt_plan *plan, int first, int count, int dst, int n_den, cons
  *                                         power_plane == WT_PLANE_NONE: c <- c * factor */
 int wt_wow_update(wt_plan *plan, int plane, int power_plane, double tau, int soft,
                   int noise_plane, float factor, int gamma_plane);
+/* The whitening form of the above (power = conv_s(c^2), watroo/utils.py:193-196) in ONE kernel:
+ * the local power is formed in registers, never written; the updated plane replaces plane
+ * `plane` by a pointer swap with WT_PLANE_SCRATCH(3).  Bit-identical to
+ * wt_smooth(square_input=1) + wt_wow_update. */
+int wt_wow_scale(wt_plan *plan, int plane, int s, double tau, int soft, int noise_plane,
+                 float factor, int gamma_plane, int flags);
 /* global reductions for wow (watroo/utils.py:180-187,209-211): out = {sum, sumsq, min, max} */
 int wt_reduce(wt_plan *plan, int plane, double out[4]);
 /* gamma blend (watroo/utils.py:212-217):

@@ -214,6 +214,41 @@ def test_fused_denoise_sum_is_bit_identical(W):
     np.testing.assert_array_equal(c2.data, c1.data)
 
 
+def test_fused_wow_scale_and_inline_variance_are_bit_identical(W):
+    """wt_wow_scale == wt_smooth(square) + wt_wow_update; bilateral with in-kernel variance ==
+    variance kernel + bilateral kernel (same arithmetic, shared device helpers)."""
+    from wavelets_amd import _lib as L
+    ctx = L.default_context()
+    a = rnd((300, 260), 31)
+    nm = (np.abs(rnd((300, 260), 32)) + .5).astype(np.float32)
+    for fam in (L.B3SPLINE, L.TRIANGLE):
+        for s in (0, 1, 3, 6):
+            for tau, soft, noise, gam in ((0.0, True, False, False), (1.3, True, False, True),
+                                          (0.9, False, True, True)):
+                p1 = L.Plan(ctx, 300, 260, fam, 1)
+                p2 = L.Plan(ctx, 300, 260, fam, 1)
+                NZ, G, PW = L.PLANE_SCRATCH(5), L.PLANE_SCRATCH(4), L.PLANE_SCRATCH(2)
+                for p in (p1, p2):
+                    p.upload(0, a)
+                    p.upload(NZ, nm)
+                    p.upload(G, 0.5 * a)
+                nzp = NZ if noise else L.PLANE_NONE
+                gp = G if gam else L.PLANE_NONE
+                p1.smooth(0, PW, s, square_input=True)
+                p1.wow_update(0, PW, tau, soft, nzp, 0.75, gp)
+                p2.wow_scale(0, s, tau, soft, nzp, 0.75, gp)
+                np.testing.assert_array_equal(p2.download(0), p1.download(0))
+                np.testing.assert_array_equal(p2.download(G), p1.download(G))
+        p1 = L.Plan(ctx, 300, 260, fam, 4)
+        p2 = L.Plan(ctx, 300, 260, fam, 4)
+        for p in (p1, p2):
+            p.upload(L.PLANE_INPUT, a)
+        p1.decompose_bilateral(L.PLANE_INPUT, 4, [1.5, 1, 1, 1], True, flags=L.FLAG_SEPARATE_VARIANCE)
+        p2.decompose_bilateral(L.PLANE_INPUT, 4, [1.5, 1, 1, 1], True, flags=0)
+        for s in range(5):
+            np.testing.assert_array_equal(p2.download(s), p1.download(s))
+
+
 def test_anscombe_bit_exact(W):
     g = load_golden("g0_hard")
     p = g["ans_in"]

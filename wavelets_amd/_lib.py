@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libwatroo_hip.so")
 TRIANGLE, B3SPLINE = 0, 1
 PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
 NUM_SCRATCH = 6
-FLAG_FUSED, FLAG_NO_EXCHANGE = 1, 2
+FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE = 1, 2, 4
 
 
 def PLANE_SCRATCH(i):
@@ -84,6 +84,8 @@ SIGNATURES = {
                                   _c.c_int, _c.c_int]),
     "wt_wow_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
                                  _c.c_float, _c.c_int]),
+    "wt_wow_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
+                                _c.c_float, _c.c_int, _c.c_int]),
     "wt_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                   _c.c_float]),
@@ -355,6 +357,10 @@ class Plan:
     def wow_update(self, plane, power_plane, tau, soft, noise_plane, factor, gamma_plane):
         check(load().wt_wow_update(self._h, plane, power_plane, float(tau), int(soft),
                                    noise_plane, float(factor), gamma_plane))
+
+    def wow_scale(self, plane, s, tau, soft, noise_plane, factor, gamma_plane, flags=0):
+        check(load().wt_wow_scale(self._h, plane, s, float(tau), int(soft), noise_plane,
+                                  float(factor), gamma_plane, flags))
 
     def reduce(self, plane):
         """(sum, sumsq, min, max) over the GLOBAL image, fp64."""

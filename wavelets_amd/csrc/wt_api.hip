@@ -664,10 +664,13 @@ extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, 
     return launch_chain<MODE_VAR>(p, in, o, nullptr, s, f1, f2, take_sqrt, "wt_chain_kernel<variance>");
 }
 
-static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s)
+// var == nullptr: the kernel forms the variance itself (times f1, f2) from its register window
+static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s,
+                            float f1 = 1.f, float f2 = 1.f)
 {
     ChainArgs a{};
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
+    a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
     dim3 grid, block;
     WT_TRY(chain_geometry(p, s, a, grid, block));
     ProfScope ps(p->ctx, "wt_bilateral_kernel");
@@ -764,8 +767,12 @@ extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const doub
         // variance = sdev_loc(c_s)^2-form * sigma_b[s]**2 (* (s+1))   watroo/wavelets.py:434-436
         const float f1 = (float)(sigma_b[s] * sigma_b[s]);
         const float f2 = bilateral_scaling ? (float)(s + 1) : 1.f;
-        WT_TRY(launch_chain<MODE_VAR>(p, in, var, nullptr, s, f1, f2, 0, "wt_chain_kernel<variance>"));
-        WT_TRY(launch_bilateral(p, in, var, oc, ow, s));
+        if (flags & 4) {   // two-kernel form (variance plane materialised), kept for A/B tests
+            WT_TRY(launch_chain<MODE_VAR>(p, in, var, nullptr, s, f1, f2, 0, "wt_chain_kernel<variance>"));
+            WT_TRY(launch_bilateral(p, in, var, oc, ow, s));
+        } else {
+            WT_TRY(launch_bilateral(p, in, nullptr, oc, ow, s, f1, f2));
+        }
         cur = nxt;
     }
     return 0;
@@ -874,6 +881,41 @@ extern "C" int wt_wow_update(wt_plan *p, int plane, int power_plane, double tau,
     ProfScope ps(p->ctx, "wt_wow_kernel");
     hipLaunchKernelGGL(wt_wow_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, c, pw, nz, gm, n4, tau, soft, factor);
     WT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Fused wow per-scale update: local power conv_s(c^2) (watroo/utils.py:194) is formed inside
+// the kernel that applies wt_wow_update's pointwise step, and the result is written to a spare
+// plane whose pointer is then swapped with the coefficient plane ("in place" at pointer level:
+// the neighbours' taps still need the old values while the kernel runs).
+extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, int noise_plane,
+                            float factor, int gamma_plane, int flags)
+{
+    if (!p) WT_FAIL("wt_wow_scale: null plan");
+    if (plane < 0 || plane > p->max_level) WT_FAIL("wt_wow_scale: plane %d is not a coefficient plane", plane);
+    WT_TRY(check_scale(p, s, "wt_wow_scale"));
+    const int spare = WT_PLANE_SCRATCH(3);
+    float *c = nullptr, *t = nullptr, *nz = nullptr, *gm = nullptr;
+    WT_TRY(plane_base(p, plane, &c));
+    WT_TRY(plane_base(p, spare, &t));
+    WT_TRY(noise_ptr(p, noise_plane, &nz));
+    if (gamma_plane != WT_PLANE_NONE) WT_TRY(plane_base(p, gamma_plane, &gm));
+    WT_TRY(maybe_exchange(p, plane, scale_halo(p, s), flags));
+    ChainArgs a{};
+    a.in = c; a.out_c = t; a.out_w = nullptr; a.aux = nullptr;
+    a.noise = nz; a.gamma = gm; a.tau = tau; a.factor = factor; a.soft = soft; a.whiten = 1;
+    dim3 grid, block;
+    WT_TRY(chain_geometry(p, s, a, grid, block));
+    {
+        ProfScope ps(p->ctx, "wt_chain_kernel<wow>");
+        const bool small = a.d < 4, b3 = p->family == WT_B3SPLINE;
+        if (b3 && small) hipLaunchKernelGGL((wt_chain_kernel<5, MODE_WOW, true>), grid, block, 0, p->ctx->stream, a);
+        else if (b3) hipLaunchKernelGGL((wt_chain_kernel<5, MODE_WOW, false>), grid, block, 0, p->ctx->stream, a);
+        else if (small) hipLaunchKernelGGL((wt_chain_kernel<3, MODE_WOW, true>), grid, block, 0, p->ctx->stream, a);
+        else hipLaunchKernelGGL((wt_chain_kernel<3, MODE_WOW, false>), grid, block, 0, p->ctx->stream, a);
+    }
+    WT_HIP(hipGetLastError());
+    std::swap(p->coef[plane], p->scratch[3]);     // both are "first margin row" pointers
     return 0;
 }
 

@@ -83,6 +83,44 @@ __device__ __forceinline__ void wt_store4(float *row, int x, int W, float4 v)
     }
 }
 
+__device__ __forceinline__ float wt_sig(float c, float tau, double taud, int soft)
+{
+    // Coefficients.significance - watroo/wavelets.py:137-141
+    if (soft) return erff(fabsf(c / tau));
+    return ((double)fabsf(c) > taud) ? 1.f : 0.f;
+}
+
+// sdev_loc from the two smoothed moments: vari = conv(I^2) - conv(I)^2 ; <= 0 -> 1e-20
+// (watroo/wavelets.py:25-28), optional sqrt, then the two factors of wavelets.py:434-436.
+// Shared by the variance chain kernel and the bilateral kernel so both give identical bits.
+__device__ __forceinline__ float wt_var_point(float p, float m, float f1, float f2, int take_sqrt)
+{
+#pragma clang fp contract(off)
+    float t = p - m * m;
+    t = t <= 0.f ? 1e-20f : t;
+    if (take_sqrt) t = sqrtf(t);
+    return (t * f1) * f2;
+}
+
+// wow per-scale update of one coefficient - watroo/utils.py:193-203:
+//   c <- c * significance ; gamma += c ; c <- c * (factor / sqrt(clip(power)))
+// Shared by wt_wow_kernel and the fused MODE_WOW chain kernel (identical bits).
+__device__ __forceinline__ float wt_wow_point(float c, float power, bool has_power, float nn,
+                                              double tau, float tauf, int soft, float factor,
+                                              float &gamma_acc)
+{
+#pragma clang fp contract(off)
+    float t = c;
+    if (tau > 0.0) t = t * wt_sig(t, tauf * nn, tau * (double)nn, soft);
+    gamma_acc = gamma_acc + t;
+    float q = factor;
+    if (has_power) {
+        const float lp = power <= 0.f ? 1e-15f : power;   // utils.py:195
+        q = factor / sqrtf(lp);                            // utils.py:196,203
+    }
+    return t * q;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1  generic per-scale separable dilated convolution ("chain march")
 //
@@ -98,7 +136,7 @@ __device__ __forceinline__ void wt_store4(float *row, int x, int W, float4 v)
 // scales of wow() (d up to 1024) need; the fused kernels in wt_fused.h take over for the
 // small dilations of the headline path.
 // ---------------------------------------------------------------------------------------------
-enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3 };
+enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3, MODE_WOW = 4 };
 
 // Raw operands of the horizontal K-tap filter of one row at the thread's 4 pixels:
 //   d >= 4: K float4 at x + (j-hw) d      d < 4: 3 float4 covering x-4 .. x+7
@@ -120,7 +158,7 @@ __device__ __forceinline__ void wt_hrow_load(const float *row, int x, int d, int
 //   h2  = sum_j k_j v^2                              (MODE_VAR only)
 //   cen = v(x)                                       (centre pixels, for the detail plane)
 template <int K, int MODE, bool SMALL_D>
-__device__ __forceinline__ void wt_hrow_filter(const float4 (&raw)[K], int d, float4 &h,
+__device__ __forceinline__ void wt_hrow_filter(const float4 *raw, int d, float4 &h,
                                                float4 &h2, float4 &cen)
 {
     constexpr int hw = K / 2;
@@ -130,7 +168,7 @@ __device__ __forceinline__ void wt_hrow_filter(const float4 (&raw)[K], int d, fl
             float4 v = raw[j];
             if (j == hw) cen = v;
             float4 vv = f4_mul(v, v);
-            if (MODE == MODE_SMOOTH_SQ) v = vv;
+            if (MODE == MODE_SMOOTH_SQ || MODE == MODE_WOW) v = vv;
             h = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, h);
             if (MODE == MODE_VAR)
                 h2 = (j == 0) ? f4_scale(wt_tap<K>(0), vv) : f4_fma(wt_tap<K>(j), vv, h2);
@@ -143,7 +181,7 @@ __device__ __forceinline__ void wt_hrow_filter(const float4 (&raw)[K], int d, fl
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             e2[i] = e[i] * e[i];
-            if (MODE == MODE_SMOOTH_SQ) e[i] = e2[i];
+            if (MODE == MODE_SMOOTH_SQ || MODE == MODE_WOW) e[i] = e2[i];
         }
         cen = C;
         float o[4], o2[4];
@@ -194,6 +232,12 @@ struct ChainArgs {
     int chunks;   // chunks per chain
     float f1, f2; // MODE_VAR: factors applied to the clipped variance (wavelets.py:434-436)
     int take_sqrt;
+    // MODE_WOW (fused wow per-scale update) / bilateral with in-kernel variance
+    const float *noise;  // per-pixel noise map or nullptr
+    float *gamma;        // gamma accumulator plane or nullptr
+    double tau;          // significance threshold (<= 0: none)
+    float factor;        // w * power_norm
+    int soft, whiten, inline_var;
 };
 
 template <int K, int MODE, bool SMALL_D>
@@ -246,15 +290,32 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
             float4 p = f4_scale(wt_tap<K>(0), h2win[0]);
 #pragma unroll
             for (int j = 1; j < K; ++j) p = f4_fma(wt_tap<K>(j), h2win[j], p);
-            // sdev_loc: vari = conv(I^2) - conv(I)^2 ; <=0 -> 1e-20   (wavelets.py:25-28)
-            float v[4] = {p.x - o.x * o.x, p.y - o.y * o.y, p.z - o.z * o.z, p.w - o.w * o.w};
+            const float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {o.x, o.y, o.z, o.w};
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t = v[k] <= 0.f ? 1e-20f : v[k];
-                if (a.take_sqrt) t = sqrtf(t);
-                v[k] = (t * a.f1) * a.f2;
-            }
+            for (int k = 0; k < 4; ++k) v[k] = wt_var_point(pp[k], mm[k], a.f1, a.f2, a.take_sqrt);
             wt_store4(a.out_c + off, x, g.W, make_float4(v[0], v[1], v[2], v[3]));
+        } else if (MODE == MODE_WOW) {
+            // fused wow update: o = conv_s(c^2) (local power), cen[0] = c at this row; result
+            // goes to a different plane (the host swaps plane pointers afterwards)
+            const float cc[4] = {cen[0].x, cen[0].y, cen[0].z, cen[0].w};
+            const float pw[4] = {o.x, o.y, o.z, o.w};
+            float nn[4] = {1.f, 1.f, 1.f, 1.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, r4[4];
+            const bool full = x + 3 < g.W;
+            if (a.noise) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (full || x + k < g.W) nn[k] = a.noise[off + x + k];
+            }
+            if (a.gamma) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (full || x + k < g.W) gg[k] = a.gamma[off + x + k];
+            }
+            const float tauf = (float)a.tau;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r4[k] = wt_wow_point(cc[k], pw[k], a.whiten != 0, nn[k], a.tau, tauf, a.soft, a.factor, gg[k]);
+            wt_store4(a.out_c + off, x, g.W, make_float4(r4[0], r4[1], r4[2], r4[3]));
+            if (a.gamma) wt_store4(a.gamma + off, x, g.W, make_float4(gg[0], gg[1], gg[2], gg[3]));
         } else {
             wt_store4(a.out_c + off, x, g.W, o);
             if (MODE == MODE_DECOMP && a.out_w)
@@ -328,10 +389,28 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
         // software prefetch of the row that enters the window in the next iteration
         load_win_row(min(r + 1, r1 - 1) + hw, nxt);
         const int64_t off = (int64_t)(q + d * r) * g.P + x;
-        const float4 v4 = *reinterpret_cast<const float4 *>(a.aux + off);
         const float4 Ic4 = win[hw][SMALL_D ? 1 : hw];
         const float I[4] = {Ic4.x, Ic4.y, Ic4.z, Ic4.w};
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float vv[4];
+        if (a.inline_var) {
+            // variance of watroo/wavelets.py:434-436 from the neighbourhood already in
+            // registers: same arithmetic (row filters, then column filter) as the MODE_VAR chain
+            // kernel, so the result is bit-identical to the separate variance pass
+            float4 m4, p4, h, h2, cdummy;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                wt_hrow_filter<K, MODE_VAR, SMALL_D>(win[i], d, h, h2, cdummy);
+                m4 = (i == 0) ? f4_scale(wt_tap<K>(0), h) : f4_fma(wt_tap<K>(i), h, m4);
+                p4 = (i == 0) ? f4_scale(wt_tap<K>(0), h2) : f4_fma(wt_tap<K>(i), h2, p4);
+            }
+            vv[0] = wt_var_point(p4.x, m4.x, a.f1, a.f2, 0);
+            vv[1] = wt_var_point(p4.y, m4.y, a.f1, a.f2, 0);
+            vv[2] = wt_var_point(p4.z, m4.z, a.f1, a.f2, 0);
+            vv[3] = wt_var_point(p4.w, m4.w, a.f1, a.f2, 0);
+        } else {
+            const float4 v4 = *reinterpret_cast<const float4 *>(a.aux + off);
+            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        }
         float norm[4], acc[4], s2[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -426,12 +505,6 @@ __global__ __launch_bounds__(256) void wt_plane_sum_kernel(SumArgs a, float *out
     }
 }
 
-__device__ __forceinline__ float wt_sig(float c, float tau, double taud, int soft)
-{
-    // Coefficients.significance - watroo/wavelets.py:137-141
-    if (soft) return erff(fabsf(c / tau));
-    return ((double)fabsf(c) > taud) ? 1.f : 0.f;
-}
 
 // K4+K5 fused: dst = sum_k plane_k with the first n_den planes thresholded on the fly
 // (plane_k * (wgt_k * significance_k)); optionally writes the thresholded planes back so the
@@ -517,17 +590,8 @@ __global__ __launch_bounds__(256) void wt_wow_kernel(float *c, const float *powe
         const float pp[4] = {pw.x, pw.y, pw.z, pw.w};
         float gg[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float t = in[k];
-            if (tau > 0.0) t *= wt_sig(t, tauf * nn[k], tau * (double)nn[k], soft);
-            gg[k] += t;
-            float q = factor;
-            if (power) {
-                float lp = pp[k] <= 0.f ? 1e-15f : pp[k];   // utils.py:195
-                q = factor / sqrtf(lp);                      // utils.py:196,203
-            }
-            in[k] = t * q;
-        }
+        for (int k = 0; k < 4; ++k)
+            in[k] = wt_wow_point(in[k], pp[k], power != nullptr, nn[k], tau, tauf, soft, factor, gg[k]);
         reinterpret_cast<float4 *>(c)[i] = make_float4(in[0], in[1], in[2], in[3]);
         if (gamma) reinterpret_cast<float4 *>(gamma)[i] = make_float4(gg[0], gg[1], gg[2], gg[3]);
     }

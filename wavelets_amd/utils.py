@@ -149,14 +149,14 @@ def wow(data,
             factor = np.float32(w * power_norm / local_power)             # ref:203
             plan.wow_update(s, PLANE_NONE, 0.0, soft_threshold, PLANE_NONE, factor, gplane)
         else:
-            power_plane = PLANE_NONE
-            if whitening and h < 1:                                       # ref:193-196
-                plan.smooth(s, _POWER_PLANE, s, square_input=True)
-                power_plane = _POWER_PLANE
             t = coefficients._tau(d, s)                                   # ref:199
             tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
             factor = np.float32(w * power_norm)
-            plan.wow_update(s, power_plane, tau, soft_threshold, noise_plane, factor, gplane)
+            if whitening and h < 1:                                       # ref:193-196 + 199-203
+                # local power conv_s(c^2), significance, gamma sum and whitening in one kernel
+                plan.wow_scale(s, s, tau, soft_threshold, noise_plane, factor, gplane)
+            else:
+                plan.wow_update(s, PLANE_NONE, tau, soft_threshold, noise_plane, factor, gplane)
 
     plan.plane_sum(0, nplanes, PLANE_OUT)                                 # ref:205
 
