@@ -42,7 +42,7 @@ enum { WT_TRIANGLE = 0, WT_B3SPLINE = 1 };      /* watroo/wavelets.py:232-287 */
 
 #define WT_PLANE_INPUT (-1)
 #define WT_PLANE_OUT (-2)
-#define WT_NUM_SCRATCH 6
+#define WT_NUM_SCRATCH 16
 #define WT_PLANE_SCRATCH(i) (-3 - (i))
 #define WT_PLANE_NONE (-1000)
 
@@ -169,6 +169,18 @@ int wt_reduce(wt_plan *plan, int plane, double out[4]);
  *   g <- clip((g-gmin)/(gmax-gmin),0,1)**(1/gamma); recon <- (1-h)*recon + h*g */
 int wt_gamma_blend(wt_plan *plan, int recon, int gamma_plane, float gmin, float gmax,
                    float inv_gamma, float h);
+/* ---- Richardson-Lucy support (watroo/utils.py:222-290) -------------- */
+/* cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with a small arbitrary kernel
+ * (watroo/utils.py:257,286): correlation, anchor = kernel centre.  `kernel` is a host pointer
+ * to kh*kw floats (<= 4096 taps). */
+int wt_filter2d(wt_plan *plan, int src, int dst, const float *kernel, int kh, int kw, int flags);
+/* elementwise dst = a OP b: 0 a-b, 1 a+b, 2 a*b, 3 a/b, 4 (a+b)/b  (watroo/utils.py:259,280-281,288) */
+int wt_binary(wt_plan *plan, int op, int a, int b, int dst);
+/* multiresolution-support update of a residual plane (watroo/utils.py:263-276):
+ * sig = significance(plane, tau); hard: mrs = persistent ? max(mrs,sig) : sig, plane *= mrs;
+ * soft: mrs = persistent ? mrs*sig : sig, plane *= mrs**inv_pow */
+int wt_mrs_update(wt_plan *plan, int plane, int mrs_plane, double tau, int soft, int noise_plane,
+                  int persistent, float inv_pow);
 /* generalized_anscombe (watroo/wavelets.py:14-21) */
 int wt_anscombe(wt_plan *plan, int src, int dst, float alpha, float g, float sigma,
                 int inverse);

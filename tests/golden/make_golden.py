@@ -76,7 +76,7 @@ NE_KIND = _install_standins()
 sys.path.insert(0, "/root/reference")
 import watroo  # noqa: E402
 from watroo import (AtrousTransform, B3spline, Triangle, Coefficients,  # noqa: E402
-                    generalized_anscombe, convolution, denoise, wow)
+                    generalized_anscombe, convolution, denoise, wow, richardson_lucy)
 from watroo.wavelets import atrous_convolution, sdev_loc  # noqa: E402
 
 FAM = {"b3spline": B3spline, "triangle": Triangle}
@@ -245,6 +245,35 @@ def g7_recursive_g8_tests():
     save("g7_misc", "semantic(cv2 stand-in)", **out)
 
 
+def g9_richardson_lucy():
+    """SURVEY 8f rank 1.  Positive image blurred by a small PSF + noise; fft=False branch."""
+    out = {}
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[:48, :40]
+    truth = (5 + 40 * np.exp(-((yy - 20) ** 2 + (xx - 15) ** 2) / 18.)
+             + 25 * np.exp(-((yy - 33) ** 2 + (xx - 28) ** 2) / 8.)).astype(np.float32)
+    g = np.exp(-(np.arange(-2, 3) ** 2) / 2.0)
+    psf = np.outer(g, g * np.array([1, 1, 1, .8, .6]))      # 5x5, deliberately asymmetric
+    psf = (psf / psf.sum()).astype(np.float32)
+    import cv2
+    blurred = cv2.filter2D(truth, -1, psf[::-1, ::-1], None, (-1, -1), 0, cv2.BORDER_REFLECT)
+    data = (blurred + rng.standard_normal(truth.shape) * .5).astype(np.float32)
+    out["data"], out["psf"] = data, psf
+    cases = {
+        "soft": dict(iterations=3),
+        "hard": dict(iterations=3, threshold_type='hard'),
+        "uniform": dict(iterations=2, uniform_init=True),
+        "soft_nonpersistent": dict(iterations=3, persistent_mrs=False, denoise_coefficients=(4, 2)),
+        "hard_nonpersistent": dict(iterations=2, threshold_type='hard', persistent_mrs=False),
+    }
+    for name, kw in cases.items():
+        out[f"rl_{name}"] = richardson_lucy(data.copy(), psf, **kw)
+    even = np.ones((4, 6), np.float32) / 24
+    out["psf_even"] = even
+    out["filter_even"] = cv2.filter2D(data, -1, even, None, (-1, -1), 0, cv2.BORDER_REFLECT)
+    save("g9_richardson_lucy", "semantic(cv2 stand-in)", **out)
+
+
 if __name__ == "__main__":
     if REAL_NE:
         assert NE_KIND.startswith("real"), "run with /opt/conda/bin/python3.9"
@@ -256,3 +285,4 @@ if __name__ == "__main__":
         g4_wow()
         g5_bilateral()
         g7_recursive_g8_tests()
+        g9_richardson_lucy()

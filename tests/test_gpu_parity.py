@@ -422,6 +422,49 @@ def test_large_dilation_scales(W, C):
     close(c.data, ref, 1e-5 * np.abs(a).max())
 
 
+# --------------------------------------------------------------------------- richardson_lucy (8f)
+RL_CASES = {
+    "soft": dict(iterations=3),
+    "hard": dict(iterations=3, threshold_type='hard'),
+    "uniform": dict(iterations=2, uniform_init=True),
+    "soft_nonpersistent": dict(iterations=3, persistent_mrs=False, denoise_coefficients=(4, 2)),
+    "hard_nonpersistent": dict(iterations=2, threshold_type='hard', persistent_mrs=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RL_CASES))
+def test_richardson_lucy_vs_golden(W, name):
+    g = load_golden("g9_richardson_lucy")
+    got = W.richardson_lucy(g["data"].copy(), g["psf"], **RL_CASES[name])
+    ref = g[f"rl_{name}"]
+    if "hard" in name:      # a pixel within rounding of tau may flip its support bit
+        bad = np.abs(got - ref) > 1e-4 * np.abs(ref).max() + 1e-4 * np.abs(ref)
+        assert bad.sum() <= 4
+    else:
+        close(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
+    with pytest.raises(NotImplementedError):
+        W.richardson_lucy(g["data"], g["psf"], fft=True)
+
+
+def test_filter2d_vs_oracle(W, O):
+    from wavelets_amd import _lib as L
+    g = load_golden("g9_richardson_lucy")
+    ctx = L.default_context()
+    for shape, ksh in (((48, 40), None), ((200, 333), (7, 3)), ((65, 129), (1, 9)), ((130, 70), (31, 31))):
+        a = g["data"] if ksh is None else rnd(shape, 41)
+        k = g["psf_even"] if ksh is None else rnd(ksh, 42)
+        plan = L.Plan(ctx, a.shape[0], a.shape[1], L.B3SPLINE, 0)
+        plan.upload(L.PLANE_INPUT, a)
+        plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, k)
+        ref = O.filter2d_reflect(a, k)
+        close(plan.download(L.PLANE_OUT), ref, 1e-5 * max(1.0, np.abs(ref).max()))
+    close(plan.download(L.PLANE_OUT) * 0 + 1, 1, 0)
+    plan = L.Plan(ctx, 48, 40, L.B3SPLINE, 0)
+    plan.upload(L.PLANE_INPUT, g["data"])
+    plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, g["psf_even"])
+    close(plan.download(L.PLANE_OUT), g["filter_even"], 1e-5 * np.abs(g["data"]).max())
+
+
 # --------------------------------------------------------------------------- C-ABI behaviour
 def test_abi_errors_and_profile(W):
     from wavelets_amd import _lib

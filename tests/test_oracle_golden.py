@@ -211,3 +211,27 @@ def test_reflect_index_matches_np_pad():
         ref = np.pad(base, pad, mode="symmetric")
         got = O.reflect_index(np.arange(-pad, n + pad), n)
         np.testing.assert_array_equal(got, ref)
+
+
+# ------------------------------------------------- richardson_lucy
+RL_CASES = {
+    "soft": dict(iterations=3),
+    "hard": dict(iterations=3, threshold_type='hard'),
+    "uniform": dict(iterations=2, uniform_init=True),
+    "soft_nonpersistent": dict(iterations=3, persistent_mrs=False, denoise_coefficients=(4, 2)),
+    "hard_nonpersistent": dict(iterations=2, threshold_type='hard', persistent_mrs=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RL_CASES))
+def test_richardson_lucy_vs_reference(name):
+    g = load_golden("g9_richardson_lucy")
+    got = O.richardson_lucy(g["data"].copy(), g["psf"], **RL_CASES[name])
+    ref = g[f"rl_{name}"]
+    close(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
+
+
+def test_filter2d_even_kernel_anchor():
+    g = load_golden("g9_richardson_lucy")
+    close(O.filter2d_reflect(g["data"], g["psf_even"]), g["filter_even"],
+          1e-5 * np.abs(g["data"]).max())

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libwatroo_hip.so")
 
 TRIANGLE, B3SPLINE = 0, 1
 PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
-NUM_SCRATCH = 6
+NUM_SCRATCH = 16
 FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE = 1, 2, 4
 
 
@@ -89,6 +89,10 @@ SIGNATURES = {
     "wt_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                   _c.c_float]),
+    "wt_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_mrs_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
+                                 _c.c_int, _c.c_float]),
     "wt_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                _c.c_int]),
 }
@@ -371,6 +375,21 @@ class Plan:
     def gamma_blend(self, recon, gamma_plane, gmin, gmax, inv_gamma, h):
         check(load().wt_gamma_blend(self._h, recon, gamma_plane, gmin, gmax, inv_gamma, h))
 
+    def filter2d(self, src, dst, kernel, flags=0):
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        if k.ndim != 2:
+            raise ValueError("filter2d kernel must be 2-D")
+        check(load().wt_filter2d(self._h, src, dst, k.ctypes.data_as(_fp), k.shape[0], k.shape[1],
+                                 flags))
+
+    def binary(self, op, a, b, dst):
+        check(load().wt_binary(self._h, {"sub": 0, "add": 1, "mul": 2, "div": 3,
+                                         "add_div": 4}[op], a, b, dst))
+
+    def mrs_update(self, plane, mrs_plane, tau, soft, noise_plane, persistent, inv_pow):
+        check(load().wt_mrs_update(self._h, plane, mrs_plane, float(tau), int(soft), noise_plane,
+                                   int(persistent), float(inv_pow)))
+
     def anscombe(self, src, dst, alpha=1.0, g=0.0, sigma=0.0, inverse=False):
         check(load().wt_anscombe(self._h, src, dst, alpha, g, sigma, int(inverse)))
 
@@ -384,7 +403,7 @@ _pool = []            # [(key, plan)] most recently released last
 
 
 def _plan_bytes(plan):
-    return (plan.nrows + 2 * plan.halo) * plan.pitch * 4 * (plan.max_level + 1 + 2 + NUM_SCRATCH)
+    return (plan.nrows + 2 * plan.halo) * plan.pitch * 4 * (plan.max_level + 1 + 2 + 4)
 
 
 def acquire_plan(ctx, H, W, family, max_level):

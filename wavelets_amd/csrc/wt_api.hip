@@ -195,6 +195,7 @@ extern "C" int wt_ctx_create(int device, wt_ctx **out)
     WT_HIP(hipMalloc(&c->d_partials, (kPartialBlocks * 4 + 8) * sizeof(double)));
     c->partial_blocks = kPartialBlocks;
     WT_HIP(hipHostMalloc(&c->h_pinned, 65536, hipHostMallocDefault));
+    WT_HIP(hipMalloc(&c->d_psf, 4096 * sizeof(float)));
     *out = c;
     return 0;
 }
@@ -215,6 +216,7 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
     (void)hipFree(c->d_hist);
     (void)hipFree(c->d_partials);
     (void)hipHostFree(c->h_pinned);
+    (void)hipFree(c->d_psf);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -947,6 +949,66 @@ extern "C" int wt_anscombe(wt_plan *p, int src, int dst, float alpha, float g, f
     const int64_t n4 = plan_n4(p);
     ProfScope ps(p->ctx, "wt_anscombe_kernel");
     hipLaunchKernelGGL(wt_anscombe_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, s, d, n4, alpha, c1, c2, c3, inverse);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================================
+// Richardson-Lucy support
+// =============================================================================================
+extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int flags)
+{
+    if (!p || !kernel) WT_FAIL("wt_filter2d: null pointer");
+    if (kh < 1 || kw < 1 || kh * kw > 4096) WT_FAIL("wt_filter2d: kernel %d x %d unsupported (<= 4096 taps)", kh, kw);
+    if (src == dst) WT_FAIL("wt_filter2d: src and dst must differ");
+    const size_t lds = (size_t)(WT_F2D_TW + kw - 1) * (WT_F2D_TH + kh - 1) * sizeof(float);
+    if (lds > 160 * 1024) WT_FAIL("wt_filter2d: kernel %d x %d needs %zu B of LDS", kh, kw, lds);
+    if (p->nranks > 1 && kh / 2 > p->g.halo) WT_FAIL("wt_filter2d: kernel needs %d halo rows, plan has %d", kh / 2, p->g.halo);
+    wt_ctx *c = p->ctx;
+    float *in = nullptr, *o = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, dst, &o));
+    WT_TRY(maybe_exchange(p, src, kh / 2, flags));
+    // the taps travel through pinned memory so the copy is ordered on the stream
+    WT_HIP(hipStreamSynchronize(c->stream));
+    memcpy(c->h_pinned, kernel, (size_t)kh * kw * sizeof(float));
+    WT_HIP(hipMemcpyAsync(c->d_psf, c->h_pinned, (size_t)kh * kw * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    dim3 grid((p->g.W + WT_F2D_TW - 1) / WT_F2D_TW, (p->g.nrows + WT_F2D_TH - 1) / WT_F2D_TH), block(64, 4);
+    if (grid.y > 65535u) WT_FAIL("wt_filter2d: strip too tall");
+    ProfScope ps(c, "wt_filter2d_kernel");
+    if (lds > 64 * 1024) WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(wt_filter2d_kernel, grid, block, lds, c->stream, in, o, p->g, c->d_psf, kh, kw);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst)
+{
+    if (!p) WT_FAIL("wt_binary: null plan");
+    if (op < 0 || op > WT_OP_ADD_DIV) WT_FAIL("wt_binary: unknown op %d", op);
+    float *pa = nullptr, *pb = nullptr, *pd = nullptr;
+    WT_TRY(plane_base(p, a, &pa));
+    WT_TRY(plane_base(p, b, &pb));
+    WT_TRY(plane_base(p, dst, &pd));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_binary_kernel");
+    hipLaunchKernelGGL(wt_binary_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, pa, pb, pd, n4, op);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_mrs_update(wt_plan *p, int plane, int mrs_plane, double tau, int soft, int noise_plane,
+                             int persistent, float inv_pow)
+{
+    if (!p) WT_FAIL("wt_mrs_update: null plan");
+    if (plane == mrs_plane) WT_FAIL("wt_mrs_update: plane and mrs_plane must differ");
+    float *c = nullptr, *m = nullptr, *nz = nullptr;
+    WT_TRY(plane_base(p, plane, &c));
+    WT_TRY(plane_base(p, mrs_plane, &m));
+    WT_TRY(noise_ptr(p, noise_plane, &nz));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_mrs_kernel");
+    hipLaunchKernelGGL(wt_mrs_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, c, m, nz, n4, tau, soft, persistent, inv_pow);
     WT_HIP(hipGetLastError());
     return 0;
 }

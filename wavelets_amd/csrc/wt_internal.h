@@ -80,6 +80,7 @@ struct wt_ctx {
     double *d_partials = nullptr; // reduction partials
     int partial_blocks = 0;
     void *h_pinned = nullptr;     // 64 KiB pinned host scratch
+    float *d_psf = nullptr;       // PSF taps of wt_filter2d (<= 4096 floats)
 };
 
 struct wt_plan {

@@ -661,6 +661,104 @@ __global__ __launch_bounds__(256) void wt_anscombe_kernel(const float *src, floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Richardson-Lucy support (watroo/utils.py:222-290)
+// ---------------------------------------------------------------------------------------------
+// cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with an arbitrary small PSF
+// (watroo/utils.py:257,286): correlation, anchor = kernel centre (k/2), symmetric border.
+// 64 x 16 output tile + halo staged in LDS; the PSF taps are wave-uniform scalar loads.
+#define WT_F2D_TW 64
+#define WT_F2D_TH 16
+__global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float *out, Geo g,
+                                                          const float *psf, int kh, int kw)
+{
+    extern __shared__ float tile[];
+    const int ax = kw / 2, ay = kh / 2;
+    const int tw = WT_F2D_TW + kw - 1, th = WT_F2D_TH + kh - 1;
+    const int x0 = blockIdx.x * WT_F2D_TW, ly0 = blockIdx.y * WT_F2D_TH;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const float *row = wt_row(in, g, g.row0 + ly0 + ty - ay);
+        tile[i] = row[wt_refl(x0 + tx - ax, g.W)];
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) {
+            const float k = psf[i * kw + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[r] = fmaf(k, tile[(threadIdx.y * 4 + r + i) * tw + threadIdx.x + j], acc[r]);
+        }
+    if (x < g.W) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ly = ly0 + threadIdx.y * 4 + r;
+            if (ly < g.nrows) out[(int64_t)ly * g.P + x] = acc[r];
+        }
+    }
+}
+
+// elementwise binary ops of the RL iteration (watroo/utils.py:259,280-281,288)
+enum { WT_OP_SUB = 0, WT_OP_ADD = 1, WT_OP_MUL = 2, WT_OP_DIV = 3, WT_OP_ADD_DIV = 4 };
+__global__ __launch_bounds__(256) void wt_binary_kernel(const float *a, const float *b, float *dst,
+                                                        int64_t n4, int op)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 u = reinterpret_cast<const float4 *>(a)[i];
+        const float4 v = reinterpret_cast<const float4 *>(b)[i];
+        const float x[4] = {u.x, u.y, u.z, u.w}, y[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            switch (op) {
+                case WT_OP_SUB: o[k] = x[k] - y[k]; break;
+                case WT_OP_ADD: o[k] = x[k] + y[k]; break;
+                case WT_OP_MUL: o[k] = x[k] * y[k]; break;
+                case WT_OP_DIV: o[k] = x[k] / y[k]; break;
+                default: o[k] = (x[k] + y[k]) / y[k]; break;   // res += phi; res /= phi
+            }
+        }
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// multiresolution-support update of one residual plane (watroo/utils.py:263-276):
+//   sig = significance(c);  hard: mrs = persistent ? max(mrs, sig) : sig ;  c *= mrs
+//                           soft: mrs = persistent ? mrs * sig   : sig ;  c *= mrs ** inv_pow
+__global__ __launch_bounds__(256) void wt_mrs_kernel(float *c, float *mrs, const float *noise,
+                                                     int64_t n4, double tau, int soft,
+                                                     int persistent, float inv_pow)
+{
+    const float tauf = (float)tau;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(c)[i];
+        const float4 m4 = reinterpret_cast<const float4 *>(mrs)[i];
+        float4 nz = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (noise) nz = reinterpret_cast<const float4 *>(noise)[i];
+        float cc[4] = {v.x, v.y, v.z, v.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sg = tau > 0.0 ? wt_sig(cc[k], tauf * nn[k], tau * (double)nn[k], soft) : 1.f;
+            if (soft) {
+                mm[k] = persistent ? mm[k] * sg : sg;
+                cc[k] = cc[k] * powf(mm[k], inv_pow);
+            } else {
+                mm[k] = persistent ? fmaxf(mm[k], sg) : sg;
+                cc[k] = cc[k] * mm[k];
+            }
+        }
+        reinterpret_cast<float4 *>(c)[i] = make_float4(cc[0], cc[1], cc[2], cc[3]);
+        reinterpret_cast<float4 *>(mrs)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void wt_fill_kernel(float *dst, int64_t n4, float value)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;

@@ -2,8 +2,8 @@
 
 Same signatures and plumbing as /root/reference/watroo/utils.py (cited ``ref:LINE``); the
 planes never leave HBM between the transform and the final reconstruction download.
-``richardson_lucy`` (ref:222-290) is a consumer of this path and is listed as "next" in
-SURVEY.md section 8(f); calling it raises NotImplementedError.
+``richardson_lucy`` (ref:222-290) keeps its whole iteration
+on the device.
 """
 import copy
 import warnings
@@ -174,7 +174,60 @@ def wow(data,
     return recon, coefficients
 
 
-def richardson_lucy(*args, **kwargs):
-    """Wavelet-regularised Richardson-Lucy deconvolution (ref:222-290) - a consumer of the
-    transform, ranked "next" in SURVEY.md section 8(f); not part of this engine yet."""
-    raise NotImplementedError("richardson_lucy is out of scope for the HIP engine (SURVEY 8f)")
+def richardson_lucy(data, psf,
+                    iterations=10, denoise_coefficients=(5, 2, 1),
+                    threshold_type='soft', uniform_init=False, persistent_mrs=True, fft=False):
+    """Wavelet-regularised Richardson-Lucy deconvolution (ref:222-290), device-resident across
+    iterations: per iteration one PSF correlation (ref:257), the residual's a-trous transform
+    (ref:261), the multiresolution-support update per scale (ref:263-276), the plane sum
+    (ref:278) and the second PSF correlation (ref:286) - nothing returns to the host until
+    the final estimate.  ``fft=True`` (circular rFFT convolution, ref:245-254,284) is not
+    implemented on the GPU."""
+    if fft:
+        raise NotImplementedError("richardson_lucy(fft=True) is not implemented in the HIP "
+                                  "engine; use the direct PSF correlation (fft=False)")
+    img = _to_f32_image(data, "data")
+    psf = np.ascontiguousarray(psf, dtype=np.float32)
+    if psf.ndim != 2:
+        raise ValueError("psf must be 2-D")
+    level = len(denoise_coefficients)
+    soft = threshold_type == 'soft'
+    sf = B3spline(2)                                                     # ref:229 default transform
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
+    DATA, PSI, PHI, RES, CONV = (PLANE_SCRATCH(i) for i in (6, 7, 8, 9, 10))
+    MRS = [PLANE_SCRATCH(11 + s) for s in range(level)]
+    if level > 5:
+        raise ValueError("richardson_lucy supports at most 5 denoise coefficients")
+    plan.upload(DATA, img)
+    plan.decompose(DATA, level)                                          # ref:230
+    coefficients = Coefficients(plan, sf)
+    if uniform_init:                                                     # ref:232-234
+        tot = plan.reduce(DATA)[0]
+        plan.fill(PSI, np.float32(np.float32(tot) / img.size))
+    else:                                                                # ref:236-237
+        coefficients._denoise_sum(list(denoise_coefficients), soft_threshold=soft,
+                                  write_back=True)
+        plan.copy(PLANE_OUT, PSI)
+    for m in MRS:                                                        # ref:240-243
+        plan.fill(m, 1.0 if soft else 0.0)
+    psf_flipped = np.ascontiguousarray(psf[::-1, ::-1])
+    for iteration in range(iterations):                                  # ref:252
+        plan.filter2d(PSI, PHI, psf_flipped)                             # ref:257
+        plan.binary("sub", DATA, PHI, RES)                               # ref:259
+        plan.decompose(RES, level)                                       # ref:261
+        res_coefficients = Coefficients.__new__(Coefficients)            # same plan, no release
+        res_coefficients.scaling_function, res_coefficients.bilateral = sf, None
+        res_coefficients._plan, res_coefficients._host = plan, None
+        res_coefficients._nplanes, res_coefficients._noise_uploaded = level + 1, None
+        res_coefficients.noise = coefficients.noise                      # ref:262
+        for s, c in enumerate(denoise_coefficients):                     # ref:263-276
+            t = res_coefficients._tau(c, s)
+            tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
+            plan.mrs_update(s, MRS[s], tau, soft, noise_plane, persistent_mrs,
+                            1.0 / (iteration + 1))
+        res_coefficients._plan = None                                    # keep the plan out of the pool
+        plan.plane_sum(0, level + 1, RES)                                # ref:278
+        plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
+        plan.filter2d(RES, CONV, psf)                                    # ref:286
+        plan.binary("mul", PSI, CONV, PSI)                               # ref:288
+    return plan.download(PSI)
