@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="one kernel per scale")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--brief", action="store_true", help="one short line (tuning sweeps)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the launcher plumbing (gloo rendezvous, RCCL communicator) even "
+                         "with one rank (plumbing check on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,12 +105,19 @@ def main():
                      "(one rank per GPU)")
         args.gpus = world
 
+    # ORDER MATTERS: torch wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 /
+    # librccl).  If libwatroo_hip.so pulls in the system ROCm first and torch is imported
+    # afterwards, the process ends up with TWO HSA runtimes and whichever initialises second
+    # sees "no ROCm-capable device".  Importing torch first makes the dynamic loader resolve
+    # our library's sonames to the already-loaded (torch) copies: one consistent stack.
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch  # noqa: F401  (before anything loads libwatroo_hip.so)
+        import torch.distributed as dist
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if dist is not None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
@@ -115,10 +125,15 @@ def main():
     from wavelets_amd._lib import PLANE_INPUT, PLANE_OUT
 
     ctx = _lib.Context(local_rank)
-    if world > 1:
-        ids = [_lib.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(rank, world, ids[0])
+    if dist is not None:
+        def bcast(obj, src):
+            box = [obj]
+            dist.broadcast_object_list(box, src=src)
+            return box[0]
+        from wavelets_amd.parallel import init_comm
+        init_comm(ctx, rank, world, bcast)
+        if args.force_dist:
+            assert ctx.comm_selftest(1 << 20), "RCCL self-test failed"
 
     side = args.size or (8192 if world == 1 else 32768)
     H = W = side

@@ -414,6 +414,18 @@ def test_8192_b3_l6_properties(W):
     assert k._device().reduce(6)[2:] == (3.25, 3.25)
 
 
+def test_strip_shaped_wide_image(W, C):
+    """4096 x 32768: the per-GPU strip shape of BASELINE cfg 4 at 8 GPUs (512 MiB planes)."""
+    a = rnd((4096, 32768), 17)
+    amax = np.abs(a).max()
+    c = W.AtrousTransform(W.B3spline)(a, 6)
+    ref = C.decompose(a, 6, "b3spline")
+    plan = c._device()
+    for s in range(7):
+        close(plan.download(s), ref[s], 1e-5 * amax)
+    close(c.sum(axis=0), a, 1e-5 * amax)
+
+
 def test_large_dilation_scales(W, C):
     """wow-sized dilations (d up to 512) on a 2048x1024 image vs the C oracle."""
     a = rnd((2048, 1024), 9)

@@ -93,10 +93,18 @@ def _worker(rank, world, port, H, W, family, level, fused, result_dir):
     (3, 99, 20, "b3spline", 4, False),     # per-scale exchange, halos 2,4,8,16
 ])
 def test_strips_match_unsharded_bitwise(tmp_path, world, H, W, family, level, fused):
-    import torch.multiprocessing as mp
+    # stdlib multiprocessing (spawn): the pytest process itself never imports torch, so a GPU
+    # test session is not exposed to torch's bundled ROCm runtime (see bench.py / INTEGRATION.md)
+    import multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, H, W, family, level, fused, str(tmp_path)),
-             nprocs=world, join=True)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, family, level, fused,
+                                                str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
     for r in range(world):
         assert open(tmp_path / f"r{r}.txt").read() == "1 1", f"rank {r} mismatch"
 

@@ -141,7 +141,8 @@ class Context:
         L = load()
         if device_count() == 0:
             raise WatrooHipError("no HIP device visible: the a-trous engine needs an MI355X "
-                                 "(there is no CPU fallback)")
+                                 "(there is no CPU fallback) ["
+                                 + L.wt_last_error().decode("utf-8", "replace") + "]")
         check(L.wt_ctx_create(device, _c.byref(self._h)))
         _live.add(self)
 

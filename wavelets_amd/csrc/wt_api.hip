@@ -32,8 +32,11 @@ extern "C" int wt_device_count(int *count)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) {
+        wt_set_error("hipGetDeviceCount failed: %d (%s)", (int)e, hipGetErrorString(e));
         (void)hipGetLastError();
         n = 0;
+    } else {
+        wt_set_error("hipGetDeviceCount: %d device(s)", n);
     }
     *count = n;
     return 0;
