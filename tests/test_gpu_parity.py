@@ -93,6 +93,29 @@ def test_ragged_shapes_and_multibounce(W, O, shape):
             close(c.data, O.atrous_standard(a, L, fam), tol)
 
 
+def test_random_shape_sweep_fused_and_unfused(W, O):
+    """40 random (H, W, level, family) cases, fused and per-scale schedules, vs the oracle."""
+    from wavelets_amd import _lib as L
+    rng = np.random.default_rng(123)
+    ctx = L.default_context()
+    for case in range(40):
+        H = int(rng.integers(1, 90)) if case % 3 else int(rng.integers(200, 700))
+        Wd = int(rng.integers(1, 90)) if case % 2 else int(rng.integers(250, 1300))
+        level = int(rng.integers(1, 8))
+        fam = FAMS[case % 2]
+        a = rng.standard_normal((H, Wd)).astype(np.float32)
+        ref = O.atrous_standard(a, level, fam)
+        tol = 1e-5 * max(1.0, np.abs(a).max())
+        for flags in (L.FLAG_FUSED, 0):
+            plan = L.Plan(ctx, H, Wd, {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam], level)
+            plan.upload(L.PLANE_INPUT, a)
+            plan.decompose(L.PLANE_INPUT, level, flags)
+            got = np.stack([plan.download(s) for s in range(level + 1)])
+            np.testing.assert_allclose(got, ref, atol=tol, rtol=0,
+                                       err_msg=f"case {case}: {H}x{Wd} L={level} {fam} flags={flags}")
+            plan.close()
+
+
 def test_output_param_and_input_untouched(W):
     a = rnd((40, 44), 4)
     keep = a.copy()
