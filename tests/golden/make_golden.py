@@ -274,6 +274,20 @@ def g9_richardson_lucy():
     save("g9_richardson_lucy", "semantic(cv2 stand-in)", **out)
 
 
+def g10_enhance():
+    """utils.enhance (importable by path, not in __all__)."""
+    from watroo.utils import enhance
+    out = {}
+    a = img((40, 36), 31)
+    rgb = np.stack([img((40, 36), 32 + i) for i in range(3)])
+    out["img"], out["rgb"] = a, rgb
+    out["enh_2d"] = enhance(a.copy(), weights=[.5, 2, 1], denoise=[4, 2])
+    out["enh_2d_noise"] = enhance(a.copy(), 0.8, weights=[1.5], denoise=[3, 2], soft_threshold=False)
+    out["enh_rgb"] = enhance(rgb.copy(), weights=[[.5, 2], [1], [2, 2, 1]], denoise=[[3], [4, 2], None])
+    out["enh_rgb_tri"] = enhance(rgb.copy(), weights=2., denoise=3., scaling_function_class=Triangle)
+    save("g10_enhance", "semantic(cv2 stand-in)", **out)
+
+
 if __name__ == "__main__":
     if REAL_NE:
         assert NE_KIND.startswith("real"), "run with /opt/conda/bin/python3.9"
@@ -286,3 +300,4 @@ if __name__ == "__main__":
         g5_bilateral()
         g7_recursive_g8_tests()
         g9_richardson_lucy()
+        g10_enhance()

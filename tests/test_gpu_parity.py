@@ -500,6 +500,28 @@ def test_filter2d_vs_oracle(W, O):
     close(plan.download(L.PLANE_OUT), g["filter_even"], 1e-5 * np.abs(g["data"]).max())
 
 
+def test_enhance_and_noise_calibration(W):
+    """utils.enhance (per-channel) and compute_noise_weights run on top of
+    the GPU transform."""
+    from wavelets_amd.utils import enhance, prepare_params
+    g = load_golden("g10_enhance")
+    a, rgb = g["img"], g["rgb"]
+    tol = 1e-5 * np.abs(a).max() * 4
+    close(enhance(a.copy(), weights=[.5, 2, 1], denoise=[4, 2]), g["enh_2d"], tol)
+    got = enhance(a.copy(), 0.8, weights=[1.5], denoise=[3, 2], soft_threshold=False)
+    assert (np.abs(got - g["enh_2d_noise"]) > tol).sum() <= 2
+    close(enhance(rgb.copy(), weights=[[.5, 2], [1], [2, 2, 1]], denoise=[[3], [4, 2], None]),
+          g["enh_rgb"], tol)
+    close(enhance(rgb.copy(), weights=2., denoise=3., scaling_function_class=W.Triangle),
+          g["enh_rgb_tri"], tol)
+    with pytest.raises(ValueError, match="Invalid number of parameters"):
+        prepare_params([1, 2], 3)                                 # ref utils.py:26
+    # Monte-Carlo sigma_e calibration reproduces the tabulated values (ref wavelets.py:221-229)
+    np.random.seed(0)
+    got = W.B3spline(2).compute_noise_weights(4, n_trials=3)
+    np.testing.assert_allclose(got, W.B3spline(2).sigma_e()[:4], rtol=0.05)
+
+
 # --------------------------------------------------------------------------- C-ABI behaviour
 def test_abi_errors_and_profile(W):
     from wavelets_amd import _lib

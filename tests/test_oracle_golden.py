@@ -235,3 +235,15 @@ def test_filter2d_even_kernel_anchor():
     g = load_golden("g9_richardson_lucy")
     close(O.filter2d_reflect(g["data"], g["psf_even"]), g["filter_even"],
           1e-5 * np.abs(g["data"]).max())
+
+
+def test_enhance_vs_reference():
+    g = load_golden("g10_enhance")
+    a, rgb = g["img"], g["rgb"]
+    tol = 1e-5 * np.abs(a).max() * 4
+    close(O.enhance(a.copy(), weights=[.5, 2, 1], denoise=[4, 2]), g["enh_2d"], tol)
+    got = O.enhance(a.copy(), 0.8, weights=[1.5], denoise=[3, 2], soft_threshold=False)
+    assert (np.abs(got - g["enh_2d_noise"]) > tol).sum() <= 2
+    close(O.enhance(rgb.copy(), weights=[[.5, 2], [1], [2, 2, 1]], denoise=[[3], [4, 2], None]),
+          g["enh_rgb"], tol)
+    close(O.enhance(rgb.copy(), weights=2., denoise=3., family="triangle"), g["enh_rgb_tri"], tol)

@@ -12,7 +12,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwatroo_hip.so")
+LIB_PATH = os.environ.get("WATROO_HIP_LIB", os.path.join(_HERE, "libwatroo_hip.so"))   # override: A/B builds
 
 TRIANGLE, B3SPLINE = 0, 1
 PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000

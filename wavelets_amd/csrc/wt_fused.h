@@ -129,7 +129,10 @@ __device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk,
 // the NS horizontal filters of a step are mutually independent (one s_barrier per row instead
 // of NS, 4*NS LDS reads in flight together).  LDS rows are double-buffered by step parity.
 template <int K, int NS, int D, int NW, int PDREQ>
-__global__ __launch_bounds__(NW * 64) void wt_fused_kernel(FusedArgs a)
+#ifndef WT_FUSED_WPS4
+#define WT_FUSED_WPS4 2   // waves per SIMD requested for the 4-wave workgroup variant
+#endif
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fused_kernel(FusedArgs a)
 {
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
@@ -286,7 +289,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     const int phases = std::min(D, g.nrows);
     const int n_max = (g.nrows + D - 1) / D;             // longest chain
     // one round: as many workgroups as the chip holds at once (256 CUs x resident WGs/CU)
-    const int wg_per_cu = std::max(1, 8 / NW);
+    const int wg_per_cu = NW == 4 ? WT_FUSED_WPS4 : std::max(1, 8 / NW);
     static const int rounds = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 1;
     const int slots = 256 * wg_per_cu * rounds;
     int chunks = std::max(1, slots / std::max(1, nx * phases));

@@ -14,10 +14,56 @@ from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_co
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _family_of, _to_f32_image,
                        PLANE_INPUT)
 
-__all__ = ['denoise', 'wow', 'richardson_lucy']
+__all__ = ['denoise', 'wow', 'richardson_lucy']     # enhance / prepare_params importable by path, as in the reference
 
 _POWER_PLANE = PLANE_SCRATCH(3)
 _GAMMA_PLANE = PLANE_SCRATCH(4)
+
+
+def prepare_params(param, ndims):
+    """Normalise a scalar / list / per-channel list parameter (ref:10-33)."""
+    if ndims == 2:
+        if param is None:
+            return []
+        return copy.copy(param) if type(param) is list else [param]
+    if type(param) is not list:
+        return [[], ] * ndims if param is None else [[param], ] * ndims
+    if len(param) != ndims:
+        raise ValueError("Invalid number of parameters")                  # ref:26
+    out = [prepare_params(p, 2) for p in param]
+    if None in out:
+        out[out.index(None)] = []
+    return out
+
+
+def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **kwargs):
+    """De-noising and / or enhancement by modification of the wavelet coefficients, per channel
+    for (3, H, W) images (ref:36-80): transform over ``len(weights)`` scales, threshold with
+    ``denoise`` sigmas, recombine with ``weights``.  ``args = (img[, noise])``; ``kwargs`` go to
+    ``AtrousTransform``."""
+    img = np.asarray(args[0])
+    channels = [0, 1, 2] if img.ndim == 3 else [Ellipsis]                 # ref:47-50
+    if out is None:
+        out = np.empty(img.shape, np.float32)
+    weights = prepare_params(weights, img.ndim)
+    denoise = prepare_params(denoise, img.ndim)
+    atrous = AtrousTransform(**kwargs)
+    for c in channels:
+        dns = denoise if c is Ellipsis else denoise[c]
+        wgt = weights if c is Ellipsis else weights[c]
+        if len(wgt) < len(dns):                                           # ref:65-68
+            wgt.extend([1] * (len(dns) - len(wgt)))
+        elif len(dns) < len(wgt):
+            dns.extend([0] * (len(wgt) - len(dns)))
+        coeffs = atrous(img[c], len(wgt))                                 # ref:70
+        if len(args) == 2:
+            coeffs.noise = args[1] if c is Ellipsis else args[1][c]       # ref:71-72
+        else:
+            coeffs.noise = coeffs.get_noise()
+        plan = coeffs._denoise_sum(dns, weights=wgt, soft_threshold=soft_threshold,
+                                   write_back=False)                       # ref:76-78
+        out[c] = plan.download(PLANE_OUT)
+    return out
 
 
 def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None,
