@@ -299,7 +299,8 @@ extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, i
     int n = 0, s = 0;
     while (s < level) {
         int ns = 1;
-        if (fused && s <= WT_FUSED_MAX_FIRST_SCALE) ns = std::min(WT_FUSED_MAX_SCALES, level - s);
+        if (fused && s <= 3) ns = std::min(WT_FUSED_MAX_SCALES, level - s);
+        else if (fused && s == 6) ns = std::min(2, level - s);   // D = 64: two scales (x halo hw*3*64)
         if (n >= cap) WT_FAIL("wt_schedule: capacity %d too small", cap);
         triples[3 * n + 0] = s;
         triples[3 * n + 1] = ns;
@@ -726,7 +727,7 @@ extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, i
         WT_TRY(plane_base(p, s0, &ow));
         return launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>");
     }
-    if (!(s0 == 0 || s0 == 3) || ns < 2) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
+    if (!(s0 == 0 || s0 == 3 || (s0 == 6 && ns == 2)) || ns < 2) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
     float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
     for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
     return wt_fused_launch(p, in, oc, ow, s0, ns);

@@ -317,7 +317,7 @@ static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
 {
     static const int nw_env = getenv("WT_FUSED_NW") ? atoi(getenv("WT_FUSED_NW")) : 0;
     static const int pd_env = getenv("WT_FUSED_PD") ? atoi(getenv("WT_FUSED_PD")) : 0;
-    const int nw = nw_env ? nw_env : (s0 == 0 ? 4 : 8);
+    const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : (s0 == 0 ? 4 : 8);
     const int pd = pd_env ? pd_env : (s0 == 0 ? 8 : 4);
 #define WT_FUSED_CASE(S0, NS_, D_, NAME)                                                          \
     if (s0 == S0 && ns == NS_) {                                                                  \
@@ -331,6 +331,8 @@ static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
     WT_FUSED_CASE(3, 3, 8, "wt_fused<d8x3>")
     WT_FUSED_CASE(3, 2, 8, "wt_fused<d8x2>")
 #undef WT_FUSED_CASE
+    // D = 64 (scales 6-7): taps are 16 / 32 lanes apart; 8-wave workgroups only
+    if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4>(p, a, "wt_fused<d64x2>");
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
