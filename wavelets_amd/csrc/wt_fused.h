@@ -232,6 +232,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
             const float4 cur = pf[kk % PD];
             pf[kk % PD] = load_row(t + PD);
             float4 (*buf)[NL] = vbuf[kk & 1];
+            if (a.debug & 4) {   // ablation: same loads / stores / addresses, no filtering at all
+                store_at(aw0, t - LAG0, cur);
+                if constexpr (NS > 1) store_at(aw1, t - LAG1, cur);
+                if constexpr (NS > 2) store_at(aw2, t - LAG2, cur);
+                store_at(ac, t - LAGC, cur);
+                aw0 += step_bytes; aw1 += step_bytes; aw2 += step_bytes; ac += step_bytes;
+                continue;
+            }
             float4 cen0, cen1, cen2, v0, v1, v2;
             v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
             buf[0][gl] = v0;
