@@ -58,6 +58,30 @@ __global__ __launch_bounds__(256) void tile_kernel(Ptrs in, Ptrs out, long n4, l
     }
 }
 
+// Row-march pattern of the fused a-trous pass, without the arithmetic: a 256-thread workgroup
+// owns a 1024-pixel column strip and walks down `rows` consecutive image rows, reading one row
+// segment (16 B per lane) and writing it to 4 planes, with PD rows of software prefetch.
+template <int PD>
+__global__ __launch_bounds__(256) void march_kernel(Ptrs in, Ptrs out, int W4, int rows, int nstrips)
+{
+    const int strip = blockIdx.x % nstrips, chunk = blockIdx.x / nstrips;
+    const long base = (long)chunk * rows * W4 + (long)strip * 256 + threadIdx.x;
+    float4 pf[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) pf[i] = in.p[0][base + (long)min(i, rows - 1) * W4];
+    for (int r = 0; r < rows; r += PD) {
+#pragma unroll
+        for (int k = 0; k < PD; ++k) {
+            const int rr = r + k;
+            if (rr >= rows) break;
+            const float4 cur = pf[k];
+            pf[k] = in.p[0][base + (long)min(rr + PD, rows - 1) * W4];
+            const long o = base + (long)rr * W4;
+            out.p[0][o] = cur; out.p[1][o] = cur; out.p[2][o] = cur; out.p[3][o] = cur;
+        }
+    }
+}
+
 template <typename F>
 static double timeit(F f, int reps = 20)
 {
@@ -89,7 +113,19 @@ int main(int argc, char **argv)
     RUN(7, 1, 1, 1, 512) RUN(7, 1, 1, 1, 1024) RUN(7, 1, 1, 3, 1024)
     RUN(1, 4, 1, 0, 2048) RUN(1, 4, 1, 1, 2048) RUN(1, 4, 1, 0, 16384) RUN(1, 4, 1, 0, 65536) RUN(1, 4, 1, 1, 65536)
     RUN(1, 1, 1, 0, 65536) RUN(1, 1, 1, 1, 65536) RUN(1, 1, 1, 3, 65536) RUN(1, 1, 1, 0, 262144)
-    for (long tile : {4096L, 16384L, 65536L}) {
+    {
+        const int W4 = side / 4, nstrips = W4 / 256;
+        for (int rows : {2048, 1024, 512, 256, 128, 64, 32}) {
+            const int chunks = side / rows, grid = chunks * nstrips;
+#define MARCH(PD)                                                                                  \
+            {                                                                                      \
+                double ms = timeit([&] { hipLaunchKernelGGL((march_kernel<PD>), dim3(grid), dim3(256), 0, 0, in, out, W4, rows, nstrips); }); \
+                printf("march R1W4 rows/WG %4d  WGs %5d  PD%d : %.4f ms  %.0f GB/s\n", rows, grid, PD, ms, 5.0 * bytes / ms / 1e6); \
+            }
+            MARCH(1) MARCH(4) MARCH(8)
+        }
+    }
+    for (long tile : {4096L}) {
         long grid = (n4 + tile - 1) / tile;
         double ms = timeit([&] { hipLaunchKernelGGL((tile_kernel<7, 1>), dim3(grid), dim3(256), 0, 0, in, out, n4, tile); });
         printf("tile R7 W1 tile%ld grid%ld : %.4f ms %.0f GB/s\n", tile, grid, ms, 8 * (double)bytes / ms / 1e6);

@@ -318,7 +318,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
 }
 
 // Tuned on MI355X (8192^2, B3): the D = 1 pass prefers 4-wave workgroups (2 resident per CU)
-// with 8 rows of prefetch; the D = 8 pass prefers 8-wave workgroups (x halo 224 of 2048 px
+// the D = 8 pass prefers 8-wave workgroups (x halo 224 of 2048 px
 // instead of 224 of 1024).  WT_FUSED_NW / WT_FUSED_PD override both (tuning sweeps).
 template <int K>
 static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
@@ -326,7 +326,7 @@ static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
     static const int nw_env = getenv("WT_FUSED_NW") ? atoi(getenv("WT_FUSED_NW")) : 0;
     static const int pd_env = getenv("WT_FUSED_PD") ? atoi(getenv("WT_FUSED_PD")) : 0;
     const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : (s0 == 0 ? 4 : 8);
-    const int pd = pd_env ? pd_env : (s0 == 0 ? 8 : 4);
+    const int pd = pd_env ? pd_env : 4;
 #define WT_FUSED_CASE(S0, NS_, D_, NAME)                                                          \
     if (s0 == S0 && ns == NS_) {                                                                  \
         if (nw == 8) return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 8, 8>(p, a, NAME)             \
