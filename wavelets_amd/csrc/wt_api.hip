@@ -427,15 +427,39 @@ extern "C" int wt_plane_ptr(wt_plan *p, int plane, void **dev_ptr)
 // =============================================================================================
 // host <-> device, copies
 // =============================================================================================
+// Host transfers.  Large user buffers are pinned for the duration of the call
+// (hipHostRegister) so the copy is one DMA at PCIe rate instead of a staged pageable copy;
+// WT_PIN_THRESHOLD (bytes, default 4 MiB; 0 disables) sets the cut-over.
+static size_t pin_threshold()
+{
+    static const long long v = getenv("WT_PIN_THRESHOLD") ? atoll(getenv("WT_PIN_THRESHOLD")) : (4ll << 20);
+    return (size_t)v;
+}
+
+static bool try_pin(const void *host, size_t bytes)
+{
+    const size_t thr = pin_threshold();
+    if (thr == 0 || bytes < thr) return false;
+    if (hipHostRegister(const_cast<void *>(host), bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();   // already registered / not registrable: fall back to pageable
+        return false;
+    }
+    return true;
+}
+
 extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_stride)
 {
     if (!p || !host) WT_FAIL("wt_upload: null pointer");
     if (host_stride < p->g.W) WT_FAIL("wt_upload: host stride %lld < width %d", (long long)host_stride, p->g.W);
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
-    WT_HIP(hipMemcpy2DAsync(b, (size_t)p->g.P * 4, host, (size_t)host_stride * 4, (size_t)p->g.W * 4,
-                            (size_t)p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream));
-    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    const size_t span = ((size_t)(p->g.nrows - 1) * (size_t)host_stride + (size_t)p->g.W) * 4;
+    const bool pinned = try_pin(host, span);
+    hipError_t e = hipMemcpy2DAsync(b, (size_t)p->g.P * 4, host, (size_t)host_stride * 4, (size_t)p->g.W * 4,
+                                    (size_t)p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
+    if (pinned) (void)hipHostUnregister(const_cast<float *>(host));
+    WT_HIP(e);
     return 0;
 }
 
@@ -445,9 +469,13 @@ extern "C" int wt_download(wt_plan *p, int plane, float *host, int64_t host_stri
     if (host_stride < p->g.W) WT_FAIL("wt_download: host stride %lld < width %d", (long long)host_stride, p->g.W);
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
-    WT_HIP(hipMemcpy2DAsync(host, (size_t)host_stride * 4, b, (size_t)p->g.P * 4, (size_t)p->g.W * 4,
-                            (size_t)p->g.nrows, hipMemcpyDeviceToHost, p->ctx->stream));
-    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    const size_t span = ((size_t)(p->g.nrows - 1) * (size_t)host_stride + (size_t)p->g.W) * 4;
+    const bool pinned = try_pin(host, span);
+    hipError_t e = hipMemcpy2DAsync(host, (size_t)host_stride * 4, b, (size_t)p->g.P * 4, (size_t)p->g.W * 4,
+                                    (size_t)p->g.nrows, hipMemcpyDeviceToHost, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
+    if (pinned) (void)hipHostUnregister(host);
+    WT_HIP(e);
     return 0;
 }
 
