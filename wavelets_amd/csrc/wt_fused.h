@@ -138,7 +138,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
     constexpr int KM = K - 1;
     constexpr int LAT_IN = hw * ((1 << NS) - 1);         // rows of input beyond a stored row
     constexpr int LAT = LAT_IN + (NS - 1);               // + pipeline skew between the scales
-    constexpr int HX = (hw * ((1 << NS) - 1) * D + 3) / 4 * 4;  // x halo, rounded to float4
+    // x halo rounded up to 32 pixels (128 B): with strip starts that are multiples of 32 pixels
+    // every wave's 1-KiB row access is cache-line aligned (8 lines, not 9 with two half lines)
+    constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
     constexpr int U = KM << (NS - 1);                    // register-rotation period
     constexpr int PD = (U % PDREQ == 0) ? PDREQ : 4;     // rows prefetched ahead
     constexpr int NL = NW * 64;                          // lanes (float4 columns) per WG
@@ -233,10 +235,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
             pf[kk % PD] = load_row(t + PD);
             float4 (*buf)[NL] = vbuf[kk & 1];
             if (a.debug & 4) {   // ablation: same loads / stores / addresses, no filtering at all
+                if (a.debug & 16) {   // ... and do not even issue the predicated-off stores
+                    if ((unsigned)(t - LAG0 - r0) < span) store_at(aw0, t - LAG0, cur);
+                    if constexpr (NS > 1) if ((unsigned)(t - LAG1 - r0) < span) store_at(aw1, t - LAG1, cur);
+                    if constexpr (NS > 2) if ((unsigned)(t - LAG2 - r0) < span) store_at(aw2, t - LAG2, cur);
+                    if ((unsigned)(t - LAGC - r0) < span) store_at(ac, t - LAGC, cur);
+                } else {
                 store_at(aw0, t - LAG0, cur);
                 if constexpr (NS > 1) store_at(aw1, t - LAG1, cur);
                 if constexpr (NS > 2) store_at(aw2, t - LAG2, cur);
                 store_at(ac, t - LAGC, cur);
+                }
                 aw0 += step_bytes; aw1 += step_bytes; aw2 += step_bytes; ac += step_bytes;
                 continue;
             }
@@ -285,15 +294,16 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
 {
     constexpr int hw = K / 2;
     constexpr int LAT = hw * ((1 << NS) - 1) + (NS - 1);
-    constexpr int HX = (hw * ((1 << NS) - 1) * D + 3) / 4 * 4;
+    constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
     constexpr int NL = NW * 64;
     constexpr int VXMAX = NL * 4 - 2 * HX;               // widest valid strip per WG
     static_assert(VXMAX >= 64, "workgroup too narrow for this halo");
     const Geo &g = p->g;
     FusedArgs a = base;
     const int W4 = (g.W + 3) / 4 * 4;
-    const int nx = (W4 + VXMAX - 1) / VXMAX;
-    a.Vx = ((W4 + nx - 1) / nx + 3) / 4 * 4;             // balanced strips, multiple of 4
+    const int nx = (W4 + VXMAX / 32 * 32 - 1) / (VXMAX / 32 * 32);
+    a.Vx = std::min(VXMAX / 32 * 32, ((W4 + nx - 1) / nx + 31) / 32 * 32);   // balanced, 128-B aligned
+    if ((int64_t)a.Vx * nx < W4) WT_FAIL("fused pass: strip sizing failed");
     const int phases = std::min(D, g.nrows);
     const int n_max = (g.nrows + D - 1) / D;             // longest chain
     // one round: as many workgroups as the chip holds at once (256 CUs x resident WGs/CU)
