@@ -783,9 +783,10 @@ __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int64_t n4
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+        const float4 v = wt_ldnt4(p + 4 * i);
         const int x = (int)(i % P4) * 4;
-        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t b[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
+                               __float_as_uint(v.w)};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t u = b[k] & 0x7fffffffu;
