@@ -100,8 +100,9 @@ int wt_download(wt_plan *plan, int plane, float *host, int64_t host_stride);
 int wt_copy_plane(wt_plan *plan, int src, int dst);
 int wt_fill_plane(wt_plan *plan, int plane, float value);
 /* In-process stand-in for the RCCL halo exchange between two plans on the SAME device
- * ("virtual strips"): copies upper's top rows into lower... see tests. `upper` owns the rows
- * just above `lower`.  Copies `rows` rows each way for `plane`. */
+ * ("virtual strips", tests/test_gpu_strips.py): `upper` owns the rows just above `lower`;
+ * upper's last `rows` rows go to lower's top margin and lower's first `rows` rows to upper's
+ * bottom margin - exactly the rows and margins the RCCL exchange moves. */
 int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane, int64_t rows);
 /* RCCL halo exchange of `rows` margin rows of `plane` with the strip neighbours. */
 int wt_halo_exchange(wt_plan *plan, int plane, int64_t rows);
