@@ -50,6 +50,9 @@ enum { WT_TRIANGLE = 0, WT_B3SPLINE = 1 };      /* watroo/wavelets.py:232-287 */
 int wt_abi_version(void);
 const char *wt_last_error(void);
 int wt_device_count(int *count);
+/* process-wide tuning / A-B switches.  "row_kernel" (default 1): single-scale operators use
+ * the LDS row kernel where the dilation allows, 0 forces the chain-march kernel (same bits). */
+int wt_set_option(const char *name, int value);
 
 /* ---- context ---------------------------------------------------------------------- */
 int wt_ctx_create(int device, wt_ctx **out);

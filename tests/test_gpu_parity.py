@@ -272,6 +272,37 @@ def test_fused_wow_scale_and_inline_variance_are_bit_identical(W):
             np.testing.assert_array_equal(p2.download(s), p1.download(s))
 
 
+def test_row_kernel_equals_chain_kernel_bitwise(W):
+    """The LDS row kernel and the chain-march kernel share their arithmetic (WtVert): every
+    single-scale operator gives identical bits with either, for all dilations both cover."""
+    from wavelets_amd import _lib as L
+    ctx = L.default_context()
+    a = rnd((333, 1500), 51)
+    S3, S4, G = L.PLANE_SCRATCH(6), L.PLANE_SCRATCH(7), L.PLANE_SCRATCH(4)
+    try:
+        for fam in (L.B3SPLINE, L.TRIANGLE):
+            for s in range(0, 9):
+                outs = []
+                for row in (1, 0):
+                    L.set_option("row_kernel", row)
+                    p = L.Plan(ctx, 333, 1500, fam, 1)
+                    p.upload(L.PLANE_INPUT, a)
+                    p.upload(0, a)
+                    p.upload(G, 0.25 * a)
+                    res = []
+                    p.smooth(L.PLANE_INPUT, S3, s); res.append(p.download(S3))
+                    p.smooth(L.PLANE_INPUT, S3, s, True); res.append(p.download(S3))
+                    p.local_variance(L.PLANE_INPUT, S3, s, 1.5, 2.0); res.append(p.download(S3))
+                    p.atrous_scale(L.PLANE_INPUT, S3, S4, s); res += [p.download(S3), p.download(S4)]
+                    p.wow_scale(0, s, 1.1, True, L.PLANE_NONE, 0.8, G); res += [p.download(0), p.download(G)]
+                    outs.append(res)
+                    p.close()
+                for x, y in zip(*outs):
+                    np.testing.assert_array_equal(x, y, err_msg=f"family {fam} scale {s}")
+    finally:
+        L.set_option("row_kernel", 1)
+
+
 def test_anscombe_bit_exact(W):
     g = load_golden("g0_hard")
     p = g["ans_in"]

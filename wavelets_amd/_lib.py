@@ -39,6 +39,7 @@ SIGNATURES = {
     "wt_abi_version": (_c.c_int, []),
     "wt_last_error": (_c.c_char_p, []),
     "wt_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "wt_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
     "wt_ctx_create": (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
     "wt_ctx_destroy": (_c.c_int, [_vp]),
     "wt_ctx_sync": (_c.c_int, [_vp]),
@@ -123,6 +124,10 @@ def load():
 def check(rc):
     if rc != 0:
         raise WatrooHipError(load().wt_last_error().decode("utf-8", "replace"))
+
+
+def set_option(name, value):
+    check(load().wt_set_option(name.encode(), int(value)))
 
 
 def device_count():

@@ -633,6 +633,89 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
     return 0;
 }
 
+// tuning / A-B switches (wt_set_option)
+static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
+
+extern "C" int wt_set_option(const char *name, int value)
+{
+    if (!name) WT_FAIL("wt_set_option: null name");
+    if (!strcmp(name, "row_kernel")) { g_opt_row_kernel = value != 0; return 0; }
+    WT_FAIL("wt_set_option: unknown option '%s'", name);
+}
+
+// Row kernel (taps from an LDS copy of the row) where the horizontal halo fits the workgroup.
+template <int K, int MODE, int NW>
+static int launch_row_t(wt_plan *p, ChainArgs a, int HX, const char *name)
+{
+    constexpr int NL = NW * 64;
+    const Geo &g = p->g;
+    const int d = a.d;
+    const int VXMAX = (NL * 4 - 2 * HX) / 32 * 32;
+    const int W4 = (g.W + 3) / 4 * 4;
+    const int nx = (W4 + VXMAX - 1) / VXMAX;
+    RowArgs ra{};
+    ra.HX = HX;
+    ra.Vx = std::min(VXMAX, ((W4 + nx - 1) / nx + 31) / 32 * 32);
+    const int phases = std::min(d, g.nrows);
+    const int n_max = (g.nrows + d - 1) / d;
+    // one to two rounds of resident workgroups (16 waves per CU at <= 128 VGPRs)
+    const int slots = 256 * (16 / NW) * 2;
+    int chunks = std::max(1, slots / std::max(1, nx * phases));
+    int S = (n_max + chunks - 1) / chunks;
+    S = std::max(S, std::min(n_max, 16));
+    chunks = (n_max + S - 1) / S;
+    a.S = S;
+    a.chunks = chunks;
+    ra.c = a;
+    const int64_t gy = (int64_t)d * chunks;
+    if (gy > 65535) WT_FAIL("row kernel: grid too large");
+    dim3 grid(nx, (unsigned)gy), block(NL);
+    ProfScope ps(p->ctx, name);
+    if (d < 4) hipLaunchKernelGGL((wt_row_kernel<K, MODE, true, NW>), grid, block, 0, p->ctx->stream, ra);
+    else hipLaunchKernelGGL((wt_row_kernel<K, MODE, false, NW>), grid, block, 0, p->ctx->stream, ra);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+static const char *row_name(int mode)
+{
+    switch (mode) {
+        case MODE_SMOOTH: return "wt_row_kernel<smooth>";
+        case MODE_SMOOTH_SQ: return "wt_row_kernel<smooth_sq>";
+        case MODE_DECOMP: return "wt_row_kernel<decomp>";
+        case MODE_VAR: return "wt_row_kernel<variance>";
+        default: return "wt_row_kernel<wow>";
+    }
+}
+
+template <int MODE>
+static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
+{
+    const bool no_row = !g_opt_row_kernel;
+    const int hw = family_taps(p->family) / 2;
+    const int d = 1 << s;
+    const int HX = std::max(32, (hw * d + 31) / 32 * 32);
+    const bool b3 = p->family == WT_B3SPLINE;
+    a.g = p->g;
+    a.d = d;
+    if (!no_row && 2 * HX <= 256) {
+        return b3 ? launch_row_t<5, MODE, 4>(p, a, HX, row_name(MODE)) : launch_row_t<3, MODE, 4>(p, a, HX, row_name(MODE));
+    }
+    if (!no_row && 2 * HX <= 512) {
+        return b3 ? launch_row_t<5, MODE, 8>(p, a, HX, row_name(MODE)) : launch_row_t<3, MODE, 8>(p, a, HX, row_name(MODE));
+    }
+    dim3 grid, block;
+    WT_TRY(chain_geometry(p, s, a, grid, block));
+    ProfScope ps(p->ctx, name);
+    const bool small = a.d < 4;
+    if (b3 && small) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, true>), grid, block, 0, p->ctx->stream, a);
+    else if (b3) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, false>), grid, block, 0, p->ctx->stream, a);
+    else if (small) hipLaunchKernelGGL((wt_chain_kernel<3, MODE, true>), grid, block, 0, p->ctx->stream, a);
+    else hipLaunchKernelGGL((wt_chain_kernel<3, MODE, false>), grid, block, 0, p->ctx->stream, a);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int MODE>
 static int launch_chain(wt_plan *p, const float *in, float *out_c, float *out_w, int s, float f1,
                         float f2, int take_sqrt, const char *name)
@@ -640,16 +723,7 @@ static int launch_chain(wt_plan *p, const float *in, float *out_c, float *out_w,
     ChainArgs a{};
     a.in = in; a.out_c = out_c; a.out_w = out_w; a.aux = nullptr;
     a.f1 = f1; a.f2 = f2; a.take_sqrt = take_sqrt;
-    dim3 grid, block;
-    WT_TRY(chain_geometry(p, s, a, grid, block));
-    ProfScope ps(p->ctx, name);
-    const bool small = a.d < 4, b3 = p->family == WT_B3SPLINE;
-    if (b3 && small) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, true>), grid, block, 0, p->ctx->stream, a);
-    else if (b3) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, false>), grid, block, 0, p->ctx->stream, a);
-    else if (small) hipLaunchKernelGGL((wt_chain_kernel<3, MODE, true>), grid, block, 0, p->ctx->stream, a);
-    else hipLaunchKernelGGL((wt_chain_kernel<3, MODE, false>), grid, block, 0, p->ctx->stream, a);
-    WT_HIP(hipGetLastError());
-    return 0;
+    return launch_chain_args<MODE>(p, a, s, name);
 }
 
 static int maybe_exchange(wt_plan *p, int plane, int64_t rows, int flags)
@@ -938,17 +1012,7 @@ extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, 
     ChainArgs a{};
     a.in = c; a.out_c = t; a.out_w = nullptr; a.aux = nullptr;
     a.noise = nz; a.gamma = gm; a.tau = tau; a.factor = factor; a.soft = soft; a.whiten = 1;
-    dim3 grid, block;
-    WT_TRY(chain_geometry(p, s, a, grid, block));
-    {
-        ProfScope ps(p->ctx, "wt_chain_kernel<wow>");
-        const bool small = a.d < 4, b3 = p->family == WT_B3SPLINE;
-        if (b3 && small) hipLaunchKernelGGL((wt_chain_kernel<5, MODE_WOW, true>), grid, block, 0, p->ctx->stream, a);
-        else if (b3) hipLaunchKernelGGL((wt_chain_kernel<5, MODE_WOW, false>), grid, block, 0, p->ctx->stream, a);
-        else if (small) hipLaunchKernelGGL((wt_chain_kernel<3, MODE_WOW, true>), grid, block, 0, p->ctx->stream, a);
-        else hipLaunchKernelGGL((wt_chain_kernel<3, MODE_WOW, false>), grid, block, 0, p->ctx->stream, a);
-    }
-    WT_HIP(hipGetLastError());
+    WT_TRY(launch_chain_args<MODE_WOW>(p, a, s, "wt_chain_kernel<wow>"));
     std::swap(p->coef[plane], p->scratch[3]);     // both are "first margin row" pointers
     return 0;
 }

@@ -116,7 +116,10 @@ __device__ __forceinline__ float wt_wow_point(float c, float power, bool has_pow
     float q = factor;
     if (has_power) {
         const float lp = power <= 0.f ? 1e-15f : power;   // utils.py:195
-        q = factor / sqrtf(lp);                            // utils.py:196,203
+        // factor / sqrt(lp) (utils.py:196,203) as factor * rsq(lp): v_rsq_f32 is 1 ulp, well
+        // inside the wow tolerance, and saves the IEEE sqrt + divide sequences (~40 VALU per
+        // pixel, which is what made the fused wow kernel 1.5x slower than its filter alone)
+        q = factor * __builtin_amdgcn_rsqf(lp);
     }
     return t * q;
 }
@@ -240,6 +243,83 @@ struct ChainArgs {
     int soft, whiten, inline_var;
 };
 
+// Vertical half shared by the chain-march kernel (taps fetched from global memory) and the
+// row kernel (taps fetched from an LDS copy of the row): horizontal filter of each incoming row,
+// K-row sliding window of the filtered rows, vertical filter, mode epilogue.  One code path so
+// that both kernels produce identical bits.
+template <int K, int MODE, bool SMALL_D>
+struct WtVert {
+    static constexpr int hw = K / 2;
+    float4 hwin[K], h2win[K], cen[hw + 1];
+
+    // warm-up rows r0-hw .. r0+hw-1 (j = 0 .. K-2)
+    __device__ __forceinline__ void prime(int j, const float4 *raw, int d)
+    {
+        float4 ct;
+        hwin[j] = make_float4(0, 0, 0, 0);
+        h2win[j] = make_float4(0, 0, 0, 0);
+        wt_hrow_filter<K, MODE, SMALL_D>(raw, d, hwin[j], h2win[j], ct);
+        if (j >= hw) cen[j - hw] = ct;
+    }
+
+    // row r+hw enters; emits row r of the outputs at element offset `off` (row start), pixel x
+    __device__ __forceinline__ void emit(const float4 *raw, const ChainArgs &a, int64_t off, int x,
+                                         bool lane_ok)
+    {
+        const Geo &g = a.g;
+        hwin[K - 1] = make_float4(0, 0, 0, 0);
+        h2win[K - 1] = make_float4(0, 0, 0, 0);
+        wt_hrow_filter<K, MODE, SMALL_D>(raw, a.d, hwin[K - 1], h2win[K - 1], cen[hw]);
+        float4 o = f4_scale(wt_tap<K>(0), hwin[0]);
+#pragma unroll
+        for (int j = 1; j < K; ++j) o = f4_fma(wt_tap<K>(j), hwin[j], o);
+        if (MODE == MODE_VAR) {
+            float4 p = f4_scale(wt_tap<K>(0), h2win[0]);
+#pragma unroll
+            for (int j = 1; j < K; ++j) p = f4_fma(wt_tap<K>(j), h2win[j], p);
+            const float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {o.x, o.y, o.z, o.w};
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = wt_var_point(pp[k], mm[k], a.f1, a.f2, a.take_sqrt);
+            if (lane_ok) wt_store4(a.out_c + off, x, g.W, make_float4(v[0], v[1], v[2], v[3]));
+        } else if (MODE == MODE_WOW) {
+            // fused wow update: o = conv_s(c^2) (local power), cen[0] = c at this row; result
+            // goes to a different plane (the host swaps plane pointers afterwards)
+            const float cc[4] = {cen[0].x, cen[0].y, cen[0].z, cen[0].w};
+            const float pw[4] = {o.x, o.y, o.z, o.w};
+            float nn[4] = {1.f, 1.f, 1.f, 1.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, r4[4];
+            const bool full = x + 3 < g.W;
+            if (a.noise && lane_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (full || x + k < g.W) nn[k] = a.noise[off + x + k];
+            }
+            if (a.gamma && lane_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (full || x + k < g.W) gg[k] = a.gamma[off + x + k];
+            }
+            const float tauf = (float)a.tau;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r4[k] = wt_wow_point(cc[k], pw[k], a.whiten != 0, nn[k], a.tau, tauf, a.soft, a.factor, gg[k]);
+            if (lane_ok) {
+                wt_store4(a.out_c + off, x, g.W, make_float4(r4[0], r4[1], r4[2], r4[3]));
+                if (a.gamma) wt_store4(a.gamma + off, x, g.W, make_float4(gg[0], gg[1], gg[2], gg[3]));
+            }
+        } else if (lane_ok) {
+            wt_store4(a.out_c + off, x, g.W, o);
+            if (MODE == MODE_DECOMP && a.out_w)
+                wt_store4(a.out_w + off, x, g.W, f4_sub(cen[0], o));
+        }
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) {
+            hwin[j] = hwin[j + 1];
+            h2win[j] = h2win[j + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < hw; ++j) cen[j] = cen[j + 1];
+    }
+};
+
 template <int K, int MODE, bool SMALL_D>
 __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
 {
@@ -259,18 +339,13 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
     const int r1 = min(r0 + a.S, n_q);
     if (r0 >= r1) return;
 
-    float4 hwin[K], h2win[K], cen[hw + 1];
-    float4 dummy = make_float4(0, 0, 0, 0);
+    WtVert<K, MODE, SMALL_D> vert;
     const int gy0 = g.row0 + q;  // global row of chain element 0
     float4 raw[K], nxt[K];
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
-        float4 ct;
-        hwin[j] = dummy;
-        h2win[j] = dummy;
         wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * (r0 - hw + j)), x, d, g.W, raw);
-        wt_hrow_filter<K, MODE, SMALL_D>(raw, d, hwin[j], h2win[j], ct);
-        if (j >= hw) cen[j - hw] = ct;
+        vert.prime(j, raw, d);
     }
     // software prefetch: the operands of the NEXT chain row are in flight while this row is
     // filtered (the kernel is latency-bound at 3-4 waves/SIMD otherwise)
@@ -279,55 +354,101 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
 #pragma unroll
         for (int j = 0; j < K; ++j) raw[j] = nxt[j];
         wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * min(r + 1, r1 - 1) + d * hw), x, d, g.W, nxt);
-        hwin[K - 1] = dummy;
-        h2win[K - 1] = dummy;
-        wt_hrow_filter<K, MODE, SMALL_D>(raw, d, hwin[K - 1], h2win[K - 1], cen[hw]);
-        float4 o = f4_scale(wt_tap<K>(0), hwin[0]);
-#pragma unroll
-        for (int j = 1; j < K; ++j) o = f4_fma(wt_tap<K>(j), hwin[j], o);
-        const int64_t off = (int64_t)(q + d * r) * g.P;
-        if (MODE == MODE_VAR) {
-            float4 p = f4_scale(wt_tap<K>(0), h2win[0]);
-#pragma unroll
-            for (int j = 1; j < K; ++j) p = f4_fma(wt_tap<K>(j), h2win[j], p);
-            const float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {o.x, o.y, o.z, o.w};
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = wt_var_point(pp[k], mm[k], a.f1, a.f2, a.take_sqrt);
-            wt_store4(a.out_c + off, x, g.W, make_float4(v[0], v[1], v[2], v[3]));
-        } else if (MODE == MODE_WOW) {
-            // fused wow update: o = conv_s(c^2) (local power), cen[0] = c at this row; result
-            // goes to a different plane (the host swaps plane pointers afterwards)
-            const float cc[4] = {cen[0].x, cen[0].y, cen[0].z, cen[0].w};
-            const float pw[4] = {o.x, o.y, o.z, o.w};
-            float nn[4] = {1.f, 1.f, 1.f, 1.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, r4[4];
-            const bool full = x + 3 < g.W;
-            if (a.noise) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (full || x + k < g.W) nn[k] = a.noise[off + x + k];
-            }
-            if (a.gamma) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (full || x + k < g.W) gg[k] = a.gamma[off + x + k];
-            }
-            const float tauf = (float)a.tau;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                r4[k] = wt_wow_point(cc[k], pw[k], a.whiten != 0, nn[k], a.tau, tauf, a.soft, a.factor, gg[k]);
-            wt_store4(a.out_c + off, x, g.W, make_float4(r4[0], r4[1], r4[2], r4[3]));
-            if (a.gamma) wt_store4(a.gamma + off, x, g.W, make_float4(gg[0], gg[1], gg[2], gg[3]));
+        vert.emit(raw, a, (int64_t)(q + d * r) * g.P, x, true);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b  "row" kernel: the same single-scale operators for the dilations whose horizontal halo
+// fits a workgroup (hw*d <= 1/8 of its width).  A workgroup of NW waves marches down one chunk
+// of one polyphase chain like the fused pass: ONE coalesced 16-byte load per lane per row, the
+// row is shared through LDS (double-buffered, one barrier per row) and the K dilated taps are
+// LDS reads at lane offsets +-d/4, +-2d/4 (or the two adjacent lanes for d < 4) - instead of K
+// global loads per row.  Arithmetic is WtVert, i.e. bit-identical to the chain kernel.
+// ---------------------------------------------------------------------------------------------
+struct RowArgs {
+    ChainArgs c;
+    int Vx;   // valid (stored) pixels per x-strip, multiple of 32
+    int HX;   // x halo in pixels, multiple of 32
+};
+
+template <int K, int MODE, bool SMALL_D, int NW>
+__global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
+{
+    constexpr int hw = K / 2;
+    constexpr int NL = NW * 64;
+    __shared__ float4 rowbuf[2][NL];
+    const ChainArgs &a = ra.c;
+    const Geo g = a.g;
+    const int d = a.d;
+    const int gl = threadIdx.x;
+    const int X0 = blockIdx.x * ra.Vx;
+    const int x = X0 - ra.HX + 4 * gl;
+    const int item = blockIdx.y;
+    const int q = item % d;
+    const int c = item / d;
+    if (c >= a.chunks || q >= g.nrows) return;           // whole workgroup exits together
+    const int n_q = (g.nrows - q + d - 1) / d;
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+
+    const bool lane_ok = (x >= X0) && (x < X0 + ra.Vx) && (x < g.W);
+    const bool lane_interior = (x >= 0) && (x + 3 < g.W);
+    const bool wave_has_edge = !__all(lane_interior);
+    const int xc = min(max(x, 0), g.P - 4);
+    const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + 2, g.W),
+              xi3 = wt_refl(x + 3, g.W);
+    const int gy0 = g.row0 + q;
+    const int t_last = r1 - 1 + hw;
+    auto load_row = [&](int t) -> float4 {
+        const float *row = wt_row(a.in, g, gy0 + d * min(t, t_last));
+        float4 v = *reinterpret_cast<const float4 *>(row + xc);
+        if (wave_has_edge) {
+            if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
+        }
+        return v;
+    };
+    // taps of this lane out of the shared row (out-of-range lanes clamp: halo lanes only)
+    const int lo = d / 4;                                // lane offset of one dilation step
+    auto gather = [&](const float4 *rowv, float4 own, float4 (&raw)[K]) {
+        if constexpr (SMALL_D) {
+            raw[0] = rowv[max(gl - 1, 0)];
+            raw[1] = own;
+            raw[2] = rowv[min(gl + 1, NL - 1)];
         } else {
-            wt_store4(a.out_c + off, x, g.W, o);
-            if (MODE == MODE_DECOMP && a.out_w)
-                wt_store4(a.out_w + off, x, g.W, f4_sub(cen[0], o));
-        }
 #pragma unroll
-        for (int j = 0; j < K - 1; ++j) {
-            hwin[j] = hwin[j + 1];
-            h2win[j] = h2win[j + 1];
+            for (int j = 0; j < K; ++j)
+                raw[j] = (j == hw) ? own : rowv[min(max(gl + (j - hw) * lo, 0), NL - 1)];
         }
-#pragma unroll
-        for (int j = 0; j < hw; ++j) cen[j] = cen[j + 1];
+    };
+
+    WtVert<K, MODE, SMALL_D> vert;
+    float4 raw[K];
+    float4 pf0 = load_row(r0 - hw), pf1 = load_row(r0 - hw + 1);
+    // steps t = r0-hw .. r1-1+hw ; step index k selects the LDS buffer
+    const int nsteps = (r1 - r0) + 2 * hw;
+    for (int k = 0; k < nsteps; ++k) {
+        const int t = r0 - hw + k;
+        const float4 cur = pf0;
+        pf0 = pf1;
+        pf1 = load_row(t + 2);
+        float4 *rowv = rowbuf[k & 1];
+        rowv[gl] = cur;
+        __syncthreads();
+        gather(rowv, cur, raw);
+        if (k < K - 1) {
+            // warm-up rows (uniform branch): fill the window
+            switch (k) {
+                case 0: vert.prime(0, raw, d); break;
+                case 1: vert.prime(1, raw, d); break;
+                case 2: if constexpr (K > 3) vert.prime(2, raw, d); break;
+                default: if constexpr (K > 3) vert.prime(3, raw, d); break;
+            }
+        } else {
+            const int r = t - hw;
+            vert.emit(raw, a, (int64_t)(q + d * r) * g.P, x, lane_ok);
+        }
     }
 }
 
