@@ -102,7 +102,22 @@ SHAPES = [((37, 53), 1), ((64, 48), 2), ((16, 16), 3)]
 
 
 def g0_hard():
-    """Reference's own numpy operator + pointwise code: no cv2 anywhere in the arithmetic."""
+    """Reference's own numpy operator + pointwise code: no cv2 anywhere in the arithmetic.
+    To prove it, the stand-in's filter2D is replaced by a function that raises while this
+    group is generated (the `cv2` module only has to EXIST for `import watroo` to succeed)."""
+    import cv2 as _cv2
+    _real = _cv2.filter2D
+
+    def _forbidden(*a, **k):
+        raise AssertionError("hard-pin group must not call cv2.filter2D")
+    _cv2.filter2D = _forbidden
+    try:
+        _g0_hard_body()
+    finally:
+        _cv2.filter2D = _real
+
+
+def _g0_hard_body():
     out = {}
     for shape, seed in SHAPES:
         a = img(shape, seed)
