@@ -93,6 +93,15 @@ int wt_plan_info(wt_plan *plan, int64_t out[8]);
  * up to `cap` passes as triples {first_scale, n_scales, halo_rows_of_input}.  The same
  * schedule drives the kernels and the halo exchange; tests use it for the gloo CPU model. */
 int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int *n_passes);
+/* Border rule of the single-scale operators on this plan: 0 (default) symmetric reflection =
+ * cv2.BORDER_REFLECT; 1 = symmetric reflection inside each polyphase component of the
+ * operator's dilation - the rule atrous_recursive applies to its sub-arrays
+ * (watroo/wavelets.py:354-390).  Mode 1: per-scale kernels only, single GPU. */
+int wt_plan_set_border(wt_plan *plan, int border);
+/* dst plane <- window of a (larger) source plan's plane starting at (y0, x0); device copy.
+ * (atrous_recursive pads by hw*2^(level-1) and crops at the end, watroo/wavelets.py:394-406) */
+int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0,
+                  int64_t x0);
 /* device pointer of a plane's local row 0 (for zero-copy interop / virtual-strip tests) */
 int wt_plane_ptr(wt_plan *plan, int plane, void **dev_ptr);
 

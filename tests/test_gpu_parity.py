@@ -137,8 +137,26 @@ def test_dtype_policy(W, O):
     expected = np.zeros(regular.data.shape)
     expected[-1] = 1
     assert np.isclose(regular, expected).all()
+    recursive = W.AtrousTransform()(ones, 4, recursive=True)   # reference tests/test_wavelets.py:15-19
+    assert np.isclose(regular, recursive).all()
+
+
+def test_recursive_algorithm(W, O):
+    """a14: recursive=True (polyphase sub-array borders) on the GPU vs golden and oracle."""
+    g = load_golden("g7_misc")
+    a = g["img"]
+    c = W.AtrousTransform()(a, 3, recursive=True)
+    close(c.data, g["recursive_b3_L3"], 1e-5 * np.abs(a).max())
+    for shape, L, fam in (((96, 80), 5, "b3spline"), ((37, 53), 4, "triangle"), ((130, 257), 6, "triangle"),
+                          ((64, 200), 1, "b3spline")):
+        b = rnd(shape, 61)
+        got = W.AtrousTransform(cls_of(W, fam))(b, L, recursive=True)
+        ref = O.atrous_recursive(b, L, fam)
+        assert got.data.shape == ref.shape
+        close(got.data, ref, 1e-5 * np.abs(b).max())
+        close(got.sum(axis=0), b, 1e-5 * np.abs(b).max())
     with pytest.raises(NotImplementedError):
-        W.AtrousTransform()(ones, 4, recursive=True)
+        W.AtrousTransform(bilateral=1)(a, 3, recursive=True)
 
 
 def test_reference_wow_smoke_tests(W):

@@ -247,3 +247,18 @@ def test_enhance_vs_reference():
     close(O.enhance(rgb.copy(), weights=[[.5, 2], [1], [2, 2, 1]], denoise=[[3], [4, 2], None]),
           g["enh_rgb"], tol)
     close(O.enhance(rgb.copy(), weights=2., denoise=3., family="triangle"), g["enh_rgb_tri"], tol)
+
+
+def test_recursive_vs_reference():
+    """a14: the recursive algorithm (differs from the standard one near borders at s >= 3)."""
+    g = load_golden("g7_misc")
+    a = g["img"]
+    got = O.atrous_recursive(a, 3)
+    close(got, g["recursive_b3_L3"], 1e-5 * np.abs(a).max())
+    ones = np.ones((128, 128))
+    assert np.isclose(O.atrous_standard(ones, 4), O.atrous_recursive(ones, 4)).all()  # ref tests/test_wavelets.py:15-19
+    b = np.random.default_rng(3).standard_normal((96, 80)).astype(np.float32)
+    std, rec = O.atrous_standard(b, 5), O.atrous_recursive(b, 5)
+    assert np.abs(std[:3] - rec[:3]).max() < 1e-5          # identical operators up to scale 2
+    assert np.abs(std[4] - rec[4]).max() > 1e-3            # but not at the borders of scale >= 3
+    assert np.abs(std[4, 40:56, 30:50] - rec[4, 40:56, 30:50]).max() < 1e-5

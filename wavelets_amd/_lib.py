@@ -60,6 +60,8 @@ SIGNATURES = {
     "wt_plan_info": (_c.c_int, [_vp, _c.POINTER(_i64)]),
     "wt_schedule": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.c_int,
                                _c.POINTER(_c.c_int)]),
+    "wt_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
+    "wt_crop_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
     "wt_plane_ptr": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_vp)]),
     "wt_upload": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
     "wt_download": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
@@ -300,6 +302,12 @@ class Plan:
         check(load().wt_download(self._h, plane, out.ctypes.data_as(_fp), out.strides[0] // 4))
         return out
 
+    def set_border(self, border):
+        check(load().wt_plan_set_border(self._h, int(border)))
+
+    def crop_from(self, src_plan, src_plane, dst_plane, y0, x0):
+        check(load().wt_crop_plane(src_plan._h, src_plane, self._h, dst_plane, y0, x0))
+
     def copy(self, src, dst):
         check(load().wt_copy_plane(self._h, src, dst))
 
@@ -417,7 +425,9 @@ def acquire_plan(ctx, H, W, family, max_level):
     key = (id(ctx), H, W, family, max_level)
     for i in range(len(_pool) - 1, -1, -1):
         if _pool[i][0] == key:
-            return _pool.pop(i)[1]
+            plan = _pool.pop(i)[1]
+            plan.set_border(0)
+            return plan
     return Plan(ctx, H, W, family, max_level)
 
 

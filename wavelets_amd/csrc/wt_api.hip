@@ -367,7 +367,7 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
     }
     wt_plan *p = new wt_plan();
     p->ctx = ctx;
-    p->g = Geo{(int)W, (int)P, (int)H, (int)row0, (int)nrows, (int)halo};
+    p->g = Geo{(int)W, (int)P, (int)H, (int)row0, (int)nrows, (int)halo, 0};
     p->family = family;
     p->max_level = max_level;
     p->rank = rank;
@@ -412,6 +412,31 @@ extern "C" int wt_plan_info(wt_plan *p, int64_t out[8])
     if (!p || !out) WT_FAIL("wt_plan_info: null pointer");
     out[0] = p->g.H; out[1] = p->g.W; out[2] = p->g.P; out[3] = p->g.row0;
     out[4] = p->g.nrows; out[5] = p->g.halo; out[6] = p->max_level; out[7] = p->family;
+    return 0;
+}
+
+extern "C" int wt_plan_set_border(wt_plan *p, int border)
+{
+    if (!p) WT_FAIL("wt_plan_set_border: null plan");
+    if (border != 0 && border != 1) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
+    if (border && p->nranks > 1) WT_FAIL("wt_plan_set_border: the polyphase border is single-GPU only");
+    p->g.border = border;
+    return 0;
+}
+
+// dst_plane of `dst` <- the dst-sized window of src_plane of `src` starting at (y0, x0)
+extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0, int64_t x0)
+{
+    if (!src || !dst) WT_FAIL("wt_crop_plane: null plan");
+    if (src->nranks != 1 || dst->nranks != 1) WT_FAIL("wt_crop_plane: single-GPU plans only");
+    if (y0 < 0 || x0 < 0 || y0 + dst->g.nrows > src->g.nrows || x0 + dst->g.W > src->g.W)
+        WT_FAIL("wt_crop_plane: window outside the source plane");
+    float *s_ = nullptr, *d_ = nullptr;
+    WT_TRY(plane_base(src, src_plane, &s_));
+    WT_TRY(plane_base(dst, dst_plane, &d_));
+    WT_HIP(hipMemcpy2DAsync(d_, (size_t)dst->g.P * 4, s_ + (size_t)y0 * src->g.P + x0, (size_t)src->g.P * 4,
+                            (size_t)dst->g.W * 4, (size_t)dst->g.nrows, hipMemcpyDeviceToDevice, src->ctx->stream));
+    if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
     return 0;
 }
 
@@ -776,6 +801,7 @@ extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, 
 static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s,
                             float f1 = 1.f, float f2 = 1.f)
 {
+    if (p->g.border) WT_FAIL("bilateral kernels implement the symmetric border only");
     ChainArgs a{};
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
@@ -829,6 +855,7 @@ extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, i
         WT_TRY(plane_base(p, s0, &ow));
         return launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>");
     }
+    if (p->g.border) WT_FAIL("wt_decompose_pass: fused passes implement the symmetric border only (use flags without bit0)");
     if (!(s0 == 0 || s0 == 3 || (s0 == 6 && ns == 2)) || ns < 2) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
     float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
     for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
@@ -1057,6 +1084,7 @@ extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, in
     if (!p || !kernel) WT_FAIL("wt_filter2d: null pointer");
     if (kh < 1 || kw < 1 || kh * kw > 4096) WT_FAIL("wt_filter2d: kernel %d x %d unsupported (<= 4096 taps)", kh, kw);
     if (src == dst) WT_FAIL("wt_filter2d: src and dst must differ");
+    if (p->g.border) WT_FAIL("wt_filter2d implements the symmetric border only");
     const size_t lds = (size_t)(WT_F2D_TW + kw - 1) * (WT_F2D_TH + kh - 1) * sizeof(float);
     if (lds > 160 * 1024) WT_FAIL("wt_filter2d: kernel %d x %d needs %zu B of LDS", kh, kw, lds);
     if (p->nranks > 1 && kh / 2 > p->g.halo) WT_FAIL("wt_filter2d: kernel needs %d halo rows, plan has %d", kh / 2, p->g.halo);

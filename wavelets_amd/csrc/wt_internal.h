@@ -46,6 +46,8 @@ struct Geo {
     int row0;   // global row index of local row 0
     int nrows;  // rows owned by this strip
     int halo;   // margin rows allocated above and below
+    int border; // 0: symmetric reflection (cv2.BORDER_REFLECT); 1: symmetric reflection WITHIN each
+                // polyphase component of the operator's dilation (atrous_recursive, wavelets.py:330-406)
 };
 
 // ------------------------------------------------------------------ RCCL (dlopen'ed lazily: the

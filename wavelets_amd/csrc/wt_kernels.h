@@ -21,6 +21,20 @@ __device__ __forceinline__ int wt_refl(int i, int n)
     return m < n ? m : p - 1 - m;
 }
 
+// Border rule of the reference's RECURSIVE algorithm (watroo/wavelets.py:354-390): each
+// polyphase sub-array (offset o, stride d) is filtered on its own with BORDER_REFLECT, i.e. an
+// out-of-range index reflects inside its own residue class:  i = o + d j  ->  o + d refl(j, n_o).
+__device__ __forceinline__ int wt_refl_b(int i, int n, int d, int border)
+{
+    if ((unsigned)i < (unsigned)n) return i;
+    if (border == 0) return wt_refl(i, n);
+    int o = i % d;
+    if (o < 0) o += d;
+    const int j = (i - o) / d;
+    const int n_o = (n - o + d - 1) / d;
+    return o + d * wt_refl(j, n_o);
+}
+
 template <int K>
 __device__ __forceinline__ constexpr float wt_tap(int i)
 {
@@ -61,6 +75,19 @@ __device__ __forceinline__ const float *wt_row(const float *base, const Geo &g, 
 {
     const int ry = wt_refl(gy, g.H);
     return base + (int64_t)(ry - g.row0) * g.P;
+}
+
+// border-mode aware forms used by the single-scale operators (d = dilation of the operator)
+__device__ __forceinline__ const float *wt_row_b(const float *base, const Geo &g, int gy, int d)
+{
+    const int ry = wt_refl_b(gy, g.H, d, g.border);
+    return base + (int64_t)(ry - g.row0) * g.P;
+}
+__device__ __forceinline__ float4 wt_load4_b(const float *row, int xo, int W, int d, int border)
+{
+    if (xo >= 0 && xo + 3 < W) return *reinterpret_cast<const float4 *>(row + xo);
+    return make_float4(row[wt_refl_b(xo, W, d, border)], row[wt_refl_b(xo + 1, W, d, border)],
+                       row[wt_refl_b(xo + 2, W, d, border)], row[wt_refl_b(xo + 3, W, d, border)]);
 }
 
 // 4 consecutive pixels starting at pixel xo (xo % 4 == 0) of a row, reflected at the image
@@ -144,15 +171,16 @@ enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3, MODE_
 // Raw operands of the horizontal K-tap filter of one row at the thread's 4 pixels:
 //   d >= 4: K float4 at x + (j-hw) d      d < 4: 3 float4 covering x-4 .. x+7
 template <int K, bool SMALL_D>
-__device__ __forceinline__ void wt_hrow_load(const float *row, int x, int d, int W, float4 (&raw)[K])
+__device__ __forceinline__ void wt_hrow_load(const float *row, int x, int d, int W, float4 (&raw)[K],
+                                             int border = 0)
 {
     constexpr int hw = K / 2;
     if constexpr (!SMALL_D) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) raw[j] = wt_load4(row, x + (j - hw) * d, W);
+        for (int j = 0; j < K; ++j) raw[j] = wt_load4_b(row, x + (j - hw) * d, W, d, border);
     } else {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) raw[j] = wt_load4(row, x - 4 + 4 * j, W);
+        for (int j = 0; j < 3; ++j) raw[j] = wt_load4_b(row, x - 4 + 4 * j, W, d, border);
     }
 }
 
@@ -344,16 +372,16 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
     float4 raw[K], nxt[K];
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
-        wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * (r0 - hw + j)), x, d, g.W, raw);
+        wt_hrow_load<K, SMALL_D>(wt_row_b(a.in, g, gy0 + d * (r0 - hw + j), d), x, d, g.W, raw, g.border);
         vert.prime(j, raw, d);
     }
     // software prefetch: the operands of the NEXT chain row are in flight while this row is
     // filtered (the kernel is latency-bound at 3-4 waves/SIMD otherwise)
-    wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * (r0 + hw)), x, d, g.W, nxt);
+    wt_hrow_load<K, SMALL_D>(wt_row_b(a.in, g, gy0 + d * (r0 + hw), d), x, d, g.W, nxt, g.border);
     for (int r = r0; r < r1; ++r) {
 #pragma unroll
         for (int j = 0; j < K; ++j) raw[j] = nxt[j];
-        wt_hrow_load<K, SMALL_D>(wt_row(a.in, g, gy0 + d * min(r + 1, r1 - 1) + d * hw), x, d, g.W, nxt);
+        wt_hrow_load<K, SMALL_D>(wt_row_b(a.in, g, gy0 + d * min(r + 1, r1 - 1) + d * hw, d), x, d, g.W, nxt, g.border);
         vert.emit(raw, a, (int64_t)(q + d * r) * g.P, x, true);
     }
 }
@@ -397,12 +425,12 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
     const bool lane_interior = (x >= 0) && (x + 3 < g.W);
     const bool wave_has_edge = !__all(lane_interior);
     const int xc = min(max(x, 0), g.P - 4);
-    const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + 2, g.W),
-              xi3 = wt_refl(x + 3, g.W);
+    const int xi0 = wt_refl_b(x, g.W, d, g.border), xi1 = wt_refl_b(x + 1, g.W, d, g.border),
+              xi2 = wt_refl_b(x + 2, g.W, d, g.border), xi3 = wt_refl_b(x + 3, g.W, d, g.border);
     const int gy0 = g.row0 + q;
     const int t_last = r1 - 1 + hw;
     auto load_row = [&](int t) -> float4 {
-        const float *row = wt_row(a.in, g, gy0 + d * min(t, t_last));
+        const float *row = wt_row_b(a.in, g, gy0 + d * min(t, t_last), d);
         float4 v = *reinterpret_cast<const float4 *>(row + xc);
         if (wave_has_edge) {
             if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);

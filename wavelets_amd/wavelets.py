@@ -5,8 +5,8 @@ Same public names, argument meaning and error behaviour as the reference module
 ``libwatroo_hip.so`` on the GPU and coefficient planes stay resident in HBM.
 
 Scope: 2-D images, float32 compute.  float64 / integer inputs are
-converted to float32 (the reference keeps float64, ref:297,319-320); 1-D / 3-D arrays and
-``recursive=True`` raise ``NotImplementedError`` - there is deliberately no CPU fallback.
+converted to float32 (the reference keeps float64, ref:297,319-320); 1-D / 3-D arrays raise
+``NotImplementedError`` - there is deliberately no CPU fallback.
 """
 import copy
 
@@ -420,16 +420,43 @@ class AtrousTransform:
     def __call__(self, arr, level, recursive=False):
         """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328)."""
         img = _to_f32_image(arr)
-        if recursive:
-            raise NotImplementedError(
-                "recursive=True (ref:330-406) is out of scope for the HIP engine; use the "
-                "standard algorithm")
         scaling_function = self.scaling_function_class(img.ndim)
+        if recursive:
+            return self._recursive(img, level, scaling_function)
         plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                             _family_of(scaling_function), level)
         plan.upload(PLANE_INPUT, img)
         self._run(plan, level)
         return Coefficients(plan, scaling_function, self.bilateral)
+
+    def _recursive(self, img, level, scaling_function):
+        """The reference's recursive algorithm (ref:330-406) on the GPU.  It pads once by
+        hw*2**(level-1) (ref:394-395), filters every polyphase sub-array on its own with a
+        symmetric border (ref:354-390) and crops (ref:405-406) - which differs from the
+        standard algorithm near the borders from scale 3 on.  Here: the padded image is
+        transformed by the per-scale kernels under the plan's polyphase border rule
+        (wt_plan_set_border) and the planes are cropped on the device."""
+        if self.bilateral is not None:
+            raise NotImplementedError("recursive=True with bilateral filtering is not "
+                                      "implemented in the HIP engine")
+        if level < 1:
+            raise ValueError("recursive=True needs level >= 1")
+        ctx = default_context()
+        fam = _family_of(scaling_function)
+        pad = (len(scaling_function.coefficients_1d) // 2) * 2 ** (level - 1)
+        padded = np.pad(img, pad, mode='symmetric')
+        big = acquire_plan(ctx, padded.shape[0], padded.shape[1], fam, level)
+        plan = acquire_plan(ctx, img.shape[0], img.shape[1], fam, level)
+        try:
+            big.set_border(1)
+            big.upload(PLANE_INPUT, padded)
+            big.decompose(PLANE_INPUT, level, 0)          # one kernel per scale
+            for s in range(level + 1):
+                plan.crop_from(big, s, s, pad, pad)
+        finally:
+            big.set_border(0)
+            release_plan(big)
+        return Coefficients(plan, scaling_function, None)
 
     def _run(self, plan, level, src=PLANE_INPUT, flags=FLAG_FUSED):
         if self.bilateral is None:
