@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=0, help="override image side (testing)")
+    ap.add_argument("--rows", type=int, default=0, help="override image height (strip-shaped tests)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per scale")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--brief", action="store_true", help="one short line (tuning sweeps)")
@@ -137,6 +138,8 @@ def main():
 
     side = args.size or (8192 if world == 1 else 32768)
     H = W = side
+    if args.rows:
+        H = args.rows
     nrows = H // world
     row0 = rank * nrows
     if rank == world - 1:

@@ -306,14 +306,26 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     if ((int64_t)a.Vx * nx < W4) WT_FAIL("fused pass: strip sizing failed");
     const int phases = std::min(D, g.nrows);
     const int n_max = (g.nrows + D - 1) / D;             // longest chain
-    // one round: as many workgroups as the chip holds at once (256 CUs x resident WGs/CU)
+    // Chunking: the resident capacity is `slots` workgroups (256 CUs x workgroups per CU) and a
+    // workgroup's cost is its S stored rows plus the 2*LAT warm-up rows.  Pick the chunk count
+    // that minimises (dispatch rounds) x (rows per workgroup): usually ONE round with every
+    // slot filled; when the x-strips x phases alone under-fill the chip (tall narrow-ish strips:
+    // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
     const int wg_per_cu = NW == 4 ? WT_FUSED_WPS4 : std::max(1, 8 / NW);
-    static const int rounds = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 1;
-    const int slots = 256 * wg_per_cu * rounds;
-    int chunks = std::max(1, slots / std::max(1, nx * phases));
-    int S = (n_max + chunks - 1) / chunks;
-    S = std::max(S, std::min(n_max, 2 * LAT));           // keep warm-up <= ~50 % of a chunk
-    chunks = (n_max + S - 1) / S;
+    static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
+    const int slots = 256 * wg_per_cu;
+    const int64_t nbase = (int64_t)nx * phases;
+    int chunks = 1, S = n_max;
+    double best = 1e300;
+    for (int c = 1; c <= 4096 && c <= n_max; ++c) {
+        const int Sc = (n_max + c - 1) / c;
+        if (Sc < std::min(n_max, 2 * LAT) && c > 1) break;       // keep warm-up <= ~50 % of a chunk
+        const int cc = (n_max + Sc - 1) / Sc;                    // chunks actually needed
+        const int64_t rounds = (nbase * cc + slots - 1) / slots;
+        if (rounds_env && rounds > rounds_env) break;
+        const double cost = (double)rounds * (Sc + 2 * LAT + 8);
+        if (cost < best) { best = cost; chunks = cc; S = Sc; }
+    }
     a.S = S;
     a.chunks = chunks;
     static const int dbg = getenv("WT_FUSED_DEBUG") ? atoi(getenv("WT_FUSED_DEBUG")) : 0;
