@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box (not part of the pytest suite: minutes, not seconds).
+
+Random (H, W, level, family) images: fused / per-scale (row + chain kernels) / chain-only
+schedules against the C oracle; virtual row strips against the unsharded result (bitwise);
+recursive=True against the numpy oracle.  Prints one line per failure and a summary.
+
+    python tools/fuzz.py [n_cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import atrous_numpy as O        # noqa: E402
+from oracle import cref                     # noqa: E402
+import wavelets_amd as W                    # noqa: E402
+from wavelets_amd import _lib as L          # noqa: E402
+from wavelets_amd.parallel import partition_rows, required_halo   # noqa: E402
+
+FAM = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}
+
+
+def planes(plan, n):
+    return np.stack([plan.download(s) for s in range(n)])
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    ctx = L.default_context()
+    cref.build()
+    fails = 0
+    for case in range(n_cases):
+        kind = case % 4
+        H = int(rng.integers(1, 1600)) if kind else int(rng.integers(1, 64))
+        Wd = int(rng.integers(1, 3000)) if kind != 1 else int(rng.integers(1, 64))
+        level = int(rng.integers(1, 10))
+        fam = ("b3spline", "triangle")[int(rng.integers(0, 2))]
+        a = rng.standard_normal((H, Wd)).astype(np.float32)
+        ref = cref.decompose(a, level, fam)
+        tol = 1e-5 * max(1.0, float(np.abs(a).max()))
+        tag = f"case {case}: {H}x{Wd} L={level} {fam}"
+        got = {}
+        for name, flags, row in (("fused", L.FLAG_FUSED, 1), ("perscale", 0, 1), ("chain", 0, 0)):
+            L.set_option("row_kernel", row)
+            plan = L.Plan(ctx, H, Wd, FAM[fam], level)
+            plan.upload(L.PLANE_INPUT, a)
+            plan.decompose(L.PLANE_INPUT, level, flags)
+            got[name] = planes(plan, level + 1)
+            plan.plane_sum(0, level + 1)
+            rec = plan.download(L.PLANE_OUT)
+            plan.close()
+            err = float(np.abs(got[name] - ref).max())
+            if not err <= tol or not np.array_equal(rec, got[name].sum(axis=0)):
+                fails += 1
+                print(f"FAIL {tag} [{name}] max err {err:.3e} tol {tol:.1e}")
+        L.set_option("row_kernel", 1)
+        if not np.array_equal(got["perscale"], got["chain"]):
+            fails += 1
+            print(f"FAIL {tag}: row kernel != chain kernel")
+        # virtual strips == unsharded (bitwise), when the strips are tall enough for the halo
+        k = int(rng.integers(2, 6))
+        fused = bool(rng.integers(0, 2))
+        if H >= k and required_halo(FAM[fam], level, fused) <= H // k:
+            flags = L.FLAG_FUSED if fused else 0
+            plans = []
+            for r, (row0, n) in enumerate(partition_rows(H, k)):
+                p = L.Plan(ctx, H, Wd, FAM[fam], level, row0=row0, nrows=n, rank=r, nranks=k)
+                p.upload(L.PLANE_INPUT, a[row0:row0 + n])
+                plans.append(p)
+            cur = L.PLANE_INPUT
+            for i, (s0, ns, halo) in enumerate(L.schedule(FAM[fam], level, fused)):
+                nxt = level if s0 + ns == level else L.PLANE_SCRATCH(i & 1)
+                for up, lo in zip(plans[:-1], plans[1:]):
+                    L.Plan.halo_exchange_local(up, lo, cur, halo)
+                for p in plans:
+                    p.decompose_pass(cur, nxt, s0, ns, flags | L.FLAG_NO_EXCHANGE)
+                cur = nxt
+            sh = np.concatenate([planes(p, level + 1) for p in plans], axis=1)
+            if not np.array_equal(sh, got["fused" if fused else "perscale"]):
+                fails += 1
+                print(f"FAIL {tag}: {k} strips (fused={fused}) != unsharded")
+            for p in plans:
+                p.close()
+        if case % 5 == 0 and H * Wd < 400000 and level <= 6:
+            r = W.AtrousTransform(W.B3spline if fam == "b3spline" else W.Triangle)(a, level, recursive=True)
+            e = float(np.abs(r.data - O.atrous_recursive(a, level, fam)).max())
+            if not e <= tol:
+                fails += 1
+                print(f"FAIL {tag}: recursive max err {e:.3e}")
+    print(f"fuzz: {n_cases} cases, {fails} failures")
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
