@@ -313,10 +313,22 @@ def test_row_kernel_equals_chain_kernel_bitwise(W):
                     p.local_variance(L.PLANE_INPUT, S3, s, 1.5, 2.0); res.append(p.download(S3))
                     p.atrous_scale(L.PLANE_INPUT, S3, S4, s); res += [p.download(S3), p.download(S4)]
                     p.wow_scale(0, s, 1.1, True, L.PLANE_NONE, 0.8, G); res += [p.download(0), p.download(G)]
+                    p.local_variance(L.PLANE_INPUT, S4, s, 1.0, 1.0)
+                    p.bilateral_conv(L.PLANE_INPUT, S4, S3, s); res.append(p.download(S3))
                     outs.append(res)
                     p.close()
                 for x, y in zip(*outs):
                     np.testing.assert_array_equal(x, y, err_msg=f"family {fam} scale {s}")
+            outs = []
+            for row in (1, 0):                      # bilateral transform, in-kernel variance
+                L.set_option("row_kernel", row)
+                p = L.Plan(ctx, 333, 1500, fam, 8)
+                p.upload(L.PLANE_INPUT, a)
+                p.decompose_bilateral(L.PLANE_INPUT, 8, [1.5] + [1] * 8, True)
+                outs.append([p.download(k) for k in range(9)])
+                p.close()
+            for x, y in zip(*outs):
+                np.testing.assert_array_equal(x, y, err_msg=f"family {fam} bilateral transform")
     finally:
         L.set_option("row_kernel", 1)
 

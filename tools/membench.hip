@@ -82,6 +82,31 @@ __global__ __launch_bounds__(256) void march_kernel(Ptrs in, Ptrs out, int W4, i
     }
 }
 
+// the same march with 8 bytes per lane (float2): half the registers per lane in the real kernel,
+// i.e. twice the resident waves - does the narrower access still stream?
+template <int PD>
+__global__ __launch_bounds__(256) void march2_kernel(Ptrs in, Ptrs out, int W2, int rows, int nstrips)
+{
+    const int strip = blockIdx.x % nstrips, chunk = blockIdx.x / nstrips;
+    const long base = (long)chunk * rows * W2 + (long)strip * 256 + threadIdx.x;
+    const float2 *src = (const float2 *)in.p[0];
+    float2 pf[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) pf[i] = src[base + (long)min(i, rows - 1) * W2];
+    for (int r = 0; r < rows; r += PD) {
+#pragma unroll
+        for (int k = 0; k < PD; ++k) {
+            const int rr = r + k;
+            if (rr >= rows) break;
+            const float2 cur = pf[k];
+            pf[k] = src[base + (long)min(rr + PD, rows - 1) * W2];
+            const long o = base + (long)rr * W2;
+            ((float2 *)out.p[0])[o] = cur; ((float2 *)out.p[1])[o] = cur;
+            ((float2 *)out.p[2])[o] = cur; ((float2 *)out.p[3])[o] = cur;
+        }
+    }
+}
+
 template <typename F>
 static double timeit(F f, int reps = 20)
 {
@@ -123,6 +148,16 @@ int main(int argc, char **argv)
                 printf("march R1W4 rows/WG %4d  WGs %5d  PD%d : %.4f ms  %.0f GB/s\n", rows, grid, PD, ms, 5.0 * bytes / ms / 1e6); \
             }
             MARCH(1) MARCH(4) MARCH(8)
+        }
+    }
+    {
+        const int W2 = side / 2, nstrips = W2 / 256;
+        for (int rows : {512, 256, 128, 64}) {
+            const int chunks = side / rows, grid = chunks * nstrips;
+            double ms = timeit([&] { hipLaunchKernelGGL((march2_kernel<1>), dim3(grid), dim3(256), 0, 0, in, out, W2, rows, nstrips); });
+            printf("march2 (8 B/lane) R1W4 rows/WG %4d  WGs %5d  PD1 : %.4f ms  %.0f GB/s\n", rows, grid, ms, 5.0 * bytes / ms / 1e6);
+            ms = timeit([&] { hipLaunchKernelGGL((march2_kernel<4>), dim3(grid), dim3(256), 0, 0, in, out, W2, rows, nstrips); });
+            printf("march2 (8 B/lane) R1W4 rows/WG %4d  WGs %5d  PD4 : %.4f ms  %.0f GB/s\n", rows, grid, ms, 5.0 * bytes / ms / 1e6);
         }
     }
     for (long tile : {4096L}) {
