@@ -96,7 +96,9 @@ int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int
 /* Border rule of the single-scale operators on this plan: 0 (default) symmetric reflection =
  * cv2.BORDER_REFLECT; 1 = symmetric reflection inside each polyphase component of the
  * operator's dilation - the rule atrous_recursive applies to its sub-arrays
- * (watroo/wavelets.py:354-390).  Mode 1: per-scale kernels only, single GPU. */
+ * (watroo/wavelets.py:354-390); 2 = scipy 'mirror' (reflection without edge duplication), the
+ * border of the 1-D branch (watroo/wavelets.py:66-69; a 1-D signal is a 1 x N image).
+ * Modes 1 and 2: per-scale kernels only, single GPU. */
 int wt_plan_set_border(wt_plan *plan, int border);
 /* dst plane <- window of a (larger) source plan's plane starting at (y0, x0); device copy.
  * (atrous_recursive pads by hw*2^(level-1) and crops at the end, watroo/wavelets.py:394-406) */

@@ -303,6 +303,33 @@ def g10_enhance():
     save("g10_enhance", "semantic(cv2 stand-in)", **out)
 
 
+def g11_one_dimensional():
+    """1-D branch (scipy.ndimage.convolve, mode='mirror'): no cv2 involved -> hard pin."""
+    import cv2 as _cv2
+    _real = _cv2.filter2D
+
+    def _forbidden(*a, **k):
+        raise AssertionError("1-D group must not call cv2.filter2D")
+    _cv2.filter2D = _forbidden
+    try:
+        out = {}
+        for n, seed in ((300, 41), (17, 42), (5, 43)):
+            a = img((n,), seed)
+            out[f"sig_{n}"] = a
+            for fam, cls in FAM.items():
+                for L in (1, 3, 5):
+                    out[f"coef_{fam}_{n}_L{L}"] = AtrousTransform(cls)(a, L).data
+                out[f"conv_{fam}_{n}_s2"] = convolution(a, cls(1), s=2)
+        a = img((300,), 41)
+        c = AtrousTransform(B3spline)(a, 4)
+        out["noise_300"] = np.float64(c.get_noise())
+        c.denoise([5, 3])
+        out["den_300"] = c.data
+        save("g11_1d", "hard", **out)
+    finally:
+        _cv2.filter2D = _real
+
+
 if __name__ == "__main__":
     if REAL_NE:
         assert NE_KIND.startswith("real"), "run with /opt/conda/bin/python3.9"
@@ -316,3 +343,4 @@ if __name__ == "__main__":
         g7_recursive_g8_tests()
         g9_richardson_lucy()
         g10_enhance()
+        g11_one_dimensional()

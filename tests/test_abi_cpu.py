@@ -71,7 +71,7 @@ def test_argument_errors_match_reference():
     with pytest.raises(ValueError, match="Unsupported number of dimensions"):
         W.B3spline(4)                                           # ref wavelets.py:189
     with pytest.raises(NotImplementedError):
-        W.AtrousTransform()(np.ones(16), 1)                     # 1-D: out of scope, loud
+        W.AtrousTransform()(np.ones((4, 4, 4)), 1)              # 3-D: out of scope, loud
 
 
 def test_scaling_function_objects_match_oracle_constants():

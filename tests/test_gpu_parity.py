@@ -141,6 +141,38 @@ def test_dtype_policy(W, O):
     assert np.isclose(regular, recursive).all()
 
 
+def test_one_dimensional_signals(W, O):
+    """1-D branch (ref wavelets.py:65-69, 'mirror' border) as 1 x N images; hard-pinned fixture
+    (the reference's 1-D path is scipy, no cv2)."""
+    g = load_golden("g11_1d")
+    for n in (300, 17, 5):
+        a = g[f"sig_{n}"]
+        tol = 1e-5 * np.abs(a).max()
+        for fam in FAMS:
+            cls = cls_of(W, fam)
+            for L in (1, 3, 5):
+                c = W.AtrousTransform(cls)(a, L)
+                assert c.data.shape == (L + 1, n) and len(c) == L + 1
+                close(c.data, g[f"coef_{fam}_{n}_L{L}"], tol)
+                close(np.sum(c, axis=0), a, 2 * tol)
+            close(W.convolution(a, cls(1), s=2), g[f"conv_{fam}_{n}_s2"], tol)
+    a = g["sig_300"]
+    c = W.AtrousTransform(W.B3spline)(a, 4)
+    np.testing.assert_allclose(c.get_noise(), g["noise_300"], rtol=1e-5)
+    c.denoise([5, 3])
+    close(c.data, g["den_300"], 1e-5 * np.abs(a).max())
+    c2 = W.AtrousTransform(W.B3spline)(a, 2)
+    c2.denoise([5, 3])
+    got = W.denoise(a, [5, 3])                         # convenience function on a 1-D signal
+    assert got.shape == a.shape
+    np.testing.assert_array_equal(got, c2.sum(axis=0))
+    big = rnd((1, 100003), 71).reshape(-1)             # long signal, odd length
+    close(W.AtrousTransform(W.Triangle)(big, 9).data, O.atrous_standard_1d(big, 9, "triangle"),
+          1e-5 * np.abs(big).max())
+    with pytest.raises(NotImplementedError):
+        W.AtrousTransform()(np.ones((4, 4, 4)), 1)     # 3-D stays out of scope
+
+
 def test_recursive_algorithm(W, O):
     """a14: recursive=True (polyphase sub-array borders) on the GPU vs golden and oracle."""
     g = load_golden("g7_misc")

@@ -262,3 +262,14 @@ def test_recursive_vs_reference():
     assert np.abs(std[:3] - rec[:3]).max() < 1e-5          # identical operators up to scale 2
     assert np.abs(std[4] - rec[4]).max() > 1e-3            # but not at the borders of scale >= 3
     assert np.abs(std[4, 40:56, 30:50] - rec[4, 40:56, 30:50]).max() < 1e-5
+
+
+def test_one_dimensional_hard_pin():
+    """1-D branch (scipy 'mirror' border): generated without cv2 -> the oracle must match."""
+    g = load_golden("g11_1d")
+    for n in (300, 17, 5):
+        a = g[f"sig_{n}"]
+        for fam in FAMS:
+            for L in (1, 3, 5):
+                close(O.atrous_standard_1d(a, L, fam), g[f"coef_{fam}_{n}_L{L}"], 2e-6 * np.abs(a).max())
+            close(O.convolution_1d(a, fam, 2), g[f"conv_{fam}_{n}_s2"], 2e-6 * np.abs(a).max())

@@ -418,8 +418,8 @@ extern "C" int wt_plan_info(wt_plan *p, int64_t out[8])
 extern "C" int wt_plan_set_border(wt_plan *p, int border)
 {
     if (!p) WT_FAIL("wt_plan_set_border: null plan");
-    if (border != 0 && border != 1) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
-    if (border && p->nranks > 1) WT_FAIL("wt_plan_set_border: the polyphase border is single-GPU only");
+    if (border < 0 || border > 2) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
+    if (border && p->nranks > 1) WT_FAIL("wt_plan_set_border: non-default borders are single-GPU only");
     p->g.border = border;
     return 0;
 }

@@ -47,7 +47,8 @@ struct Geo {
     int nrows;  // rows owned by this strip
     int halo;   // margin rows allocated above and below
     int border; // 0: symmetric reflection (cv2.BORDER_REFLECT); 1: symmetric reflection WITHIN each
-                // polyphase component of the operator's dilation (atrous_recursive, wavelets.py:330-406)
+                // polyphase component of the operator's dilation (atrous_recursive, wavelets.py:330-406);
+                // 2: 'mirror' (no edge duplication) - the 1-D branch, wavelets.py:66-69
 };
 
 // ------------------------------------------------------------------ RCCL (dlopen'ed lazily: the

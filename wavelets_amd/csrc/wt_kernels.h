@@ -28,6 +28,15 @@ __device__ __forceinline__ int wt_refl_b(int i, int n, int d, int border)
 {
     if ((unsigned)i < (unsigned)n) return i;
     if (border == 0) return wt_refl(i, n);
+    if (border == 2) {
+        // scipy.ndimage 'mirror' (1-D branch of convolution(), watroo/wavelets.py:66-69):
+        // reflection about the centre of the edge sample, d c b | a b c d | c b a
+        if (n == 1) return 0;
+        const int p = 2 * n - 2;
+        int m = i % p;
+        if (m < 0) m += p;
+        return m < n ? m : p - m;
+    }
     int o = i % d;
     if (o < 0) o += d;
     const int j = (i - o) / d;

@@ -66,12 +66,28 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     return out
 
 
+def generalized_anscombe_1d(sig):
+    """forward Anscombe of a 1-D signal on the GPU (as a 1 x N image)"""
+    from .wavelets import generalized_anscombe
+    return generalized_anscombe(sig.reshape(1, -1)).reshape(-1)
+
+
 def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None,
             soft_threshold=True, anscombe=False):
     """Denoise ``data``: transform over ``len(weights)`` scales, threshold each scale at
     ``weights[s]`` sigma, sum the planes (ref:83-102).  Optional Anscombe pre/post transform.
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
     """
+    if np.ndim(data) == 1:                      # 1-D signals: generic (unfused) call sequence
+        sig = np.asarray(data, np.float32)
+        if anscombe:
+            sig = generalized_anscombe_1d(sig)
+        coefficients = AtrousTransform(scaling_function, bilateral=bilateral)(sig, len(weights))
+        coefficients.noise = noise
+        plan = coefficients._denoise_sum(weights, soft_threshold=soft_threshold, write_back=False)
+        if anscombe:
+            plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)
+        return plan.download(PLANE_OUT).reshape(-1)
     img = _to_f32_image(data, "data")
     level = len(weights)
     transform = AtrousTransform(scaling_function, bilateral=bilateral)

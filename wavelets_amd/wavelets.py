@@ -5,8 +5,9 @@ Same public names, argument meaning and error behaviour as the reference module
 ``libwatroo_hip.so`` on the GPU and coefficient planes stay resident in HBM.
 
 Scope: 2-D images, float32 compute.  float64 / integer inputs are
-converted to float32 (the reference keeps float64, ref:297,319-320); 1-D / 3-D arrays raise
-``NotImplementedError`` - there is deliberately no CPU fallback.
+converted to float32 (the reference keeps float64, ref:297,319-320); 1-D signals run as
+1 x N images with the 1-D branch's 'mirror' border; 3-D arrays raise ``NotImplementedError`` -
+there is deliberately no CPU fallback.
 """
 import copy
 
@@ -135,6 +136,15 @@ def _family_of(scaling_function):
     return fam
 
 
+def _is_1d(arr):
+    return np.ndim(arr) == 1
+
+
+def _to_f32_row(arr):
+    """1-D signal -> the (1, N) float32 image the engine runs it as."""
+    return np.ascontiguousarray(arr, dtype=np.float32).reshape(1, -1)
+
+
 def _to_f32_image(arr, what="arr"):
     arr = np.asarray(arr)
     if arr.ndim > 3:
@@ -165,14 +175,21 @@ def generalized_anscombe(signal, alpha=1, g=0, sigma=0, inverse=False):
 def convolution(arr, scaling_function, s=0, output=None):
     """Dilated smoothing with ``scaling_function`` at scale ``s``; symmetric borders.
     Mirrors ref:35-45 (2-D branch: cv2.filter2D with the zero-stuffed kernel,
-    BORDER_REFLECT).  ``output`` is written in place and returned, as in the reference."""
-    img = _to_f32_image(arr)
+    BORDER_REFLECT).  ``output`` is written in place and returned, as in the reference.
+    1-D arrays take the reference's 1-D branch (ref:65-69: scipy 'mirror' border) as a
+    1 x N image under the engine's mirror border rule."""
+    one_d = _is_1d(arr)
+    img = _to_f32_row(arr) if one_d else _to_f32_image(arr)
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                         _family_of(scaling_function), 0)
     try:
+        if one_d:
+            plan.set_border(2)
         plan.upload(PLANE_INPUT, img)
         plan.smooth(PLANE_INPUT, PLANE_OUT, s)
         res = plan.download(PLANE_OUT)
+        if one_d:
+            res = res.reshape(-1)
     finally:
         release_plan(plan)
     if output is None:
@@ -246,14 +263,16 @@ class Coefficients:
         self._plan = None
         self._host = None
         self._noise_uploaded = None
+        self._ndim = getattr(scaling_function, "n_dim", 2)      # 1: planes are 1 x N images
         if isinstance(data, Plan):
             self._plan = data
             self._nplanes = data.max_level + 1
         else:
             data = np.asarray(data)
-            if data.ndim != 3:
-                raise NotImplementedError("Coefficients: the HIP engine covers 2-D images "
-                                          "(a (level+1, H, W) stack)")
+            if data.ndim not in (2, 3):
+                raise NotImplementedError("Coefficients: the HIP engine covers 1-D signals "
+                                          "((level+1, N) stacks) and 2-D images ((level+1, H, W))")
+            self._ndim = data.ndim - 1
             self._host = np.ascontiguousarray(data, dtype=np.float32)
             self._nplanes = self._host.shape[0]
 
@@ -264,20 +283,33 @@ class Coefficients:
             pass
 
     # -- host mirror -------------------------------------------------------------------
+    def _img_shape(self):
+        shp = self._plan.shape if self._plan is not None else None
+        if self._ndim == 1:
+            return (shp[1],) if shp is not None else self._host.shape[1:]
+        return shp if shp is not None else self._host.shape[1:]
+
+    def _as_plane(self, a):
+        """host plane in the engine's 2-D layout (a 1-D signal is a 1 x N image)"""
+        return a.reshape(1, -1) if self._ndim == 1 else a
+
+    def _from_plane(self, a):
+        return a.reshape(-1) if self._ndim == 1 else a
+
     @property
     def data(self):
         if self._host is None:
-            host = np.empty((self._nplanes,) + self._plan.shape, np.float32)
+            host = np.empty((self._nplanes,) + self._img_shape(), np.float32)
             for s in range(self._nplanes):
-                self._plan.download(s, host[s])
+                self._plan.download(s, self._as_plane(host[s]))
             self._host = host
         return self._host
 
     @data.setter
     def data(self, value):
         value = np.ascontiguousarray(value, dtype=np.float32)
-        if value.ndim != 3 or value.shape[0] != self._nplanes:
-            raise ValueError("Coefficients.data must keep its (level+1, H, W) shape")
+        if value.ndim != self._ndim + 1 or value.shape[0] != self._nplanes:
+            raise ValueError("Coefficients.data must keep its (level+1, ...) shape")
         self._host = value
 
     def _device(self):
@@ -285,18 +317,18 @@ class Coefficients:
         (re-uploading a user-owned mirror).  Call ONCE per public operation; helpers that
         run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
-            _, H, W = self._host.shape
+            H, W = (1, self._host.shape[1]) if self._ndim == 1 else self._host.shape[1:]
             self._plan = acquire_plan(default_context(), H, W,
                                       _family_of(self.scaling_function), self._nplanes - 1)
         if self._host is not None:
             for s in range(self._nplanes):
-                self._plan.upload(s, self._host[s])
+                self._plan.upload(s, self._as_plane(self._host[s]))
         return self._plan
 
     def _refresh_host(self, planes):
         if self._host is not None:
             for s in planes:
-                self._plan.download(s, self._host[s])
+                self._plan.download(s, self._as_plane(self._host[s]))
 
     # -- reference interface -----------------------------------------------------------
     def __len__(self):
@@ -308,8 +340,7 @@ class Coefficients:
 
     @property
     def shape(self):
-        return (self._nplanes,) + (self._plan.shape if self._plan is not None
-                                   else self._host.shape[1:])
+        return (self._nplanes,) + tuple(self._img_shape())
 
     @property
     def sigma_e(self):
@@ -339,7 +370,7 @@ class Coefficients:
         plan = self._plan
         if self._noise_uploaded is not self.noise:
             plan.upload(_NOISE_PLANE, np.broadcast_to(
-                np.asarray(self.noise, np.float32), plan.shape))
+                self._as_plane(np.asarray(self.noise, np.float32)), plan.shape))
             self._noise_uploaded = self.noise
         return float(sigma * self.sigma_e[scale]), _NOISE_PLANE
 
@@ -349,9 +380,9 @@ class Coefficients:
         plan = self._device()
         t = self._tau(sigma, scale)
         if t is None:
-            return np.ones(plan.shape, np.float32)
+            return np.ones(self._img_shape(), np.float32)
         plan.significance(scale, _TMP_PLANE, t[0], soft_threshold, t[1])
-        sig = plan.download(_TMP_PLANE)
+        sig = self._from_plane(plan.download(_TMP_PLANE))
         return sig if soft_threshold else sig.astype(bool)
 
     def denoise(self, sigma, weights=None, soft_threshold=True):
@@ -398,7 +429,7 @@ class Coefficients:
         if axis == 0 and dtype is None and not kwargs:
             plan = self._device()
             plan.plane_sum(0, self._nplanes, PLANE_OUT)
-            res = plan.download(PLANE_OUT)
+            res = self._from_plane(plan.download(PLANE_OUT))
             if out is None:
                 return res
             out[...] = res
@@ -419,6 +450,8 @@ class AtrousTransform:
 
     def __call__(self, arr, level, recursive=False):
         """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328)."""
+        if _is_1d(arr):
+            return self._call_1d(arr, level, recursive)
         img = _to_f32_image(arr)
         scaling_function = self.scaling_function_class(img.ndim)
         if recursive:
@@ -428,6 +461,21 @@ class AtrousTransform:
         plan.upload(PLANE_INPUT, img)
         self._run(plan, level)
         return Coefficients(plan, scaling_function, self.bilateral)
+
+    def _call_1d(self, arr, level, recursive):
+        """1-D signals (ref:65-69, 'mirror' border): run as a 1 x N image with the engine's
+        mirror border rule and the per-scale kernels."""
+        if recursive or self.bilateral is not None:
+            raise NotImplementedError("1-D transforms support the standard, non-bilateral "
+                                      "algorithm only in the HIP engine")
+        row = _to_f32_row(arr)
+        scaling_function = self.scaling_function_class(1)
+        plan = acquire_plan(default_context(), 1, row.shape[1], _family_of(scaling_function), level)
+        plan.set_border(2)
+        plan.upload(PLANE_INPUT, row)
+        plan.decompose(PLANE_INPUT, level, 0)
+        plan.set_border(0)
+        return Coefficients(plan, scaling_function, None)
 
     def _recursive(self, img, level, scaling_function):
         """The reference's recursive algorithm (ref:330-406) on the GPU.  It pads once by
