@@ -184,6 +184,13 @@ int wt_reduce(wt_plan *plan, int plane, double out[4]);
  *   g <- clip((g-gmin)/(gmax-gmin),0,1)**(1/gamma); recon <- (1-h)*recon + h*g */
 int wt_gamma_blend(wt_plan *plan, int recon, int gamma_plane, float gmin, float gmax,
                    float inv_gamma, float h);
+/* ---- 3-D cubes (watroo/wavelets.py:46-64) ---------------------------- */
+/* A (Z, Y, X) cube lives on a plan as a (Z*Y) x X image (depth = Z).  convolution() 3-D branch:
+ * per-slice 2-D filter, then the same K-tap dilated filter along axis 0 (BORDER_REFLECT). */
+int wt_smooth3d(wt_plan *plan, int src, int dst, int s, int depth);
+/* atrous_standard on the cube: planes[0..level-1] <- detail, planes[level] <- smooth. */
+int wt_decompose3d(wt_plan *plan, int src, int level, int depth);
+
 /* ---- Richardson-Lucy support (watroo/utils.py:222-290) -------------- */
 /* cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with a small arbitrary kernel
  * (watroo/utils.py:257,286): correlation, anchor = kernel centre.  `kernel` is a host pointer

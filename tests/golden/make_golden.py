@@ -330,6 +330,25 @@ def g11_one_dimensional():
         _cv2.filter2D = _real
 
 
+def g12_three_dimensional():
+    """3-D branch (per-slice filter2D + axis-0 filter2D), SURVEY 8f rank 2."""
+    out = {}
+    for shape, seed in (((12, 10, 14), 51), ((5, 33, 20), 52)):
+        a = img(shape, seed)
+        tag = "x".join(map(str, shape))
+        out[f"cube_{tag}"] = a
+        for fam, cls in FAM.items():
+            for L in (1, 3):
+                out[f"coef_{fam}_{tag}_L{L}"] = AtrousTransform(cls)(a, L).data
+            out[f"conv_{fam}_{tag}_s1"] = convolution(a, cls(3), s=1)
+    a = img((12, 10, 14), 51)
+    c = AtrousTransform(B3spline)(a, 3)
+    out["noise_3d"] = np.float64(c.get_noise())
+    c.denoise([5, 3])
+    out["den_3d"] = c.data
+    save("g12_3d", "semantic(cv2 stand-in)", **out)
+
+
 if __name__ == "__main__":
     if REAL_NE:
         assert NE_KIND.startswith("real"), "run with /opt/conda/bin/python3.9"
@@ -344,3 +363,4 @@ if __name__ == "__main__":
         g9_richardson_lucy()
         g10_enhance()
         g11_one_dimensional()
+        g12_three_dimensional()

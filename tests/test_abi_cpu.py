@@ -70,8 +70,6 @@ def test_argument_errors_match_reference():
         W.wow([1, 2, 3])                                        # ref utils.py:133
     with pytest.raises(ValueError, match="Unsupported number of dimensions"):
         W.B3spline(4)                                           # ref wavelets.py:189
-    with pytest.raises(NotImplementedError):
-        W.AtrousTransform()(np.ones((4, 4, 4)), 1)              # 3-D: out of scope, loud
 
 
 def test_scaling_function_objects_match_oracle_constants():

@@ -169,8 +169,33 @@ def test_one_dimensional_signals(W, O):
     big = rnd((1, 100003), 71).reshape(-1)             # long signal, odd length
     close(W.AtrousTransform(W.Triangle)(big, 9).data, O.atrous_standard_1d(big, 9, "triangle"),
           1e-5 * np.abs(big).max())
-    with pytest.raises(NotImplementedError):
-        W.AtrousTransform()(np.ones((4, 4, 4)), 1)     # 3-D stays out of scope
+
+
+def test_three_dimensional_cubes(W, O):
+    """3-D branch (ref wavelets.py:46-64): per-slice 2-D filter + axis-0 filter, cube stored as
+    a (Z*Y) x X image; Coefficients methods with the 3-D sigma_e table."""
+    g = load_golden("g12_3d")
+    for tag in ("12x10x14", "5x33x20"):
+        a = g[f"cube_{tag}"]
+        tol = 1e-5 * np.abs(a).max()
+        for fam in FAMS:
+            cls = cls_of(W, fam)
+            for L in (1, 3):
+                c = W.AtrousTransform(cls)(a, L)
+                assert c.data.shape == (L + 1,) + a.shape
+                close(c.data, g[f"coef_{fam}_{tag}_L{L}"], tol)
+                close(np.sum(c, axis=0), a, 2 * tol)
+            close(W.convolution(a, cls(3), s=1), g[f"conv_{fam}_{tag}_s1"], tol)
+    a = g["cube_12x10x14"]
+    c = W.AtrousTransform(W.B3spline)(a, 3)
+    np.testing.assert_allclose(c.get_noise(), g["noise_3d"], rtol=1e-5)
+    c.denoise([5, 3])
+    close(c.data, g["den_3d"], 1e-5 * np.abs(a).max())
+    big = rnd((40, 70, 130), 81)
+    close(W.AtrousTransform(W.Triangle)(big, 4).data, O.atrous_standard_3d(big, 4, "triangle"),
+          1e-5 * np.abs(big).max())
+    with pytest.raises(ValueError, match="Unsupported number of dimensions"):
+        W.AtrousTransform()(np.ones((2, 2, 2, 2)), 1)
 
 
 def test_recursive_algorithm(W, O):

@@ -273,3 +273,14 @@ def test_one_dimensional_hard_pin():
             for L in (1, 3, 5):
                 close(O.atrous_standard_1d(a, L, fam), g[f"coef_{fam}_{n}_L{L}"], 2e-6 * np.abs(a).max())
             close(O.convolution_1d(a, fam, 2), g[f"conv_{fam}_{n}_s2"], 2e-6 * np.abs(a).max())
+
+
+def test_three_dimensional_vs_reference():
+    g = load_golden("g12_3d")
+    for tag in ("12x10x14", "5x33x20"):
+        a = g[f"cube_{tag}"]
+        tol = 1e-5 * np.abs(a).max()
+        for fam in FAMS:
+            for L in (1, 3):
+                close(O.atrous_standard_3d(a, L, fam), g[f"coef_{fam}_{tag}_L{L}"], tol)
+            close(O.convolution_3d(a, fam, 1), g[f"conv_{fam}_{tag}_s1"], tol)

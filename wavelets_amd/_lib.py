@@ -92,6 +92,8 @@ SIGNATURES = {
     "wt_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                   _c.c_float]),
+    "wt_smooth3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_decompose3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp, _c.c_int, _c.c_int, _c.c_int]),
     "wt_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_mrs_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
@@ -388,6 +390,12 @@ class Plan:
 
     def gamma_blend(self, recon, gamma_plane, gmin, gmax, inv_gamma, h):
         check(load().wt_gamma_blend(self._h, recon, gamma_plane, gmin, gmax, inv_gamma, h))
+
+    def smooth3d(self, src, dst, s, depth):
+        check(load().wt_smooth3d(self._h, src, dst, s, depth))
+
+    def decompose3d(self, src, level, depth):
+        check(load().wt_decompose3d(self._h, src, level, depth))
 
     def filter2d(self, src, dst, kernel, flags=0):
         k = np.ascontiguousarray(kernel, dtype=np.float32)

@@ -1077,6 +1077,77 @@ extern "C" int wt_anscombe(wt_plan *p, int src, int dst, float alpha, float g, f
 }
 
 // =============================================================================================
+// 3-D cubes: a (Z, Y, X) cube is a (Z*Y) x X image on the plan
+// =============================================================================================
+extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst);
+static int conv3d_planes(wt_plan *p, float *in, float *tmp, float *out, int s, int depth)
+{
+    const Geo whole = p->g;
+    const int Y = whole.H / depth;
+    // per-slice 2-D filter: the single-scale kernels run on each Y x X slice as its own image
+    p->g.H = Y;
+    p->g.nrows = Y;
+    int rc = 0;
+    for (int z = 0; z < depth && !rc; ++z) {
+        const size_t off = (size_t)z * Y * whole.P;
+        rc = launch_chain<MODE_SMOOTH>(p, in + off, tmp + off, nullptr, s, 1.f, 1.f, 0, "wt_chain_kernel<smooth>");
+    }
+    p->g = whole;
+    if (rc) return rc;
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_zfilter_kernel");
+    if (p->family == WT_B3SPLINE)
+        hipLaunchKernelGGL((wt_zfilter_kernel<5>), dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, tmp, out, n4, whole.P / 4, Y, depth, 1 << s);
+    else
+        hipLaunchKernelGGL((wt_zfilter_kernel<3>), dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, tmp, out, n4, whole.P / 4, Y, depth, 1 << s);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check3d(const wt_plan *p, int depth, int s, const char *who)
+{
+    if (p->nranks != 1 || p->g.border) WT_FAIL("%s: single-GPU plans with the symmetric border only", who);
+    if (depth < 1 || p->g.H % depth) WT_FAIL("%s: plan height %d is not a multiple of depth %d", who, p->g.H, depth);
+    if (s < 0 || s > 20) WT_FAIL("%s: scale %d out of range", who, s);
+    return 0;
+}
+
+extern "C" int wt_smooth3d(wt_plan *p, int src, int dst, int s, int depth)
+{
+    if (!p) WT_FAIL("wt_smooth3d: null plan");
+    WT_TRY(check3d(p, depth, s, "wt_smooth3d"));
+    const int tmpid = WT_PLANE_SCRATCH(15);
+    if (src == dst || src == tmpid || dst == tmpid) WT_FAIL("wt_smooth3d: src, dst and scratch 15 must differ");
+    float *in = nullptr, *tmp = nullptr, *out = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, tmpid, &tmp));
+    WT_TRY(plane_base(p, dst, &out));
+    return conv3d_planes(p, in, tmp, out, s, depth);
+}
+
+extern "C" int wt_decompose3d(wt_plan *p, int src, int level, int depth)
+{
+    if (!p) WT_FAIL("wt_decompose3d: null plan");
+    WT_TRY(check3d(p, depth, 0, "wt_decompose3d"));
+    if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose3d: level %d exceeds plan max_level %d", level, p->max_level);
+    if (src >= 0 && src <= level) WT_FAIL("wt_decompose3d: src plane %d is one of the output planes", src);
+    if (level == 0) return wt_copy_plane(p, src, 0);
+    int cur = src;
+    for (int s = 0; s < level; ++s) {
+        const int nxt = (s == level - 1) ? level : WT_PLANE_SCRATCH(s & 1);
+        if (cur == nxt) WT_FAIL("wt_decompose3d: scratch planes 0/1 are used internally");
+        float *in = nullptr, *tmp = nullptr, *oc = nullptr;
+        WT_TRY(plane_base(p, cur, &in));
+        WT_TRY(plane_base(p, WT_PLANE_SCRATCH(15), &tmp));
+        WT_TRY(plane_base(p, nxt, &oc));
+        WT_TRY(conv3d_planes(p, in, tmp, oc, s, depth));
+        WT_TRY(wt_binary(p, WT_OP_SUB, cur, nxt, s));        // w_s = c_s - c_{s+1}   (wavelets.py:442)
+        cur = nxt;
+    }
+    return 0;
+}
+
+// =============================================================================================
 // Richardson-Lucy support
 // =============================================================================================
 extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int flags)

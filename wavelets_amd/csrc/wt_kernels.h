@@ -917,6 +917,29 @@ __global__ __launch_bounds__(256) void wt_mrs_kernel(float *c, float *mrs, const
     }
 }
 
+// 3-D branch of convolution() (watroo/wavelets.py:46-64): after the per-slice 2-D filter, a K-tap
+// dilated filter along axis 0 (cv2.filter2D of every (Z, Y) slice with the (K', 1) kernel,
+// BORDER_REFLECT).  The cube is stored as a (Z*Y) x X image, so axis 0 is rows Y apart.
+template <int K>
+__global__ __launch_bounds__(256) void wt_zfilter_kernel(const float *in, float *out, int64_t n4,
+                                                         int P4, int Y, int Z, int d)
+{
+    constexpr int hw = K / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / P4), c4 = (int)(i % P4);
+        const int z = row / Y, y = row - z * Y;
+        float4 acc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int zz = wt_refl(z + (j - hw) * d, Z);
+            const float4 v = reinterpret_cast<const float4 *>(in)[((int64_t)zz * Y + y) * P4 + c4];
+            acc = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, acc);
+        }
+        reinterpret_cast<float4 *>(out)[i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void wt_fill_kernel(float *dst, int64_t n4, float value)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;

@@ -6,8 +6,8 @@ Same public names, argument meaning and error behaviour as the reference module
 
 Scope: 2-D images, float32 compute.  float64 / integer inputs are
 converted to float32 (the reference keeps float64, ref:297,319-320); 1-D signals run as
-1 x N images with the 1-D branch's 'mirror' border; 3-D arrays raise ``NotImplementedError`` -
-there is deliberately no CPU fallback.
+1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes as (Z*Y) x X images
+(per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no CPU fallback.
 """
 import copy
 
@@ -179,17 +179,24 @@ def convolution(arr, scaling_function, s=0, output=None):
     1-D arrays take the reference's 1-D branch (ref:65-69: scipy 'mirror' border) as a
     1 x N image under the engine's mirror border rule."""
     one_d = _is_1d(arr)
-    img = _to_f32_row(arr) if one_d else _to_f32_image(arr)
+    three_d = np.ndim(arr) == 3
+    if three_d:
+        cube = np.ascontiguousarray(arr, dtype=np.float32)
+        img = cube.reshape(cube.shape[0] * cube.shape[1], cube.shape[2])
+    else:
+        img = _to_f32_row(arr) if one_d else _to_f32_image(arr)
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                         _family_of(scaling_function), 0)
     try:
         if one_d:
             plan.set_border(2)
         plan.upload(PLANE_INPUT, img)
-        plan.smooth(PLANE_INPUT, PLANE_OUT, s)
+        if three_d:
+            plan.smooth3d(PLANE_INPUT, PLANE_OUT, s, cube.shape[0])
+        else:
+            plan.smooth(PLANE_INPUT, PLANE_OUT, s)
         res = plan.download(PLANE_OUT)
-        if one_d:
-            res = res.reshape(-1)
+        res = res.reshape(np.shape(arr))
     finally:
         release_plan(plan)
     if output is None:
@@ -256,25 +263,32 @@ class Coefficients:
     it and afterwards refreshes it in place, so references held by the caller stay valid.
     """
 
-    def __init__(self, data, scaling_function, bilateral=None):
+    def __init__(self, data, scaling_function, bilateral=None, _shape=None):
         self.scaling_function = scaling_function
         self.bilateral = bilateral
         self.noise = None
         self._plan = None
         self._host = None
         self._noise_uploaded = None
-        self._ndim = getattr(scaling_function, "n_dim", 2)      # 1: planes are 1 x N images
+        # logical shape of one plane: (N,), (H, W) or (Z, Y, X); the engine stores it as a 2-D
+        # image: 1 x N, H x W or (Z*Y) x X
         if isinstance(data, Plan):
             self._plan = data
             self._nplanes = data.max_level + 1
+            if _shape is not None:
+                self._shape = tuple(_shape)
+            elif getattr(scaling_function, "n_dim", 2) == 1:
+                self._shape = (data.shape[1],)
+            else:
+                self._shape = tuple(data.shape)
         else:
             data = np.asarray(data)
-            if data.ndim not in (2, 3):
-                raise NotImplementedError("Coefficients: the HIP engine covers 1-D signals "
-                                          "((level+1, N) stacks) and 2-D images ((level+1, H, W))")
-            self._ndim = data.ndim - 1
+            if data.ndim not in (2, 3, 4):
+                raise ValueError("Unsupported number of dimensions")
             self._host = np.ascontiguousarray(data, dtype=np.float32)
             self._nplanes = self._host.shape[0]
+            self._shape = tuple(self._host.shape[1:])
+        self._ndim = len(self._shape)
 
     def __del__(self):
         try:
@@ -284,17 +298,22 @@ class Coefficients:
 
     # -- host mirror -------------------------------------------------------------------
     def _img_shape(self):
-        shp = self._plan.shape if self._plan is not None else None
+        return self._shape
+
+    def _plane_hw(self):
+        """(rows, cols) of the 2-D image a plane is stored as"""
         if self._ndim == 1:
-            return (shp[1],) if shp is not None else self._host.shape[1:]
-        return shp if shp is not None else self._host.shape[1:]
+            return 1, self._shape[0]
+        if self._ndim == 3:
+            return self._shape[0] * self._shape[1], self._shape[2]
+        return self._shape
 
     def _as_plane(self, a):
-        """host plane in the engine's 2-D layout (a 1-D signal is a 1 x N image)"""
-        return a.reshape(1, -1) if self._ndim == 1 else a
+        """host plane in the engine's 2-D layout (1 x N, H x W, (Z*Y) x X)"""
+        return a.reshape(self._plane_hw())
 
     def _from_plane(self, a):
-        return a.reshape(-1) if self._ndim == 1 else a
+        return a.reshape(self._shape)
 
     @property
     def data(self):
@@ -317,7 +336,7 @@ class Coefficients:
         (re-uploading a user-owned mirror).  Call ONCE per public operation; helpers that
         run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
-            H, W = (1, self._host.shape[1]) if self._ndim == 1 else self._host.shape[1:]
+            H, W = self._plane_hw()
             self._plan = acquire_plan(default_context(), H, W,
                                       _family_of(self.scaling_function), self._nplanes - 1)
         if self._host is not None:
@@ -452,6 +471,8 @@ class AtrousTransform:
         """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328)."""
         if _is_1d(arr):
             return self._call_1d(arr, level, recursive)
+        if np.ndim(arr) == 3:
+            return self._call_3d(arr, level, recursive)
         img = _to_f32_image(arr)
         scaling_function = self.scaling_function_class(img.ndim)
         if recursive:
@@ -476,6 +497,20 @@ class AtrousTransform:
         plan.decompose(PLANE_INPUT, level, 0)
         plan.set_border(0)
         return Coefficients(plan, scaling_function, None)
+
+    def _call_3d(self, arr, level, recursive):
+        """(Z, Y, X) cubes (ref:46-64): per-slice 2-D filter then the same filter along axis 0;
+        the cube lives on the GPU as a (Z*Y) x X image."""
+        if recursive or self.bilateral is not None:
+            raise NotImplementedError("3-D transforms support the standard, non-bilateral "
+                                      "algorithm only in the HIP engine")
+        cube = np.ascontiguousarray(arr, dtype=np.float32)
+        Z, Y, X = cube.shape
+        scaling_function = self.scaling_function_class(3)
+        plan = acquire_plan(default_context(), Z * Y, X, _family_of(scaling_function), level)
+        plan.upload(PLANE_INPUT, cube.reshape(Z * Y, X))
+        plan.decompose3d(PLANE_INPUT, level, Z)
+        return Coefficients(plan, scaling_function, None, _shape=(Z, Y, X))
 
     def _recursive(self, img, level, scaling_function):
         """The reference's recursive algorithm (ref:330-406) on the GPU.  It pads once by
