@@ -12,18 +12,24 @@
 //    (per lane: (K-1)*(2^NS-1) float4 = 28 for B3/NS=3), never re-read from memory.
 //  * x: a workgroup of NW waves covers NW*256 contiguous pixels of the row (lane = 4 adjacent
 //    pixels = one 16-byte coalesced access), including the cumulative halo
-//    hw*(2^NS-1)*D pixels on each side whose results are discarded.  The horizontal filter
+//    hw*(2^NS-1)*D pixels on each side (rounded up to 32 pixels so that every wave access
+//    covers whole 128-byte lines) whose results are discarded.  The horizontal filter
 //    needs the vertically-filtered row of the neighbouring lanes: it is staged through a
 //    per-scale LDS row (one ds_write_b128 + K-1 ds_read_b128 per lane per scale) - for D >= 4
 //    the dilated taps are whole-lane offsets, for D = 1 the taps of dilation 1 and 2 are
-//    recombined from the two adjacent lanes' float4.
+//    recombined from the two adjacent lanes' float4.  The NS scales of a step are software-
+//    pipelined (scale a works on the row scale a-1 produced one step earlier): one barrier per
+//    row, LDS rows double-buffered by step parity.
 //  * borders: the chain simply continues through reflected rows / columns; symmetric
 //    extension commutes with the symmetric filters, so every intermediate scale is the exact
 //    symmetric extension too.  In a multi-GPU strip the rows beyond the strip come from the
 //    halo margins (RCCL exchange of the pass input) instead.
 //  * latency of the cascade: output row of scale a lags the input row by hw*(2^(a+1)-1)
-//    chain steps, so a chunk of S rows reads S + 2*hw*(2^NS-1) rows (warm-up).
-//    The host sizes chunks so that the whole grid is resident at once (one round).
+//    chain steps (+ a for the pipeline skew), so a chunk of S rows reads S + 2*hw*(2^NS-1)
+//    rows (warm-up).  The host picks the chunk count that minimises (dispatch rounds) x (rows
+//    per workgroup) - normally one round with every resident slot filled.
+//  * stores are branch-free: raw buffer descriptors with a zero length (row outside the chunk)
+//    or an out-of-range lane offset (halo lane) are dropped by the hardware range check.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -38,10 +44,12 @@ struct FusedArgs {
     float *out_c;                          // c_{s0+NS}
     float *out_w[WT_FUSED_MAX_SCALES];     // w_{s0+a}
     Geo g;
-    int Vx;       // valid (stored) pixels per x-strip, multiple of 4
+    int Vx;       // valid (stored) pixels per x-strip, multiple of 32
     int S;        // chain steps stored per chunk
     int chunks;   // chunks per chain
-    int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores, 2 = loads re-read one row
+    int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
+                  // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
+                  // not issue the predicated-off stores
 };
 
 template <int K, int SHIFT_PX, int NLANES>
