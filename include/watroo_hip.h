@@ -104,6 +104,11 @@ int wt_plan_set_border(wt_plan *plan, int border);
  * (atrous_recursive pads by hw*2^(level-1) and crops at the end, watroo/wavelets.py:394-406) */
 int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0,
                   int64_t x0);
+/* the reverse: dst[y0:y0+src.nrows, x0:x0+src.W] = src (both windows in LOCAL rows; same
+ * device).  With wt_crop_plane this scatters / gathers row strips of a resident image without
+ * a host round trip (tools/check_large.py builds and checks a 32768^2 image this way). */
+int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0,
+                   int64_t x0);
 /* device pointer of a plane's local row 0 (for zero-copy interop / virtual-strip tests) */
 int wt_plane_ptr(wt_plan *plan, int plane, void **dev_ptr);
 

@@ -8,6 +8,8 @@ chain/fused kernels reading neighbour rows from the margins - is the production 
 The RCCL transport itself is covered by test_rccl_single_rank_selftest and, on CPU, the
 schedule/partition logic by tests/test_strips_gloo_cpu.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -131,3 +133,34 @@ def test_strip_transform_single_rank(L):
     st.denoise([5, 3])
     ref.denoise([5, 3])
     np.testing.assert_allclose(st.sum(), ref.data.sum(axis=0), atol=1e-5 * np.abs(img).max())
+
+
+def test_paste_and_crop_scatter_gather_strips(L):
+    """wt_paste_plane / wt_crop_plane move row strips between resident plans (no host trip)."""
+    from wavelets_amd.parallel import partition_rows
+    ctx = L.default_context()
+    a = np.random.default_rng(3).standard_normal((90, 70)).astype(np.float32)
+    whole = L.Plan(ctx, 90, 70, L.B3SPLINE, 1)
+    whole.fill(L.PLANE_INPUT, 0.0)
+    for r, (row0, n) in enumerate(partition_rows(90, 4)):
+        p = L.Plan(ctx, 90, 70, L.B3SPLINE, 1, row0=row0, nrows=n, rank=r, nranks=4)
+        p.upload(L.PLANE_INPUT, a[row0:row0 + n])
+        p.paste_into(whole, L.PLANE_INPUT, L.PLANE_INPUT, row0, 0)
+        p.crop_from(whole, L.PLANE_INPUT, L.PLANE_OUT, row0, 0)
+        assert np.array_equal(p.download(L.PLANE_OUT), a[row0:row0 + n])
+        with pytest.raises(L.WatrooHipError, match="outside"):
+            p.paste_into(whole, L.PLANE_INPUT, L.PLANE_INPUT, 90 - n + 1, 0)
+        p.close()
+    assert np.array_equal(whole.download(L.PLANE_INPUT), a)
+    whole.close()
+
+
+def test_large_geometry_device_side_checks():
+    """tools/check_large.py at 16384^2 (the per-GPU strip geometry of the N=8 bench is
+    4096 x 32768; the script at 32768 takes ~15 s and ~90 GB - run it by hand)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "check_large.py"), "16384"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "check_large: OK" in r.stdout, r.stdout + r.stderr

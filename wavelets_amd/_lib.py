@@ -62,6 +62,7 @@ SIGNATURES = {
                                _c.POINTER(_c.c_int)]),
     "wt_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
     "wt_crop_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
+    "wt_paste_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
     "wt_plane_ptr": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_vp)]),
     "wt_upload": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
     "wt_download": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
@@ -309,6 +310,9 @@ class Plan:
 
     def crop_from(self, src_plan, src_plane, dst_plane, y0, x0):
         check(load().wt_crop_plane(src_plan._h, src_plane, self._h, dst_plane, y0, x0))
+
+    def paste_into(self, dst_plan, src_plane, dst_plane, y0, x0):
+        check(load().wt_paste_plane(self._h, src_plane, dst_plan._h, dst_plane, y0, x0))
 
     def copy(self, src, dst):
         check(load().wt_copy_plane(self._h, src, dst))

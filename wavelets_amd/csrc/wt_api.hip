@@ -428,7 +428,7 @@ extern "C" int wt_plan_set_border(wt_plan *p, int border)
 extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0, int64_t x0)
 {
     if (!src || !dst) WT_FAIL("wt_crop_plane: null plan");
-    if (src->nranks != 1 || dst->nranks != 1) WT_FAIL("wt_crop_plane: single-GPU plans only");
+    if (src->ctx->device != dst->ctx->device) WT_FAIL("wt_crop_plane: plans on different devices");
     if (y0 < 0 || x0 < 0 || y0 + dst->g.nrows > src->g.nrows || x0 + dst->g.W > src->g.W)
         WT_FAIL("wt_crop_plane: window outside the source plane");
     float *s_ = nullptr, *d_ = nullptr;
@@ -436,6 +436,21 @@ extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_
     WT_TRY(plane_base(dst, dst_plane, &d_));
     WT_HIP(hipMemcpy2DAsync(d_, (size_t)dst->g.P * 4, s_ + (size_t)y0 * src->g.P + x0, (size_t)src->g.P * 4,
                             (size_t)dst->g.W * 4, (size_t)dst->g.nrows, hipMemcpyDeviceToDevice, src->ctx->stream));
+    if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
+    return 0;
+}
+
+extern "C" int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0, int64_t x0)
+{
+    if (!src || !dst) WT_FAIL("wt_paste_plane: null plan");
+    if (src->ctx->device != dst->ctx->device) WT_FAIL("wt_paste_plane: plans on different devices");
+    if (y0 < 0 || x0 < 0 || y0 + src->g.nrows > dst->g.nrows || x0 + src->g.W > dst->g.W)
+        WT_FAIL("wt_paste_plane: window outside the destination plane");
+    float *s_ = nullptr, *d_ = nullptr;
+    WT_TRY(plane_base(src, src_plane, &s_));
+    WT_TRY(plane_base(dst, dst_plane, &d_));
+    WT_HIP(hipMemcpy2DAsync(d_ + (size_t)y0 * dst->g.P + x0, (size_t)dst->g.P * 4, s_, (size_t)src->g.P * 4,
+                            (size_t)src->g.W * 4, (size_t)src->g.nrows, hipMemcpyDeviceToDevice, src->ctx->stream));
     if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
     return 0;
 }
