@@ -251,14 +251,21 @@ def main():
             "kernels": kernels,
         }
         if world == 1:
-            # PCIe-inclusive rate (host numpy in, reconstruction out) - never `value`
+            # PCIe-inclusive rate (host numpy in, reconstruction out as a numpy array) - never
+            # `value`.  First call: the result's page-locked block is allocated; later calls
+            # reuse it from the host pool (wavelets_amd/_lib.py _HostPool), which is the steady
+            # state of a frame loop.
             img = make_strip(nrows, W, seed=0)
-            recon = np.empty((nrows, W), np.float32)
-            t = time.perf_counter()
-            plan.upload(PLANE_INPUT, img)
-            step()
-            plan.download(PLANE_OUT, recon)
-            out["pcie_inclusive_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
+            rates = []
+            for _ in range(3):
+                t = time.perf_counter()
+                plan.upload(PLANE_INPUT, img)
+                step()
+                recon = plan.download(PLANE_OUT)
+                rates.append(H * W / (time.perf_counter() - t) / 1e6)
+                del recon
+            out["pcie_inclusive_first_call_mpix_s"] = round(rates[0], 1)
+            out["pcie_inclusive_mpix_s"] = round(max(rates[1:]), 1)
             if not args.no_cpu and not args.brief:
                 out["cpu_baseline"] = cpu_baseline()
         if args.brief:

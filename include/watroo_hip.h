@@ -113,6 +113,13 @@ int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int
 int wt_plane_ptr(wt_plan *plan, int plane, void **dev_ptr);
 
 /* ---- host <-> device ---------------------------------------------------------------- */
+/* Page-locked host memory for results handed back to the caller.  A fresh pageable array costs
+ * a first-touch page fault per 4 KiB during the download (8192^2: 17-31 ms instead of 4.7 ms at
+ * 57 GB/s); the Python host side keeps a pool of these blocks behind the ndarrays it returns
+ * (wavelets_amd/_lib.py host_empty) - the reference returns fresh numpy arrays at
+ * watroo/utils.py:98,205,219 and watroo/wavelets.py:426. */
+int wt_host_alloc(wt_ctx *ctx, size_t bytes, void **host_ptr);
+int wt_host_free(void *host_ptr);
 /* host image = this strip's rows, `host_stride` floats between rows (>= W). */
 int wt_upload(wt_plan *plan, int plane, const float *host, int64_t host_stride);
 int wt_download(wt_plan *plan, int plane, float *host, int64_t host_stride);

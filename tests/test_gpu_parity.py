@@ -669,3 +669,36 @@ def test_rccl_single_rank_selftest(W):
     ctx.comm_init(0, 1, _lib.Context.unique_id())
     assert ctx.comm_selftest(1 << 18)
     ctx.close()
+
+
+def test_host_pool_recycles_pinned_result_blocks(W):
+    """Results >= 1 MiB come back in page-locked blocks that return to a pool when the last view
+    of the array dies (wavelets_amd/_lib.py _HostPool) and back the next result of that size."""
+    import gc
+    from wavelets_amd import _lib as L
+    ctx = L.default_context()
+    a = L.host_empty((600, 700), ctx)
+    assert a.dtype == np.float32 and a.shape == (600, 700) and a.flags.writeable
+    addr = a.ctypes.data
+    a[:] = 3.0
+    v = a[5:10]
+    del a
+    gc.collect()
+    assert v[0, 0] == 3.0                        # a live view keeps the block checked out
+    b = L.host_empty((600, 700), ctx)
+    assert b.ctypes.data != addr
+    baddr = b.ctypes.data
+    del v, b
+    gc.collect()
+    c = L.host_empty((600, 700), ctx)
+    assert c.ctypes.data in (addr, baddr)         # recycled
+    small = L.host_empty((10, 10), ctx)
+    assert small.flags.owndata                    # small results stay ordinary numpy arrays
+    img = np.random.default_rng(0).standard_normal((700, 900)).astype(np.float32)
+    r1 = W.denoise(img, [5, 3])
+    keep = r1.copy()
+    p1 = r1.ctypes.data
+    del r1
+    gc.collect()
+    r2 = W.denoise(img, [5, 3])
+    assert r2.ctypes.data == p1 and np.array_equal(r2, keep)

@@ -487,6 +487,23 @@ static bool try_pin(const void *host, size_t bytes)
     return true;
 }
 
+extern "C" int wt_host_alloc(wt_ctx *c, size_t bytes, void **host_ptr)
+{
+    if (!c || !host_ptr) WT_FAIL("wt_host_alloc: null pointer");
+    if (bytes == 0) WT_FAIL("wt_host_alloc: zero bytes");
+    *host_ptr = nullptr;
+    WT_HIP(hipSetDevice(c->device));
+    WT_HIP(hipHostMalloc(host_ptr, bytes, hipHostMallocPortable));
+    return 0;
+}
+
+extern "C" int wt_host_free(void *host_ptr)
+{
+    if (!host_ptr) return 0;
+    WT_HIP(hipHostFree(host_ptr));
+    return 0;
+}
+
 extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_stride)
 {
     if (!p || !host) WT_FAIL("wt_upload: null pointer");

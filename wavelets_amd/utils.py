@@ -10,6 +10,7 @@ import warnings
 
 import numpy as np
 
+from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _family_of, _to_f32_image,
                        PLANE_INPUT)
@@ -44,7 +45,7 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     img = np.asarray(args[0])
     channels = [0, 1, 2] if img.ndim == 3 else [Ellipsis]                 # ref:47-50
     if out is None:
-        out = np.empty(img.shape, np.float32)
+        out = _lib.host_empty(img.shape)
     weights = prepare_params(weights, img.ndim)
     denoise = prepare_params(denoise, img.ndim)
     atrous = AtrousTransform(**kwargs)

@@ -318,7 +318,7 @@ class Coefficients:
     @property
     def data(self):
         if self._host is None:
-            host = np.empty((self._nplanes,) + self._img_shape(), np.float32)
+            host = _lib.host_empty((self._nplanes,) + self._img_shape(), self._plan.ctx)
             for s in range(self._nplanes):
                 self._plan.download(s, self._as_plane(host[s]))
             self._host = host
