@@ -1249,13 +1249,12 @@ extern "C" int wt_reduce(wt_plan *p, int plane, double out[4])
     wt_ctx *c = p->ctx;
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
-    const int64_t n4 = plan_n4(p);
-    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, c->partial_blocks);
+    const int blocks = std::min(p->g.nrows, c->partial_blocks);
     double *dout = c->d_partials + (size_t)c->partial_blocks * 4;
     {
         ProfScope ps(c, "wt_reduce_kernel");
-        hipLaunchKernelGGL(wt_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, b, n4, p->g.P / 4, p->g.W, c->d_partials);
-        hipLaunchKernelGGL(wt_reduce_final_kernel, dim3(1), dim3(64), 0, c->stream, c->d_partials, blocks, dout);
+        hipLaunchKernelGGL(wt_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, b, p->g.nrows, p->g.P / 4, p->g.W, c->d_partials);
+        hipLaunchKernelGGL(wt_reduce_final_kernel, dim3(1), dim3(256), 0, c->stream, c->d_partials, blocks, dout);
     }
     WT_HIP(hipGetLastError());
     if (p->nranks > 1) {

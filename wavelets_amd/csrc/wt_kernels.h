@@ -1001,58 +1001,77 @@ __global__ __launch_bounds__(256) void wt_min_greater_kernel(const float *p, int
     if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(result, best);
 }
 
-// K7  {sum, sumsq, min, max} in fp64, deterministic two-stage reduction (per-block partials,
-// then one block folds them in index order).
-__global__ __launch_bounds__(256) void wt_reduce_kernel(const float *p, int64_t n4, int P4, int W,
+// K7  {sum, sumsq, min, max}: fp64 sums, deterministic two-stage reduction (per-block partials
+// over whole rows, then one block folds them in a fixed order).  Rows are walked with 2-D
+// indices (no 64-bit modulo per element); min/max are taken in fp32, which is exact.
+__global__ __launch_bounds__(256) void wt_reduce_kernel(const float *p, int nrows, int P4, int W,
                                                         double *partials)
 {
-    double s = 0.0, s2 = 0.0, mn = 1e300, mx = -1e300;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4 *>(p)[i];
-        const int x = (int)(i % P4) * 4;
-        const float b[4] = {v.x, v.y, v.z, v.w};
+    double s = 0.0, s2 = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const float4 *row = reinterpret_cast<const float4 *>(p) + (int64_t)r * P4;
+        for (int x4 = threadIdx.x; x4 * 4 < W; x4 += 256) {
+            const float4 v = row[x4];
+            const float b[4] = {v.x, v.y, v.z, v.w};
+            const int nv = min(4, W - x4 * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (x + k < W) {
-                const double t = (double)b[k];
-                s += t;
-                s2 += t * t;
-                mn = fmin(mn, t);
-                mx = fmax(mx, t);
-            }
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) {
+                    const double t = (double)b[k];
+                    s += t;
+                    s2 = fma(t, t, s2);
+                    mn = fminf(mn, b[k]);
+                    mx = fmaxf(mx, b[k]);
+                }
+        }
     }
-    __shared__ double red[4][4];
+    __shared__ double red[4][2];
+    __shared__ float redf[4][2];
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_down(s, off);
         s2 += __shfl_down(s2, off);
-        mn = fmin(mn, __shfl_down(mn, off));
-        mx = fmax(mx, __shfl_down(mx, off));
+        mn = fminf(mn, __shfl_down(mn, off));
+        mx = fmaxf(mx, __shfl_down(mx, off));
     }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        red[wave][0] = s; red[wave][1] = s2; red[wave][2] = mn; red[wave][3] = mx;
+        red[wave][0] = s; red[wave][1] = s2; redf[wave][0] = mn; redf[wave][1] = mx;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) {
             s += red[w][0]; s2 += red[w][1];
-            mn = fmin(mn, red[w][2]); mx = fmax(mx, red[w][3]);
+            mn = fminf(mn, redf[w][0]); mx = fmaxf(mx, redf[w][1]);
         }
         double *o = partials + (int64_t)blockIdx.x * 4;
-        o[0] = s; o[1] = s2; o[2] = mn; o[3] = mx;
+        o[0] = s; o[1] = s2; o[2] = (double)mn; o[3] = (double)mx;
     }
 }
 
-__global__ void wt_reduce_final_kernel(const double *partials, int nblocks, double *out)
+// one 256-thread block: thread t folds partials t, t+256, ... in index order, then a fixed tree
+__global__ __launch_bounds__(256) void wt_reduce_final_kernel(const double *partials, int nblocks, double *out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0.0, s2 = 0.0, mn = 1e300, mx = -1e300;
-    for (int b = 0; b < nblocks; ++b) {
+    double s = 0.0, s2 = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
         s += partials[b * 4 + 0];
         s2 += partials[b * 4 + 1];
         mn = fmin(mn, partials[b * 4 + 2]);
         mx = fmax(mx, partials[b * 4 + 3]);
     }
-    out[0] = s; out[1] = s2; out[2] = mn; out[3] = mx;
+    __shared__ double red[256][4];
+    red[threadIdx.x][0] = s; red[threadIdx.x][1] = s2; red[threadIdx.x][2] = mn; red[threadIdx.x][3] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[threadIdx.x][0] += red[threadIdx.x + off][0];
+            red[threadIdx.x][1] += red[threadIdx.x + off][1];
+            red[threadIdx.x][2] = fmin(red[threadIdx.x][2], red[threadIdx.x + off][2]);
+            red[threadIdx.x][3] = fmax(red[threadIdx.x][3], red[threadIdx.x + off][3]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = red[0][0]; out[1] = red[0][1]; out[2] = red[0][2]; out[3] = red[0][3];
+    }
 }
