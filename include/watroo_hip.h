@@ -208,6 +208,14 @@ int wt_decompose3d(wt_plan *plan, int src, int level, int depth);
  * (watroo/utils.py:257,286): correlation, anchor = kernel centre.  `kernel` is a host pointer
  * to kh*kw floats (<= 4096 taps). */
 int wt_filter2d(wt_plan *plan, int src, int dst, const float *kernel, int kh, int kw, int flags);
+/* General form: explicit anchor (ay, ax) and border WT_BORDER_SYMMETRIC or WT_BORDER_PERIODIC.
+ * The periodic border with anchor k/2 (correlation) or k-1-k/2 (flipped kernel = convolution)
+ * is the circular product the reference forms with rfft2/irfft2 when fft=True
+ * (watroo/utils.py:245-254, 284); whole-image plans only. */
+#define WT_BORDER_SYMMETRIC 0
+#define WT_BORDER_PERIODIC 3
+int wt_filter2d_ex(wt_plan *plan, int src, int dst, const float *kernel, int kh, int kw, int ay,
+                   int ax, int border, int flags);
 /* elementwise dst = a OP b: 0 a-b, 1 a+b, 2 a*b, 3 a/b, 4 (a+b)/b  (watroo/utils.py:259,280-281,288) */
 int wt_binary(wt_plan *plan, int op, int a, int b, int dst);
 /* multiresolution-support update of a residual plane (watroo/utils.py:263-276):

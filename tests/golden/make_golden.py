@@ -289,6 +289,30 @@ def g9_richardson_lucy():
     save("g9_richardson_lucy", "semantic(cv2 stand-in)", **out)
 
 
+def g13_richardson_lucy_fft():
+    """richardson_lucy(fft=True): circular rfft2 products (numpy only, no cv2 in the loop)."""
+    g9 = np.load(os.path.join(HERE, "g9_richardson_lucy.npz"))
+    data, psf = g9["data"], g9["psf"]
+    out = {"data": data, "psf": psf}
+    rng = np.random.default_rng(77)
+    even = rng.uniform(0.2, 1.0, (4, 6)).astype(np.float32)     # even-sized, asymmetric PSF
+    even /= even.sum()
+    out["psf_even"] = even
+    out["rl_fft_soft"] = richardson_lucy(data.copy(), psf, iterations=3, fft=True)
+    out["rl_fft_hard"] = richardson_lucy(data.copy(), psf, iterations=2, threshold_type='hard', fft=True)
+    out["rl_fft_even"] = richardson_lucy(data.copy(), even, iterations=2, fft=True,
+                                         denoise_coefficients=(4, 2))
+    # the two circular products on their own (pins anchor / roll conventions for the even PSF)
+    pad = np.zeros_like(data)
+    H, W = data.shape
+    kh, kw = even.shape
+    pad[H // 2 - kh // 2:H // 2 - kh // 2 + kh, W // 2 - kw // 2:W // 2 - kw // 2 + kw] = even
+    f = np.fft.rfft2(np.roll(pad, (H // 2, W // 2), axis=(0, 1)))
+    out["circ_conv_even"] = np.fft.irfft2(np.fft.rfft2(data) * f)
+    out["circ_corr_even"] = np.fft.irfft2(np.fft.rfft2(data) * f.conj())
+    save("g13_rl_fft", "hard(numpy fft; transform via cv2 stand-in)", **out)
+
+
 def g10_enhance():
     """utils.enhance (importable by path, not in __all__)."""
     from watroo.utils import enhance
@@ -350,7 +374,9 @@ def g12_three_dimensional():
 
 
 if __name__ == "__main__":
-    if REAL_NE:
+    if "--only" in sys.argv:                      # e.g. --only g13_richardson_lucy_fft
+        globals()[sys.argv[sys.argv.index("--only") + 1]]()
+    elif REAL_NE:
         assert NE_KIND.startswith("real"), "run with /opt/conda/bin/python3.9"
         g5_bilateral("g5_realne")
     else:
@@ -361,6 +387,7 @@ if __name__ == "__main__":
         g5_bilateral()
         g7_recursive_g8_tests()
         g9_richardson_lucy()
+        g13_richardson_lucy_fft()
         g10_enhance()
         g11_one_dimensional()
         g12_three_dimensional()

@@ -595,8 +595,59 @@ def test_richardson_lucy_vs_golden(W, name):
         assert bad.sum() <= 4
     else:
         close(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
-    with pytest.raises(NotImplementedError):
-        W.richardson_lucy(g["data"], g["psf"], fft=True)
+
+
+RL_FFT_CASES = {
+    "rl_fft_soft": ("psf", dict(iterations=3)),
+    "rl_fft_hard": ("psf", dict(iterations=2, threshold_type='hard')),
+    "rl_fft_even": ("psf_even", dict(iterations=2, denoise_coefficients=(4, 2))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RL_FFT_CASES))
+def test_richardson_lucy_fft_vs_golden(W, name):
+    """fft=True (the reference's circular rfft2 products) as direct periodic correlations."""
+    g = load_golden("g13_rl_fft")
+    psf, kw = RL_FFT_CASES[name]
+    got = W.richardson_lucy(g["data"].copy(), g[psf], fft=True, **kw)
+    ref = g[name]
+    if "hard" in name:
+        bad = np.abs(got - ref) > 1e-4 * np.abs(ref).max() + 1e-4 * np.abs(ref)
+        assert bad.sum() <= 4
+    else:
+        close(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
+
+
+def test_filter2d_periodic_vs_golden_and_oracle(W, O):
+    from wavelets_amd import _lib as L
+    g = load_golden("g13_rl_fft")
+    d, k = g["data"], g["psf_even"]
+    kh, kw = k.shape
+    ctx = L.default_context()
+    plan = L.Plan(ctx, d.shape[0], d.shape[1], L.B3SPLINE, 0)
+    plan.upload(L.PLANE_INPUT, d)
+    tol = 1e-5 * np.abs(d).max()
+    plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, np.ascontiguousarray(k[::-1, ::-1]),
+                  anchor=(kh - 1 - kh // 2, kw - 1 - kw // 2), periodic=True)
+    close(plan.download(L.PLANE_OUT), g["circ_conv_even"], tol)
+    plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, k, anchor=(kh // 2, kw // 2), periodic=True)
+    close(plan.download(L.PLANE_OUT), g["circ_corr_even"], tol)
+    plan.close()
+    # PSF larger than the image wraps more than once; odd shapes; off-centre anchor
+    for shape, ksh, anchor in (((9, 7), (21, 19), (3, 17)), ((130, 75), (7, 3), (0, 2)), ((33, 260), (1, 9), (0, 4))):
+        a, kk = rnd(shape, 5), rnd(ksh, 6)
+        plan = L.Plan(ctx, shape[0], shape[1], L.B3SPLINE, 0)
+        plan.upload(L.PLANE_INPUT, a)
+        plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, kk, anchor=anchor, periodic=True)
+        ref = O.filter2d_periodic(a, kk, anchor)
+        close(plan.download(L.PLANE_OUT), ref, 1e-5 * max(1.0, np.abs(ref).max()))
+        with pytest.raises(L.WatrooHipError, match="anchor"):
+            plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, kk, anchor=(ksh[0], 0), periodic=True)
+        plan.close()
+    strip = L.Plan(ctx, 64, 32, L.B3SPLINE, 0, row0=0, nrows=32, rank=0, nranks=2)
+    with pytest.raises(L.WatrooHipError, match="whole-image"):
+        strip.filter2d(L.PLANE_INPUT, L.PLANE_OUT, rnd((3, 3), 1), periodic=True)
+    strip.close()
 
 
 def test_filter2d_vs_oracle(W, O):

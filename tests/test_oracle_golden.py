@@ -231,6 +231,32 @@ def test_richardson_lucy_vs_reference(name):
     close(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
 
 
+RL_FFT_CASES = {
+    "rl_fft_soft": ("psf", dict(iterations=3)),
+    "rl_fft_hard": ("psf", dict(iterations=2, threshold_type='hard')),
+    "rl_fft_even": ("psf_even", dict(iterations=2, denoise_coefficients=(4, 2))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RL_FFT_CASES))
+def test_richardson_lucy_fft_vs_reference(name):
+    """fft=True: the oracle's direct periodic correlations against the reference's rfft2 path."""
+    g = load_golden("g13_rl_fft")
+    psf, kw = RL_FFT_CASES[name]
+    got = O.richardson_lucy(g["data"].copy(), g[psf], fft=True, **kw)
+    close(got, g[name], atol=1e-4 * np.abs(g[name]).max(), rtol=1e-4)
+
+
+def test_periodic_products_even_psf_anchor():
+    g = load_golden("g13_rl_fft")
+    d, k = g["data"], g["psf_even"]
+    kh, kw = k.shape
+    tol = 1e-5 * np.abs(d).max()
+    close(O.filter2d_periodic(d, k[::-1, ::-1], (kh - 1 - kh // 2, kw - 1 - kw // 2)),
+          g["circ_conv_even"], tol)
+    close(O.filter2d_periodic(d, k, (kh // 2, kw // 2)), g["circ_corr_even"], tol)
+
+
 def test_filter2d_even_kernel_anchor():
     g = load_golden("g9_richardson_lucy")
     close(O.filter2d_reflect(g["data"], g["psf_even"]), g["filter_even"],

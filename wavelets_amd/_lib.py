@@ -98,6 +98,7 @@ SIGNATURES = {
     "wt_smooth3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_filter2d_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp] + [_c.c_int] * 6),
     "wt_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_mrs_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
                                  _c.c_int, _c.c_float]),
@@ -480,12 +481,13 @@ class Plan:
     def decompose3d(self, src, level, depth):
         check(load().wt_decompose3d(self._h, src, level, depth))
 
-    def filter2d(self, src, dst, kernel, flags=0):
+    def filter2d(self, src, dst, kernel, flags=0, anchor=None, periodic=False):
         k = np.ascontiguousarray(kernel, dtype=np.float32)
         if k.ndim != 2:
             raise ValueError("filter2d kernel must be 2-D")
-        check(load().wt_filter2d(self._h, src, dst, k.ctypes.data_as(_fp), k.shape[0], k.shape[1],
-                                 flags))
+        ay, ax = (k.shape[0] // 2, k.shape[1] // 2) if anchor is None else anchor
+        check(load().wt_filter2d_ex(self._h, src, dst, k.ctypes.data_as(_fp), k.shape[0],
+                                    k.shape[1], ay, ax, 3 if periodic else 0, flags))
 
     def binary(self, op, a, b, dst):
         check(load().wt_binary(self._h, {"sub": 0, "add": 1, "mul": 2, "div": 3,

@@ -1182,20 +1182,27 @@ extern "C" int wt_decompose3d(wt_plan *p, int src, int level, int depth)
 // =============================================================================================
 // Richardson-Lucy support
 // =============================================================================================
-extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int flags)
+extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int ay, int ax,
+                             int border, int flags)
 {
     if (!p || !kernel) WT_FAIL("wt_filter2d: null pointer");
     if (kh < 1 || kw < 1 || kh * kw > 4096) WT_FAIL("wt_filter2d: kernel %d x %d unsupported (<= 4096 taps)", kh, kw);
+    if (ay < 0 || ay >= kh || ax < 0 || ax >= kw) WT_FAIL("wt_filter2d: anchor (%d, %d) outside the %d x %d kernel", ay, ax, kh, kw);
     if (src == dst) WT_FAIL("wt_filter2d: src and dst must differ");
-    if (p->g.border) WT_FAIL("wt_filter2d implements the symmetric border only");
+    if (border != WT_BORDER_SYMMETRIC && border != WT_BORDER_PERIODIC) WT_FAIL("wt_filter2d: border %d unsupported (symmetric or periodic)", border);
+    if (p->g.border) WT_FAIL("wt_filter2d ignores the plan's border mode; reset it to symmetric first");
+    const bool wrap = border == WT_BORDER_PERIODIC;
+    if (wrap && (p->nranks > 1 || p->g.row0 != 0 || p->g.nrows != p->g.H))
+        WT_FAIL("wt_filter2d: the periodic border needs a whole-image plan");
     const size_t lds = (size_t)(WT_F2D_TW + kw - 1) * (WT_F2D_TH + kh - 1) * sizeof(float);
     if (lds > 160 * 1024) WT_FAIL("wt_filter2d: kernel %d x %d needs %zu B of LDS", kh, kw, lds);
-    if (p->nranks > 1 && kh / 2 > p->g.halo) WT_FAIL("wt_filter2d: kernel needs %d halo rows, plan has %d", kh / 2, p->g.halo);
+    const int reach = std::max(ay, kh - 1 - ay);
+    if (p->nranks > 1 && reach > p->g.halo) WT_FAIL("wt_filter2d: kernel needs %d halo rows, plan has %d", reach, p->g.halo);
     wt_ctx *c = p->ctx;
     float *in = nullptr, *o = nullptr;
     WT_TRY(plane_base(p, src, &in));
     WT_TRY(plane_base(p, dst, &o));
-    WT_TRY(maybe_exchange(p, src, kh / 2, flags));
+    WT_TRY(maybe_exchange(p, src, reach, flags));
     // the taps travel through pinned memory so the copy is ordered on the stream
     WT_HIP(hipStreamSynchronize(c->stream));
     memcpy(c->h_pinned, kernel, (size_t)kh * kw * sizeof(float));
@@ -1203,10 +1210,20 @@ extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, in
     dim3 grid((p->g.W + WT_F2D_TW - 1) / WT_F2D_TW, (p->g.nrows + WT_F2D_TH - 1) / WT_F2D_TH), block(64, 4);
     if (grid.y > 65535u) WT_FAIL("wt_filter2d: strip too tall");
     ProfScope ps(c, "wt_filter2d_kernel");
-    if (lds > 64 * 1024) WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(wt_filter2d_kernel, grid, block, lds, c->stream, in, o, p->g, c->d_psf, kh, kw);
+    if (wrap) {
+        if (lds > 64 * 1024) WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(wt_filter2d_kernel<true>, grid, block, lds, c->stream, in, o, p->g, c->d_psf, kh, kw, ay, ax);
+    } else {
+        if (lds > 64 * 1024) WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(wt_filter2d_kernel<false>, grid, block, lds, c->stream, in, o, p->g, c->d_psf, kh, kw, ay, ax);
+    }
     WT_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int flags)
+{
+    return wt_filter2d_ex(p, src, dst, kernel, kh, kw, kh / 2, kw / 2, WT_BORDER_SYMMETRIC, flags);
 }
 
 extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst)

@@ -827,18 +827,31 @@ __global__ __launch_bounds__(256) void wt_anscombe_kernel(const float *src, floa
 // 64 x 16 output tile + halo staged in LDS; the PSF taps are wave-uniform scalar loads.
 #define WT_F2D_TW 64
 #define WT_F2D_TH 16
+// WRAP: periodic border (the circular convolution of the reference's rFFT path,
+// watroo/utils.py:245-254,284), whole-image plans only; (ay, ax) = anchor of the correlation.
+__device__ __forceinline__ int wt_wrap(int i, int n)
+{
+    const int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+template <bool WRAP>
 __global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float *out, Geo g,
-                                                          const float *psf, int kh, int kw)
+                                                          const float *psf, int kh, int kw, int ay, int ax)
 {
     extern __shared__ float tile[];
-    const int ax = kw / 2, ay = kh / 2;
     const int tw = WT_F2D_TW + kw - 1, th = WT_F2D_TH + kh - 1;
     const int x0 = blockIdx.x * WT_F2D_TW, ly0 = blockIdx.y * WT_F2D_TH;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     for (int i = tid; i < tw * th; i += 256) {
         const int ty = i / tw, tx = i - ty * tw;
-        const float *row = wt_row(in, g, g.row0 + ly0 + ty - ay);
-        tile[i] = row[wt_refl(x0 + tx - ax, g.W)];
+        if (WRAP) {
+            const float *row = in + (int64_t)wt_wrap(ly0 + ty - ay, g.H) * g.P;
+            tile[i] = row[wt_wrap(x0 + tx - ax, g.W)];
+        } else {
+            const float *row = wt_row(in, g, g.row0 + ly0 + ty - ay);
+            tile[i] = row[wt_refl(x0 + tx - ax, g.W)];
+        }
     }
     __syncthreads();
     const int x = x0 + threadIdx.x;

@@ -244,11 +244,9 @@ def richardson_lucy(data, psf,
     iterations: per iteration one PSF correlation (ref:257), the residual's a-trous transform
     (ref:261), the multiresolution-support update per scale (ref:263-276), the plane sum
     (ref:278) and the second PSF correlation (ref:286) - nothing returns to the host until
-    the final estimate.  ``fft=True`` (circular rFFT convolution, ref:245-254,284) is not
-    implemented on the GPU."""
-    if fft:
-        raise NotImplementedError("richardson_lucy(fft=True) is not implemented in the HIP "
-                                  "engine; use the direct PSF correlation (fft=False)")
+    the final estimate.  ``fft=True`` selects the reference's circular (periodic-border)
+    products (ref:245-254, 284); they are evaluated as direct periodic correlations of the PSF
+    (equal to the rFFT products up to rounding) so the loop stays on the device."""
     img = _to_f32_image(data, "data")
     psf = np.ascontiguousarray(psf, dtype=np.float32)
     if psf.ndim != 2:
@@ -274,8 +272,14 @@ def richardson_lucy(data, psf,
     for m in MRS:                                                        # ref:240-243
         plan.fill(m, 1.0 if soft else 0.0)
     psf_flipped = np.ascontiguousarray(psf[::-1, ::-1])
+    kh, kw = psf.shape
+    # fft=True: psi (*) psf circular with the PSF centre psf.shape // 2 at the origin (ref:246-250)
+    # = periodic correlation with the flipped PSF anchored at k - 1 - k // 2; the second product
+    # with conj(fft_psf) (ref:284) = periodic correlation with the PSF anchored at k // 2
+    fwd = dict(anchor=(kh - 1 - kh // 2, kw - 1 - kw // 2), periodic=True) if fft else {}
+    bwd = dict(anchor=(kh // 2, kw // 2), periodic=True) if fft else {}
     for iteration in range(iterations):                                  # ref:252
-        plan.filter2d(PSI, PHI, psf_flipped)                             # ref:257
+        plan.filter2d(PSI, PHI, psf_flipped, **fwd)                      # ref:255-257
         plan.binary("sub", DATA, PHI, RES)                               # ref:259
         plan.decompose(RES, level)                                       # ref:261
         res_coefficients = Coefficients.__new__(Coefficients)            # same plan, no release
@@ -291,6 +295,6 @@ def richardson_lucy(data, psf,
         res_coefficients._plan = None                                    # keep the plan out of the pool
         plan.plane_sum(0, level + 1, RES)                                # ref:278
         plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
-        plan.filter2d(RES, CONV, psf)                                    # ref:286
+        plan.filter2d(RES, CONV, psf, **bwd)                             # ref:284-286
         plan.binary("mul", PSI, CONV, PSI)                               # ref:288
     return plan.download(PSI)
