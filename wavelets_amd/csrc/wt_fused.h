@@ -104,12 +104,27 @@ typedef float wt_v4f __attribute__((ext_vector_type(4)));
 // write gets an out-of-range offset; the hardware range check drops those stores.  Control
 // flow stays uniform, so the compiler's vmcnt bookkeeping is exact (loads stay in flight
 // across the stores and barriers of several steps).
+// AUX = cache-policy bits of the store (gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+template <int AUX>
 __device__ __forceinline__ void wt_bstore4(uint64_t row_addr, bool row_ok, int row_bytes, unsigned voff, float4 v)
 {
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)row_addr, 0, row_ok ? row_bytes : 0, 0x00020000);
     wt_v4f t = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
 }
+
+// The detail planes are write-once streams that nothing re-reads before the pass is over:
+// nontemporal stores.  The smooth plane is the NEXT pass's input and keeps the default policy
+// (up to 4096^2 it is still in the Infinity Cache when the next pass starts: 0.125 -> 0.097 ms
+// for the D = 8 pass).  Measured on several MI355X hosts at 8192^2: +-1.5 % on most, but 25 %
+// faster on a host where plain stores ran the passes at 0.46 ms instead of 0.33 ms, i.e. the
+// streaming stores also remove most of the host-to-host spread.
+#ifndef WT_FUSED_W_AUX
+#define WT_FUSED_W_AUX 2
+#endif
+#ifndef WT_FUSED_C_AUX
+#define WT_FUSED_C_AUX 0
+#endif
 
 // Vertical half of one scale of one step: push `cur` (a row of c_{s0+A}) into the window and
 // return the vertically filtered row (centred hw*2^A steps back); `cen` = matching row of
@@ -188,7 +203,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
     auto load_row = [&](int t) -> float4 {
         // steps past t_last only flush the pipeline / unroll padding: keep the address in range
         const float *row = wt_row(a.in, g, gy0 + D * ((a.debug & 2) ? r0 : min(t, t_last)));
+#ifdef WT_FUSED_NT_LOAD
+        float4 v = wt_ldnt4(row + xc);
+#else
         float4 v = *reinterpret_cast<const float4 *>(row + xc);
+#endif
         if (wave_has_edge) {
             if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
         }
@@ -202,9 +221,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
     auto row_addr0 = [&](float *base, int ro) -> uint64_t {
         return (uint64_t)base + (uint64_t)((int64_t)(q + (int64_t)D * ro) * (int64_t)row_bytes);
     };
-    auto store_at = [&](uint64_t addr, int ro, float4 v) {
+    auto store_at = [&](uint64_t addr, int ro, float4 v) {          // detail planes
         const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
-        wt_bstore4(addr, ok, row_bytes, voff, v);
+        wt_bstore4<WT_FUSED_W_AUX>(addr, ok, row_bytes, voff, v);
+    };
+    auto store_c = [&](uint64_t addr, int ro, float4 v) {           // smooth plane
+        const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
+        wt_bstore4<WT_FUSED_C_AUX>(addr, ok, row_bytes, voff, v);
     };
 
     constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0;
@@ -271,15 +294,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
             __syncthreads();
             const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
             store_at(aw0, t - LAG0, f4_sub(cen0, n0));
-            if constexpr (NS == 1) store_at(ac, t - LAGC, n0);
+            if constexpr (NS == 1) store_c(ac, t - LAGC, n0);
             if constexpr (NS > 1) {
                 const float4 n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
                 store_at(aw1, t - LAG1, f4_sub(cen1, n1));
-                if constexpr (NS == 2) store_at(ac, t - LAGC, n1);
+                if constexpr (NS == 2) store_c(ac, t - LAGC, n1);
                 if constexpr (NS > 2) {
                     const float4 n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
                     store_at(aw2, t - LAG2, f4_sub(cen2, n2));
-                    store_at(ac, t - LAGC, n2);
+                    store_c(ac, t - LAGC, n2);
                 }
                 c2 = n1;
             }

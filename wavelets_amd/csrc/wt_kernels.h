@@ -646,6 +646,18 @@ __device__ __forceinline__ float4 wt_ldnt4(const float *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+__device__ __forceinline__ void wt_stnt4(float *p, float4 v)
+{
+    wt_nt4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<wt_nt4 *>(p));
+}
+// The reconstruction is a write-once stream too; with default stores its dirty lines are still
+// being written back when the next transform's first pass starts (8192^2: that pass 0.36 ->
+// 0.32 ms in a frame loop).
+#ifndef WT_SUM_NT_STORE
+#define WT_SUM_NT_STORE 1
+#endif
+
 // K5  np.sum(planes, axis=0): sequential fp32 accumulation in plane order (bit-exact vs numpy).
 // One float4 per thread (no grid-stride loop): a large grid of short-lived waves keeps the most
 // loads in flight for this 7-reads-1-write stream.
@@ -659,7 +671,8 @@ __global__ __launch_bounds__(256) void wt_plane_sum_kernel(SumArgs a, float *out
             const float4 v = wt_ldnt4(a.p[k] + 4 * i);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        reinterpret_cast<float4 *>(out)[i] = acc;
+        if (WT_SUM_NT_STORE) wt_stnt4(out + 4 * i, acc);
+        else reinterpret_cast<float4 *>(out)[i] = acc;
     }
 }
 
@@ -696,13 +709,12 @@ __global__ __launch_bounds__(256) void wt_denoise_sum_kernel(DenoiseSumArgs a, c
                     const float sgn = tau > 0.0 ? wt_sig(c[j], tauf * nn[j], tau * (double)nn[j], a.soft) : 1.f;
                     c[j] = c[j] * (a.wgt[k] * sgn);
                 }
-                if (a.write_back)
-                    reinterpret_cast<float4 *>(a.p[k])[i] = make_float4(c[0], c[1], c[2], c[3]);
+                if (a.write_back) wt_stnt4(a.p[k] + 4 * i, make_float4(c[0], c[1], c[2], c[3]));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = k == 0 ? c[j] : acc[j] + c[j];
         }
-        reinterpret_cast<float4 *>(out)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        wt_stnt4(out + 4 * i, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
