@@ -32,14 +32,28 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 629
 
 
 def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
-    """Compulsory HBM bytes per pixel of one launch of `kernel`."""
+    """Compulsory HBM bytes per pixel attributed to one launch of `kernel`.
+
+    SURVEY 8(d): decompose = 4*(L+2) (read the input, write L+1 planes), sum = 4*(L+2) (read
+    L+1 planes, write one); 64 B/pixel for L = 6.  A fused pass over NS scales is charged its
+    share: 4*NS for the detail planes it writes, +4 for the input (first pass) or the smooth
+    plane (last pass); the accumulate variants additionally the sum's share of the planes they
+    fold in: 4*NS, +8 in the last pass (smooth plane read, reconstruction written).  The
+    intermediate smooth plane between two passes is NOT algorithmic (it is the price of the
+    two-pass structure).  Shares add up to 32 (decompose) and 64 (decompose + sum) for L = 6."""
     if kernel.startswith("wt_plane_sum"):
         return 4.0 * (level + 2)                 # read level+1 planes, write one
     if kernel.startswith("wt_chain_kernel<decomp>"):
-        return 12.0                              # read c_s, write w_s and c_{s+1}
+        return 8.0                               # write w_s; read c_0 / write c_L once overall
     if kernel.startswith("wt_fused"):
-        ns = int(kernel.rstrip(">").split("x")[-1]) if "x" in kernel else 3
-        return 4.0 * (ns + 2)                    # read c_s0, write ns detail planes + c_{s0+ns}
+        tag = kernel[kernel.index("<") + 1:-1]                    # e.g. d8x3
+        d, ns = int(tag[1:tag.index("x")]), int(tag.split("x")[1])
+        first = d == 1
+        last = {1: 0, 8: 3, 64: 6}[d] + ns == level
+        b = 4.0 * ns + (4.0 if first else 0.0) + (4.0 if last else 0.0)
+        if kernel.startswith("wt_fused_acc") or kernel.startswith("wt_fused_sum"):
+            b += 4.0 * ns + (8.0 if last else 0.0)
+        return b
     return None
 
 
@@ -90,6 +104,9 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override image side (testing)")
     ap.add_argument("--rows", type=int, default=0, help="override image height (strip-shaped tests)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per scale")
+    ap.add_argument("--two-call", action="store_true",
+                    help="decompose and plane sum as two calls (the sum re-reads the planes) "
+                         "instead of wt_decompose_sum")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--brief", action="store_true", help="one short line (tuning sweeps)")
     ap.add_argument("--force-dist", action="store_true",
@@ -149,9 +166,14 @@ def main():
     plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
     flags = 0 if args.unfused else _lib.FLAG_FUSED
 
+    two_call = args.two_call or args.unfused
+
     def step():
-        plan.decompose(PLANE_INPUT, LEVEL, flags)
-        plan.plane_sum(0, LEVEL + 1, PLANE_OUT)
+        if two_call:
+            plan.decompose(PLANE_INPUT, LEVEL, flags)
+            plan.plane_sum(0, LEVEL + 1, PLANE_OUT)
+        else:       # same outputs (7 planes + reconstruction, bit-identical), sum carried along
+            plan.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, flags)
 
     def fence():
         ctx.sync()
@@ -240,7 +262,7 @@ def main():
                                    + ("" if world == 1 else f"; {world} row strips, RCCL halo "
                                       "exchange per pass"),
                        "image": [H, W], "levels": LEVEL, "family": FAMILY,
-                       "fused": not args.unfused,
+                       "fused": not args.unfused, "sum_in_passes": not two_call,
                        "schedule": _lib.schedule(fam, LEVEL, not args.unfused),
                        "parallelism": f"strips{world}"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),

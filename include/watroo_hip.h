@@ -143,6 +143,17 @@ int wt_decompose(wt_plan *plan, int src, int level, int flags);
 /* one pass of the schedule (wt_schedule): scales [s0,s0+ns) from plane `cur` (c_{s0}) into
  * detail planes s0..s0+ns-1 and plane `nxt` (c_{s0+ns}); exchanges the pass halo first. */
 int wt_decompose_pass(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags);
+/* wt_decompose followed by wt_plane_sum(0, level+1, dst) - the transform and its synthesis
+ * np.sum(coefficients, axis=0) (watroo/wavelets.py:408-444 then watroo/utils.py:98,205) - in the
+ * SAME passes: all level+1 planes are written as usual and the plane-order sum rides along
+ * (each pass reads the running sum and writes it back), so the planes are not re-read:
+ * 4*(L+2) + 8*passes - 4 B/pixel of traffic instead of 8*(L+2).  Bit-identical to the two-call
+ * form.  Schedules that contain single-scale passes run as the two calls. */
+int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
+/* one pass of that (fused passes only): `first` = the sum starts with this pass's first detail
+ * plane, `last` = the smooth plane `nxt` is added and the sum is complete. */
+int wt_decompose_pass_sum(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags,
+                          int sum_plane, int first, int last);
 /* one scale of the above on explicit planes (per-scale operator; virtual-strip tests):
  * dst_c <- h_s (*) src ; dst_w <- src - dst_c (dst_w may be WT_PLANE_NONE). */
 int wt_atrous_scale(wt_plan *plan, int src, int dst_c, int dst_w, int s, int flags);

@@ -753,3 +753,35 @@ def test_host_pool_recycles_pinned_result_blocks(W):
     gc.collect()
     r2 = W.denoise(img, [5, 3])
     assert r2.ctypes.data == p1 and np.array_equal(r2, keep)
+
+
+@pytest.mark.parametrize("fam", FAMS)
+def test_decompose_sum_is_bitwise_the_two_call_form(fam):
+    """wt_decompose_sum (sum carried through the fused passes) == wt_decompose + wt_plane_sum,
+    planes and reconstruction, for every level (levels 4 and 7 take the two-call fallback)."""
+    from wavelets_amd import _lib as L
+    ctx = L.default_context()
+    f = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam]
+    for (H, Wd) in ((37, 53), (300, 1000), (1, 700), (513, 129), (1100, 2100)):
+        for level in range(0, 9):
+            a = rnd((H, Wd), 100 + level)
+            p = L.Plan(ctx, H, Wd, f, level)
+            p.upload(L.PLANE_INPUT, a)
+            p.decompose(L.PLANE_INPUT, level, L.FLAG_FUSED)
+            ref = [p.download(s) for s in range(level + 1)]
+            p.plane_sum(0, level + 1, L.PLANE_OUT)
+            rsum = p.download(L.PLANE_OUT)
+            for s in range(level + 1):
+                p.fill(s, np.nan)
+            p.fill(L.PLANE_OUT, np.nan)
+            p.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, L.FLAG_FUSED)
+            for s in range(level + 1):
+                np.testing.assert_array_equal(p.download(s), ref[s], err_msg=f"{H}x{Wd} L={level} plane {s}")
+            np.testing.assert_array_equal(p.download(L.PLANE_OUT), rsum, err_msg=f"{H}x{Wd} L={level} sum")
+            p.close()
+    p = L.Plan(ctx, 64, 64, f, 3)
+    with pytest.raises(L.WatrooHipError, match="output planes"):
+        p.decompose_sum(L.PLANE_INPUT, 3, 2)
+    with pytest.raises(L.WatrooHipError, match="differ"):
+        p.decompose_sum(L.PLANE_INPUT, 3, L.PLANE_INPUT)
+    p.close()

@@ -82,6 +82,37 @@ def test_sharded_decompose_equals_unsharded_bitwise(L, fam_name, level, fused, k
     np.testing.assert_array_equal(gather(plans, L.PLANE_OUT), whole.download(L.PLANE_OUT))
 
 
+@pytest.mark.parametrize("fam_name,level,k,shape", [
+    ("b3spline", 6, 3, (768, 1100)),
+    ("triangle", 8, 2, (1024, 160)),
+    ("b3spline", 3, 4, (130, 70)),
+    ("triangle", 5, 2, (300, 257)),
+])
+def test_sharded_decompose_sum_equals_unsharded_bitwise(L, fam_name, level, k, shape):
+    """the sum carried through the fused passes (wt_decompose_sum) on strips: planes AND the
+    reconstruction equal the unsharded two-call result bit for bit"""
+    fam = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam_name]
+    ctx = L.default_context()
+    img = rnd(shape, 13)
+    whole = L.Plan(ctx, shape[0], shape[1], fam, level)
+    whole.upload(L.PLANE_INPUT, img)
+    whole.decompose(L.PLANE_INPUT, level, L.FLAG_FUSED)
+    whole.plane_sum(0, level + 1)
+    plans = make_strips(L, ctx, img, fam, level, k)
+    cur = L.PLANE_INPUT
+    sched = L.schedule(fam, level, True)
+    for i, (s0, ns, halo) in enumerate(sched):
+        nxt = level if s0 + ns == level else L.PLANE_SCRATCH(i & 1)
+        exchange_all(L, plans, cur, halo)
+        for p in plans:
+            p.decompose_pass_sum(cur, nxt, s0, ns, L.FLAG_FUSED | L.FLAG_NO_EXCHANGE, L.PLANE_OUT,
+                                 first=i == 0, last=i == len(sched) - 1)
+        cur = nxt
+    for s in range(level + 1):
+        np.testing.assert_array_equal(gather(plans, s), whole.download(s), err_msg=f"plane {s}")
+    np.testing.assert_array_equal(gather(plans, L.PLANE_OUT), whole.download(L.PLANE_OUT))
+
+
 def test_sharded_operators_equal_unsharded(L):
     """smooth / smooth of squares / local variance / bilateral conv on strips with halos"""
     fam = L.B3SPLINE

@@ -74,6 +74,8 @@ SIGNATURES = {
     "wt_halo_exchange": (_c.c_int, [_vp, _c.c_int, _i64]),
     "wt_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose_pass": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_decompose_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_decompose_pass_sum": (_c.c_int, [_vp] + [_c.c_int] * 8),
     "wt_atrous_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float,
@@ -415,6 +417,14 @@ class Plan:
     # ---- hot path
     def decompose(self, src, level, flags=FLAG_FUSED):
         check(load().wt_decompose(self._h, src, level, flags))
+
+    def decompose_sum(self, src, level, dst=PLANE_OUT, flags=FLAG_FUSED):
+        """decompose + plane sum in the same passes (bit-identical to the two calls)."""
+        check(load().wt_decompose_sum(self._h, src, level, dst, flags))
+
+    def decompose_pass_sum(self, cur, nxt, s0, ns, flags, sum_plane, first, last):
+        check(load().wt_decompose_pass_sum(self._h, cur, nxt, s0, ns, flags, sum_plane,
+                                           int(first), int(last)))
 
     def decompose_pass(self, cur, nxt, s0, ns, flags=FLAG_FUSED):
         check(load().wt_decompose_pass(self._h, cur, nxt, s0, ns, flags))

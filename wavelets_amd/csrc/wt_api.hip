@@ -867,7 +867,10 @@ extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, i
 // =============================================================================================
 // One pass of the schedule: scales [s0, s0+ns) from plane `cur` (= c_{s0}) into the detail
 // planes s0..s0+ns-1 and plane `nxt` (= c_{s0+ns}).
-extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, int flags)
+// acc / p_sum: 0 = plain pass; 1 / 2 = the pass also carries the plane sum in plane `p_sum`
+// (2 = last pass of the schedule: the smooth plane is added too) - fused passes only.
+static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int flags, int acc, bool first_of_sum,
+                               int p_sum)
 {
     if (!p) WT_FAIL("wt_decompose_pass: null plan");
     if (ns < 1 || ns > WT_FUSED_MAX_SCALES || s0 < 0 || s0 + ns - 1 > p->max_level)
@@ -888,10 +891,61 @@ extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, i
         return launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>");
     }
     if (p->g.border) WT_FAIL("wt_decompose_pass: fused passes implement the symmetric border only (use flags without bit0)");
-    if (!(s0 == 0 || s0 == 3 || (s0 == 6 && ns == 2)) || ns < 2) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
+    if (!wt_fused_has_pass(s0, ns)) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
     float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
     for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
-    return wt_fused_launch(p, in, oc, ow, s0, ns);
+    float *ps = nullptr;
+    if (acc) WT_TRY(plane_base(p, p_sum, &ps));
+    return wt_fused_launch(p, in, oc, ow, s0, ns, acc, first_of_sum ? nullptr : ps, ps);
+}
+
+extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, int flags)
+{
+    return decompose_pass_impl(p, cur, nxt, s0, ns, flags, 0, false, WT_PLANE_NONE);
+}
+
+extern "C" int wt_decompose_pass_sum(wt_plan *p, int cur, int nxt, int s0, int ns, int flags, int sum_plane, int first,
+                                     int last)
+{
+    if (!p) WT_FAIL("wt_decompose_pass_sum: null plan");
+    if (!wt_fused_has_pass(s0, ns)) WT_FAIL("wt_decompose_pass_sum: no fused kernel for first scale %d x %d scales", s0, ns);
+    if (sum_plane == cur || sum_plane == nxt || (sum_plane >= s0 && sum_plane < s0 + ns))
+        WT_FAIL("wt_decompose_pass_sum: the sum plane aliases a plane of the pass");
+    return decompose_pass_impl(p, cur, nxt, s0, ns, flags, last ? 2 : 1, first != 0, sum_plane);
+}
+
+// Decomposition and np.sum(planes, axis=0) in the same passes: every plane is still written,
+// but the sum is carried along (8*(L+2) -> 4*(L+2) + 8*(passes) B/pixel instead of re-reading
+// the L+1 planes).  Bit-identical to wt_decompose followed by wt_plane_sum (same plane order).
+extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int flags)
+{
+    if (!p) WT_FAIL("wt_decompose_sum: null plan");
+    if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose_sum: level %d exceeds plan max_level %d", level, p->max_level);
+    if (src >= 0 && src <= level) WT_FAIL("wt_decompose_sum: src plane %d is one of the output planes", src);
+    if (dst >= 0 && dst <= level) WT_FAIL("wt_decompose_sum: dst plane %d is one of the output planes", dst);
+    if (dst == src) WT_FAIL("wt_decompose_sum: dst and src must differ");
+    if (src == WT_PLANE_SCRATCH(0) || src == WT_PLANE_SCRATCH(1) || dst == WT_PLANE_SCRATCH(0) || dst == WT_PLANE_SCRATCH(1))
+        WT_FAIL("wt_decompose_sum: scratch planes 0/1 are used internally");
+    int32_t tr[3 * 32];
+    int np = 0;
+    bool fusable = (flags & 1) && level > 0 && !p->g.border && wt_fused_supported(p);
+    if (fusable) {
+        WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
+        for (int i = 0; i < np; ++i) fusable = fusable && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1]);
+    }
+    if (!fusable) {      // a schedule with single-scale passes: the two-step form
+        WT_TRY(wt_decompose(p, src, level, flags));
+        return wt_plane_sum(p, 0, level + 1, dst);
+    }
+    int cur = src;
+    for (int i = 0; i < np; ++i) {
+        const int s0 = tr[3 * i], ns = tr[3 * i + 1];
+        const bool last = s0 + ns == level;
+        const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+        WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags, last ? 2 : 1, i == 0, dst));
+        cur = nxt;
+    }
+    return 0;
 }
 
 extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)

@@ -47,6 +47,11 @@ struct FusedArgs {
     int Vx;       // valid (stored) pixels per x-strip, multiple of 32
     int S;        // chain steps stored per chunk
     int chunks;   // chunks per chain
+    // accumulate variants (ACC != 0): the plane sum np.sum(planes, axis=0) carried through the
+    // passes in plane order - p_in = w_0 + ... + w_{s0-1} (nullptr for the first pass),
+    // p_out = p_in + w_{s0} + ... + w_{s0+NS-1} (+ c_{s0+NS} in the last pass); may alias p_in
+    const float *p_in;
+    float *p_out;
     int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
@@ -151,7 +156,7 @@ __device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk,
 // a-1 produced in step j-1, so the NS vertical filters, the NS LDS row writes, ONE barrier and
 // the NS horizontal filters of a step are mutually independent (one s_barrier per row instead
 // of NS, 4*NS LDS reads in flight together).  LDS rows are double-buffered by step parity.
-template <int K, int NS, int D, int NW, int PDREQ>
+template <int K, int NS, int D, int NW, int PDREQ, int ACC>
 #ifndef WT_FUSED_WPS4
 #define WT_FUSED_WPS4 2   // waves per SIMD requested for the 4-wave workgroup variant
 #endif
@@ -170,6 +175,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
     static_assert(U % PD == 0 && U % 2 == 0, "prefetch depth / LDS parity must divide the unroll period");
 
     __shared__ float4 vbuf[2][NS][NL];
+    // output row of scale a at step t: t - a - hw*(2^(a+1)-1)
+    constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw;
+    constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : LAG2);
+    // ACC: the running sum of a row waits in per-lane LDS rings until the next scale's detail
+    // row of the SAME image row comes out of the cascade (G1, then G2 steps later); only lanes
+    // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
+    constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0;
+    constexpr int NV = NL - HX / 2;
+    __shared__ float4 ring[ACC ? (G1 + G2) * NV + 1 : 1];
 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
@@ -250,13 +264,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
     float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
-    // output row of scale a at step t: t - a - hw*(2^(a+1)-1)
-    constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw;
-    constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : LAG2);
     uint64_t aw0 = row_addr0(a.out_w[0], t0 - LAG0);
     uint64_t aw1 = NS > 1 ? row_addr0(a.out_w[A1], t0 - LAG1) : 0;
     uint64_t aw2 = NS > 2 ? row_addr0(a.out_w[A2], t0 - LAG2) : 0;
     uint64_t ac = row_addr0(a.out_c, t0 - LAGC);
+    // ---- ACC state
+    const bool has_pin = ACC && a.p_in != nullptr;
+    uint64_t ap = ACC ? row_addr0(a.p_out, t0 - LAGC) : 0;
+    auto load_acc = [&](int t) -> float4 {               // p_in row of chain element t - LAG0
+        const int ro = min(max(t - LAG0, r0), r1 - 1);
+        return *reinterpret_cast<const float4 *>(a.p_in + (int64_t)(q + (int64_t)D * ro) * g.P + xc);
+    };
+    float4 pa[ACC ? PD : 1];
+    if (has_pin) {
+#pragma unroll
+        for (int i = 0; i < PD; ++i) pa[i] = load_acc(t0 + i);
+    }
+    const int li = lane_store ? (x - X0) >> 2 : 0;       // slot in the ring rows
+    int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
+    auto store_p = [&](uint64_t addr, int ro, float4 v) {
+        const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
+        // the finished reconstruction is a write-once stream; an intermediate sum is re-read
+        // by the next pass
+        wt_bstore4<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(addr, ok, row_bytes, voff, v);
+    };
 
     for (int kb = 0; kb < nsteps; kb += U) {
 #pragma unroll
@@ -280,6 +311,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
                 aw0 += step_bytes; aw1 += step_bytes; aw2 += step_bytes; ac += step_bytes;
                 continue;
             }
+            float4 pin_cur = zero;
+            if (has_pin) {
+                pin_cur = pa[kk % PD];
+                pa[kk % PD] = load_acc(t + PD);
+            }
             float4 cen0, cen1, cen2, v0, v1, v2;
             v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
             buf[0][gl] = v0;
@@ -293,18 +329,47 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
             }
             __syncthreads();
             const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
-            store_at(aw0, t - LAG0, f4_sub(cen0, n0));
+            const float4 d0 = f4_sub(cen0, n0);
+            store_at(aw0, t - LAG0, d0);
             if constexpr (NS == 1) store_c(ac, t - LAGC, n0);
+            float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
             if constexpr (NS > 1) {
-                const float4 n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
-                store_at(aw1, t - LAG1, f4_sub(cen1, n1));
+                n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
+                d1 = f4_sub(cen1, n1);
+                store_at(aw1, t - LAG1, d1);
                 if constexpr (NS == 2) store_c(ac, t - LAGC, n1);
                 if constexpr (NS > 2) {
-                    const float4 n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
-                    store_at(aw2, t - LAG2, f4_sub(cen2, n2));
+                    n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
+                    d2 = f4_sub(cen2, n2);
+                    store_at(aw2, t - LAG2, d2);
                     store_c(ac, t - LAGC, n2);
                 }
                 c2 = n1;
+            }
+            if constexpr (ACC != 0) {
+                // plane-order sum of image row rho: ((p_in + w_s0) + w_s0+1) + w_s0+2 (+ c): the
+                // partial sum of a row is parked in the ring until the next scale's detail row
+                // of the same image row appears (G1, then G2 steps later)
+                float4 s = has_pin ? f4_add(pin_cur, d0) : d0;          // row t - LAG0
+                if constexpr (NS > 1) {
+                    if (lane_store) {
+                        float4 *r1 = ring + (i1 * NV + li);
+                        const float4 old = *r1;
+                        *r1 = s;
+                        s = f4_add(old, d1);                              // row t - LAG1
+                        if constexpr (NS > 2) {
+                            float4 *r2 = ring + ((G1 + i2) * NV + li);
+                            const float4 old2 = *r2;
+                            *r2 = s;
+                            s = f4_add(old2, d2);                         // row t - LAG2
+                        }
+                    }
+                    i1 = (i1 + 1 == G1) ? 0 : i1 + 1;
+                    if constexpr (NS > 2) i2 = (i2 + 1 == G2) ? 0 : i2 + 1;
+                }
+                if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
+                store_p(ap, t - LAGC, s);
+                ap += step_bytes;
             }
             c1 = n0;
             aw0 += step_bytes;
@@ -320,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
 // ---------------------------------------------------------------------------------------------
 static inline bool wt_fused_supported(const wt_plan *) { return true; }
 
-template <int K, int NS, int D, int NW, int PD>
+template <int K, int NS, int D, int NW, int PD, int ACC>
 static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name)
 {
     constexpr int hw = K / 2;
@@ -365,44 +430,49 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     if (gy > 65535) WT_FAIL("fused pass: grid too large");
     dim3 grid(nx, (unsigned)gy), block(NL);
     ProfScope ps(p->ctx, name);
-    hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD>), grid, block, 0, p->ctx->stream, a);
+    hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }
 
-// Tuned on MI355X (8192^2, B3): the D = 1 pass prefers 4-wave workgroups (2 resident per CU)
-// the D = 8 pass prefers 8-wave workgroups (x halo 224 of 2048 px
-// instead of 224 of 1024).  WT_FUSED_NW / WT_FUSED_PD override both (tuning sweeps).
-template <int K>
-static int wt_fused_dispatch(wt_plan *p, const FusedArgs &a, int s0, int ns)
+// Tuned on MI355X (8192^2, B3): the D = 1 pass prefers 4-wave workgroups (2 resident per CU),
+// the D = 8 and D = 64 passes 8-wave workgroups (x halo 256 of 2048 px instead of 256 of 1024);
+// 4 rows of prefetch.  acc: 0 = plain pass, 1 = also carry the plane sum (p_in -> p_out),
+// 2 = last pass of a sum (adds the smooth plane, streaming store).
+template <int K, int ACC>
+static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns)
 {
-    static const int nw_env = getenv("WT_FUSED_NW") ? atoi(getenv("WT_FUSED_NW")) : 0;
-    static const int pd_env = getenv("WT_FUSED_PD") ? atoi(getenv("WT_FUSED_PD")) : 0;
-    const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : (s0 == 0 ? 4 : 8);
-    const int pd = pd_env ? pd_env : 4;
-#define WT_FUSED_CASE(S0, NS_, D_, NAME)                                                          \
-    if (s0 == S0 && ns == NS_) {                                                                  \
-        if (nw == 8) return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 8, 8>(p, a, NAME)             \
-                                    : wt_fused_launch_t<K, NS_, D_, 8, 4>(p, a, NAME);            \
-        return pd == 8 ? wt_fused_launch_t<K, NS_, D_, 4, 8>(p, a, NAME)                          \
-                       : wt_fused_launch_t<K, NS_, D_, 4, 4>(p, a, NAME);                         \
-    }
-    WT_FUSED_CASE(0, 3, 1, "wt_fused<d1x3>")
-    WT_FUSED_CASE(0, 2, 1, "wt_fused<d1x2>")
-    WT_FUSED_CASE(3, 3, 8, "wt_fused<d8x3>")
-    WT_FUSED_CASE(3, 2, 8, "wt_fused<d8x2>")
-#undef WT_FUSED_CASE
-    // D = 64 (scales 6-7): taps are 16 / 32 lanes apart; 8-wave workgroups only
-    if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4>(p, a, "wt_fused<d64x2>");
+    static const char *names[3][5] = {
+        {"wt_fused<d1x3>", "wt_fused<d1x2>", "wt_fused<d8x3>", "wt_fused<d8x2>", "wt_fused<d64x2>"},
+        {"wt_fused_acc<d1x3>", "wt_fused_acc<d1x2>", "wt_fused_acc<d8x3>", "wt_fused_acc<d8x2>", "wt_fused_acc<d64x2>"},
+        {"wt_fused_sum<d1x3>", "wt_fused_sum<d1x2>", "wt_fused_sum<d8x3>", "wt_fused_sum<d8x2>", "wt_fused_sum<d64x2>"}};
+    if (s0 == 0 && ns == 3) return wt_fused_launch_t<K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0]);
+    if (s0 == 0 && ns == 2) return wt_fused_launch_t<K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1]);
+    if (s0 == 3 && ns == 3) return wt_fused_launch_t<K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2]);
+    if (s0 == 3 && ns == 2) return wt_fused_launch_t<K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3]);
+    // D = 64 (scales 6-7): taps are 16 / 32 lanes apart
+    if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4]);
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
-static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns)
+static inline bool wt_fused_has_pass(int s0, int ns)
+{
+    return (s0 == 0 && (ns == 2 || ns == 3)) || (s0 == 3 && (ns == 2 || ns == 3)) || (s0 == 6 && ns == 2);
+}
+
+// acc: see wt_fused_dispatch_acc; p_in / p_out only for acc != 0
+static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns,
+                           int acc = 0, const float *p_in = nullptr, float *p_out = nullptr)
 {
     FusedArgs a{};
     a.in = in;
     a.out_c = out_c;
     for (int i = 0; i < ns; ++i) a.out_w[i] = out_w[i];
     a.g = p->g;
-    return p->family == WT_B3SPLINE ? wt_fused_dispatch<5>(p, a, s0, ns) : wt_fused_dispatch<3>(p, a, s0, ns);
+    a.p_in = p_in;
+    a.p_out = p_out;
+    const bool b3 = p->family == WT_B3SPLINE;
+    if (acc == 1) return b3 ? wt_fused_dispatch_acc<5, 1>(p, a, s0, ns) : wt_fused_dispatch_acc<3, 1>(p, a, s0, ns);
+    if (acc == 2) return b3 ? wt_fused_dispatch_acc<5, 2>(p, a, s0, ns) : wt_fused_dispatch_acc<3, 2>(p, a, s0, ns);
+    return b3 ? wt_fused_dispatch_acc<5, 0>(p, a, s0, ns) : wt_fused_dispatch_acc<3, 0>(p, a, s0, ns);
 }

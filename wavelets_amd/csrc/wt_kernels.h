@@ -73,6 +73,10 @@ __device__ __forceinline__ float4 f4_fma(float k, float4 a, float4 c)
 {
     return make_float4(fmaf(k, a.x, c.x), fmaf(k, a.y, c.y), fmaf(k, a.z, c.z), fmaf(k, a.w, c.w));
 }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b)
+{
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b)
 {
     return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
