@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 --pmc passes of tools/profile_round.sh.
+
+    python tools/pmc_summary.py gpurun_out/final profiles/r01_e [side]
+
+Reads <dir>/pmc_fetch and <dir>/pmc_write (one counter per pass, as MI355X_MICROARCH.md
+prescribes), writes <prefix>_pmc_summary.csv (KiB per dispatch, averaged) and updates
+profiles/traffic.json with HBM bytes per launch: 2 * FETCH_SIZE (gfx950 correction) +
+WRITE_SIZE, keyed by the names bench.py's live profiler uses."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+side = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def scope_name(kernel):
+    """rocprof kernel name -> ProfScope name of wt_api.hip / wt_fused.h"""
+    m = re.match(r"void wt_fused_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)
+    if m:
+        _, ns, d, _, _, acc = map(int, m.groups())
+        return f"{('wt_fused', 'wt_fused_acc', 'wt_fused_sum')[acc]}<d{d}x{ns}>"
+    return re.sub(r"^void ", "", kernel).split("(")[0].split("<")[0]
+
+
+rows, traffic = [], {}
+for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    acc = {}
+    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = acc.setdefault(r["Kernel_Name"], [0, 0.0])
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    for k, (n, tot) in sorted(acc.items()):
+        rows.append((counter, k, n, tot / n))
+        if k.startswith("void wt_") or k.startswith("wt_"):
+            key = f"{scope_name(k)}@{side}"
+            traffic[key] = traffic.get(key, 0.0) + (2 if counter == "FETCH_SIZE" else 1) * tot / n * 1024
+
+with open(prefix + "_pmc_summary.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
+            f"--steps 5 --warmup 1 --no-cpu --brief; {side}x{side} f32 B3 L=6\n"
+            "# KiB per dispatch, averaged. gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE*1024\n"
+            "counter,kernel,dispatches,avg_value_KiB\n")
+    for c, k, n, v in rows:
+        f.write(f'{c},"{k}",{n},{v:.1f}\n')
+tpath = os.path.join(ROOT, "profiles", "traffic.json")
+old = json.load(open(tpath)) if os.path.exists(tpath) else {}
+old.update({k: round(v) for k, v in traffic.items() if "wt_fused" in k or "plane_sum" in k})
+json.dump(old, open(tpath, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: round(v) for k, v in traffic.items()}, indent=1))

@@ -1,6 +1,6 @@
 rm -rf gpurun_out/final; mkdir -p gpurun_out/final
 R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/final/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/final/pytest_gpu.log
 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 python tools/bench_configs.py 2 3 5 w > gpurun_out/final/configs.txt 2>&1
 cd /tmp && export TMPDIR=/tmp

@@ -316,6 +316,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
                 pin_cur = pa[kk % PD];
                 pa[kk % PD] = load_acc(t + PD);
             }
+            // ACC: the ring slots that come due in this step were written G1 / G2 steps ago -
+            // read them before the barrier so the LDS latency hides behind the vertical filters
+            float4 old1 = zero, old2 = zero;
+            if constexpr (ACC != 0 && NS > 1) {
+                if (lane_store) {
+                    old1 = ring[i1 * NV + li];
+                    if constexpr (NS > 2) old2 = ring[(G1 + i2) * NV + li];
+                }
+            }
             float4 cen0, cen1, cen2, v0, v1, v2;
             v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
             buf[0][gl] = v0;
@@ -352,18 +361,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fus
                 // of the same image row appears (G1, then G2 steps later)
                 float4 s = has_pin ? f4_add(pin_cur, d0) : d0;          // row t - LAG0
                 if constexpr (NS > 1) {
+                    float4 s1 = f4_add(old1, d1);                         // row t - LAG1
+                    float4 s2 = s1;
+                    if constexpr (NS > 2) s2 = f4_add(old2, d2);          // row t - LAG2
                     if (lane_store) {
-                        float4 *r1 = ring + (i1 * NV + li);
-                        const float4 old = *r1;
-                        *r1 = s;
-                        s = f4_add(old, d1);                              // row t - LAG1
-                        if constexpr (NS > 2) {
-                            float4 *r2 = ring + ((G1 + i2) * NV + li);
-                            const float4 old2 = *r2;
-                            *r2 = s;
-                            s = f4_add(old2, d2);                         // row t - LAG2
-                        }
+                        ring[i1 * NV + li] = s;
+                        if constexpr (NS > 2) ring[(G1 + i2) * NV + li] = s1;
                     }
+                    s = s2;
                     i1 = (i1 + 1 == G1) ? 0 : i1 + 1;
                     if constexpr (NS > 2) i2 = (i2 + 1 == G2) ? 0 : i2 + 1;
                 }
