@@ -164,6 +164,11 @@ def test_strip_transform_single_rank(L):
     st.denoise([5, 3])
     ref.denoise([5, 3])
     np.testing.assert_allclose(st.sum(), ref.data.sum(axis=0), atol=1e-5 * np.abs(img).max())
+    st6 = StripTransform(L.default_context(), 256, 192, 6)
+    st6.upload(img)
+    rec = st6.decompose_sum()
+    st6.decompose()
+    np.testing.assert_array_equal(rec, st6.sum())
 
 
 def test_paste_and_crop_scatter_gather_strips(L):

@@ -81,6 +81,12 @@ class StripTransform:
     def decompose(self):
         self.plan.decompose(PLANE_INPUT, self.level, FLAG_FUSED if self.fused else 0)
 
+    def decompose_sum(self, out=None):
+        """Transform and reconstruction of this strip in the same passes (wt_decompose_sum)."""
+        self.plan.decompose_sum(PLANE_INPUT, self.level, PLANE_OUT,
+                                FLAG_FUSED if self.fused else 0)
+        return self.plan.download(PLANE_OUT, out)
+
     @property
     def sigma_e(self):
         return self.scaling_function.sigma_e()
