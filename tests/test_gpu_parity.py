@@ -785,3 +785,14 @@ def test_decompose_sum_is_bitwise_the_two_call_form(fam):
     with pytest.raises(L.WatrooHipError, match="differ"):
         p.decompose_sum(L.PLANE_INPUT, 3, L.PLANE_INPUT)
     p.close()
+
+
+def test_algorithm_entry_points_return_plane_stacks(W, O):
+    """AtrousTransform.atrous_standard / atrous_recursive (ref:408-444, 330-406) called directly."""
+    a = rnd((70, 90), 9)
+    t = W.AtrousTransform(W.Triangle)
+    std = t.atrous_standard(a, 3, W.Triangle(2))
+    assert isinstance(std, np.ndarray) and std.shape == (4, 70, 90) and std.dtype == np.float32
+    close(std, O.atrous_standard(a, 3, "triangle"), 1e-5 * np.abs(a).max())
+    rec = t.atrous_recursive(a, 3, W.B3spline(2))          # the instance decides the family
+    close(rec, O.atrous_recursive(a, 3, "b3spline"), 1e-5 * np.abs(a).max())

@@ -58,8 +58,11 @@ def main():
         profile(f"cfg5 wow(bilateral=1, denoise_coefficients=[5,2]) {side}^2",
                 lambda: W.wow(a, bilateral=1, denoise_coefficients=[5, 2]), a.size, reps=1)
     if "w" in which:
-        a = rng.standard_normal((8192, 8192), dtype=np.float32)
-        profile("wow(default) 8192^2", lambda: W.wow(a), a.size, reps=1)
+        side = int(os.environ.get("WOW_SIDE", "8192"))
+        a = rng.standard_normal((side, side), dtype=np.float32)
+        profile(f"wow(default) {side}^2", lambda: W.wow(a), a.size, reps=3)
+        profile(f"wow(denoise_coefficients=[5,2]) {side}^2",
+                lambda: W.wow(a, denoise_coefficients=[5, 2]), a.size, reps=3)
 
 
 if __name__ == "__main__":

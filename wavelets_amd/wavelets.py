@@ -483,6 +483,22 @@ class AtrousTransform:
         self._run(plan, level)
         return Coefficients(plan, scaling_function, self.bilateral)
 
+    # the reference's two algorithm entry points return the stacked planes as an ndarray
+    # (ref:330-406, 408-444); kept for code that calls them directly
+    _recasting_types = [np.int32, np.int64, '>f4', '>f8', 'int16', 'uint16', 'int32', 'uint32']
+
+    def _as_class(self, scaling_function):
+        other = AtrousTransform(type(scaling_function), self.bilateral, self.bilateral_scaling)
+        return other
+
+    def atrous_standard(self, arr, level, scaling_function):
+        """(level + 1, ...) float32 ndarray of planes, standard algorithm (ref:408-444)."""
+        return self._as_class(scaling_function)(arr, level, recursive=False).data
+
+    def atrous_recursive(self, arr, level, scaling_function):
+        """(level + 1, ...) float32 ndarray of planes, recursive algorithm (ref:330-406)."""
+        return self._as_class(scaling_function)(arr, level, recursive=True).data
+
     def _call_1d(self, arr, level, recursive):
         """1-D signals (ref:65-69, 'mirror' border): run as a 1 x N image with the engine's
         mirror border rule and the per-scale kernels."""
