@@ -390,6 +390,39 @@ def test_row_kernel_equals_chain_kernel_bitwise(W):
         L.set_option("row_kernel", 1)
 
 
+def test_lattice_kernel_equals_chain_kernel_bitwise(W):
+    """Large dilations (d >= 64) run on the lattice kernel (C lattice columns per thread share
+    taps in registers); same WtVert arithmetic, so identical bits to the chain kernel.  Shapes
+    cover C = 4, C = 2, ragged lattice groups, short chains and multi-bounce reflection."""
+    from wavelets_amd import _lib as L
+    ctx = L.default_context()
+    S3, S4, G = L.PLANE_SCRATCH(6), L.PLANE_SCRATCH(7), L.PLANE_SCRATCH(4)
+    try:
+        for (H, Wd) in ((300, 2052), (1300, 1024), (77, 4100)):
+            a = rnd((H, Wd), 52)
+            for fam in (L.B3SPLINE, L.TRIANGLE):
+                for s in (6, 7, 8, 9, 10):
+                    outs = []
+                    for lat in (1, 0):
+                        L.set_option("lattice_kernel", lat)
+                        p = L.Plan(ctx, H, Wd, fam, 1)
+                        p.upload(L.PLANE_INPUT, a)
+                        p.upload(0, a)
+                        p.upload(G, 0.25 * a)
+                        res = []
+                        p.smooth(L.PLANE_INPUT, S3, s); res.append(p.download(S3))
+                        p.smooth(L.PLANE_INPUT, S3, s, True); res.append(p.download(S3))
+                        p.local_variance(L.PLANE_INPUT, S3, s, 1.5, 2.0); res.append(p.download(S3))
+                        p.atrous_scale(L.PLANE_INPUT, S3, S4, s); res += [p.download(S3), p.download(S4)]
+                        p.wow_scale(0, s, 1.1, True, L.PLANE_NONE, 0.8, G); res += [p.download(0), p.download(G)]
+                        outs.append(res)
+                        p.close()
+                    for x, y in zip(*outs):
+                        np.testing.assert_array_equal(x, y, err_msg=f"{H}x{Wd} family {fam} scale {s}")
+    finally:
+        L.set_option("lattice_kernel", 1)
+
+
 def test_anscombe_bit_exact(W):
     g = load_golden("g0_hard")
     p = g["ans_in"]

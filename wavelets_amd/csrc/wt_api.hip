@@ -662,12 +662,12 @@ static int check_scale(const wt_plan *p, int s, const char *who)
 
 // chunking of the polyphase chains: enough (phase, chunk) items to fill the chip, chunks long
 // enough that the K-1 warm-up rows stay a small fraction
-static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim3 &block)
+static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim3 &block, int gx_override = 0)
 {
     const Geo &g = p->g;
     const int d = 1 << s;
     const int X = (g.W + 3) / 4;                 // float4 columns
-    const int gx = (X + 63) / 64;
+    const int gx = gx_override ? gx_override : (X + 63) / 64;
     const int n_max = (g.nrows + d - 1) / d;     // longest chain
     const int64_t want_items = std::max<int64_t>(1, (int64_t)524288 / std::max(1, gx * 64));
     int chunks_target = (int)std::max<int64_t>(1, want_items / std::min(d, g.nrows));
@@ -692,11 +692,13 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
 
 // tuning / A-B switches (wt_set_option)
 static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
+static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
 
 extern "C" int wt_set_option(const char *name, int value)
 {
     if (!name) WT_FAIL("wt_set_option: null name");
     if (!strcmp(name, "row_kernel")) { g_opt_row_kernel = value != 0; return 0; }
+    if (!strcmp(name, "lattice_kernel")) { g_opt_lattice = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }
 
@@ -745,6 +747,17 @@ static const char *row_name(int mode)
     }
 }
 
+static const char *lattice_name(int mode)
+{
+    switch (mode) {
+        case MODE_SMOOTH: return "wt_lattice_kernel<smooth>";
+        case MODE_SMOOTH_SQ: return "wt_lattice_kernel<smooth_sq>";
+        case MODE_DECOMP: return "wt_lattice_kernel<decomp>";
+        case MODE_VAR: return "wt_lattice_kernel<var>";
+        default: return "wt_lattice_kernel<wow>";
+    }
+}
+
 template <int MODE>
 static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
 {
@@ -755,13 +768,29 @@ static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
     const bool b3 = p->family == WT_B3SPLINE;
     a.g = p->g;
     a.d = d;
+    dim3 grid, block;
+    // d >= 64: lattice kernel (C lattice columns per thread share their taps); measured faster
+    // than the 8-wave row kernel from d = 64 up and 2.6x faster than the chain kernel at d >= 256
+    static const int lat_min_d = getenv("WT_LATTICE_MIN_D") ? std::max(4, atoi(getenv("WT_LATTICE_MIN_D"))) : 64;
+    const int lat_c = (g_opt_lattice && d >= lat_min_d && p->g.border == 0 && p->g.W % 4 == 0) ? (p->g.W >= 4 * d ? 4 : (p->g.W >= 2 * d ? 2 : 0)) : 0;
+    if (lat_c) {
+        const int J = (p->g.W + d - 1) / d;                       // lattice columns per phase
+        const int tx = ((J + lat_c - 1) / lat_c) * (d / 4);       // threads along x
+        WT_TRY(chain_geometry(p, s, a, grid, block, (tx + 63) / 64));
+        ProfScope ps(p->ctx, lattice_name(MODE));
+        if (b3 && lat_c == 4) hipLaunchKernelGGL((wt_lattice_kernel<5, MODE, 4>), grid, block, 0, p->ctx->stream, a);
+        else if (b3) hipLaunchKernelGGL((wt_lattice_kernel<5, MODE, 2>), grid, block, 0, p->ctx->stream, a);
+        else if (lat_c == 4) hipLaunchKernelGGL((wt_lattice_kernel<3, MODE, 4>), grid, block, 0, p->ctx->stream, a);
+        else hipLaunchKernelGGL((wt_lattice_kernel<3, MODE, 2>), grid, block, 0, p->ctx->stream, a);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
     if (!no_row && 2 * HX <= 256) {
         return b3 ? launch_row_t<5, MODE, 4>(p, a, HX, row_name(MODE)) : launch_row_t<3, MODE, 4>(p, a, HX, row_name(MODE));
     }
     if (!no_row && 2 * HX <= 512) {
         return b3 ? launch_row_t<5, MODE, 8>(p, a, HX, row_name(MODE)) : launch_row_t<3, MODE, 8>(p, a, HX, row_name(MODE));
     }
-    dim3 grid, block;
     WT_TRY(chain_geometry(p, s, a, grid, block));
     ProfScope ps(p->ctx, name);
     const bool small = a.d < 4;

@@ -400,6 +400,80 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1c  "lattice" kernel: the chain march for LARGE dilations (d >= 256, wow() scales 8-10, where
+// the x halo no longer fits a workgroup and the chain kernel pays K tap loads per row).  A thread
+// owns C columns of the POLYPHASE LATTICE in x as well - pixels x0, x0+d, ..., x0+(C-1)d of its
+// chain - so neighbouring lattice columns share taps in registers: C+K-1 row loads feed C
+// horizontal filters (2 loads per output for C = 4 instead of 5).  Lanes run over the phase
+// (consecutive pixels), so every load is still a coalesced 16 B per lane; reflection is per tap
+// address as in the chain kernel, so any width / border mode works.  Arithmetic is WtVert per
+// lattice column: bit-identical to the chain and row kernels.
+// ---------------------------------------------------------------------------------------------
+template <int K, int MODE, int C>
+__global__ __launch_bounds__(256, 2) void wt_lattice_kernel(ChainArgs a)
+{
+    constexpr int hw = K / 2;
+    constexpr int NR = C + K - 1;                // row operands per step
+    const Geo g = a.g;
+    int bx, by;
+    wt_xcd_remap(bx, by);
+    const int d = a.d;
+    const int p4 = d >> 2;                       // float4 phases per lattice column (d % 4 == 0)
+    const int t = bx * 64 + threadIdx.x;
+    const int gi = t / p4, ph = t - gi * p4;
+    const int x0 = 4 * ph + d * C * gi;          // first lattice column of this thread
+    if (x0 >= g.W) return;
+    const int item = by * blockDim.y + threadIdx.y;
+    const int q = item % d;
+    const int c = item / d;
+    if (c >= a.chunks || q >= g.nrows) return;
+    const int n_q = (g.nrows - q + d - 1) / d;
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+
+    // The operand columns do not depend on the row: with W % 4 == 0 (host-checked) an aligned
+    // group of 4 pixels is either inside the image or entirely outside, and the symmetric
+    // reflection of an outside group is an aligned group read backwards (even number of
+    // bounces: forwards).  One offset and one flag per operand, no branches in the row loop.
+    int off[NR];
+    unsigned rev = 0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int xo = x0 + (j - hw) * d;
+        const int a0 = wt_refl(xo, g.W), a3 = wt_refl(xo + 3, g.W);
+        off[j] = min(a0, a3);
+        if (a3 < a0) rev |= 1u << j;
+    }
+    WtVert<K, MODE, false> vert[C];
+    const int gy0 = g.row0 + q;
+    float4 lat[NR], nxt[NR];
+    auto load_lat = [&](int r, float4 (&dst)[NR]) {
+        const float *row = wt_row(a.in, g, gy0 + d * r);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + off[j]);
+            dst[j] = (rev >> j) & 1u ? make_float4(v.w, v.z, v.y, v.x) : v;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        load_lat(r0 - hw + j, lat);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) vert[cc].prime(j, lat + cc, d);
+    }
+    load_lat(r0 + hw, nxt);
+    for (int r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) lat[j] = nxt[j];
+        load_lat(min(r + 1, r1 - 1) + hw, nxt);
+        const int64_t o = (int64_t)(q + d * r) * g.P;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) vert[cc].emit(lat + cc, a, o, x0 + cc * d, x0 + cc * d < g.W);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1b  "row" kernel: the same single-scale operators for the dilations whose horizontal halo
 // fits a workgroup (hw*d <= 1/8 of its width).  A workgroup of NW waves marches down one chunk
 // of one polyphase chain like the fused pass: ONE coalesced 16-byte load per lane per row, the
