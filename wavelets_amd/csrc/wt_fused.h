@@ -157,10 +157,13 @@ __device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk,
 // the NS horizontal filters of a step are mutually independent (one s_barrier per row instead
 // of NS, 4*NS LDS reads in flight together).  LDS rows are double-buffered by step parity.
 template <int K, int NS, int D, int NW, int PDREQ, int ACC>
+#ifndef WT_FUSED_WPS4_K3
+#define WT_FUSED_WPS4_K3 3   // 3-tap family: 148 VGPRs, three 4-wave workgroups per CU (0.345 -> 0.32 ms)
+#endif
 #ifndef WT_FUSED_WPS4
 #define WT_FUSED_WPS4 2   // waves per SIMD requested for the 4-wave workgroup variant
 #endif
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WPS4 : 2)) void wt_fused_kernel(FusedArgs a)
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : 2)) void wt_fused_kernel(FusedArgs a)
 {
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
@@ -412,7 +415,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // that minimises (dispatch rounds) x (rows per workgroup): usually ONE round with every
     // slot filled; when the x-strips x phases alone under-fill the chip (tall narrow-ish strips:
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
-    const int wg_per_cu = NW == 4 ? WT_FUSED_WPS4 : std::max(1, 8 / NW);
+    const int wg_per_cu = NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
     const int slots = 256 * wg_per_cu;
     const int64_t nbase = (int64_t)nx * phases;
