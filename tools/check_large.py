@@ -22,8 +22,7 @@ for i in range(side // 2048):
     helper.upload(L.PLANE_INPUT, block * np.float32(1 + 0.01 * i))
     helper.paste_into(whole, L.PLANE_INPUT, L.PLANE_INPUT, i * 2048, 0)
 helper.close()
-whole.decompose(L.PLANE_INPUT, LEVEL)
-whole.plane_sum(0, LEVEL + 1)
+whole.decompose_sum(L.PLANE_INPUT, LEVEL, L.PLANE_OUT)      # what bench.py runs
 D = L.PLANE_SCRATCH(6)
 whole.binary("sub", L.PLANE_OUT, L.PLANE_INPUT, D)
 s, s2, lo, hi = whole.reduce(D)
@@ -46,15 +45,23 @@ cur = L.PLANE_INPUT
 FUSED = not os.environ.get('UNFUSED')
 if not FUSED:
     whole.decompose(L.PLANE_INPUT, LEVEL, 0)
+    whole.plane_sum(0, LEVEL + 1)
 for i, (s0, ns, halo) in enumerate(L.schedule(L.B3SPLINE, LEVEL, FUSED)):
     nxt = LEVEL if s0 + ns == LEVEL else L.PLANE_SCRATCH(i & 1)
     for up, lo_ in zip(plans[:-1], plans[1:]):
         L.Plan.halo_exchange_local(up, lo_, cur, halo)
     for p in plans:
-        p.decompose_pass(cur, nxt, s0, ns, (L.FLAG_FUSED if FUSED else 0) | L.FLAG_NO_EXCHANGE)
+        if FUSED:
+            p.decompose_pass_sum(cur, nxt, s0, ns, L.FLAG_FUSED | L.FLAG_NO_EXCHANGE, L.PLANE_OUT,
+                                 first=i == 0, last=s0 + ns == LEVEL)
+        else:
+            p.decompose_pass(cur, nxt, s0, ns, L.FLAG_NO_EXCHANGE)
     cur = nxt
+if not FUSED:
+    for p in plans:
+        p.plane_sum(0, LEVEL + 1)
 worst = 0.0
-for s in range(LEVEL + 1):
+for s in list(range(LEVEL + 1)) + [L.PLANE_OUT]:
     for p in plans:
         # bring the matching rows of the unsharded plane next to the strip's plane and subtract
         p.crop_from(whole, s, D, p.row0, 0)

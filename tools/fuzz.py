@@ -53,6 +53,14 @@ def main():
             got[name] = planes(plan, level + 1)
             plan.plane_sum(0, level + 1)
             rec = plan.download(L.PLANE_OUT)
+            if name == "fused":
+                rec_fused = rec          # the sum carried through the passes: identical bits
+                plan.fill(L.PLANE_OUT, np.nan)
+                plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, flags)
+                if not (np.array_equal(plan.download(L.PLANE_OUT), rec)
+                        and np.array_equal(planes(plan, level + 1), got[name])):
+                    fails += 1
+                    print(f"FAIL {tag}: decompose_sum != decompose + plane_sum")
             plan.close()
             err = float(np.abs(got[name] - ref).max())
             if not err <= tol or not np.array_equal(rec, got[name].sum(axis=0)):
@@ -77,13 +85,23 @@ def main():
                 nxt = level if s0 + ns == level else L.PLANE_SCRATCH(i & 1)
                 for up, lo in zip(plans[:-1], plans[1:]):
                     L.Plan.halo_exchange_local(up, lo, cur, halo)
+                sched = L.schedule(FAM[fam], level, fused)
+                use_sum = fused and all((s_, n_) in ((0, 2), (0, 3), (3, 2), (3, 3), (6, 2)) for s_, n_, _ in sched)
                 for p in plans:
-                    p.decompose_pass(cur, nxt, s0, ns, flags | L.FLAG_NO_EXCHANGE)
+                    if use_sum:
+                        p.decompose_pass_sum(cur, nxt, s0, ns, flags | L.FLAG_NO_EXCHANGE, L.PLANE_OUT,
+                                             first=i == 0, last=i == len(sched) - 1)
+                    else:
+                        p.decompose_pass(cur, nxt, s0, ns, flags | L.FLAG_NO_EXCHANGE)
                 cur = nxt
             sh = np.concatenate([planes(p, level + 1) for p in plans], axis=1)
             if not np.array_equal(sh, got["fused" if fused else "perscale"]):
                 fails += 1
                 print(f"FAIL {tag}: {k} strips (fused={fused}) != unsharded")
+            if use_sum and not np.array_equal(np.concatenate([p.download(L.PLANE_OUT) for p in plans]),
+                                              got["fused"].sum(axis=0) if False else rec_fused):
+                fails += 1
+                print(f"FAIL {tag}: {k} strips decompose_pass_sum reconstruction != unsharded")
             for p in plans:
                 p.close()
         if case % 5 == 0 and H * Wd < 400000 and level <= 6:
