@@ -768,6 +768,7 @@ static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
     const bool b3 = p->family == WT_B3SPLINE;
     a.g = p->g;
     a.d = d;
+    a.nt = (int64_t)p->g.nrows * p->g.P * 4 >= ((int64_t)32 << 20);   // planes >> L2: streaming stores
     dim3 grid, block;
     // d >= 64: lattice kernel (C lattice columns per thread share their taps); measured faster
     // than the 8-wave row kernel from d = 64 up and 2.6x faster than the chain kernel at d >= 256
