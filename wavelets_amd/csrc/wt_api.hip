@@ -1376,11 +1376,10 @@ static int select_pass(wt_plan *p, const float *b, uint32_t prefix_mask, uint32_
                        uint32_t bin_mask, int64_t k, uint32_t *bin, int64_t *below, int64_t *in_bin)
 {
     wt_ctx *c = p->ctx;
-    const int64_t n4 = plan_n4(p);
     WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
     {
         ProfScope ps(c, "wt_hist_kernel");
-        hipLaunchKernelGGL(wt_hist_kernel, dim3(flat_grid(n4)), dim3(256), 0, c->stream, b, n4, p->g.P / 4, p->g.W,
+        hipLaunchKernelGGL(wt_hist_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, b, p->g.nrows, p->g.P / 4, p->g.W,
                            prefix_mask, prefix_val, shift, bin_mask, c->d_hist);
     }
     WT_HIP(hipGetLastError());
@@ -1427,10 +1426,9 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
         // the upper median is the smallest element strictly greater than v_lo
         uint32_t *res = c->d_hist + WT_HIST_BINS;
         WT_HIP(hipMemsetAsync(res, 0xff, sizeof(uint32_t), c->stream));
-        const int64_t n4 = plan_n4(p);
         {
             ProfScope ps(c, "wt_min_greater_kernel");
-            hipLaunchKernelGGL(wt_min_greater_kernel, dim3(flat_grid(n4)), dim3(256), 0, c->stream, b, n4, p->g.P / 4, p->g.W, ulo, res);
+            hipLaunchKernelGGL(wt_min_greater_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, b, p->g.nrows, p->g.P / 4, p->g.W, ulo, res);
         }
         WT_HIP(hipGetLastError());
         if (p->nranks > 1) WT_NCCL(g_rccl.AllReduce(res, res, 1, NCCL_UINT32, NCCL_MIN, c->comm, c->stream));

@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void wt_fill_kernel(float *dst, int64_t n4, fl
 // non-empty bin per block.  Pixels in the pitch padding (x >= W) are masked.
 // ---------------------------------------------------------------------------------------------
 #define WT_HIST_BINS 2048
-__global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int64_t n4, int P4, int W,
+__global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows, int P4, int W,
                                                       uint32_t prefix_mask, uint32_t prefix_val,
                                                       int shift, uint32_t bin_mask,
                                                       uint32_t *hist)
@@ -1074,17 +1074,28 @@ __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int64_t n4
     __shared__ uint32_t lh[WT_HIST_BINS];
     for (int i = threadIdx.x; i < WT_HIST_BINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = wt_ldnt4(p + 4 * i);
-        const int x = (int)(i % P4) * 4;
-        const uint32_t b[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
-                               __float_as_uint(v.w)};
+    // whole rows per block, 2-D indices (no 64-bit modulo per element); 4 independent 16-byte
+    // loads per thread in flight before the LDS atomics of the first one are issued
+    const int X4 = (W + 3) >> 2;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const float *row = p + (int64_t)r * P4 * 4;
+        for (int x4 = threadIdx.x; x4 < X4; x4 += 1024) {
+            float4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t u = b[k] & 0x7fffffffu;
-            if (x + k < W && (u & prefix_mask) == prefix_val)
-                atomicAdd(&lh[(u >> shift) & bin_mask], 1u);
+            for (int u = 0; u < 4; ++u) v[u] = wt_ldnt4(row + 4 * min(x4 + 256 * u, X4 - 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int xx = x4 + 256 * u;
+                const int nv = xx < X4 ? min(4, W - xx * 4) : 0;
+                const uint32_t b[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y),
+                                       __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = b[k] & 0x7fffffffu;
+                    if (k < nv && (w & prefix_mask) == prefix_val)
+                        atomicAdd(&lh[(w >> shift) & bin_mask], 1u);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1092,25 +1103,35 @@ __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int64_t n4
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-// smallest |x| bit pattern strictly greater than `than` (for the upper median when N is even)
-__global__ __launch_bounds__(256) void wt_min_greater_kernel(const float *p, int64_t n4, int P4,
+// smallest |x| bit pattern strictly greater than `than` (for the upper median when N is even);
+// one global atomic per block
+__global__ __launch_bounds__(256) void wt_min_greater_kernel(const float *p, int nrows, int P4,
                                                              int W, uint32_t than,
                                                              uint32_t *result)
 {
     uint32_t best = 0xffffffffu;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
-        const int x = (int)(i % P4) * 4;
-        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const float *row = p + (int64_t)r * P4 * 4;
+        for (int x4 = threadIdx.x; x4 * 4 < W; x4 += 256) {
+            const float4 v = wt_ldnt4(row + 4 * x4);
+            const int nv = min(4, W - x4 * 4);
+            const uint32_t b[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
+                                   __float_as_uint(v.w)};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t u = b[k] & 0x7fffffffu;
-            if (x + k < W && u > than) best = min(best, u);
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = b[k] & 0x7fffffffu;
+                if (k < nv && u > than) best = min(best, u);
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_down((int)best, off));
-    if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(result, best);
+    __shared__ uint32_t wb[4];
+    if ((threadIdx.x & 63) == 0) wb[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = min(min(wb[0], wb[1]), min(wb[2], wb[3]));
+        if (best != 0xffffffffu) atomicMin(result, best);
+    }
 }
 
 // K7  {sum, sumsq, min, max}: fp64 sums, deterministic two-stage reduction (per-block partials
