@@ -313,6 +313,34 @@ def g13_richardson_lucy_fft():
     save("g13_rl_fft", "hard(numpy fft; transform via cv2 stand-in)", **out)
 
 
+def g14_wow_denoise_nd():
+    """wow / denoise on 1-D signals and (Z, Y, X) cubes (the reference is ndim-generic)."""
+    out = {}
+    sig = img((300,), 61)
+    cube = img((20, 24, 28), 62)
+    pos = img((20, 24, 28), 63, positive=True)
+    out["sig"], out["cube"], out["pos"] = sig, cube, pos
+    cases = {
+        "default": dict(),
+        "den": dict(denoise_coefficients=[5, 2], n_scales=3),
+        "gamma": dict(denoise_coefficients=[4, 2], n_scales=2, h=0.5, gamma=2.5),
+        "pv": dict(preserve_variance=True, weights=[0.5, 2]),
+        "tri": dict(scaling_function=Triangle, denoise_coefficients=[3]),
+    }
+    for tag, arr in (("sig", sig), ("cube", cube)):
+        for name, kw in cases.items():
+            r, c = wow(arr.copy(), **kw)
+            out[f"wow_{tag}_{name}"] = r
+            if name in ("den", "default"):
+                out[f"wow_{tag}_{name}_coef"] = c.data
+        out[f"den_{tag}"] = denoise(arr.copy(), [5, 3])
+        out[f"den_{tag}_tri_hard"] = denoise(arr.copy(), [4, 2, 1], Triangle, soft_threshold=False)
+        out[f"den_{tag}_noise"] = denoise(arr.copy(), [5, 3], noise=0.7)
+    out["den_pos_anscombe"] = denoise(pos.copy(), [5, 3], anscombe=True)
+    out["ans_pos"] = generalized_anscombe(pos.copy())
+    save("g14_wow_denoise_nd", "1-D: hard; 3-D: semantic(cv2 stand-in)", **out)
+
+
 def g10_enhance():
     """utils.enhance (importable by path, not in __all__)."""
     from watroo.utils import enhance

@@ -829,3 +829,45 @@ def test_algorithm_entry_points_return_plane_stacks(W, O):
     close(std, O.atrous_standard(a, 3, "triangle"), 1e-5 * np.abs(a).max())
     rec = t.atrous_recursive(a, 3, W.B3spline(2))          # the instance decides the family
     close(rec, O.atrous_recursive(a, 3, "b3spline"), 1e-5 * np.abs(a).max())
+
+
+ND_WOW_CASES = {
+    "default": dict(),
+    "den": dict(denoise_coefficients=[5, 2], n_scales=3),
+    "gamma": dict(denoise_coefficients=[4, 2], n_scales=2, h=0.5, gamma=2.5),
+    "pv": dict(preserve_variance=True, weights=[0.5, 2]),
+    "tri": dict(scaling_function="Triangle", denoise_coefficients=[3]),
+}
+
+
+@pytest.mark.parametrize("tag", ["sig", "cube"])
+def test_wow_and_denoise_nd_vs_golden(W, tag):
+    """wow / denoise / generalized_anscombe on 1-D signals and (Z, Y, X) cubes (the reference is
+    ndim-generic: utils.py:105-219 over wavelets.py:46-69)."""
+    g = load_golden("g14_wow_denoise_nd")
+    a = g[tag]
+    for name, kw in ND_WOW_CASES.items():
+        kw = {k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()}
+        if "scaling_function" in kw:
+            kw["scaling_function"] = W.Triangle
+        r, c = W.wow(a.copy(), **kw)
+        ref = g[f"wow_{tag}_{name}"]
+        assert r.shape == a.shape and r.dtype == np.float32
+        close(r, ref, atol=3e-5 * np.abs(ref).max())
+        if f"wow_{tag}_{name}_coef" in g:
+            assert c.data.shape == g[f"wow_{tag}_{name}_coef"].shape
+            close(c.data, g[f"wow_{tag}_{name}_coef"], atol=3e-5 * np.abs(ref).max())
+    tol = 1e-5 * np.abs(a).max()
+    close(W.denoise(a.copy(), [5, 3]), g[f"den_{tag}"], tol)
+    close(W.denoise(a.copy(), [5, 3], noise=0.7), g[f"den_{tag}_noise"], tol)
+    got = W.denoise(a.copy(), [4, 2, 1], W.Triangle, soft_threshold=False)
+    assert got.shape == a.shape and (np.abs(got - g[f"den_{tag}_tri_hard"]) > tol).sum() <= 2
+    if tag == "cube":
+        close(W.denoise(g["pos"].copy(), [5, 3], anscombe=True), g["den_pos_anscombe"],
+              2e-5 * np.abs(g["pos"]).max())
+        close(W.generalized_anscombe(g["pos"]), g["ans_pos"], 1e-5 * np.abs(g["ans_pos"]).max())
+        # wow on an existing 3-D Coefficients object mutates and returns it (ref:128-131,152-153)
+        c = W.AtrousTransform(W.B3spline)(a, 2)
+        r, c2 = W.wow(c)
+        assert c2 is c
+        close(r, g["wow_cube_default"], atol=3e-5 * np.abs(g["wow_cube_default"]).max())

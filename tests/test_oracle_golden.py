@@ -310,3 +310,34 @@ def test_three_dimensional_vs_reference():
             for L in (1, 3):
                 close(O.atrous_standard_3d(a, L, fam), g[f"coef_{fam}_{tag}_L{L}"], tol)
             close(O.convolution_3d(a, fam, 1), g[f"conv_{fam}_{tag}_s1"], tol)
+
+
+# ------------------------------------------------- wow / denoise on 1-D signals and 3-D cubes
+ND_WOW_CASES = {
+    "default": dict(),
+    "den": dict(denoise_coefficients=[5, 2], n_scales=3),
+    "gamma": dict(denoise_coefficients=[4, 2], n_scales=2, h=0.5, gamma=2.5),
+    "pv": dict(preserve_variance=True, weights=[0.5, 2]),
+    "tri": dict(family="triangle", denoise_coefficients=[3]),
+}
+
+
+@pytest.mark.parametrize("tag", ["sig", "cube"])
+def test_wow_and_denoise_nd_vs_reference(tag):
+    g = load_golden("g14_wow_denoise_nd")
+    a = g[tag]
+    for name, kw in ND_WOW_CASES.items():
+        kw = {k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()}
+        r, c = O.wow(a.copy(), **kw)
+        ref = g[f"wow_{tag}_{name}"]
+        close(r, ref, atol=2e-5 * np.abs(ref).max())
+        if f"wow_{tag}_{name}_coef" in g:
+            close(c.data, g[f"wow_{tag}_{name}_coef"], atol=2e-5 * np.abs(ref).max())
+    tol = 1e-5 * np.abs(a).max()
+    close(O.denoise(a.copy(), [5, 3]), g[f"den_{tag}"], tol)
+    close(O.denoise(a.copy(), [5, 3], noise=0.7), g[f"den_{tag}_noise"], tol)
+    got = O.denoise(a.copy(), [4, 2, 1], "triangle", soft_threshold=False)
+    assert (np.abs(got - g[f"den_{tag}_tri_hard"]) > tol).sum() <= 2
+    if tag == "cube":
+        close(O.denoise(g["pos"].copy(), [5, 3], anscombe=True), g["den_pos_anscombe"],
+              1e-5 * np.abs(g["pos"]).max())

@@ -13,12 +13,14 @@ import numpy as np
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _family_of, _to_f32_image,
+                       generalized_anscombe,
                        PLANE_INPUT)
 
 __all__ = ['denoise', 'wow', 'richardson_lucy']     # enhance / prepare_params importable by path, as in the reference
 
 _POWER_PLANE = PLANE_SCRATCH(3)
 _GAMMA_PLANE = PLANE_SCRATCH(4)
+_SQ_PLANE, _POW_PLANE = PLANE_SCRATCH(6), PLANE_SCRATCH(7)     # 3-D wow: c^2 and its 3-D smoothing
 
 
 def prepare_params(param, ndims):
@@ -67,28 +69,22 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     return out
 
 
-def generalized_anscombe_1d(sig):
-    """forward Anscombe of a 1-D signal on the GPU (as a 1 x N image)"""
-    from .wavelets import generalized_anscombe
-    return generalized_anscombe(sig.reshape(1, -1)).reshape(-1)
-
-
 def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None,
             soft_threshold=True, anscombe=False):
     """Denoise ``data``: transform over ``len(weights)`` scales, threshold each scale at
     ``weights[s]`` sigma, sum the planes (ref:83-102).  Optional Anscombe pre/post transform.
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
     """
-    if np.ndim(data) == 1:                      # 1-D signals: generic (unfused) call sequence
-        sig = np.asarray(data, np.float32)
+    if np.ndim(data) in (1, 3):                 # signals and cubes: the generic call sequence
+        arr = np.asarray(data, np.float32)
         if anscombe:
-            sig = generalized_anscombe_1d(sig)
-        coefficients = AtrousTransform(scaling_function, bilateral=bilateral)(sig, len(weights))
+            arr = generalized_anscombe(arr)
+        coefficients = AtrousTransform(scaling_function, bilateral=bilateral)(arr, len(weights))
         coefficients.noise = noise
         plan = coefficients._denoise_sum(weights, soft_threshold=soft_threshold, write_back=False)
         if anscombe:
             plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)
-        return plan.download(PLANE_OUT).reshape(-1)
+        return coefficients._from_plane(plan.download(PLANE_OUT))
     img = _to_f32_image(data, "data")
     level = len(weights)
     transform = AtrousTransform(scaling_function, bilateral=bilateral)
@@ -137,8 +133,8 @@ def wow(data,
     the whitened ones, exactly as in the reference.
     """
     if type(data) is np.ndarray:                                          # ref:121-127
-        if data.ndim != 2:
-            _to_f32_image(data, "data")
+        if data.ndim > 3:
+            raise ValueError("Unsupported number of dimensions")
         max_scales = int(np.round(np.log2(min(data.shape))
                                   - np.log2(len(scaling_function.coefficients_1d))))
         if n_scales is None:
@@ -148,7 +144,7 @@ def wow(data,
         n_dims = data.ndim
     elif type(data) is Coefficients:                                      # ref:128-131
         n_scales = len(data) - 1
-        n_dims = 2
+        n_dims = data._ndim
         scaling_function = data.scaling_function.__class__
     else:
         raise ValueError('Unknown input type')                            # ref:133
@@ -191,6 +187,33 @@ def wow(data,
 
     nplanes = len(coefficients)
     gplane = _GAMMA_PLANE if use_gamma else PLANE_NONE
+    if coefficients._ndim == 1:
+        plan.set_border(2)        # the 1-D branch filters with scipy's 'mirror' border (ref:65-69)
+    try:
+        _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
+                    preserve_variance, whitening, h, soft_threshold, gplane)
+    finally:
+        plan.set_border(0)
+
+    plan.plane_sum(0, nplanes, PLANE_OUT)                                 # ref:205
+
+    if use_gamma:                                                         # ref:207-217
+        if gamma_min is None or gamma_max is None:
+            _, _, lo, hi = plan.reduce(_GAMMA_PLANE)
+            if gamma_min is None:
+                gamma_min = lo
+            if gamma_max is None:
+                gamma_max = hi
+        plan.gamma_blend(PLANE_OUT, _GAMMA_PLANE, gamma_min, gamma_max, 1 / gamma, h)
+
+    recon = coefficients._from_plane(plan.download(PLANE_OUT))
+    coefficients._refresh_host(range(nplanes))
+    return recon, coefficients
+
+
+def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
+                preserve_variance, whitening, h, soft_threshold, gplane):
+    """The per-scale loop of wow (ref:174-203)."""
     for s, (_, w, d) in enumerate(zip(range(nplanes), recomposition_weights, sdc)):  # ref:174
         need_moments = preserve_variance or (s == n_scales and whitening and h < 1)
         if need_moments:
@@ -215,26 +238,16 @@ def wow(data,
             t = coefficients._tau(d, s)                                   # ref:199
             tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
             factor = np.float32(w * power_norm)
-            if whitening and h < 1:                                       # ref:193-196 + 199-203
+            if whitening and h < 1 and coefficients._ndim == 3:           # ref:193-196 on a cube
+                # local power = 3-D conv_s(c^2): per-slice 2-D filter + axis-0 filter
+                plan.binary("mul", s, s, _SQ_PLANE)
+                plan.smooth3d(_SQ_PLANE, _POW_PLANE, s, coefficients._shape[0])
+                plan.wow_update(s, _POW_PLANE, tau, soft_threshold, noise_plane, factor, gplane)
+            elif whitening and h < 1:                                     # ref:193-196 + 199-203
                 # local power conv_s(c^2), significance, gamma sum and whitening in one kernel
                 plan.wow_scale(s, s, tau, soft_threshold, noise_plane, factor, gplane)
             else:
                 plan.wow_update(s, PLANE_NONE, tau, soft_threshold, noise_plane, factor, gplane)
-
-    plan.plane_sum(0, nplanes, PLANE_OUT)                                 # ref:205
-
-    if use_gamma:                                                         # ref:207-217
-        if gamma_min is None or gamma_max is None:
-            _, _, lo, hi = plan.reduce(_GAMMA_PLANE)
-            if gamma_min is None:
-                gamma_min = lo
-            if gamma_max is None:
-                gamma_max = hi
-        plan.gamma_blend(PLANE_OUT, _GAMMA_PLANE, gamma_min, gamma_max, 1 / gamma, h)
-
-    recon = plan.download(PLANE_OUT)
-    coefficients._refresh_host(range(nplanes))
-    return recon, coefficients
 
 
 def richardson_lucy(data, psf,

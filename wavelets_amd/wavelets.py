@@ -162,12 +162,17 @@ def _to_f32_image(arr, what="arr"):
 def generalized_anscombe(signal, alpha=1, g=0, sigma=0, inverse=False):
     """Generalised Anscombe variance-stabilising transform and its algebraic inverse
     (ref:14-21), evaluated on the GPU in float32."""
-    img = _to_f32_image(signal, "signal")
+    arr = np.asarray(signal)
+    if arr.ndim > 3:
+        raise ValueError("Unsupported number of dimensions")
+    shape = arr.shape
+    # pointwise: any dimensionality runs as a (rows, last axis) image
+    img = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, shape[-1] if arr.ndim else 1)
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _lib.B3SPLINE, 0)
     try:
         plan.upload(PLANE_INPUT, img)
         plan.anscombe(PLANE_INPUT, PLANE_OUT, alpha, g, sigma, inverse)
-        return plan.download(PLANE_OUT)
+        return plan.download(PLANE_OUT).reshape(shape)
     finally:
         release_plan(plan)
 
