@@ -100,6 +100,12 @@ int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int
  * border of the 1-D branch (watroo/wavelets.py:66-69; a 1-D signal is a 1 x N image).
  * Modes 1 and 2: per-scale kernels only, single GPU. */
 int wt_plan_set_border(wt_plan *plan, int border);
+/* User-defined scaling function (a subclass of AbstractScalingFunction with its own
+ * coefficients_1d, watroo/wavelets.py:152-229): `ntaps` odd 1-D taps (<= 15) replace the plan's
+ * built-in family for wt_decompose / wt_decompose_pass (one scale) / wt_atrous_scale /
+ * wt_smooth, which then run generic separable kernels (no fused passes); the other operators
+ * (variance, bilateral, fused wow update, 3-D) fail.  ntaps = 0 restores the family.  Single GPU. */
+int wt_plan_set_taps(wt_plan *plan, const float *taps, int ntaps);
 /* dst plane <- window of a (larger) source plan's plane starting at (y0, x0); device copy.
  * (atrous_recursive pads by hw*2^(level-1) and crops at the end, watroo/wavelets.py:394-406) */
 int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0,

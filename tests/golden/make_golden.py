@@ -341,6 +341,48 @@ def g14_wow_denoise_nd():
     save("g14_wow_denoise_nd", "1-D: hard; 3-D: semantic(cv2 stand-in)", **out)
 
 
+def g15_custom_scaling_function():
+    """User-defined scaling functions: AbstractScalingFunction subclasses with their own taps
+    (symmetric 7-tap binomial; an ASYMMETRIC 5-tap one, which pins filter2D's correlation
+    orientation in 2-D and ndimage.convolve's convolution orientation in 1-D)."""
+    from watroo.wavelets import AbstractScalingFunction
+
+    class Binomial7(AbstractScalingFunction):
+        coefficients_1d = np.array([1, 6, 15, 20, 15, 6, 1]) / 64
+        sigma_e_1d = np.array([0.8, 0.25, 0.15, 0.1, 0.07, 0.05])
+        sigma_e_2d = np.array([0.93, 0.17, 0.07, 0.03, 0.015, 0.0075])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('binomial7', *args, **kwargs)
+
+    class Skew5(AbstractScalingFunction):
+        coefficients_1d = np.array([0.05, 0.25, 0.4, 0.2, 0.1])
+        sigma_e_1d = np.array([0.7, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.9, 0.2, 0.09, 0.04, 0.02, 0.01])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('skew5', *args, **kwargs)
+
+    out = {}
+    a = img((61, 83), 71)
+    sig = img((200,), 72)
+    out["img"], out["sig"] = a, sig
+    for name, cls in (("bin7", Binomial7), ("skew5", Skew5)):
+        out[f"{name}_taps"] = cls.coefficients_1d
+        out[f"{name}_sigma_e_1d"], out[f"{name}_sigma_e_2d"] = cls.sigma_e_1d, cls.sigma_e_2d
+        out[f"{name}_coef_2d_L3"] = AtrousTransform(cls)(a, 3).data
+        out[f"{name}_coef_2d_L5"] = AtrousTransform(cls)(a, 5).data      # multi-bounce reflection
+        out[f"{name}_coef_1d_L3"] = AtrousTransform(cls)(sig, 3).data
+        out[f"{name}_conv_2d_s2"] = convolution(a, cls(2), s=2)
+        out[f"{name}_conv_1d_s1"] = convolution(sig, cls(1), s=1)
+        out[f"{name}_den_2d"] = denoise(a.copy(), [5, 3], cls)
+        out[f"{name}_den_1d"] = denoise(sig.copy(), [4, 2], cls, noise=0.8)
+        r, c = wow(a.copy(), cls, denoise_coefficients=[5, 2], n_scales=3)
+        out[f"{name}_wow"], out[f"{name}_wow_coef"] = r, c.data
+        out[f"{name}_rec_L3"] = AtrousTransform(cls)(a, 3, recursive=True).data
+    save("g15_custom", "1-D: hard; 2-D: semantic(cv2 stand-in)", **out)
+
+
 def g10_enhance():
     """utils.enhance (importable by path, not in __all__)."""
     from watroo.utils import enhance

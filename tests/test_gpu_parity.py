@@ -871,3 +871,40 @@ def test_wow_and_denoise_nd_vs_golden(W, tag):
         r, c2 = W.wow(c)
         assert c2 is c
         close(r, g["wow_cube_default"], atol=3e-5 * np.abs(g["wow_cube_default"]).max())
+
+
+@pytest.mark.parametrize("name", ["bin7", "skew5"])
+def test_custom_scaling_function_vs_golden(W, name):
+    """User-defined AbstractScalingFunction subclasses (ref:152-229) run on plans with run-time
+    taps (wt_plan_set_taps): transform (2-D, 1-D, recursive), convolution, denoise, wow."""
+    g = load_golden("g15_custom")
+    a, sig = g["img"], g["sig"]
+
+    class Custom(W.AbstractScalingFunction):
+        coefficients_1d = g[f"{name}_taps"]
+        sigma_e_1d = g[f"{name}_sigma_e_1d"]
+        sigma_e_2d = g[f"{name}_sigma_e_2d"]
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(name, *args, **kwargs)
+
+    tol = 1e-5 * np.abs(a).max()
+    close(W.AtrousTransform(Custom)(a, 3).data, g[f"{name}_coef_2d_L3"], tol)
+    close(W.AtrousTransform(Custom)(a, 5).data, g[f"{name}_coef_2d_L5"], tol)
+    close(W.AtrousTransform(Custom)(sig, 3).data, g[f"{name}_coef_1d_L3"], tol)
+    close(W.convolution(a, Custom(2), s=2), g[f"{name}_conv_2d_s2"], tol)
+    close(W.convolution(sig, Custom(1), s=1), g[f"{name}_conv_1d_s1"], tol)
+    close(W.denoise(a.copy(), [5, 3], Custom), g[f"{name}_den_2d"], 2 * tol)
+    close(W.denoise(sig.copy(), [4, 2], Custom, noise=0.8), g[f"{name}_den_1d"], 2 * tol)
+    r, c = W.wow(a.copy(), Custom, denoise_coefficients=[5, 2], n_scales=3)
+    close(r, g[f"{name}_wow"], 3e-5 * np.abs(g[f"{name}_wow"]).max())
+    close(c.data, g[f"{name}_wow_coef"], 3e-5 * np.abs(g[f"{name}_wow"]).max())
+    close(W.AtrousTransform(Custom)(a, 3, recursive=True).data, g[f"{name}_rec_L3"], tol)
+    # a re-tapped subclass of a built-in family must not inherit its fused kernels
+    class Retapped(W.B3spline):
+        coefficients_1d = g[f"{name}_taps"]
+    close(W.AtrousTransform(Retapped)(a, 3).data, g[f"{name}_coef_2d_L3"], tol)
+    with pytest.raises(NotImplementedError):
+        W.AtrousTransform(Custom, bilateral=1)(a, 2)
+    with pytest.raises(NotImplementedError):
+        W.AtrousTransform(Custom)(np.zeros((4, 5, 6), np.float32), 1)

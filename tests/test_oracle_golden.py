@@ -341,3 +341,24 @@ def test_wow_and_denoise_nd_vs_reference(tag):
     if tag == "cube":
         close(O.denoise(g["pos"].copy(), [5, 3], anscombe=True), g["den_pos_anscombe"],
               1e-5 * np.abs(g["pos"]).max())
+
+
+# ------------------------------------------------- user-defined scaling functions
+@pytest.mark.parametrize("name", ["bin7", "skew5"])
+def test_custom_scaling_function_vs_reference(name):
+    """AbstractScalingFunction subclasses with their own taps (symmetric 7-tap, asymmetric 5-tap:
+    filter2D correlates in 2-D, ndimage.convolve convolves in 1-D)."""
+    g = load_golden("g15_custom")
+    a, sig = g["img"], g["sig"]
+    fam = O.CustomFamily(g[f"{name}_taps"], {1: g[f"{name}_sigma_e_1d"], 2: g[f"{name}_sigma_e_2d"]})
+    tol = 2e-6 * np.abs(a).max()
+    close(O.atrous_standard(a, 3, fam), g[f"{name}_coef_2d_L3"], tol)
+    close(O.atrous_standard(a, 5, fam), g[f"{name}_coef_2d_L5"], tol)
+    close(O.atrous_standard_1d(sig, 3, fam), g[f"{name}_coef_1d_L3"], tol)
+    close(O.convolution(a, fam, 2), g[f"{name}_conv_2d_s2"], tol)
+    close(O.convolution_1d(sig, fam, 1), g[f"{name}_conv_1d_s1"], tol)
+    close(O.denoise(a.copy(), [5, 3], fam), g[f"{name}_den_2d"], 5 * tol)
+    close(O.denoise(sig.copy(), [4, 2], fam, noise=0.8), g[f"{name}_den_1d"], 5 * tol)
+    r, c = O.wow(a.copy(), fam, denoise_coefficients=[5, 2], n_scales=3)
+    close(r, g[f"{name}_wow"], 2e-5 * np.abs(g[f"{name}_wow"]).max())
+    close(O.atrous_recursive(a, 3, fam), g[f"{name}_rec_L3"], tol)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "wt_schedule": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.c_int,
                                _c.POINTER(_c.c_int)]),
     "wt_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
+    "wt_plan_set_taps": (_c.c_int, [_vp, _fp, _c.c_int]),
     "wt_crop_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
     "wt_paste_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
     "wt_plane_ptr": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_vp)]),
@@ -349,14 +350,30 @@ class Plan:
         self._h = _vp()
         self.ctx = ctx
         nrows = H if nrows is None else nrows
-        check(load().wt_plan_create_strip(ctx._h, H, W, family, max_level, row0, nrows,
-                                          halo_rows, rank, nranks, _c.byref(self._h)))
+        # `family` is TRIANGLE / B3SPLINE, or a tuple of 1-D taps for a user-defined scaling
+        # function (wt_plan_set_taps); the tuple is kept as self.family (plan-pool key)
+        taps = tuple(float(t) for t in family) if isinstance(family, (tuple, list)) else None
+        check(load().wt_plan_create_strip(ctx._h, H, W, B3SPLINE if taps else family, max_level,
+                                          row0, nrows, halo_rows, rank, nranks,
+                                          _c.byref(self._h)))
         info = (_i64 * 8)()
         check(load().wt_plan_info(self._h, info))
         (self.H, self.W, self.pitch, self.row0, self.nrows, self.halo, self.max_level,
          self.family) = [int(v) for v in info]
         self.rank, self.nranks = rank, nranks
         _live.add(self)
+        if taps:
+            self.set_taps(taps)
+            self.family = taps
+
+    @property
+    def custom(self):
+        """True when the plan filters with user-defined taps (generic kernels, no fusion)."""
+        return isinstance(self.family, tuple)
+
+    def set_taps(self, taps):
+        arr = (_c.c_float * max(len(taps), 1))(*taps)
+        check(load().wt_plan_set_taps(self._h, arr, len(taps)))
 
     def close(self):
         if self._h:

@@ -425,6 +425,39 @@ extern "C" int wt_plan_set_border(wt_plan *p, int border)
 }
 
 // dst_plane of `dst` <- the dst-sized window of src_plane of `src` starting at (y0, x0)
+extern "C" int wt_plan_set_taps(wt_plan *p, const float *taps, int ntaps)
+{
+    if (!p) WT_FAIL("wt_plan_set_taps: null plan");
+    if (ntaps == 0) { p->ntaps = 0; return 0; }
+    if (!taps) WT_FAIL("wt_plan_set_taps: null taps");
+    if (ntaps < 1 || ntaps > WT_MAX_CUSTOM_TAPS || !(ntaps & 1))
+        WT_FAIL("wt_plan_set_taps: %d taps unsupported (odd, 1..%d)", ntaps, WT_MAX_CUSTOM_TAPS);
+    if (p->nranks > 1) WT_FAIL("wt_plan_set_taps: user-defined scaling functions are single-GPU only");
+    for (int i = 0; i < ntaps; ++i) p->taps[i] = taps[i];
+    p->ntaps = ntaps;
+    return 0;
+}
+
+// separable filter with the plan's run-time taps: rows into scratch 15, then columns (+ detail)
+static int launch_custom(wt_plan *p, const float *in, float *out_c, float *out_w, int s, int square, const char *name)
+{
+    if (s < 0 || s > 24) WT_FAIL("%s: scale %d out of range", name, s);
+    float *tmp = nullptr;
+    WT_TRY(plane_base(p, WT_PLANE_SCRATCH(15), &tmp));
+    if (in == tmp || out_c == tmp || out_w == tmp) WT_FAIL("%s: scratch plane 15 is used internally for user-defined taps", name);
+    if (out_c == in || out_w == in) WT_FAIL("%s: in-place operation", name);
+    CustomTaps t{};
+    t.n = p->ntaps;
+    for (int i = 0; i < p->ntaps; ++i) t.k[i] = p->taps[i];
+    const int d = 1 << s;
+    dim3 grid((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)), block(256);
+    ProfScope ps(p->ctx, "wt_custom_kernels");
+    hipLaunchKernelGGL(wt_custom_rows_kernel, grid, block, 0, p->ctx->stream, in, tmp, p->g, d, t, square);
+    hipLaunchKernelGGL(wt_custom_cols_kernel, grid, block, 0, p->ctx->stream, (const float *)tmp, in, out_c, out_w, p->g, d, t);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0, int64_t x0)
 {
     if (!src || !dst) WT_FAIL("wt_crop_plane: null plan");
@@ -761,6 +794,11 @@ static const char *lattice_name(int mode)
 template <int MODE>
 static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
 {
+    if (p->ntaps) {      // user-defined scaling function: generic separable kernels
+        if (MODE == MODE_SMOOTH || MODE == MODE_SMOOTH_SQ || MODE == MODE_DECOMP)
+            return launch_custom(p, a.in, a.out_c, MODE == MODE_DECOMP ? a.out_w : nullptr, s, MODE == MODE_SMOOTH_SQ, name);
+        WT_FAIL("%s: not available with user-defined taps (smooth / decompose only)", name);
+    }
     const bool no_row = !g_opt_row_kernel;
     const int hw = family_taps(p->family) / 2;
     const int d = 1 << s;
@@ -864,6 +902,7 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
                             float f1 = 1.f, float f2 = 1.f)
 {
     if (p->g.border) WT_FAIL("bilateral kernels implement the symmetric border only");
+    if (p->ntaps) WT_FAIL("bilateral kernels are not available with user-defined taps");
     ChainArgs a{};
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
@@ -958,7 +997,7 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
         WT_FAIL("wt_decompose_sum: scratch planes 0/1 are used internally");
     int32_t tr[3 * 32];
     int np = 0;
-    bool fusable = (flags & 1) && level > 0 && !p->g.border && wt_fused_supported(p);
+    bool fusable = (flags & 1) && level > 0 && !p->g.border && !p->ntaps && wt_fused_supported(p);
     if (fusable) {
         WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
         for (int i = 0; i < np; ++i) fusable = fusable && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1]);
@@ -987,6 +1026,7 @@ extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
     if (level == 0) return wt_copy_plane(p, src, 0);
     int32_t tr[3 * 32];
     int np = 0;
+    if (p->ntaps) flags &= ~1;          // user-defined taps: one generic pass per scale
     WT_TRY(wt_schedule(p->family, level, (flags & 1) && wt_fused_supported(p), tr, 32, &np));
     int cur = src;  // plane holding c_s
     for (int i = 0; i < np; ++i) {
@@ -1223,6 +1263,7 @@ static int conv3d_planes(wt_plan *p, float *in, float *tmp, float *out, int s, i
 static int check3d(const wt_plan *p, int depth, int s, const char *who)
 {
     if (p->nranks != 1 || p->g.border) WT_FAIL("%s: single-GPU plans with the symmetric border only", who);
+    if (p->ntaps) WT_FAIL("%s: not available with user-defined taps", who);
     if (depth < 1 || p->g.H % depth) WT_FAIL("%s: plan height %d is not a multiple of depth %d", who, p->g.H, depth);
     if (s < 0 || s > 20) WT_FAIL("%s: scale %d out of range", who, s);
     return 0;

@@ -86,6 +86,8 @@ struct wt_ctx {
     float *d_psf = nullptr;       // PSF taps of wt_filter2d (<= 4096 floats)
 };
 
+#define WT_MAX_CUSTOM_TAPS 15
+
 struct wt_plan {
     wt_ctx *ctx = nullptr;
     Geo g{};
@@ -102,6 +104,9 @@ struct wt_plan {
     std::vector<void *> raw_allocs;         // what hipFree gets
     size_t skew_floats = 0;
     int n_allocs = 0;
+    // user-defined scaling function (wt_plan_set_taps): odd number of 1-D taps, 0 = built-in family
+    int ntaps = 0;
+    float taps[WT_MAX_CUSTOM_TAPS] = {0};
 };
 
 // Profiling bracket: records events around a kernel launch when ctx->profiling.

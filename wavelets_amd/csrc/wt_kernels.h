@@ -921,6 +921,52 @@ __global__ __launch_bounds__(256) void wt_anscombe_kernel(const float *src, floa
 // ---------------------------------------------------------------------------------------------
 // Richardson-Lucy support (watroo/utils.py:222-290)
 // ---------------------------------------------------------------------------------------------
+// User-defined scaling functions (AbstractScalingFunction subclasses, watroo/wavelets.py:152-229):
+// the separable dilated filter with run-time taps, one pixel per thread, two passes (rows into a
+// scratch plane, then columns + epilogue).  Generic and simple on purpose - the tuned kernels
+// above are specialised to the two built-in families.
+struct CustomTaps {
+    float k[WT_MAX_CUSTOM_TAPS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wt_custom_rows_kernel(const float *in, float *tmp, Geo g, int d,
+                                                             CustomTaps t, int square)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < g.nrows; y += gridDim.y) {
+        const float *row = in + (int64_t)y * g.P;
+        float acc = 0.f;
+        for (int j = 0; j < t.n; ++j) {
+            float v = row[wt_refl_b(x + (j - hw) * d, g.W, d, g.border)];
+            if (square) v *= v;
+            acc = j == 0 ? t.k[0] * v : fmaf(t.k[j], v, acc);
+        }
+        tmp[(int64_t)y * g.P + x] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void wt_custom_cols_kernel(const float *tmp, const float *in, float *out_c,
+                                                             float *out_w, Geo g, int d, CustomTaps t)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < g.nrows; y += gridDim.y) {
+        float acc = 0.f;
+        for (int i = 0; i < t.n; ++i) {
+            const int yy = wt_refl_b(g.row0 + y + (i - hw) * d, g.H, d, g.border) - g.row0;
+            const float v = tmp[(int64_t)yy * g.P + x];
+            acc = i == 0 ? t.k[0] * v : fmaf(t.k[i], v, acc);
+        }
+        const int64_t o = (int64_t)y * g.P + x;
+        if (out_w) out_w[o] = in[o] - acc;
+        out_c[o] = acc;
+    }
+}
+
 // cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with an arbitrary small PSF
 // (watroo/utils.py:257,286): correlation, anchor = kernel centre (k/2), symmetric border.
 // 64 x 16 output tile + halo staged in LDS; the PSF taps are wave-uniform scalar loads.

@@ -243,6 +243,9 @@ def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sd
                 plan.binary("mul", s, s, _SQ_PLANE)
                 plan.smooth3d(_SQ_PLANE, _POW_PLANE, s, coefficients._shape[0])
                 plan.wow_update(s, _POW_PLANE, tau, soft_threshold, noise_plane, factor, gplane)
+            elif whitening and h < 1 and plan.custom:                     # user-defined taps
+                plan.smooth(s, _POW_PLANE, s, True)                       # conv_s(c^2), ref:194
+                plan.wow_update(s, _POW_PLANE, tau, soft_threshold, noise_plane, factor, gplane)
             elif whitening and h < 1:                                     # ref:193-196 + 199-203
                 # local power conv_s(c^2), significance, gamma sum and whitening in one kernel
                 plan.wow_scale(s, s, tau, soft_threshold, noise_plane, factor, gplane)

@@ -127,13 +127,28 @@ class B3spline(AbstractScalingFunction):
         super().__init__('b3spline', *args, **kwargs)
 
 
-def _family_of(scaling_function):
-    """Engine family enum of a scaling-function class or instance."""
+_BUILTIN_TAPS = {_lib.TRIANGLE: np.array([1 / 4, 1 / 2, 1 / 4]),
+                 _lib.B3SPLINE: np.array([1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16])}
+
+
+def _family_of(scaling_function, ndim=2):
+    """Engine family of a scaling-function class or instance: the built-in enum, or - for a
+    user-defined AbstractScalingFunction subclass (ref:152-229) - the tuple of its 1-D taps,
+    which `_lib.Plan` turns into a plan with run-time taps (generic kernels).  The engine
+    correlates like cv2.filter2D (ref:39-45); the reference's 1-D branch is a true convolution
+    (scipy.ndimage.convolve, ref:65-69), so 1-D plans get the taps reversed (a no-op for
+    symmetric taps)."""
+    taps = getattr(scaling_function, "coefficients_1d", None)
+    if taps is None:
+        raise ValueError("scaling function without coefficients_1d")
+    taps = np.asarray(taps, dtype=np.float64).ravel()
     fam = getattr(scaling_function, "_family", None)
-    if fam is None:
-        raise NotImplementedError(
-            "the HIP engine implements the Triangle and B3spline scaling functions only")
-    return fam
+    if fam is not None and np.array_equal(taps, _BUILTIN_TAPS[fam]):   # not a re-tapped subclass
+        return fam
+    if taps.size % 2 == 0 or taps.size > 15:
+        raise NotImplementedError("user-defined scaling functions need an odd number of taps "
+                                  "(at most 15) in the HIP engine")
+    return tuple(float(t) for t in (taps[::-1] if ndim == 1 else taps))
 
 
 def _is_1d(arr):
@@ -190,8 +205,11 @@ def convolution(arr, scaling_function, s=0, output=None):
         img = cube.reshape(cube.shape[0] * cube.shape[1], cube.shape[2])
     else:
         img = _to_f32_row(arr) if one_d else _to_f32_image(arr)
-    plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
-                        _family_of(scaling_function), 0)
+    fam = _family_of(scaling_function, 1 if one_d else 2)
+    if three_d and isinstance(fam, tuple):
+        raise NotImplementedError("3-D convolution with a user-defined scaling function is not "
+                                  "implemented in the HIP engine")
+    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
     try:
         if one_d:
             plan.set_border(2)
@@ -512,7 +530,7 @@ class AtrousTransform:
                                       "algorithm only in the HIP engine")
         row = _to_f32_row(arr)
         scaling_function = self.scaling_function_class(1)
-        plan = acquire_plan(default_context(), 1, row.shape[1], _family_of(scaling_function), level)
+        plan = acquire_plan(default_context(), 1, row.shape[1], _family_of(scaling_function, 1), level)
         plan.set_border(2)
         plan.upload(PLANE_INPUT, row)
         plan.decompose(PLANE_INPUT, level, 0)
@@ -528,7 +546,11 @@ class AtrousTransform:
         cube = np.ascontiguousarray(arr, dtype=np.float32)
         Z, Y, X = cube.shape
         scaling_function = self.scaling_function_class(3)
-        plan = acquire_plan(default_context(), Z * Y, X, _family_of(scaling_function), level)
+        fam = _family_of(scaling_function)
+        if isinstance(fam, tuple):
+            raise NotImplementedError("3-D transforms with a user-defined scaling function are "
+                                      "not implemented in the HIP engine")
+        plan = acquire_plan(default_context(), Z * Y, X, fam, level)
         plan.upload(PLANE_INPUT, cube.reshape(Z * Y, X))
         plan.decompose3d(PLANE_INPUT, level, Z)
         return Coefficients(plan, scaling_function, None, _shape=(Z, Y, X))
@@ -563,6 +585,9 @@ class AtrousTransform:
         return Coefficients(plan, scaling_function, None)
 
     def _run(self, plan, level, src=PLANE_INPUT, flags=FLAG_FUSED):
+        if self.bilateral is not None and plan.custom:
+            raise NotImplementedError("bilateral filtering with a user-defined scaling function "
+                                      "is not implemented in the HIP engine")
         if self.bilateral is None:
             plan.decompose(src, level, flags)                              # ref:432,442
         else:
