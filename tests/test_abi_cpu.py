@@ -88,3 +88,19 @@ def test_scaling_function_objects_match_oracle_constants():
         assert k.sum() == pytest.approx(1.0)
         assert cls(3).kernel.shape == (len(O.TAPS[fam]),) * 3
         assert cls(1).sigma_e(bilateral=1) is None              # ref: 1-D bilateral table absent
+
+
+def test_bench_algorithmic_byte_shares_add_up():
+    """bench.py attributes SURVEY 8(d)'s 64 B/pixel (L = 6) to the launches of a step: the shares
+    of the accumulate passes must add up to 8*(L+2), those of the plain passes to 4*(L+2)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.algorithmic_bytes_per_pixel
+    assert f("wt_fused_acc<d1x3>", 6) + f("wt_fused_sum<d8x3>", 6) == 64
+    assert f("wt_fused<d1x3>", 6) + f("wt_fused<d8x3>", 6) == 32
+    assert f("wt_plane_sum_kernel", 6) == 32
+    # Triangle L = 8: three passes
+    assert f("wt_fused_acc<d1x3>", 8) + f("wt_fused_acc<d8x3>", 8) + f("wt_fused_sum<d64x2>", 8) == 80
+    assert f("wt_fused_sum<d1x3>", 3) == 8 * 5       # single pass, L = 3
