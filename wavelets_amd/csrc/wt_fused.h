@@ -423,9 +423,12 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     double best = 1e300;
     for (int c = 1; c <= 4096 && c <= n_max; ++c) {
         const int Sc = (n_max + c - 1) / c;
-        if (Sc < std::min(n_max, 2 * LAT) && c > 1) break;       // keep warm-up <= ~50 % of a chunk
         const int cc = (n_max + Sc - 1) / Sc;                    // chunks actually needed
         const int64_t rounds = (nbase * cc + slots - 1) / slots;
+        // more than one round: keep the warm-up <= ~50 % of a chunk.  A grid that fits in one
+        // round anyway (small images: the chip is not full) is latency-bound by the steps of
+        // ONE workgroup, so shorter chunks win even if most of their steps are warm-up.
+        if (c > 1 && Sc < std::min(n_max, rounds > 1 ? 2 * LAT : 4)) break;
         if (rounds_env && rounds > rounds_env) break;
         const double cost = (double)rounds * (Sc + 2 * LAT + 8);
         if (cost < best) { best = cost; chunks = cc; S = Sc; }
