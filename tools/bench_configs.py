@@ -35,6 +35,10 @@ def profile(label, fn, npix, reps=3):
 def main():
     which = sys.argv[1:] or ["2", "3", "5"]
     rng = np.random.default_rng(0)
+    if "1" in which:
+        a = rng.standard_normal((512, 512), dtype=np.float32)
+        profile("cfg1 512^2 B3 L=4 denoise([5,3]) (README example)", lambda: W.denoise(a, [5, 3, 0, 0]), a.size, reps=20)
+        profile("cfg1' 512^2 denoise(a, [5,3]) (2 scales)", lambda: W.denoise(a, [5, 3]), a.size, reps=20)
     if "2" in which:
         a = rng.standard_normal((4096, 4096), dtype=np.float32)
         profile("cfg2 4096^2 B3 L=6 decompose+sum", lambda: W.AtrousTransform(W.B3spline)(a, 6).sum(axis=0), a.size)
