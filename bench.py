@@ -114,6 +114,16 @@ def main():
                          "with one rank (plumbing check on a 1-GPU box)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line (rank 0).  Native libraries print banners on fd 1
+    # (gloo: "[Gloo] Rank 0 is connected ...", RCCL: ROCm version / hostname / library path), so
+    # fd 1 points to stderr for the whole run and the result goes out through the saved fd.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(result_fd, (line + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -291,10 +301,10 @@ def main():
             if not args.no_cpu and not args.brief:
                 out["cpu_baseline"] = cpu_baseline()
         if args.brief:
-            print(f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
-                f"{k}={v['avg_ms']}" for k, v in kernels.items()), flush=True)
+            emit(f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
+                f"{k}={v['avg_ms']}" for k, v in kernels.items()))
         else:
-            print(json.dumps(out), flush=True)
+            emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
