@@ -104,3 +104,26 @@ def test_bench_algorithmic_byte_shares_add_up():
     # Triangle L = 8: three passes
     assert f("wt_fused_acc<d1x3>", 8) + f("wt_fused_acc<d8x3>", 8) + f("wt_fused_sum<d64x2>", 8) == 80
     assert f("wt_fused_sum<d1x3>", 3) == 8 * 5       # single pass, L = 3
+
+
+def _build_abi_demo():
+    import subprocess
+    import __graft_entry__ as entry
+    entry.build()
+    exe = os.path.join(ROOT, "examples", "abi_demo")
+    libdir = os.path.join(ROOT, "wavelets_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "abi_demo.c"), "-o", exe, "-L" + libdir,
+                           "-lwatroo_hip", "-Wl,-rpath," + libdir, "-lm"])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links():
+    """include/watroo_hip.h compiles as C (gcc, -Wall -Werror) and a C client links against the
+    shared library; without a GPU it must fail loudly (exit code 3, 'no HIP device')."""
+    import subprocess
+    exe = _build_abi_demo()
+    r = subprocess.run([exe, "64", "80", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode in (0, 3), r.stdout + r.stderr
+    if r.returncode == 3:
+        assert "no HIP device" in r.stderr

@@ -908,3 +908,14 @@ def test_custom_scaling_function_vs_golden(W, name):
         W.AtrousTransform(Custom, bilateral=1)(a, 2)
     with pytest.raises(NotImplementedError):
         W.AtrousTransform(Custom)(np.zeros((4, 5, 6), np.float32), 1)
+
+
+def test_plain_c_client_of_the_abi():
+    """examples/abi_demo.c: a C program (no Python, no HIP headers) drives the hot path through
+    include/watroo_hip.h and checks reconstruction, carried sum == plane sum, MAD denoise."""
+    import subprocess
+    from test_abi_cpu import _build_abi_demo
+    exe = _build_abi_demo()
+    for args in (["600", "900", "6"], ["37", "53", "3"], ["1024", "2048", "5"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "abi_demo: OK" in r.stdout, r.stdout + r.stderr
