@@ -919,3 +919,35 @@ def test_plain_c_client_of_the_abi():
     for args in (["600", "900", "6"], ["37", "53", "3"], ["1024", "2048", "5"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "abi_demo: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_concurrent_host_threads_share_the_default_context(W):
+    """ctypes releases the GIL during calls; entry points serialise per context (wt_ctx::mu), so
+    several host threads may use the default context at once."""
+    import threading
+    # pairs of equal shapes: the threads also contend for the same pooled plans
+    imgs = [rnd((300 + 40 * (i // 2), 500 + 30 * (i // 2)), 200 + i) for i in range(6)]
+    serial = [W.denoise(a, [5, 3, 2]) for a in imgs]
+    wows = [W.wow(a, denoise_coefficients=[5, 2])[0] for a in imgs[:3]]
+    out, errs = [None] * len(imgs), []
+    wout = [None] * 3
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = W.denoise(imgs[i], [5, 3, 2])
+                if i < 3:
+                    wout[i] = W.wow(imgs[i], denoise_coefficients=[5, 2])[0]
+        except Exception as e:          # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(imgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for a, b in zip(out, serial):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(wout, wows):
+        np.testing.assert_array_equal(a, b)

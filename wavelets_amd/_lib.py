@@ -246,9 +246,13 @@ def default_context(device=None):
     """Process-wide context (device from WATROO_HIP_DEVICE, default 0)."""
     if device is None:
         device = int(os.environ.get("WATROO_HIP_DEVICE", "0"))
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        with _pool_lock:
+            ctx = _default_ctx.get(device)
+            if ctx is None:
+                ctx = _default_ctx[device] = Context(device)
+    return ctx
 
 
 def schedule(family, level, fused=True):
@@ -540,14 +544,18 @@ def _plan_bytes(plan):
     return (plan.nrows + 2 * plan.halo) * plan.pitch * 4 * (plan.max_level + 1 + 2 + 4)
 
 
+_pool_lock = threading.RLock()      # plan pool and default contexts are shared by host threads
+
+
 def acquire_plan(ctx, H, W, family, max_level):
     """A whole-image plan for (H, W, family, max_level): pooled if available, else new."""
     key = (id(ctx), H, W, family, max_level)
-    for i in range(len(_pool) - 1, -1, -1):
-        if _pool[i][0] == key:
-            plan = _pool.pop(i)[1]
-            plan.set_border(0)
-            return plan
+    with _pool_lock:
+        for i in range(len(_pool) - 1, -1, -1):
+            if _pool[i][0] == key:
+                plan = _pool.pop(i)[1]
+                plan.set_border(0)
+                return plan
     return Plan(ctx, H, W, family, max_level)
 
 
@@ -555,9 +563,13 @@ def release_plan(plan):
     """Hand a plan back for reuse (its planes keep stale data; callers re-upload)."""
     if plan is None or not plan._h or plan.nranks != 1:
         return
-    _pool.append(((id(plan.ctx), plan.H, plan.W, plan.family, plan.max_level), plan))
-    total = sum(_plan_bytes(p) for _, p in _pool)
-    while _pool and (total > _POOL_MAX_BYTES or len(_pool) > 8):
-        _, old = _pool.pop(0)
-        total -= _plan_bytes(old)
+    evicted = []
+    with _pool_lock:
+        _pool.append(((id(plan.ctx), plan.H, plan.W, plan.family, plan.max_level), plan))
+        total = sum(_plan_bytes(p) for _, p in _pool)
+        while _pool and (total > _POOL_MAX_BYTES or len(_pool) > 8):
+            _, old = _pool.pop(0)
+            total -= _plan_bytes(old)
+            evicted.append(old)
+    for old in evicted:
         old.close()

@@ -24,6 +24,28 @@ void wt_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *wt_last_error(void) { return g_err; }
+
+// Per-context serialisation of the entry points (see wt_ctx::mu).  Two-plan operations lock both
+// contexts in address order.
+struct WtGuard {
+    std::recursive_mutex *a = nullptr, *b = nullptr;
+    explicit WtGuard(wt_ctx *c, wt_ctx *d = nullptr)
+    {
+        if (c == d) d = nullptr;
+        if (c && d && d < c) std::swap(c, d);
+        if (c) { a = &c->mu; a->lock(); }
+        if (d) { b = &d->mu; b->lock(); }
+    }
+    ~WtGuard()
+    {
+        if (b) b->unlock();
+        if (a) a->unlock();
+    }
+    WtGuard(const WtGuard &) = delete;
+    WtGuard &operator=(const WtGuard &) = delete;
+};
+static inline wt_ctx *ctx_of(wt_plan *p) { return p ? p->ctx : nullptr; }
+static inline wt_ctx *ctx_of(wt_ctx *c) { return c; }
 extern "C" int wt_abi_version(void) { return WT_ABI_VERSION; }
 
 extern "C" int wt_device_count(int *count)
@@ -119,6 +141,8 @@ enum { NCCL_SUM = 0, NCCL_MAX = 2, NCCL_MIN = 3 };
 
 static int rccl_load()
 {
+    static std::mutex load_mu;
+    std::lock_guard<std::mutex> lk(load_mu);
     if (g_rccl.h) return 0;
     void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -162,6 +186,7 @@ extern "C" int wt_comm_unique_id(void *id128)
 
 extern "C" int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *id128)
 {
+    WtGuard guard_(ctx_of(ctx));
     if (!ctx || !id128) WT_FAIL("wt_ctx_comm_init: null pointer");
     if (nranks < 1 || rank < 0 || rank >= nranks) WT_FAIL("wt_ctx_comm_init: bad rank %d/%d", rank, nranks);
     if (ctx->comm) WT_FAIL("wt_ctx_comm_init: communicator already initialised");
@@ -227,6 +252,7 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
 
 extern "C" int wt_ctx_sync(wt_ctx *c)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c) WT_FAIL("wt_ctx_sync: null context");
     WT_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -234,6 +260,7 @@ extern "C" int wt_ctx_sync(wt_ctx *c)
 
 extern "C" int wt_timer_start(wt_ctx *c)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c) WT_FAIL("wt_timer_start: null context");
     WT_HIP(hipEventRecord(c->t0, c->stream));
     return 0;
@@ -241,6 +268,7 @@ extern "C" int wt_timer_start(wt_ctx *c)
 
 extern "C" int wt_timer_stop(wt_ctx *c, float *ms)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c || !ms) WT_FAIL("wt_timer_stop: null pointer");
     WT_HIP(hipEventRecord(c->t1, c->stream));
     WT_HIP(hipEventSynchronize(c->t1));
@@ -250,6 +278,7 @@ extern "C" int wt_timer_stop(wt_ctx *c, float *ms)
 
 extern "C" int wt_profile_enable(wt_ctx *c, int on)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c) WT_FAIL("wt_profile_enable: null context");
     WT_TRY(prof_resolve(c));
     c->profiling = on != 0;
@@ -258,6 +287,7 @@ extern "C" int wt_profile_enable(wt_ctx *c, int on)
 
 extern "C" int wt_profile_reset(wt_ctx *c)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c) WT_FAIL("wt_profile_reset: null context");
     WT_TRY(prof_resolve(c));
     c->prof.clear();
@@ -267,6 +297,7 @@ extern "C" int wt_profile_reset(wt_ctx *c)
 
 extern "C" int wt_profile_count(wt_ctx *c, int *n)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c || !n) WT_FAIL("wt_profile_count: null pointer");
     WT_TRY(prof_resolve(c));
     *n = (int)c->prof_order.size();
@@ -275,6 +306,7 @@ extern "C" int wt_profile_count(wt_ctx *c, int *n)
 
 extern "C" int wt_profile_entry(wt_ctx *c, int i, char *name64, int64_t *calls, double *total_ms)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c || !name64 || !calls || !total_ms) WT_FAIL("wt_profile_entry: null pointer");
     WT_TRY(prof_resolve(c));
     if (i < 0 || i >= (int)c->prof_order.size()) WT_FAIL("wt_profile_entry: index %d out of range", i);
@@ -343,6 +375,7 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
                                     int64_t row0, int64_t nrows, int64_t halo_rows, int rank,
                                     int nranks, wt_plan **out)
 {
+    WtGuard guard_(ctx_of(ctx));
     if (!ctx || !out) WT_FAIL("wt_plan_create: null pointer");
     if (family != WT_TRIANGLE && family != WT_B3SPLINE) WT_FAIL("wt_plan_create: unknown family %d", family);
     if (H < 1 || W < 1 || H > (1 << 30) || W > (1 << 30)) WT_FAIL("wt_plan_create: bad image size %lld x %lld", (long long)H, (long long)W);
@@ -394,11 +427,13 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
 
 extern "C" int wt_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level, wt_plan **out)
 {
+    WtGuard guard_(ctx_of(ctx));
     return wt_plan_create_strip(ctx, H, W, family, max_level, 0, H, 0, 0, 1, out);
 }
 
 extern "C" int wt_plan_destroy(wt_plan *p)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) return 0;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
@@ -409,6 +444,7 @@ extern "C" int wt_plan_destroy(wt_plan *p)
 
 extern "C" int wt_plan_info(wt_plan *p, int64_t out[8])
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !out) WT_FAIL("wt_plan_info: null pointer");
     out[0] = p->g.H; out[1] = p->g.W; out[2] = p->g.P; out[3] = p->g.row0;
     out[4] = p->g.nrows; out[5] = p->g.halo; out[6] = p->max_level; out[7] = p->family;
@@ -417,6 +453,7 @@ extern "C" int wt_plan_info(wt_plan *p, int64_t out[8])
 
 extern "C" int wt_plan_set_border(wt_plan *p, int border)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_plan_set_border: null plan");
     if (border < 0 || border > 2) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
     if (border && p->nranks > 1) WT_FAIL("wt_plan_set_border: non-default borders are single-GPU only");
@@ -427,6 +464,7 @@ extern "C" int wt_plan_set_border(wt_plan *p, int border)
 // dst_plane of `dst` <- the dst-sized window of src_plane of `src` starting at (y0, x0)
 extern "C" int wt_plan_set_taps(wt_plan *p, const float *taps, int ntaps)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_plan_set_taps: null plan");
     if (ntaps == 0) { p->ntaps = 0; return 0; }
     if (!taps) WT_FAIL("wt_plan_set_taps: null taps");
@@ -460,6 +498,7 @@ static int launch_custom(wt_plan *p, const float *in, float *out_c, float *out_w
 
 extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0, int64_t x0)
 {
+    WtGuard guard_(ctx_of(src), ctx_of(dst));
     if (!src || !dst) WT_FAIL("wt_crop_plane: null plan");
     if (src->ctx->device != dst->ctx->device) WT_FAIL("wt_crop_plane: plans on different devices");
     if (y0 < 0 || x0 < 0 || y0 + dst->g.nrows > src->g.nrows || x0 + dst->g.W > src->g.W)
@@ -475,6 +514,7 @@ extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_
 
 extern "C" int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0, int64_t x0)
 {
+    WtGuard guard_(ctx_of(src), ctx_of(dst));
     if (!src || !dst) WT_FAIL("wt_paste_plane: null plan");
     if (src->ctx->device != dst->ctx->device) WT_FAIL("wt_paste_plane: plans on different devices");
     if (y0 < 0 || x0 < 0 || y0 + src->g.nrows > dst->g.nrows || x0 + src->g.W > dst->g.W)
@@ -490,6 +530,7 @@ extern "C" int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst
 
 extern "C" int wt_plane_ptr(wt_plan *p, int plane, void **dev_ptr)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !dev_ptr) WT_FAIL("wt_plane_ptr: null pointer");
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
@@ -522,6 +563,7 @@ static bool try_pin(const void *host, size_t bytes)
 
 extern "C" int wt_host_alloc(wt_ctx *c, size_t bytes, void **host_ptr)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c || !host_ptr) WT_FAIL("wt_host_alloc: null pointer");
     if (bytes == 0) WT_FAIL("wt_host_alloc: zero bytes");
     *host_ptr = nullptr;
@@ -539,6 +581,7 @@ extern "C" int wt_host_free(void *host_ptr)
 
 extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_stride)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !host) WT_FAIL("wt_upload: null pointer");
     if (host_stride < p->g.W) WT_FAIL("wt_upload: host stride %lld < width %d", (long long)host_stride, p->g.W);
     float *b = nullptr;
@@ -555,6 +598,7 @@ extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_
 
 extern "C" int wt_download(wt_plan *p, int plane, float *host, int64_t host_stride)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !host) WT_FAIL("wt_download: null pointer");
     if (host_stride < p->g.W) WT_FAIL("wt_download: host stride %lld < width %d", (long long)host_stride, p->g.W);
     float *b = nullptr;
@@ -574,6 +618,7 @@ static inline int flat_grid(int64_t n4) { return (int)std::min<int64_t>((n4 + 25
 
 extern "C" int wt_copy_plane(wt_plan *p, int src, int dst)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_copy_plane: null plan");
     float *s = nullptr, *d = nullptr;
     WT_TRY(plane_base(p, src, &s));
@@ -585,6 +630,7 @@ extern "C" int wt_copy_plane(wt_plan *p, int src, int dst)
 
 extern "C" int wt_fill_plane(wt_plan *p, int plane, float value)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_fill_plane: null plan");
     float *d = nullptr;
     WT_TRY(plane_base(p, plane, &d));
@@ -600,6 +646,7 @@ extern "C" int wt_fill_plane(wt_plan *p, int plane, float value)
 // =============================================================================================
 extern "C" int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane, int64_t rows)
 {
+    WtGuard guard_(ctx_of(upper), ctx_of(lower));
     if (!upper || !lower) WT_FAIL("wt_halo_exchange_local: null plan");
     if (rows == 0) return 0;
     if (upper->g.P != lower->g.P || upper->g.row0 + upper->g.nrows != lower->g.row0)
@@ -620,6 +667,7 @@ extern "C" int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane,
 
 extern "C" int wt_halo_exchange(wt_plan *p, int plane, int64_t rows)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_halo_exchange: null plan");
     if (p->nranks == 1 || rows == 0) return 0;
     wt_ctx *c = p->ctx;
@@ -647,6 +695,7 @@ extern "C" int wt_halo_exchange(wt_plan *p, int plane, int64_t rows)
 
 extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
 {
+    WtGuard guard_(ctx_of(c));
     if (!c || !ok) WT_FAIL("wt_comm_selftest: null pointer");
     if (!c->comm) WT_FAIL("wt_comm_selftest: no communicator");
     if (nfloats < 1) WT_FAIL("wt_comm_selftest: nfloats must be positive");
@@ -861,6 +910,7 @@ static inline int64_t scale_halo(const wt_plan *p, int s) { return (int64_t)(fam
 
 extern "C" int wt_atrous_scale(wt_plan *p, int src, int dst_c, int dst_w, int s, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_atrous_scale: null plan");
     WT_TRY(check_scale(p, s, "wt_atrous_scale"));
     if (src == dst_c || src == dst_w || dst_c == dst_w) WT_FAIL("wt_atrous_scale: planes must be distinct");
@@ -874,6 +924,7 @@ extern "C" int wt_atrous_scale(wt_plan *p, int src, int dst_c, int dst_w, int s,
 
 extern "C" int wt_smooth(wt_plan *p, int src, int dst, int s, int square_input, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_smooth: null plan");
     WT_TRY(check_scale(p, s, "wt_smooth"));
     if (src == dst) WT_FAIL("wt_smooth: src and dst must differ");
@@ -887,6 +938,7 @@ extern "C" int wt_smooth(wt_plan *p, int src, int dst, int s, int square_input, 
 
 extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, float f2, int take_sqrt, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_local_variance: null plan");
     WT_TRY(check_scale(p, s, "wt_local_variance"));
     if (src == dst) WT_FAIL("wt_local_variance: src and dst must differ");
@@ -920,6 +972,7 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
 
 extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_bilateral_conv: null plan");
     WT_TRY(check_scale(p, s, "wt_bilateral_conv"));
     if (src == dst || var == dst) WT_FAIL("wt_bilateral_conv: dst must differ from src and var");
@@ -970,12 +1023,14 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
 
 extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     return decompose_pass_impl(p, cur, nxt, s0, ns, flags, 0, false, WT_PLANE_NONE);
 }
 
 extern "C" int wt_decompose_pass_sum(wt_plan *p, int cur, int nxt, int s0, int ns, int flags, int sum_plane, int first,
                                      int last)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_decompose_pass_sum: null plan");
     if (!wt_fused_has_pass(s0, ns)) WT_FAIL("wt_decompose_pass_sum: no fused kernel for first scale %d x %d scales", s0, ns);
     if (sum_plane == cur || sum_plane == nxt || (sum_plane >= s0 && sum_plane < s0 + ns))
@@ -988,6 +1043,7 @@ extern "C" int wt_decompose_pass_sum(wt_plan *p, int cur, int nxt, int s0, int n
 // the L+1 planes).  Bit-identical to wt_decompose followed by wt_plane_sum (same plane order).
 extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_decompose_sum: null plan");
     if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose_sum: level %d exceeds plan max_level %d", level, p->max_level);
     if (src >= 0 && src <= level) WT_FAIL("wt_decompose_sum: src plane %d is one of the output planes", src);
@@ -1019,6 +1075,7 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
 
 extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_decompose: null plan");
     if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose: level %d exceeds plan max_level %d", level, p->max_level);
     if (src >= 0 && src <= level) WT_FAIL("wt_decompose: src plane %d is one of the output planes", src);
@@ -1040,6 +1097,7 @@ extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
 
 extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const double *sigma_b, int bilateral_scaling, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !sigma_b) WT_FAIL("wt_decompose_bilateral: null pointer");
     if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose_bilateral: level %d exceeds plan max_level %d", level, p->max_level);
     if (src >= 0 && src <= level) WT_FAIL("wt_decompose_bilateral: src plane %d is one of the output planes", src);
@@ -1074,6 +1132,7 @@ extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const doub
 // =============================================================================================
 extern "C" int wt_plane_sum(wt_plan *p, int first, int count, int dst)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_plane_sum: null plan");
     if (count < 1 || count > WT_MAX_SUM_PLANES) WT_FAIL("wt_plane_sum: count %d out of range [1,%d]", count, WT_MAX_SUM_PLANES);
     if (first < 0 || first + count - 1 > p->max_level) WT_FAIL("wt_plane_sum: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
@@ -1100,6 +1159,7 @@ static int noise_ptr(wt_plan *p, int noise_plane, float **np_);
 extern "C" int wt_denoise_sum(wt_plan *p, int first, int count, int dst, int n_den, const double *tau,
                               const double *wgt, int soft, int noise_plane, int write_back)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_denoise_sum: null plan");
     if (count < 1 || count > WT_MAX_SUM_PLANES) WT_FAIL("wt_denoise_sum: count %d out of range [1,%d]", count, WT_MAX_SUM_PLANES);
     if (first < 0 || first + count - 1 > p->max_level) WT_FAIL("wt_denoise_sum: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
@@ -1133,6 +1193,7 @@ static int noise_ptr(wt_plan *p, int noise_plane, float **np_)
 
 extern "C" int wt_significance(wt_plan *p, int plane, int dst, double tau, int soft, int noise_plane)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_significance: null plan");
     if (!(tau > 0.0)) WT_FAIL("wt_significance: tau must be positive (the sigma==0 / noise==0 short-circuits of wavelets.py:130-143 are host-side)");
     float *c = nullptr, *d = nullptr, *nz = nullptr;
@@ -1148,6 +1209,7 @@ extern "C" int wt_significance(wt_plan *p, int plane, int dst, double tau, int s
 
 extern "C" int wt_denoise(wt_plan *p, int plane, double tau, double wgt, int soft, int noise_plane)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_denoise: null plan");
     if (!(tau > 0.0)) WT_FAIL("wt_denoise: tau must be positive");
     float *c = nullptr, *nz = nullptr;
@@ -1162,6 +1224,7 @@ extern "C" int wt_denoise(wt_plan *p, int plane, double tau, double wgt, int sof
 
 extern "C" int wt_wow_update(wt_plan *p, int plane, int power_plane, double tau, int soft, int noise_plane, float factor, int gamma_plane)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_wow_update: null plan");
     float *c = nullptr, *pw = nullptr, *nz = nullptr, *gm = nullptr;
     WT_TRY(plane_base(p, plane, &c));
@@ -1182,6 +1245,7 @@ extern "C" int wt_wow_update(wt_plan *p, int plane, int power_plane, double tau,
 extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, int noise_plane,
                             float factor, int gamma_plane, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_wow_scale: null plan");
     if (plane < 0 || plane > p->max_level) WT_FAIL("wt_wow_scale: plane %d is not a coefficient plane", plane);
     WT_TRY(check_scale(p, s, "wt_wow_scale"));
@@ -1202,6 +1266,7 @@ extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, 
 
 extern "C" int wt_gamma_blend(wt_plan *p, int recon, int gamma_plane, float gmin, float gmax, float inv_gamma, float h)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_gamma_blend: null plan");
     float *r = nullptr, *g = nullptr;
     WT_TRY(plane_base(p, recon, &r));
@@ -1215,6 +1280,7 @@ extern "C" int wt_gamma_blend(wt_plan *p, int recon, int gamma_plane, float gmin
 
 extern "C" int wt_anscombe(wt_plan *p, int src, int dst, float alpha, float g, float sigma, int inverse)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_anscombe: null plan");
     if (alpha == 0.f) WT_FAIL("wt_anscombe: alpha must be non-zero");
     float *s = nullptr, *d = nullptr;
@@ -1271,6 +1337,7 @@ static int check3d(const wt_plan *p, int depth, int s, const char *who)
 
 extern "C" int wt_smooth3d(wt_plan *p, int src, int dst, int s, int depth)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_smooth3d: null plan");
     WT_TRY(check3d(p, depth, s, "wt_smooth3d"));
     const int tmpid = WT_PLANE_SCRATCH(15);
@@ -1284,6 +1351,7 @@ extern "C" int wt_smooth3d(wt_plan *p, int src, int dst, int s, int depth)
 
 extern "C" int wt_decompose3d(wt_plan *p, int src, int level, int depth)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_decompose3d: null plan");
     WT_TRY(check3d(p, depth, 0, "wt_decompose3d"));
     if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose3d: level %d exceeds plan max_level %d", level, p->max_level);
@@ -1310,6 +1378,7 @@ extern "C" int wt_decompose3d(wt_plan *p, int src, int level, int depth)
 extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int ay, int ax,
                              int border, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !kernel) WT_FAIL("wt_filter2d: null pointer");
     if (kh < 1 || kw < 1 || kh * kw > 4096) WT_FAIL("wt_filter2d: kernel %d x %d unsupported (<= 4096 taps)", kh, kw);
     if (ay < 0 || ay >= kh || ax < 0 || ax >= kw) WT_FAIL("wt_filter2d: anchor (%d, %d) outside the %d x %d kernel", ay, ax, kh, kw);
@@ -1348,11 +1417,13 @@ extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel,
 
 extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int flags)
 {
+    WtGuard guard_(ctx_of(p));
     return wt_filter2d_ex(p, src, dst, kernel, kh, kw, kh / 2, kw / 2, WT_BORDER_SYMMETRIC, flags);
 }
 
 extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_binary: null plan");
     if (op < 0 || op > WT_OP_ADD_DIV) WT_FAIL("wt_binary: unknown op %d", op);
     float *pa = nullptr, *pb = nullptr, *pd = nullptr;
@@ -1369,6 +1440,7 @@ extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst)
 extern "C" int wt_mrs_update(wt_plan *p, int plane, int mrs_plane, double tau, int soft, int noise_plane,
                              int persistent, float inv_pow)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_mrs_update: null plan");
     if (plane == mrs_plane) WT_FAIL("wt_mrs_update: plane and mrs_plane must differ");
     float *c = nullptr, *m = nullptr, *nz = nullptr;
@@ -1387,6 +1459,7 @@ extern "C" int wt_mrs_update(wt_plan *p, int plane, int mrs_plane, double tau, i
 // =============================================================================================
 extern "C" int wt_reduce(wt_plan *p, int plane, double out[4])
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !out) WT_FAIL("wt_reduce: null pointer");
     wt_ctx *c = p->ctx;
     float *b = nullptr;
@@ -1446,6 +1519,7 @@ static int select_pass(wt_plan *p, const float *b, uint32_t prefix_mask, uint32_
 
 extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
 {
+    WtGuard guard_(ctx_of(p));
     if (!p || !median) WT_FAIL("wt_abs_median: null pointer");
     wt_ctx *c = p->ctx;
     float *b = nullptr;

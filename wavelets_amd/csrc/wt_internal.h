@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +68,9 @@ struct PendingEvent {
 };
 
 struct wt_ctx {
+    // entry points that use this context (its stream, scratch buffers, plans) take this lock:
+    // calls from several host threads are serialised per context (ctypes releases the GIL)
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
