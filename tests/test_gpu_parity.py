@@ -6,6 +6,8 @@ Tolerances (fp32; SURVEY.md section 7 "Tolerance statement"):
   wow       rtol 1e-4 (+ atol 1e-4 * max|ref|)   whitening divides by local power
   bit-exact: plane sum, Anscombe, exact median, hard threshold given identical planes
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -951,3 +953,20 @@ def test_concurrent_host_threads_share_the_default_context(W):
         np.testing.assert_array_equal(a, b)
     for a, b in zip(wout, wows):
         np.testing.assert_array_equal(a, b)
+
+
+def test_integration_md_stub_runs(O):
+    """The ctypes stub INTEGRATION.md proposes for a watroo maintainer (section B) is executed
+    as written (only the library path is made absolute) and checked against the oracle."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "watroo/_hip.py" in b)
+    from wavelets_amd._lib import LIB_PATH
+    block = block.replace('ctypes.CDLL("libwatroo_hip.so")', f'ctypes.CDLL({LIB_PATH!r})')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:_hip.py", "exec"), ns)
+    a = rnd((120, 200), 77)
+    planes = ns["atrous_standard"](a, 4, "b3spline")
+    close(planes, O.atrous_standard(a, 4, "b3spline"), 1e-5 * np.abs(a).max())
+    close(ns["convolution"](a, "triangle", 2), O.convolution(a, "triangle", 2), 1e-5 * np.abs(a).max())
