@@ -79,7 +79,13 @@ class AbstractScalingFunction:
             size = (len(self.sigma_e_1d) * 2 ** n_scales,) * self.n_dim
             data = np.random.normal(size=size).astype(np.float32)
             coefficients = transform(data, n_scales)
-            std += coefficients.data[:-1].std(axis=tuple(range(1, self.n_dim + 1)))
+            # per-plane standard deviation from the device-side fp64 moments (wt_reduce): the
+            # planes are not downloaded
+            plan = coefficients._device()
+            npix = float(plan.H) * float(plan.W)
+            for s in range(n_scales):
+                tot, tot2, _, _ = plan.reduce(s)
+                std[s] += np.sqrt(max(tot2 / npix - (tot / npix) ** 2, 0.0))
         return std / n_trials
 
 
