@@ -219,6 +219,12 @@ int wt_gamma_blend(wt_plan *plan, int recon, int gamma_plane, float gmin, float 
 int wt_smooth3d(wt_plan *plan, int src, int dst, int s, int depth);
 /* atrous_standard on the cube: planes[0..level-1] <- detail, planes[level] <- smooth. */
 int wt_decompose3d(wt_plan *plan, int src, int level, int depth);
+/* bilateral transform of cubes, one scale at a time (watroo/wavelets.py:433-440 on 3-D input):
+ * wt_local_variance3d = sdev_loc(cube, variance=True) * f1 * f2 (3-D smoothing of I and I^2,
+ * scratch planes 13-15); wt_bilateral3d_conv = atrous_convolution with the K^3 kernel and that
+ * variance (watroo/wavelets.py:74-105).  The detail plane is wt_binary(SUB). */
+int wt_local_variance3d(wt_plan *plan, int src, int dst, int s, int depth, float f1, float f2);
+int wt_bilateral3d_conv(wt_plan *plan, int src, int var, int dst, int s, int depth);
 
 /* ---- Richardson-Lucy support (watroo/utils.py:222-290) -------------- */
 /* cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with a small arbitrary kernel

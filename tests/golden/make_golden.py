@@ -383,6 +383,26 @@ def g15_custom_scaling_function():
     save("g15_custom", "1-D: hard; 2-D: semantic(cv2 stand-in)", **out)
 
 
+def g16_bilateral_nd():
+    """Bilateral transforms of 1-D signals and 3-D cubes (atrous_convolution is ndim-generic)."""
+    out = {}
+    sig = img((300,), 81) + 3 * np.sin(np.arange(300, dtype=np.float32) / 9.)
+    cube = img((10, 18, 22), 82) + np.linspace(0, 4, 22, dtype=np.float32)[None, None, :]
+    out["sig"], out["cube"] = sig.astype(np.float32), cube.astype(np.float32)
+    for tag, arr in (("sig", out["sig"]), ("cube", out["cube"])):
+        for fam, cls in FAM.items():
+            out[f"{tag}_{fam}_b1_L3"] = AtrousTransform(cls, bilateral=1)(arr, 3).data
+            out[f"{tag}_{fam}_blist_scaling_L2"] = AtrousTransform(
+                cls, bilateral=[2.0, 0.7], bilateral_scaling=True)(arr, 2).data
+    c = AtrousTransform(B3spline, bilateral=1)(out["cube"], 2)
+    out["cube_bilateral_noise"] = np.float64(c.get_noise())
+    c.denoise([4, 2])
+    out["cube_bilateral_den"] = c.data
+    r, cc = wow(out["cube"].copy(), bilateral=1, n_scales=2, denoise_coefficients=[4, 2])
+    out["cube_wow_bilateral"] = r
+    save("g16_bilateral_nd", "1-D: hard (numpy + scipy mirror); 3-D: semantic(cv2 stand-in)", **out)
+
+
 def g10_enhance():
     """utils.enhance (importable by path, not in __all__)."""
     from watroo.utils import enhance

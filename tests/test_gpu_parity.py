@@ -970,3 +970,25 @@ def test_integration_md_stub_runs(O):
     planes = ns["atrous_standard"](a, 4, "b3spline")
     close(planes, O.atrous_standard(a, 4, "b3spline"), 1e-5 * np.abs(a).max())
     close(ns["convolution"](a, "triangle", 2), O.convolution(a, "triangle", 2), 1e-5 * np.abs(a).max())
+
+
+@pytest.mark.parametrize("tag", ["sig", "cube"])
+def test_bilateral_nd_vs_golden(W, tag):
+    """Bilateral transforms of 1-D signals (2-D kernels on a 1 x N image, variance under the
+    'mirror' border) and of cubes (wt_local_variance3d + wt_bilateral3d_conv)."""
+    g = load_golden("g16_bilateral_nd")
+    a = g[tag]
+    tol = 2e-5 * np.abs(a).max()
+    for fam in FAMS:
+        c = W.AtrousTransform(cls_of(W, fam), bilateral=1)(a, 3)
+        assert c.data.shape == (4,) + a.shape
+        close(c.data, g[f"{tag}_{fam}_b1_L3"], tol)
+        c = W.AtrousTransform(cls_of(W, fam), bilateral=[2.0, 0.7], bilateral_scaling=True)(a, 2)
+        close(c.data, g[f"{tag}_{fam}_blist_scaling_L2"], tol)
+    if tag == "cube":
+        c = W.AtrousTransform(W.B3spline, bilateral=1)(a, 2)
+        np.testing.assert_allclose(c.get_noise(), float(g["cube_bilateral_noise"]), rtol=1e-4)
+        c.denoise([4, 2])
+        close(c.data, g["cube_bilateral_den"], tol)
+        r, _ = W.wow(a.copy(), bilateral=1, n_scales=2, denoise_coefficients=[4, 2])
+        close(r, g["cube_wow_bilateral"], 5e-5 * np.abs(g["cube_wow_bilateral"]).max())

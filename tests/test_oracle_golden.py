@@ -362,3 +362,14 @@ def test_custom_scaling_function_vs_reference(name):
     r, c = O.wow(a.copy(), fam, denoise_coefficients=[5, 2], n_scales=3)
     close(r, g[f"{name}_wow"], 2e-5 * np.abs(g[f"{name}_wow"]).max())
     close(O.atrous_recursive(a, 3, fam), g[f"{name}_rec_L3"], tol)
+
+
+@pytest.mark.parametrize("tag", ["sig", "cube"])
+def test_bilateral_nd_vs_reference(tag):
+    """bilateral transforms of 1-D signals and cubes (atrous_convolution is ndim-generic)."""
+    g = load_golden("g16_bilateral_nd")
+    a = g[tag]
+    tol = 1e-5 * np.abs(a).max()
+    for fam in FAMS:
+        close(O.atrous_standard_nd(a, 3, fam, 1), g[f"{tag}_{fam}_b1_L3"], tol)
+        close(O.atrous_standard_nd(a, 2, fam, [2.0, 0.7], True), g[f"{tag}_{fam}_blist_scaling_L2"], tol)

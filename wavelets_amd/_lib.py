@@ -100,6 +100,8 @@ SIGNATURES = {
                                   _c.c_float]),
     "wt_smooth3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_local_variance3d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
+    "wt_bilateral3d_conv": (_c.c_int, [_vp] + [_c.c_int] * 5),
     "wt_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp, _c.c_int, _c.c_int, _c.c_int]),
     "wt_filter2d_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp] + [_c.c_int] * 6),
     "wt_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -508,6 +510,12 @@ class Plan:
 
     def smooth3d(self, src, dst, s, depth):
         check(load().wt_smooth3d(self._h, src, dst, s, depth))
+
+    def local_variance3d(self, src, dst, s, depth, f1=1.0, f2=1.0):
+        check(load().wt_local_variance3d(self._h, src, dst, s, depth, f1, f2))
+
+    def bilateral3d_conv(self, src, var, dst, s, depth):
+        check(load().wt_bilateral3d_conv(self._h, src, var, dst, s, depth))
 
     def decompose3d(self, src, level, depth):
         check(load().wt_decompose3d(self._h, src, level, depth))

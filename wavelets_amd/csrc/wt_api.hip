@@ -1349,6 +1349,56 @@ extern "C" int wt_smooth3d(wt_plan *p, int src, int dst, int s, int depth)
     return conv3d_planes(p, in, tmp, out, s, depth);
 }
 
+// sdev_loc(..., variance=True) * f1 * f2 of a cube (watroo/wavelets.py:24-32, :434-436) into `dst`
+extern "C" int wt_local_variance3d(wt_plan *p, int src, int dst, int s, int depth, float f1, float f2)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_local_variance3d: null plan");
+    WT_TRY(check3d(p, depth, s, "wt_local_variance3d"));
+    const int tmpid = WT_PLANE_SCRATCH(15), sqid = WT_PLANE_SCRATCH(14), mid = WT_PLANE_SCRATCH(13);
+    if (src == dst || src == tmpid || src == sqid || src == mid || dst == tmpid || dst == sqid || dst == mid)
+        WT_FAIL("wt_local_variance3d: src / dst must differ from each other and from scratch 13-15");
+    float *in = nullptr, *tmp = nullptr, *sq = nullptr, *mean = nullptr, *out = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, tmpid, &tmp));
+    WT_TRY(plane_base(p, sqid, &sq));
+    WT_TRY(plane_base(p, mid, &mean));
+    WT_TRY(plane_base(p, dst, &out));
+    WT_TRY(conv3d_planes(p, in, tmp, mean, s, depth));          // conv(I)
+    WT_TRY(wt_binary(p, WT_OP_MUL, src, src, sqid));            // I^2
+    WT_TRY(conv3d_planes(p, sq, tmp, out, s, depth));           // conv(I^2)
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_var_moments_kernel");
+    hipLaunchKernelGGL(wt_var_moments_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, (const float *)mean,
+                       (const float *)out, out, n4, f1, f2);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+// atrous_convolution(cube, 3-D kernel, bilateral_variance=var, s) - watroo/wavelets.py:74-105
+extern "C" int wt_bilateral3d_conv(wt_plan *p, int src, int var, int dst, int s, int depth)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_bilateral3d_conv: null plan");
+    WT_TRY(check3d(p, depth, s, "wt_bilateral3d_conv"));
+    if (src == dst || var == dst) WT_FAIL("wt_bilateral3d_conv: dst must differ from src and var");
+    float *in = nullptr, *v = nullptr, *out = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, var, &v));
+    WT_TRY(plane_base(p, dst, &out));
+    const int Y = p->g.H / depth;
+    dim3 grid((p->g.W + 255) / 256, (unsigned)std::min(p->g.H, 32768)), block(256);
+    ProfScope ps(p->ctx, "wt_bilateral3d_kernel");
+    if (p->family == WT_B3SPLINE)
+        hipLaunchKernelGGL((wt_bilateral3d_kernel<5>), grid, block, 0, p->ctx->stream, (const float *)in, (const float *)v, out,
+                           p->g.W, p->g.P, Y, depth, 1 << s);
+    else
+        hipLaunchKernelGGL((wt_bilateral3d_kernel<3>), grid, block, 0, p->ctx->stream, (const float *)in, (const float *)v, out,
+                           p->g.W, p->g.P, Y, depth, 1 << s);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int wt_decompose3d(wt_plan *p, int src, int level, int depth)
 {
     WtGuard guard_(ctx_of(p));

@@ -921,6 +921,65 @@ __global__ __launch_bounds__(256) void wt_anscombe_kernel(const float *src, floa
 // ---------------------------------------------------------------------------------------------
 // Richardson-Lucy support (watroo/utils.py:222-290)
 // ---------------------------------------------------------------------------------------------
+// Bilateral filtering of (Z, Y, X) cubes (atrous_convolution with the 3-D kernel,
+// watroo/wavelets.py:74-105 called from :438-440): every tap of the K^3 dilated neighbourhood is
+// range-weighted, out = (k_c I + sum k_t e_t I_t) / (k_c + sum k_t e_t), e_t = exp(-(I - I_t)^2 /
+// (2 var)).  One voxel per thread, taps through L1/L2; cubes are small next to the 2-D images
+// the tuned kernels serve, and the cost is the K^3 transcendental evaluations either way.
+template <int K>
+__global__ __launch_bounds__(256) void wt_bilateral3d_kernel(const float *in, const float *var, float *out,
+                                                             int X, int P, int Y, int Z, int d)
+{
+    constexpr int hw = K / 2;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= X) return;
+    for (int row = blockIdx.y; row < Z * Y; row += gridDim.y) {
+        const int z = row / Y, y = row - z * Y;
+        const int64_t o = (int64_t)row * P + x;
+        const float I = in[o];
+        const float m = -0.5f / var[o];
+        float num = wt_tap<K>(hw) * wt_tap<K>(hw) * wt_tap<K>(hw) * I;
+        float den = wt_tap<K>(hw) * wt_tap<K>(hw) * wt_tap<K>(hw);
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const int zz = wt_refl(z + (i - hw) * d, Z);
+#pragma unroll 1
+            for (int j = 0; j < K; ++j) {
+                const int yy = wt_refl(y + (j - hw) * d, Y);
+                const float kzy = wt_tap<K>(i) * wt_tap<K>(j);
+                const float *r = in + ((int64_t)zz * Y + yy) * P;
+#pragma unroll
+                for (int l = 0; l < K; ++l) {
+                    if (i == hw && j == hw && l == hw) continue;
+                    const float It = r[wt_refl(x + (l - hw) * d, X)];
+                    const float dl = I - It;
+                    const float w = kzy * wt_tap<K>(l) * __expf(dl * dl * m);
+                    num = fmaf(w, It, num);
+                    den += w;
+                }
+            }
+        }
+        out[o] = num / den;
+    }
+}
+
+// variance plane from the two smoothed moments (sdev_loc, watroo/wavelets.py:24-32, with the
+// factors of :434-436): dst = max(meansq - mean^2 -> 1e-20 if <= 0) * f1 * f2
+__global__ __launch_bounds__(256) void wt_var_moments_kernel(const float *mean, const float *meansq, float *dst,
+                                                             int64_t n4, float f1, float f2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4 *>(mean)[i];
+        const float4 b = reinterpret_cast<const float4 *>(meansq)[i];
+        const float m[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = wt_var_point(q[k], m[k], f1, f2, 0);
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // User-defined scaling functions (AbstractScalingFunction subclasses, watroo/wavelets.py:152-229):
 // the separable dilated filter with run-time taps, one pixel per thread, two passes (rows into a
 // scratch plane, then columns + epilogue).  Generic and simple on purpose - the tuned kernels

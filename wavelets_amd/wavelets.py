@@ -531,24 +531,47 @@ class AtrousTransform:
     def _call_1d(self, arr, level, recursive):
         """1-D signals (ref:65-69, 'mirror' border): run as a 1 x N image with the engine's
         mirror border rule and the per-scale kernels."""
-        if recursive or self.bilateral is not None:
-            raise NotImplementedError("1-D transforms support the standard, non-bilateral "
-                                      "algorithm only in the HIP engine")
+        if recursive:
+            raise NotImplementedError("recursive=True on 1-D signals is not implemented in the "
+                                      "HIP engine")
         row = _to_f32_row(arr)
         scaling_function = self.scaling_function_class(1)
         plan = acquire_plan(default_context(), 1, row.shape[1], _family_of(scaling_function, 1), level)
-        plan.set_border(2)
         plan.upload(PLANE_INPUT, row)
-        plan.decompose(PLANE_INPUT, level, 0)
-        plan.set_border(0)
-        return Coefficients(plan, scaling_function, None)
+        if self.bilateral is None:
+            plan.set_border(2)
+            plan.decompose(PLANE_INPUT, level, 0)
+            plan.set_border(0)
+            return Coefficients(plan, scaling_function, None)
+        # Bilateral (ref:433-440 on a 1-D signal): the variance comes from convolution()'s 1-D
+        # branch ('mirror' border, ref:24-32 over :65-69), the range-weighted convolution pads
+        # symmetrically (ref:77).  On a 1 x N image the 2-D bilateral kernel reduces to the 1-D
+        # one: the taps of the other axis all reflect onto the same row, carry weight e = 1 and
+        # factor out of numerator and denominator.
+        if plan.custom:
+            raise NotImplementedError("bilateral filtering with a user-defined scaling function "
+                                      "is not implemented in the HIP engine")
+        sb = self._sigma_bilateral(level)
+        cur = PLANE_INPUT
+        for s in range(level):
+            nxt = level if s == level - 1 else PLANE_SCRATCH(s & 1)
+            plan.set_border(2)
+            plan.local_variance(cur, _TMP_PLANE, s, float(sb[s]) ** 2,
+                                float(s + 1) if self.bilateral_scaling else 1.0)
+            plan.set_border(0)
+            plan.bilateral_conv(cur, _TMP_PLANE, nxt, s)
+            plan.binary("sub", cur, nxt, s)                                # ref:442
+            cur = nxt
+        if level == 0:
+            plan.copy(PLANE_INPUT, 0)
+        return Coefficients(plan, scaling_function, self.bilateral)
 
     def _call_3d(self, arr, level, recursive):
         """(Z, Y, X) cubes (ref:46-64): per-slice 2-D filter then the same filter along axis 0;
         the cube lives on the GPU as a (Z*Y) x X image."""
-        if recursive or self.bilateral is not None:
-            raise NotImplementedError("3-D transforms support the standard, non-bilateral "
-                                      "algorithm only in the HIP engine")
+        if recursive:
+            raise NotImplementedError("recursive=True on cubes is not implemented in the HIP "
+                                      "engine")
         cube = np.ascontiguousarray(arr, dtype=np.float32)
         Z, Y, X = cube.shape
         scaling_function = self.scaling_function_class(3)
@@ -558,8 +581,22 @@ class AtrousTransform:
                                       "not implemented in the HIP engine")
         plan = acquire_plan(default_context(), Z * Y, X, fam, level)
         plan.upload(PLANE_INPUT, cube.reshape(Z * Y, X))
-        plan.decompose3d(PLANE_INPUT, level, Z)
-        return Coefficients(plan, scaling_function, None, _shape=(Z, Y, X))
+        if self.bilateral is None:
+            plan.decompose3d(PLANE_INPUT, level, Z)
+            return Coefficients(plan, scaling_function, None, _shape=(Z, Y, X))
+        # bilateral (ref:433-440 on a cube): 3-D variance, then the K^3 range-weighted kernel
+        sb = self._sigma_bilateral(level)
+        cur = PLANE_INPUT
+        for s in range(level):
+            nxt = level if s == level - 1 else PLANE_SCRATCH(s & 1)
+            plan.local_variance3d(cur, _TMP_PLANE, s, Z, float(sb[s]) ** 2,
+                                  float(s + 1) if self.bilateral_scaling else 1.0)
+            plan.bilateral3d_conv(cur, _TMP_PLANE, nxt, s, Z)
+            plan.binary("sub", cur, nxt, s)                                # ref:442
+            cur = nxt
+        if level == 0:
+            plan.copy(PLANE_INPUT, 0)
+        return Coefficients(plan, scaling_function, self.bilateral, _shape=(Z, Y, X))
 
     def _recursive(self, img, level, scaling_function):
         """The reference's recursive algorithm (ref:330-406) on the GPU.  It pads once by
