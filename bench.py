@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spinup", type=float, default=0.25,
+                    help="seconds of untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--size", type=int, default=0, help="override image side (testing)")
     ap.add_argument("--rows", type=int, default=0, help="override image height (strip-shaped tests)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per scale")
@@ -191,6 +193,14 @@ def main():
             dist.barrier()
         ctx.sync()
 
+    # Untimed spin-up: the GPU idles at 94 MHz and its clocks ramp over the first milliseconds of
+    # work; W = 3 warm-up steps are only 2.5 ms.  Run the same step for a quarter of a second so
+    # that the timed region starts at steady clocks (measured: K = 5 reads 4 % low otherwise).
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        for _ in range(20):
+            step()
+        ctx.sync()
     for _ in range(args.warmup):
         step()
     fence()
