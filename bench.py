@@ -196,9 +196,15 @@ def main():
     # Untimed spin-up: the GPU idles at 94 MHz and its clocks ramp over the first milliseconds of
     # work; W = 3 warm-up steps are only 2.5 ms.  Run the same step for a quarter of a second so
     # that the timed region starts at steady clocks (measured: K = 5 reads 4 % low otherwise).
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup:
-        for _ in range(20):
+    if dist is None:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup:
+            for _ in range(20):
+                step()
+            ctx.sync()
+    elif args.spinup > 0:
+        # every rank must issue the same number of halo exchanges: a fixed count, not a clock
+        for _ in range(60):
             step()
         ctx.sync()
     for _ in range(args.warmup):
