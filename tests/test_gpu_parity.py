@@ -992,3 +992,22 @@ def test_bilateral_nd_vs_golden(W, tag):
         close(c.data, g["cube_bilateral_den"], tol)
         r, _ = W.wow(a.copy(), bilateral=1, n_scales=2, denoise_coefficients=[4, 2])
         close(r, g["cube_wow_bilateral"], 5e-5 * np.abs(g["cube_wow_bilateral"]).max())
+
+
+def test_coefficients_copy_and_pickle(W):
+    """copy.deepcopy / pickle of a Coefficients object give an independent host-backed object
+    (the reference's is a plain ndarray holder, so user code copies it freely)."""
+    import copy
+    import pickle
+    a = rnd((80, 96), 31)
+    c = W.AtrousTransform(W.Triangle)(a, 3)
+    c.noise = 0.9
+    d = copy.deepcopy(c)
+    e = pickle.loads(pickle.dumps(c))
+    c.denoise([5, 3])                                  # mutates c only
+    ref = W.AtrousTransform(W.Triangle)(a, 3).data
+    for o in (d, e):
+        assert o.noise == 0.9 and len(o) == 4 and o.scaling_function.name == c.scaling_function.name
+        np.testing.assert_array_equal(o.data, ref)
+        o.denoise([5, 3])
+        np.testing.assert_array_equal(o.data, c.data)

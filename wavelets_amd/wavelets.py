@@ -325,6 +325,20 @@ class Coefficients:
         except Exception:
             pass
 
+    # -- copies / pickling: a copy is a host-backed object with its own planes ---------------
+    def __deepcopy__(self, memo):
+        other = Coefficients(np.array(self.data, copy=True), copy.deepcopy(self.scaling_function, memo),
+                             copy.deepcopy(self.bilateral, memo))
+        other.noise = copy.deepcopy(self.noise, memo)
+        return other
+
+    def __copy__(self):
+        return self.__deepcopy__({})
+
+    def __reduce__(self):
+        return (_rebuild_coefficients, (np.array(self.data, copy=True), self.scaling_function,
+                                        self.bilateral, self.noise))
+
     # -- host mirror -------------------------------------------------------------------
     def _img_shape(self):
         return self._shape
@@ -483,6 +497,12 @@ class Coefficients:
             out[...] = res
             return out
         return np.sum(self.data, axis=axis, dtype=dtype, out=out, **kwargs)
+
+
+def _rebuild_coefficients(data, scaling_function, bilateral, noise):
+    c = Coefficients(data, scaling_function, bilateral)
+    c.noise = noise
+    return c
 
 
 # ------------------------------------------------------------------------------------------
