@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the launcher plumbing (gloo rendezvous, RCCL communicator) even "
                          "with one rank (plumbing check on a 1-GPU box)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="testing on a 1-GPU box: all ranks use device 0 and each gets its own "
+                         "NCCL_HOSTID, so RCCL treats them as separate hosts (socket transport)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line (rank 0).  Native libraries print banners on fd 1
@@ -129,6 +132,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.shared_gpu:
+        local_rank = 0
+        os.environ["NCCL_HOSTID"] = f"wt-virtual-host-{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "

@@ -200,3 +200,26 @@ def test_large_geometry_device_side_checks():
     r = subprocess.run([_sys.executable, os.path.join(root, "tools", "check_large.py"), "16384"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "check_large: OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("nranks,shape", [(2, (1536, 1100)), (3, (1200, 520))])
+def test_real_rccl_ranks_share_the_gpu(nranks, shape):
+    """The production RCCL sequence with REAL ranks (tools/check_rccl_ranks.py): one process per
+    rank under torch.distributed.run, unique-id broadcast, ncclCommInitRank, grouped
+    ncclSend/ncclRecv of the halo rows on the compute stream before every pass, all-reduced
+    histograms / moments.  The box has one GPU, so every rank gets its own NCCL_HOSTID: RCCL
+    treats them as separate hosts and carries the rows over its socket transport.  Each rank
+    compares planes, reconstruction, noise and denoised sum bit for bit with the unsharded plan."""
+    import socket
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tools", "check_rccl_ranks.py"), "--shape", str(shape[0]), str(shape[1])]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert r.returncode == 0 and "0 mismatches in total" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Real multi-rank check of the RCCL strip path on a box with ONE GPU.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29533 tools/check_rccl_ranks.py [--shape 1536 1100]
+
+RCCL refuses two ranks of one communicator on the same device ("Duplicate GPU detected"), so
+every rank gets its own NCCL_HOSTID: RCCL then believes the ranks live on different hosts and
+moves the halo rows through its socket transport over `lo`.  The transport is slower than xGMI;
+the CALL SEQUENCE (unique id broadcast, ncclCommInitRank, grouped ncclSend/ncclRecv on the compute
+stream before every pass, all-reduced histograms / moments) is exactly the production one, which
+is what this script verifies: every rank compares its strip of
+
+  * the 7 planes and the reconstruction of wt_decompose_sum (fused passes, B3spline L = 6),
+  * the planes of the per-scale (unfused) schedule and of Triangle L = 8,
+  * the global MAD noise (all-reduced radix-select histograms), denoise([5,3,2]) + plane sum,
+  * wt_reduce's {sum, sum^2, min, max}
+
+BIT FOR BIT with an unsharded plan computed on the same GPU by the same rank.
+Where the devices differ (a real multi-GPU node) pass --own-gpu: rank r uses device LOCAL_RANK.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", type=int, nargs=2, default=[1536, 1100])
+    ap.add_argument("--own-gpu", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.own_gpu:
+        os.environ["NCCL_HOSTID"] = f"wt-virtual-host-{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+    import numpy as np
+    import torch  # noqa: F401  (first: one ROCm runtime per process, see bench.py)
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    from wavelets_amd import _lib as L
+    from wavelets_amd.parallel import init_comm, StripTransform
+    from wavelets_amd.wavelets import B3spline, Triangle
+
+    ctx = L.Context(local_rank if args.own_gpu else 0)
+
+    def bcast(obj, src):
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    init_comm(ctx, rank, world, bcast)
+    assert ctx.comm_selftest(1 << 18), "ring send/recv + all-reduce self-test failed"
+
+    H, W = args.shape
+    img = np.random.default_rng(5).standard_normal((H, W), dtype=np.float32)
+    img[H // 3, W // 2] = 40.0
+    checks = []
+
+    def same(name, got, exp):
+        ok = np.array_equal(got, exp)
+        checks.append((name, bool(ok)))
+        if not ok:
+            d = np.abs(np.asarray(got, np.float64) - np.asarray(exp, np.float64))
+            print(f"[rank {rank}] MISMATCH {name}: max |diff| {d.max():.3e} at "
+                  f"{np.unravel_index(d.argmax(), d.shape)}", file=sys.stderr, flush=True)
+
+    for fam_cls, fam, level, fused in ((B3spline, L.B3SPLINE, 6, True),
+                                       (Triangle, L.TRIANGLE, 8, True),
+                                       (B3spline, L.B3SPLINE, 4, False)):
+        flags = L.FLAG_FUSED if fused else 0
+        tag = f"{fam_cls.__name__}/L{level}/{'fused' if fused else 'unfused'}"
+        whole = L.Plan(ctx, H, W, fam, level)
+        whole.upload(L.PLANE_INPUT, img)
+        whole.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, flags)
+
+        st = StripTransform(ctx, H, W, level, fam_cls, fused=fused)
+        r0, n = st.row0, st.nrows
+        st.upload(img[r0:r0 + n])
+        recon = st.decompose_sum()
+        for s in range(level + 1):
+            same(f"{tag} plane {s}", st.plane(s), whole.download(s)[r0:r0 + n])
+        same(f"{tag} reconstruction", recon, whole.download(L.PLANE_OUT)[r0:r0 + n])
+
+        # two-call form
+        st.decompose()
+        for s in range(level + 1):
+            same(f"{tag} decompose plane {s}", st.plane(s), whole.download(s)[r0:r0 + n])
+
+        # global scalars
+        noise_whole = whole.abs_median(0) / 0.6745 / st.sigma_e[0]
+        same(f"{tag} noise", np.float64(st.get_noise()), np.float64(noise_whole))
+        ra, rb = np.array(st.plan.reduce(level)), np.array(whole.reduce(level))
+        same(f"{tag} reduce min/max", ra[2:], rb[2:])
+        # fp64 partial sums are folded per rank and then all-reduced: same value up to fp64 rounding
+        checks.append((f"{tag} reduce sums", bool(np.allclose(ra[:2], rb[:2], rtol=1e-12, atol=1e-9))))
+
+        # denoise + sum
+        sig = [5, 3, 2][:level]
+        st.denoise(sig)
+        for scl, sg in enumerate(sig):
+            whole.denoise(scl, sg * noise_whole * st.sigma_e[scl], 1, True, L.PLANE_NONE)
+        whole.plane_sum(0, level + 1, L.PLANE_OUT)
+        same(f"{tag} denoised sum", st.sum(), whole.download(L.PLANE_OUT)[r0:r0 + n])
+        st.plan.close()
+        whole.close()
+
+    ctx.sync()
+    bad = [n for n, ok in checks if not ok]
+    flag = torch.tensor([len(bad)], dtype=torch.int64)
+    dist.all_reduce(flag)
+    if rank == 0:
+        print(f"check_rccl_ranks: {world} ranks, image {H}x{W}, {len(checks)} comparisons per "
+              f"rank, {int(flag[0])} mismatches in total")
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(1 if int(flag[0]) else 0)
+
+
+if __name__ == "__main__":
+    main()
