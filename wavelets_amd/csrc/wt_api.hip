@@ -393,7 +393,10 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
         WT_TRY(wt_schedule(family, max_level, 1, tr, 32, &np));
         for (int i = 0; i < np; ++i) halo = std::max<int64_t>(halo, tr[3 * i + 2]);
     }
-    const int64_t P = (W + 3) / 4 * 4;
+    // WT_PITCH_PAD (pixels, multiple of 4): extra row pitch for experiments with the HBM channel
+    // mapping of row-marching kernels
+    static const int64_t pitch_pad = getenv("WT_PITCH_PAD") ? std::max<int64_t>(0, atoll(getenv("WT_PITCH_PAD")) / 4 * 4) : 0;
+    const int64_t P = (W + 3) / 4 * 4 + pitch_pad;
     if ((nrows + 2 * halo) * P >= ((int64_t)1 << 31)) {
         // kernels index pixels with 64-bit offsets but rows/cols with int32
         if (nrows + 2 * halo >= ((int64_t)1 << 30)) WT_FAIL("wt_plan_create: strip too tall");
@@ -1017,6 +1020,8 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
     float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
     for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
     float *ps = nullptr;
+    if (acc && first_of_sum != (s0 == 0))
+        WT_FAIL("wt_decompose_pass_sum: first must be set for the pass that starts at scale 0 and only for it (got first=%d, s0=%d)", (int)first_of_sum, s0);
     if (acc) WT_TRY(plane_base(p, p_sum, &ps));
     return wt_fused_launch(p, in, oc, ow, s0, ns, acc, first_of_sum ? nullptr : ps, ps);
 }

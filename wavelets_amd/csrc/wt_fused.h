@@ -33,6 +33,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wt_internal.h"
 #include "wt_kernels.h"
 
@@ -118,6 +120,17 @@ __device__ __forceinline__ void wt_bstore4(uint64_t row_addr, bool row_ok, int r
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
 }
 
+// Ablation switches (FusedArgs::debug, env WT_FUSED_DEBUG) are compiled in only with
+// -DWT_FUSED_ABLATION: their loop-invariant branches cost issue slots in every step.
+#ifndef WT_FUSED_STEADY
+#define WT_FUSED_STEADY 0   // 1: predicate-free copy of the step for blocks inside the chunk (spills at 2 waves/SIMD)
+#endif
+#ifdef WT_FUSED_ABLATION
+#define WT_FUSED_DBG(a) ((a).debug)
+#else
+#define WT_FUSED_DBG(a) 0
+#endif
+
 // The detail planes are write-once streams that nothing re-reads before the pass is over:
 // nontemporal stores.  The smooth plane is the NEXT pass's input and keeps the default policy
 // (up to 4096^2 it is still in the Infinity Cache when the next pass starts: 0.125 -> 0.097 ms
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
     constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0;
     constexpr int NV = NL - HX / 2;
-    __shared__ float4 ring[ACC ? (G1 + G2) * NV + 1 : 1];
+    __shared__ float4 ring[ACC ? (G1 + G2) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
@@ -216,35 +229,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
               xi3 = wt_refl(x + 3, g.W);
     const int gy0 = g.row0 + q;                          // global row of chain element 0
 
+    const int dbg = WT_FUSED_DBG(a);
     const int t_last = r1 - 1 + LAT_IN;                  // last input row any stored output needs
+    const unsigned xoff = (unsigned)xc * 4u;             // byte offset of this lane's aligned load
     auto load_row = [&](int t) -> float4 {
-        // steps past t_last only flush the pipeline / unroll padding: keep the address in range
-        const float *row = wt_row(a.in, g, gy0 + D * ((a.debug & 2) ? r0 : min(t, t_last)));
-#ifdef WT_FUSED_NT_LOAD
-        float4 v = wt_ldnt4(row + xc);
-#else
-        float4 v = *reinterpret_cast<const float4 *>(row + xc);
-#endif
+        // steps past t_last only flush the pipeline / unroll padding: keep the address in range.
+        // Uniform row pointer + 32-bit lane offset: one global_load_dwordx4 with an SGPR base.
+        const float *row = wt_row(a.in, g, gy0 + D * ((dbg & 2) ? r0 : min(t, t_last)));
+        float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(row) + xoff);
         if (wave_has_edge) {
             if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
         }
         return v;
     };
     // Output rows advance by one chain step (D image rows) per iteration: the row addresses are
-    // carried incrementally in SGPRs (2 SALU per plane per step); a row outside [r0, r1) gets a
-    // zero-length descriptor instead of a branch.
+    // carried incrementally in SGPRs (2 SALU per plane per step).  A row outside [r0, r1) gets a
+    // zero-length descriptor instead of a branch; in STEADY blocks of U steps (every plane's row
+    // inside the chunk for the whole block - all but the first and last one or two blocks) the
+    // predicates are compile-time true and cost nothing: the march is instruction-issue bound
+    // (DESIGN.md 3.1), every scalar instruction in the step counts.
     const unsigned span = (unsigned)(r1 - r0);
     const uint64_t step_bytes = (uint64_t)D * (uint64_t)row_bytes;
     auto row_addr0 = [&](float *base, int ro) -> uint64_t {
         return (uint64_t)base + (uint64_t)((int64_t)(q + (int64_t)D * ro) * (int64_t)row_bytes);
-    };
-    auto store_at = [&](uint64_t addr, int ro, float4 v) {          // detail planes
-        const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
-        wt_bstore4<WT_FUSED_W_AUX>(addr, ok, row_bytes, voff, v);
-    };
-    auto store_c = [&](uint64_t addr, int ro, float4 v) {           // smooth plane
-        const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
-        wt_bstore4<WT_FUSED_C_AUX>(addr, ok, row_bytes, voff, v);
     };
 
     constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0;
@@ -267,124 +274,144 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
     float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
+    // address of the row each plane stores at step k = 0 (row t0 - LAG of the chain)
     uint64_t aw0 = row_addr0(a.out_w[0], t0 - LAG0);
     uint64_t aw1 = NS > 1 ? row_addr0(a.out_w[A1], t0 - LAG1) : 0;
     uint64_t aw2 = NS > 2 ? row_addr0(a.out_w[A2], t0 - LAG2) : 0;
     uint64_t ac = row_addr0(a.out_c, t0 - LAGC);
-    // ---- ACC state
-    const bool has_pin = ACC && a.p_in != nullptr;
+    // ---- ACC state.  The first pass of a sum (D = 1, s0 = 0) has no incoming partial sum, every
+    // later pass has one: decided at compile time (the host checks first == (s0 == 0)).
+    constexpr bool PIN = ACC != 0 && D != 1;
     uint64_t ap = ACC ? row_addr0(a.p_out, t0 - LAGC) : 0;
-    auto load_acc = [&](int t) -> float4 {               // p_in row of chain element t - LAG0
-        const int ro = min(max(t - LAG0, r0), r1 - 1);
-        return *reinterpret_cast<const float4 *>(a.p_in + (int64_t)(q + (int64_t)D * ro) * g.P + xc);
+    const char *pin0 = PIN ? reinterpret_cast<const char *>(a.p_in + (int64_t)(q + (int64_t)D * r0) * g.P) : nullptr;
+    auto load_acc = [&](int k) -> float4 {               // p_in row of chain element t0 + k - LAG0
+        const int rel = min(max(k - LAT_IN - LAG0, 0), (int)span - 1);
+        return *reinterpret_cast<const float4 *>(pin0 + (size_t)rel * step_bytes + xoff);
     };
-    float4 pa[ACC ? PD : 1];
-    if (has_pin) {
+    float4 pa[PIN ? PD : 1];
+    if constexpr (PIN) {
 #pragma unroll
-        for (int i = 0; i < PD; ++i) pa[i] = load_acc(t0 + i);
+        for (int i = 0; i < PD; ++i) pa[i] = load_acc(i);
     }
-    const int li = lane_store ? (x - X0) >> 2 : 0;       // slot in the ring rows
+    const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
-    auto store_p = [&](uint64_t addr, int ro, float4 v) {
-        const bool ok = ((unsigned)(ro - r0) < span) && !(a.debug & 1);
-        // the finished reconstruction is a write-once stream; an intermediate sum is re-read
-        // by the next pass
-        wt_bstore4<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(addr, ok, row_bytes, voff, v);
-    };
 
-    for (int kb = 0; kb < nsteps; kb += U) {
-#pragma unroll
-        for (int kk = 0; kk < U; ++kk) {
-            const int t = t0 + kb + kk;
-            const float4 cur = pf[kk % PD];
-            pf[kk % PD] = load_row(t + PD);
-            float4 (*buf)[NL] = vbuf[kk & 1];
-            if (a.debug & 4) {   // ablation: same loads / stores / addresses, no filtering at all
-                if (a.debug & 16) {   // ... and do not even issue the predicated-off stores
-                    if ((unsigned)(t - LAG0 - r0) < span) store_at(aw0, t - LAG0, cur);
-                    if constexpr (NS > 1) if ((unsigned)(t - LAG1 - r0) < span) store_at(aw1, t - LAG1, cur);
-                    if constexpr (NS > 2) if ((unsigned)(t - LAG2 - r0) < span) store_at(aw2, t - LAG2, cur);
-                    if ((unsigned)(t - LAGC - r0) < span) store_at(ac, t - LAGC, cur);
-                } else {
-                store_at(aw0, t - LAG0, cur);
-                if constexpr (NS > 1) store_at(aw1, t - LAG1, cur);
-                if constexpr (NS > 2) store_at(aw2, t - LAG2, cur);
-                store_at(ac, t - LAGC, cur);
-                }
-                aw0 += step_bytes; aw1 += step_bytes; aw2 += step_bytes; ac += step_bytes;
-                continue;
-            }
-            float4 pin_cur = zero;
-            if (has_pin) {
-                pin_cur = pa[kk % PD];
-                pa[kk % PD] = load_acc(t + PD);
-            }
-            // ACC: the ring slots that come due in this step were written G1 / G2 steps ago -
-            // read them before the barrier so the LDS latency hides behind the vertical filters
-            float4 old1 = zero, old2 = zero;
-            if constexpr (ACC != 0 && NS > 1) {
-                if (lane_store) {
-                    old1 = ring[i1 * NV + li];
-                    if constexpr (NS > 2) old2 = ring[(G1 + i2) * NV + li];
-                }
-            }
-            float4 cen0, cen1, cen2, v0, v1, v2;
-            v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
-            buf[0][gl] = v0;
-            if constexpr (NS > 1) {
-                v1 = wt_fused_vstage<K, A1>(w1, kk, c1, cen1);
-                buf[A1][gl] = v1;
-            }
-            if constexpr (NS > 2) {
-                v2 = wt_fused_vstage<K, A2>(w2, kk, c2, cen2);
-                buf[A2][gl] = v2;
-            }
-            __syncthreads();
-            const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
-            const float4 d0 = f4_sub(cen0, n0);
-            store_at(aw0, t - LAG0, d0);
-            if constexpr (NS == 1) store_c(ac, t - LAGC, n0);
-            float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
-            if constexpr (NS > 1) {
-                n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
-                d1 = f4_sub(cen1, n1);
-                store_at(aw1, t - LAG1, d1);
-                if constexpr (NS == 2) store_c(ac, t - LAGC, n1);
-                if constexpr (NS > 2) {
-                    n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
-                    d2 = f4_sub(cen2, n2);
-                    store_at(aw2, t - LAG2, d2);
-                    store_c(ac, t - LAGC, n2);
-                }
-                c2 = n1;
-            }
+    // One chain step.  STEADY (compile time): every store of this step is inside the chunk.
+    auto step = [&](auto steady_tag, const int kb, const int kk) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int k = kb + kk;
+        const int t = t0 + k;
+        // step k stores row t0 + k - LAG of a plane: inside the chunk iff k - (LAT_IN + LAG) < span
+        auto row_ok = [&](int lag) -> bool {
+            if constexpr (STEADY) return true;
+            return ((unsigned)(k - LAT_IN - lag) < span) && !(dbg & 1);
+        };
+        const float4 cur = pf[kk % PD];
+        pf[kk % PD] = load_row(t + PD);
+        float4 (*buf)[NL] = vbuf[kk & 1];
+#ifdef WT_FUSED_ABLATION
+        if (dbg & 4) {   // ablation: same loads / stores / addresses, no filtering at all
+            wt_bstore4<WT_FUSED_W_AUX>(aw0, row_ok(LAG0), row_bytes, voff, cur);
+            if constexpr (NS > 1) wt_bstore4<WT_FUSED_W_AUX>(aw1, row_ok(LAG1), row_bytes, voff, cur);
+            if constexpr (NS > 2) wt_bstore4<WT_FUSED_W_AUX>(aw2, row_ok(LAG2), row_bytes, voff, cur);
+            wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, cur);
             if constexpr (ACC != 0) {
-                // plane-order sum of image row rho: ((p_in + w_s0) + w_s0+1) + w_s0+2 (+ c): the
-                // partial sum of a row is parked in the ring until the next scale's detail row
-                // of the same image row appears (G1, then G2 steps later)
-                float4 s = has_pin ? f4_add(pin_cur, d0) : d0;          // row t - LAG0
-                if constexpr (NS > 1) {
-                    float4 s1 = f4_add(old1, d1);                         // row t - LAG1
-                    float4 s2 = s1;
-                    if constexpr (NS > 2) s2 = f4_add(old2, d2);          // row t - LAG2
-                    if (lane_store) {
-                        ring[i1 * NV + li] = s;
-                        if constexpr (NS > 2) ring[(G1 + i2) * NV + li] = s1;
-                    }
-                    s = s2;
-                    i1 = (i1 + 1 == G1) ? 0 : i1 + 1;
-                    if constexpr (NS > 2) i2 = (i2 + 1 == G2) ? 0 : i2 + 1;
+                float4 pv = cur;
+                if constexpr (PIN) {
+                    pv = pa[kk % PD];
+                    pa[kk % PD] = load_acc(k + PD);
                 }
-                if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
-                store_p(ap, t - LAGC, s);
+                wt_bstore4<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(ap, row_ok(LAGC), row_bytes, voff, pv);
                 ap += step_bytes;
             }
-            c1 = n0;
-            aw0 += step_bytes;
-            aw1 += step_bytes;
-            aw2 += step_bytes;
-            ac += step_bytes;
+            aw0 += step_bytes; aw1 += step_bytes; aw2 += step_bytes; ac += step_bytes;
+            return;
         }
+#endif
+        float4 pin_cur = zero;
+        if constexpr (PIN) {
+            pin_cur = pa[kk % PD];
+            pa[kk % PD] = load_acc(k + PD);
+        }
+        // ACC: the ring slots that come due in this step were written G1 / G2 steps ago - read
+        // them before the barrier so the LDS latency hides behind the vertical filters.  Lanes
+        // without stored pixels share the spare slot NV of each ring row (their sums are never
+        // stored), which keeps the ring traffic free of exec-mask branches.
+        float4 old1 = zero, old2 = zero;
+        if constexpr (ACC != 0 && NS > 1) {
+            old1 = ring[i1 * (NV + 1) + li];
+            if constexpr (NS > 2) old2 = ring[(G1 + i2) * (NV + 1) + li];
+        }
+        float4 cen0, cen1, cen2, v0, v1, v2;
+        v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
+        buf[0][gl] = v0;
+        if constexpr (NS > 1) {
+            v1 = wt_fused_vstage<K, A1>(w1, kk, c1, cen1);
+            buf[A1][gl] = v1;
+        }
+        if constexpr (NS > 2) {
+            v2 = wt_fused_vstage<K, A2>(w2, kk, c2, cen2);
+            buf[A2][gl] = v2;
+        }
+        __syncthreads();
+        const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
+        const float4 d0 = f4_sub(cen0, n0);
+        wt_bstore4<WT_FUSED_W_AUX>(aw0, row_ok(LAG0), row_bytes, voff, d0);
+        if constexpr (NS == 1) wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, n0);
+        float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
+        if constexpr (NS > 1) {
+            n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
+            d1 = f4_sub(cen1, n1);
+            wt_bstore4<WT_FUSED_W_AUX>(aw1, row_ok(LAG1), row_bytes, voff, d1);
+            if constexpr (NS == 2) wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, n1);
+            if constexpr (NS > 2) {
+                n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
+                d2 = f4_sub(cen2, n2);
+                wt_bstore4<WT_FUSED_W_AUX>(aw2, row_ok(LAG2), row_bytes, voff, d2);
+                wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, n2);
+            }
+            c2 = n1;
+        }
+        if constexpr (ACC != 0) {
+            // plane-order sum of image row rho: ((p_in + w_s0) + w_s0+1) + w_s0+2 (+ c): the
+            // partial sum of a row is parked in the ring until the next scale's detail row of the
+            // same image row appears (G1, then G2 steps later)
+            float4 s = PIN ? f4_add(pin_cur, d0) : d0;                  // row t - LAG0
+            if constexpr (NS > 1) {
+                float4 s1 = f4_add(old1, d1);                             // row t - LAG1
+                float4 s2 = s1;
+                if constexpr (NS > 2) s2 = f4_add(old2, d2);              // row t - LAG2
+                ring[i1 * (NV + 1) + li] = s;
+                if constexpr (NS > 2) ring[(G1 + i2) * (NV + 1) + li] = s1;
+                s = s2;
+                i1 = (i1 + 1 == G1) ? 0 : i1 + 1;
+                if constexpr (NS > 2) i2 = (i2 + 1 == G2) ? 0 : i2 + 1;
+            }
+            if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
+            // the finished reconstruction is a write-once stream; an intermediate sum is re-read
+            // by the next pass
+            wt_bstore4<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(ap, row_ok(LAGC), row_bytes, voff, s);
+            ap += step_bytes;
+        }
+        c1 = n0;
+        aw0 += step_bytes;
+        aw1 += step_bytes;
+        aw2 += step_bytes;
+        ac += step_bytes;
+    };
+
+    // steady blocks: kb - LAT_IN - LAGC >= 0 and kb + U - 1 - LAT_IN - LAG0 < span
+    [[maybe_unused]] const int kb_lo = LAT_IN + LAGC, kb_hi = LAT_IN + LAG0 + (int)span - U;
+    for (int kb = 0; kb < nsteps; kb += U) {
+#if WT_FUSED_STEADY
+        if (kb >= kb_lo && kb <= kb_hi && !dbg) {
+#pragma unroll
+            for (int kk = 0; kk < U; ++kk) step(std::true_type{}, kb, kk);
+            continue;
+        }
+#endif
+#pragma unroll
+        for (int kk = 0; kk < U; ++kk) step(std::false_type{}, kb, kk);
     }
 }
 
