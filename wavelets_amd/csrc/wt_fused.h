@@ -84,6 +84,13 @@ __device__ __forceinline__ float4 wt_hfilter_lds(const float4 *vrow, int gl, flo
         static_assert(SHIFT_PX == 1 || SHIFT_PX == 2, "sub-float4 shifts are 1 or 2 px");
         const float4 L = vrow[gl > 0 ? gl - 1 : 0];
         const float4 R = vrow[gl < NLANES - 1 ? gl + 1 : NLANES - 1];
+        if constexpr (SHIFT_PX == 1) {
+            // The 1-pixel taps pair (own.y, own.z).  Without this fence the vectoriser carries
+            // that odd pairing back through the vertical filter into the window and the row
+            // loads (a third copy of every row: one more load per row, waited on at once, 1.5x
+            // the vertical arithmetic and 8 more VGPRs); with it the pair is formed here.
+            asm volatile("" : "+v"(own.x), "+v"(own.y), "+v"(own.z), "+v"(own.w));
+        }
         const float e[12] = {L.x, L.y, L.z, L.w, own.x, own.y, own.z, own.w, R.x, R.y, R.z, R.w};
         float o[4];
 #pragma unroll
@@ -116,6 +123,19 @@ template <int AUX>
 __device__ __forceinline__ void wt_bstore4(uint64_t row_addr, bool row_ok, int row_bytes, unsigned voff, float4 v)
 {
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)row_addr, 0, row_ok ? row_bytes : 0, 0x00020000);
+    wt_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
+}
+
+// Store through a descriptor that stays FIXED for the whole march (base = the row the plane
+// stores at step 0, length = the chunk's byte span): the row is selected by the byte offset
+// k * step_bytes folded into voff (one v_add per step shared by all planes), a row or lane that
+// must not be written gets the parked offset 2^31 >= length.  No per-store scalar work besides
+// the row predicate: the march is instruction-issue bound.
+#define WT_FUSED_PARKED 0x80000000u
+template <int AUX>
+__device__ __forceinline__ void wt_bstore4v(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v)
+{
     wt_v4f t = {v.x, v.y, v.z, v.w};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
 }
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     // lanes that own stored pixels; a float4 that straddles W writes into the row's pitch
     // padding (allocated, never read as image data)
     const bool lane_store = (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
-    const unsigned voff = lane_store ? (unsigned)x * 4u : 0xfffffff0u;
+    const unsigned voff = lane_store ? (unsigned)x * 4u : WT_FUSED_PARKED;
     const int row_bytes = g.P * 4;
     // Every lane issues ONE aligned in-bounds dwordx4 per row; lanes whose 4 pixels are not
     // all inside the image (reflected halo at the image border, ragged right edge) patch the
@@ -242,14 +262,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         }
         return v;
     };
-    // Output rows advance by one chain step (D image rows) per iteration: the row addresses are
-    // carried incrementally in SGPRs (2 SALU per plane per step).  A row outside [r0, r1) gets a
-    // zero-length descriptor instead of a branch; in STEADY blocks of U steps (every plane's row
-    // inside the chunk for the whole block - all but the first and last one or two blocks) the
-    // predicates are compile-time true and cost nothing: the march is instruction-issue bound
-    // (DESIGN.md 3.1), every scalar instruction in the step counts.
+    // Output rows advance by one chain step (D image rows) per iteration.  Every plane has ONE
+    // descriptor for the whole march, based at the row it stores at step 0 (row t0 - LAG of the
+    // chain; before the chunk, never written) and as long as the chunk's byte span (< 2 GiB,
+    // host); step k adds k * step_bytes to the lane offset.  A row outside [r0, r1) parks the
+    // offset instead of branching, so control flow stays uniform.
     const unsigned span = (unsigned)(r1 - r0);
-    const uint64_t step_bytes = (uint64_t)D * (uint64_t)row_bytes;
+    const unsigned step_bytes = (unsigned)D * (unsigned)row_bytes;
     auto row_addr0 = [&](float *base, int ro) -> uint64_t {
         return (uint64_t)base + (uint64_t)((int64_t)(q + (int64_t)D * ro) * (int64_t)row_bytes);
     };
@@ -274,19 +293,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
     float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
-    // address of the row each plane stores at step k = 0 (row t0 - LAG of the chain)
-    uint64_t aw0 = row_addr0(a.out_w[0], t0 - LAG0);
-    uint64_t aw1 = NS > 1 ? row_addr0(a.out_w[A1], t0 - LAG1) : 0;
-    uint64_t aw2 = NS > 2 ? row_addr0(a.out_w[A2], t0 - LAG2) : 0;
-    uint64_t ac = row_addr0(a.out_c, t0 - LAGC);
+    const unsigned chunk_bytes = (unsigned)nsteps * step_bytes + (unsigned)row_bytes;   // < 2^31 (host)
+    auto plane_rsrc = [&](float *base, int lag) -> __amdgpu_buffer_rsrc_t {
+        // Length and flag words pass through an empty asm so that every descriptor owns its four
+        // SGPRs: shared words would be copied into place before every store (2 s_mov each).
+        unsigned len = chunk_bytes, flags = 0x00020000;
+        asm volatile("" : "+s"(len), "+s"(flags));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)row_addr0(base, t0 - lag), 0, len, flags);
+    };
+    const __amdgpu_buffer_rsrc_t rw0 = plane_rsrc(a.out_w[0], LAG0);
+    const __amdgpu_buffer_rsrc_t rw1 = plane_rsrc(a.out_w[A1], LAG1);
+    const __amdgpu_buffer_rsrc_t rw2 = plane_rsrc(a.out_w[A2], LAG2);
+    const __amdgpu_buffer_rsrc_t rc = plane_rsrc(a.out_c, LAGC);
     // ---- ACC state.  The first pass of a sum (D = 1, s0 = 0) has no incoming partial sum, every
     // later pass has one: decided at compile time (the host checks first == (s0 == 0)).
     constexpr bool PIN = ACC != 0 && D != 1;
-    uint64_t ap = ACC ? row_addr0(a.p_out, t0 - LAGC) : 0;
+    const __amdgpu_buffer_rsrc_t rp = plane_rsrc(ACC ? a.p_out : a.out_c, LAGC);
+    unsigned koff = 0;                                   // k * step_bytes
     const char *pin0 = PIN ? reinterpret_cast<const char *>(a.p_in + (int64_t)(q + (int64_t)D * r0) * g.P) : nullptr;
     auto load_acc = [&](int k) -> float4 {               // p_in row of chain element t0 + k - LAG0
         const int rel = min(max(k - LAT_IN - LAG0, 0), (int)span - 1);
-        return *reinterpret_cast<const float4 *>(pin0 + (size_t)rel * step_bytes + xoff);
+        return *reinterpret_cast<const float4 *>(pin0 + (size_t)((unsigned)rel * step_bytes) + xoff);
     };
     float4 pa[PIN ? PD : 1];
     if constexpr (PIN) {
@@ -302,29 +329,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         const int k = kb + kk;
         const int t = t0 + k;
         // step k stores row t0 + k - LAG of a plane: inside the chunk iff k - (LAT_IN + LAG) < span
-        auto row_ok = [&](int lag) -> bool {
-            if constexpr (STEADY) return true;
-            return ((unsigned)(k - LAT_IN - lag) < span) && !(dbg & 1);
+        const unsigned vk = voff + koff;
+        auto at = [&](int lag) -> unsigned {             // lane offset of this step's row, or parked
+            if constexpr (STEADY) return vk;
+            return (((unsigned)(k - LAT_IN - lag) < span) && !(dbg & 1)) ? vk : WT_FUSED_PARKED;
         };
         const float4 cur = pf[kk % PD];
         pf[kk % PD] = load_row(t + PD);
         float4 (*buf)[NL] = vbuf[kk & 1];
 #ifdef WT_FUSED_ABLATION
         if (dbg & 4) {   // ablation: same loads / stores / addresses, no filtering at all
-            wt_bstore4<WT_FUSED_W_AUX>(aw0, row_ok(LAG0), row_bytes, voff, cur);
-            if constexpr (NS > 1) wt_bstore4<WT_FUSED_W_AUX>(aw1, row_ok(LAG1), row_bytes, voff, cur);
-            if constexpr (NS > 2) wt_bstore4<WT_FUSED_W_AUX>(aw2, row_ok(LAG2), row_bytes, voff, cur);
-            wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, cur);
+            wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), cur);
+            if constexpr (NS > 1) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), cur);
+            if constexpr (NS > 2) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), cur);
+            wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), cur);
             if constexpr (ACC != 0) {
                 float4 pv = cur;
                 if constexpr (PIN) {
                     pv = pa[kk % PD];
                     pa[kk % PD] = load_acc(k + PD);
                 }
-                wt_bstore4<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(ap, row_ok(LAGC), row_bytes, voff, pv);
-                ap += step_bytes;
+                wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(rp, at(LAGC), pv);
             }
-            aw0 += step_bytes; aw1 += step_bytes; aw2 += step_bytes; ac += step_bytes;
+            koff += step_bytes;
             return;
         }
 #endif
@@ -356,19 +383,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         __syncthreads();
         const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
         const float4 d0 = f4_sub(cen0, n0);
-        wt_bstore4<WT_FUSED_W_AUX>(aw0, row_ok(LAG0), row_bytes, voff, d0);
-        if constexpr (NS == 1) wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, n0);
+        wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
+        if constexpr (NS == 1) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
         float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
         if constexpr (NS > 1) {
             n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
             d1 = f4_sub(cen1, n1);
-            wt_bstore4<WT_FUSED_W_AUX>(aw1, row_ok(LAG1), row_bytes, voff, d1);
-            if constexpr (NS == 2) wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, n1);
+            wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
+            if constexpr (NS == 2) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
             if constexpr (NS > 2) {
                 n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
                 d2 = f4_sub(cen2, n2);
-                wt_bstore4<WT_FUSED_W_AUX>(aw2, row_ok(LAG2), row_bytes, voff, d2);
-                wt_bstore4<WT_FUSED_C_AUX>(ac, row_ok(LAGC), row_bytes, voff, n2);
+                wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
+                wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
             }
             c2 = n1;
         }
@@ -390,14 +417,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
             if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
             // the finished reconstruction is a write-once stream; an intermediate sum is re-read
             // by the next pass
-            wt_bstore4<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(ap, row_ok(LAGC), row_bytes, voff, s);
-            ap += step_bytes;
+            wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(rp, at(LAGC), s);
         }
         c1 = n0;
-        aw0 += step_bytes;
-        aw1 += step_bytes;
-        aw2 += step_bytes;
-        ac += step_bytes;
+        koff += step_bytes;
     };
 
     // steady blocks: kb - LAT_IN - LAGC >= 0 and kb + U - 1 - LAT_IN - LAG0 < span
@@ -428,6 +451,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
     constexpr int NL = NW * 64;
     constexpr int VXMAX = NL * 4 - 2 * HX;               // widest valid strip per WG
+    constexpr int UMAX = (K - 1) << (NS - 1);
     static_assert(VXMAX >= 64, "workgroup too narrow for this halo");
     const Geo &g = p->g;
     FusedArgs a = base;
@@ -452,6 +476,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
         const int Sc = (n_max + c - 1) / c;
         const int cc = (n_max + Sc - 1) / Sc;                    // chunks actually needed
         const int64_t rounds = (nbase * cc + slots - 1) / slots;
+        // the kernel addresses the rows of a chunk with 31-bit byte offsets
+        if ((int64_t)(Sc + 2 * LAT + 2 * UMAX + 1) * D * g.P * 4 >= ((int64_t)1 << 31)) continue;
         // more than one round: keep the warm-up <= ~50 % of a chunk.  A grid that fits in one
         // round anyway (small images: the chip is not full) is latency-bound by the steps of
         // ONE workgroup, so shorter chunks win even if most of their steps are warm-up.
@@ -460,6 +486,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
         const double cost = (double)rounds * (Sc + 2 * LAT + 8);
         if (cost < best) { best = cost; chunks = cc; S = Sc; }
     }
+    if (best == 1e300) WT_FAIL("fused pass: no chunking keeps a chunk's byte span below 2 GiB");
     a.S = S;
     a.chunks = chunks;
     static const int dbg = getenv("WT_FUSED_DEBUG") ? atoi(getenv("WT_FUSED_DEBUG")) : 0;
