@@ -223,3 +223,36 @@ def test_real_rccl_ranks_share_the_gpu(nranks, shape):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
     assert r.returncode == 0 and "0 mismatches in total" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("fam_name,level,nrows,W,rank,nranks", [
+    ("b3spline", 6, 700, 1100, 1, 3),      # both neighbours: two edge ranges + interior
+    ("b3spline", 6, 512, 300, 0, 2),       # bottom neighbour only
+    ("b3spline", 5, 333, 257, 2, 3),       # top neighbour only, d1x3 + d8x2
+    ("triangle", 8, 1000, 192, 1, 3),      # three passes: D = 1, 8, 64 sub-ranges
+])
+def test_split_launches_equal_whole_pass_bitwise(L, fam_name, level, nrows, W, rank, nranks):
+    """The overlapped multi-GPU schedule launches a pass as edge rows + interior rows (row
+    sub-ranges of the fused kernel).  Option split_dry does exactly that on a strip plan without
+    any exchange: every plane and the carried sum must equal the whole-pass launch bit for bit."""
+    fam = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam_name]
+    ctx = L.default_context()
+    plan = L.Plan(ctx, nranks * nrows, W, fam, level, row0=rank * nrows, nrows=nrows, rank=rank, nranks=nranks)
+    plan.upload(L.PLANE_INPUT, rnd((nrows, W), 21))
+    flags = L.FLAG_FUSED | L.FLAG_NO_EXCHANGE
+    got = {}
+    try:
+        for mode in (0, 1):
+            L.set_option("split_dry", mode)
+            for s in range(level + 1):
+                plan.fill(s, 0.0)
+            plan.fill(L.PLANE_OUT, 0.0)
+            plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, flags)
+            got[mode] = [plan.download(s).view(np.uint32).copy() for s in list(range(level + 1)) + [L.PLANE_OUT]]
+            plan.decompose(L.PLANE_INPUT, level, flags)
+            got[mode] += [plan.download(s).view(np.uint32).copy() for s in range(level + 1)]
+    finally:
+        L.set_option("split_dry", 0)
+    for a, b in zip(got[0], got[1]):
+        np.testing.assert_array_equal(a, b)
+    plan.close()

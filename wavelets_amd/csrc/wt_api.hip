@@ -79,18 +79,18 @@ static hipEvent_t take_event(wt_ctx *c)
     return e;
 }
 
-ProfScope::ProfScope(wt_ctx *c, const char *n) : ctx(c), name(n)
+ProfScope::ProfScope(wt_ctx *c, const char *n, hipStream_t s) : ctx(c), name(n), st(s ? s : c->stream)
 {
     if (!ctx->profiling) return;
     a = take_event(ctx);
     b = take_event(ctx);
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, st);
 }
 
 ProfScope::~ProfScope()
 {
     if (!ctx->profiling || !a) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, st);
     ctx->pending.push_back({name, a, b});
 }
 
@@ -98,6 +98,7 @@ static int prof_resolve(wt_ctx *c)
 {
     if (c->pending.empty()) return 0;
     WT_HIP(hipStreamSynchronize(c->stream));
+    if (c->comm_stream) WT_HIP(hipStreamSynchronize(c->comm_stream));
     for (auto &p : c->pending) {
         float ms = 0.f;
         WT_HIP(hipEventElapsedTime(&ms, p.a, p.b));
@@ -199,6 +200,13 @@ extern "C" int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *i
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    if (!ctx->comm_stream) {
+        int lo = 0, hi = 0;   // numerically lowest value = highest priority
+        WT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        WT_HIP(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, hi));
+        WT_HIP(hipEventCreateWithFlags(&ctx->ev_to_comm, hipEventDisableTiming));
+        WT_HIP(hipEventCreateWithFlags(&ctx->ev_from_comm, hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -233,7 +241,13 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->comm_stream) {
+        (void)hipStreamDestroy(c->comm_stream);
+        (void)hipEventDestroy(c->ev_to_comm);
+        (void)hipEventDestroy(c->ev_from_comm);
+    }
     for (auto &p : c->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -668,12 +682,13 @@ extern "C" int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane,
     return 0;
 }
 
-extern "C" int wt_halo_exchange(wt_plan *p, int plane, int64_t rows)
+// st == nullptr: the context's compute stream
+static int halo_exchange_on(wt_plan *p, int plane, int64_t rows, hipStream_t st)
 {
-    WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_halo_exchange: null plan");
     if (p->nranks == 1 || rows == 0) return 0;
     wt_ctx *c = p->ctx;
+    if (!st) st = c->stream;
     if (!c->comm) WT_FAIL("wt_halo_exchange: context has no RCCL communicator (wt_ctx_comm_init)");
     if (c->nranks != p->nranks || c->rank != p->rank) WT_FAIL("wt_halo_exchange: plan rank %d/%d != communicator rank %d/%d", p->rank, p->nranks, c->rank, c->nranks);
     if (rows < 0 || rows > p->g.halo) WT_FAIL("wt_halo_exchange: %lld rows exceed the plan's halo margin %d", (long long)rows, p->g.halo);
@@ -682,18 +697,24 @@ extern "C" int wt_halo_exchange(wt_plan *p, int plane, int64_t rows)
     WT_TRY(plane_base(p, plane, &b));
     const size_t P = (size_t)p->g.P, cnt = (size_t)rows * P;
     const int up = p->rank - 1, dn = p->rank + 1;
-    ProfScope ps(c, "rccl_halo_exchange");
+    ProfScope ps(c, "rccl_halo_exchange", st);
     WT_NCCL(g_rccl.GroupStart());
     if (up >= 0) {
-        WT_NCCL(g_rccl.Send(b, cnt, NCCL_FLOAT32, up, c->comm, c->stream));
-        WT_NCCL(g_rccl.Recv(b - cnt, cnt, NCCL_FLOAT32, up, c->comm, c->stream));
+        WT_NCCL(g_rccl.Send(b, cnt, NCCL_FLOAT32, up, c->comm, st));
+        WT_NCCL(g_rccl.Recv(b - cnt, cnt, NCCL_FLOAT32, up, c->comm, st));
     }
     if (dn < p->nranks) {
-        WT_NCCL(g_rccl.Send(b + (size_t)(p->g.nrows - rows) * P, cnt, NCCL_FLOAT32, dn, c->comm, c->stream));
-        WT_NCCL(g_rccl.Recv(b + (size_t)p->g.nrows * P, cnt, NCCL_FLOAT32, dn, c->comm, c->stream));
+        WT_NCCL(g_rccl.Send(b + (size_t)(p->g.nrows - rows) * P, cnt, NCCL_FLOAT32, dn, c->comm, st));
+        WT_NCCL(g_rccl.Recv(b + (size_t)p->g.nrows * P, cnt, NCCL_FLOAT32, dn, c->comm, st));
     }
     WT_NCCL(g_rccl.GroupEnd());
     return 0;
+}
+
+extern "C" int wt_halo_exchange(wt_plan *p, int plane, int64_t rows)
+{
+    WtGuard guard_(ctx_of(p));
+    return halo_exchange_on(p, plane, rows, nullptr);
 }
 
 extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
@@ -778,12 +799,23 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
 // tuning / A-B switches (wt_set_option)
 static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
 static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
+// multi-GPU: run the halo exchange of pass i+1 beside the interior rows of pass i (0 = every
+// exchange on the compute stream, between the passes)
+static int g_opt_overlap = getenv("WT_NO_OVERLAP") ? 0 : 1;
+// workgroup slots the interior launch leaves free for the RCCL kernels of that exchange
+static int g_opt_overlap_reserve = getenv("WT_OVERLAP_RESERVE") ? atoi(getenv("WT_OVERLAP_RESERVE")) : 32;
+// measurement aid: split the passes of a strip plan as the overlapped schedule does, without any
+// exchange (FLAG_NO_EXCHANGE runs on one GPU: what do the edge / interior launches cost?)
+static int g_opt_split_dry = 0;
 
 extern "C" int wt_set_option(const char *name, int value)
 {
     if (!name) WT_FAIL("wt_set_option: null name");
     if (!strcmp(name, "row_kernel")) { g_opt_row_kernel = value != 0; return 0; }
     if (!strcmp(name, "lattice_kernel")) { g_opt_lattice = value != 0; return 0; }
+    if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
+    if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : value; return 0; }
+    if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }
 
@@ -995,7 +1027,7 @@ extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, i
 // acc / p_sum: 0 = plain pass; 1 / 2 = the pass also carries the plane sum in plane `p_sum`
 // (2 = last pass of the schedule: the smooth plane is added too) - fused passes only.
 static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int flags, int acc, bool first_of_sum,
-                               int p_sum)
+                               int p_sum, const FusedRows &rows = FusedRows())
 {
     if (!p) WT_FAIL("wt_decompose_pass: null plan");
     if (ns < 1 || ns > WT_FUSED_MAX_SCALES || s0 < 0 || s0 + ns - 1 > p->max_level)
@@ -1010,6 +1042,7 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
     WT_TRY(plane_base(p, cur, &in));
     WT_TRY(plane_base(p, nxt, &oc));
     if (ns == 1) {
+        if (rows.n) WT_FAIL("wt_decompose_pass: row ranges need a fused pass");
         WT_TRY(check_scale(p, s0, "wt_decompose_pass"));
         float *ow = nullptr;
         WT_TRY(plane_base(p, s0, &ow));
@@ -1023,7 +1056,7 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
     if (acc && first_of_sum != (s0 == 0))
         WT_FAIL("wt_decompose_pass_sum: first must be set for the pass that starts at scale 0 and only for it (got first=%d, s0=%d)", (int)first_of_sum, s0);
     if (acc) WT_TRY(plane_base(p, p_sum, &ps));
-    return wt_fused_launch(p, in, oc, ow, s0, ns, acc, first_of_sum ? nullptr : ps, ps);
+    return wt_fused_launch(p, in, oc, ow, s0, ns, acc, first_of_sum ? nullptr : ps, ps, rows);
 }
 
 extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, int flags)
@@ -1041,6 +1074,66 @@ extern "C" int wt_decompose_pass_sum(wt_plan *p, int cur, int nxt, int s0, int n
     if (sum_plane == cur || sum_plane == nxt || (sum_plane >= s0 && sum_plane < s0 + ns))
         WT_FAIL("wt_decompose_pass_sum: the sum plane aliases a plane of the pass");
     return decompose_pass_impl(p, cur, nxt, s0, ns, flags, last ? 2 : 1, first != 0, sum_plane);
+}
+
+// The passes of a schedule.  Multi-GPU strips with the overlap option: every exchange runs on the
+// communication stream, and a fused pass whose output plane the NEXT pass needs halos of is split
+// into its edge rows (the rows the neighbours need: launched first), the exchange of exactly
+// those rows (communication stream, after the edge launch) and its interior rows (compute
+// stream, beside the exchange; the grid leaves a few workgroup slots to the RCCL kernels).  Same
+// kernels, same per-pixel arithmetic: bit-identical to the serial order.
+static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t *tr, int np, bool with_sum, int dst)
+{
+    wt_ctx *c = p->ctx;
+    const bool multi = p->nranks > 1 && !(flags & 2);
+    const bool dry = g_opt_split_dry && p->nranks > 1 && (flags & 2);
+    const bool overlap = dry || (multi && g_opt_overlap && c->comm_stream);
+    auto exchange_async = [&](int plane, int64_t rows) -> int {     // after everything queued on the compute stream so far
+        if (dry) return 0;
+        WT_HIP(hipEventRecord(c->ev_to_comm, c->stream));
+        WT_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_to_comm, 0));
+        WT_TRY(halo_exchange_on(p, plane, rows, c->comm_stream));
+        WT_HIP(hipEventRecord(c->ev_from_comm, c->comm_stream));
+        return 0;
+    };
+    int cur = src;
+    bool pending = false;                                           // an exchange of `cur` is in flight
+    for (int i = 0; i < np; ++i) {
+        const int s0 = tr[3 * i], ns = tr[3 * i + 1];
+        const bool last = s0 + ns == level;
+        const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+        const int acc = with_sum ? (last ? 2 : 1) : 0;
+        if (!overlap) {
+            WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags, acc, i == 0, dst));
+            cur = nxt;
+            continue;
+        }
+        const int64_t halo = tr[3 * i + 2];
+        if (!pending && halo > 0) WT_TRY(exchange_async(cur, halo));
+        if (!dry && (pending || halo > 0)) WT_HIP(hipStreamWaitEvent(c->stream, c->ev_from_comm, 0));
+        pending = false;
+        const int64_t halo_next = i + 1 < np ? tr[3 * (i + 1) + 2] : 0;
+        const int nrows = p->g.nrows;
+        const bool fused = ns > 1;
+        if (halo_next > 0 && fused && 2 * halo_next < nrows) {
+            FusedRows edge, inner;
+            const bool up = p->rank > 0, dn = p->rank + 1 < p->nranks;
+            if (up) { edge.lo[edge.n] = 0; edge.hi[edge.n] = (int)halo_next; edge.n++; }
+            if (dn) { edge.lo[edge.n] = nrows - (int)halo_next; edge.hi[edge.n] = nrows; edge.n++; }
+            inner.n = 1;
+            inner.lo[0] = up ? (int)halo_next : 0;
+            inner.hi[0] = dn ? nrows - (int)halo_next : nrows;
+            inner.reserve = g_opt_overlap_reserve;
+            WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst, edge));
+            WT_TRY(exchange_async(nxt, halo_next));
+            WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst, inner));
+            pending = true;
+        } else {
+            WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst));
+        }
+        cur = nxt;
+    }
+    return 0;
 }
 
 // Decomposition and np.sum(planes, axis=0) in the same passes: every plane is still written,
@@ -1067,15 +1160,7 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
         WT_TRY(wt_decompose(p, src, level, flags));
         return wt_plane_sum(p, 0, level + 1, dst);
     }
-    int cur = src;
-    for (int i = 0; i < np; ++i) {
-        const int s0 = tr[3 * i], ns = tr[3 * i + 1];
-        const bool last = s0 + ns == level;
-        const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
-        WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags, last ? 2 : 1, i == 0, dst));
-        cur = nxt;
-    }
-    return 0;
+    return run_schedule(p, src, level, flags, tr, np, true, dst);
 }
 
 extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
@@ -1090,14 +1175,7 @@ extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
     int np = 0;
     if (p->ntaps) flags &= ~1;          // user-defined taps: one generic pass per scale
     WT_TRY(wt_schedule(p->family, level, (flags & 1) && wt_fused_supported(p), tr, 32, &np));
-    int cur = src;  // plane holding c_s
-    for (int i = 0; i < np; ++i) {
-        const int s0 = tr[3 * i], ns = tr[3 * i + 1];
-        const int nxt = (s0 + ns == level) ? level : WT_PLANE_SCRATCH(i & 1);
-        WT_TRY(wt_decompose_pass(p, cur, nxt, s0, ns, flags));
-        cur = nxt;
-    }
-    return 0;
+    return run_schedule(p, src, level, flags, tr, np, false, WT_PLANE_NONE);
 }
 
 extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const double *sigma_b, int bilateral_scaling, int flags)

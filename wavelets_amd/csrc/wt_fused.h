@@ -54,6 +54,10 @@ struct FusedArgs {
     // p_out = p_in + w_{s0} + ... + w_{s0+NS-1} (+ c_{s0+NS} in the last pass); may alias p_in
     const float *p_in;
     float *p_out;
+    // rows stored by this launch: up to two ranges [rlo, rhi) of strip-local rows (blockIdx.z);
+    // a whole pass is the single range [0, nrows).  Splitting a pass into its edge rows and its
+    // interior lets the halo exchange of the NEXT pass overlap with the interior (multi-GPU).
+    int rlo[2], rhi[2];
     int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
@@ -229,9 +233,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     const int q = item % D;                              // chain phase
     const int chunk = item / D;
     if (q >= g.nrows) return;                            // whole WG exits together
-    const int n_q = (g.nrows - q + D - 1) / D;           // chain length
-    const int r0 = chunk * a.S;
-    const int r1 = min(r0 + a.S, n_q);
+    // chain elements r of this phase with rlo <= q + D*r < rhi
+    const int lo = a.rlo[blockIdx.z], hi = a.rhi[blockIdx.z];
+    const int ra = lo > q ? (lo - q + D - 1) / D : 0;
+    const int rb = hi > q ? (hi - q + D - 1) / D : 0;
+    const int r0 = ra + chunk * a.S;
+    const int r1 = min(r0 + a.S, rb);
     if (r0 >= r1) return;
 
     // lanes that own stored pixels; a float4 that straddles W writes into the row's pitch
@@ -443,8 +450,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 // ---------------------------------------------------------------------------------------------
 static inline bool wt_fused_supported(const wt_plan *) { return true; }
 
+// Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = workgroup slots the chunk
+// search leaves free (for the RCCL kernels of an exchange running beside the launch).
+struct FusedRows {
+    int n = 0;
+    int lo[2] = {0, 0}, hi[2] = {0, 0};
+    int reserve = 0;
+};
+
 template <int K, int NS, int D, int NW, int PD, int ACC>
-static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name)
+static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name, const FusedRows &rows)
 {
     constexpr int hw = K / 2;
     constexpr int LAT = hw * ((1 << NS) - 1) + (NS - 1);
@@ -460,7 +475,15 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     a.Vx = std::min(VXMAX / 32 * 32, ((W4 + nx - 1) / nx + 31) / 32 * 32);   // balanced, 128-B aligned
     if ((int64_t)a.Vx * nx < W4) WT_FAIL("fused pass: strip sizing failed");
     const int phases = std::min(D, g.nrows);
-    const int n_max = (g.nrows + D - 1) / D;             // longest chain
+    int nranges = rows.n ? rows.n : 1, span_rows = 0;
+    for (int i = 0; i < 2; ++i) {
+        a.rlo[i] = rows.n ? (i < rows.n ? rows.lo[i] : 0) : 0;
+        a.rhi[i] = rows.n ? (i < rows.n ? rows.hi[i] : 0) : (i == 0 ? g.nrows : 0);
+        if (a.rlo[i] < 0 || a.rhi[i] > g.nrows || a.rlo[i] > a.rhi[i]) WT_FAIL("fused pass: bad row range [%d,%d)", a.rlo[i], a.rhi[i]);
+        span_rows = std::max(span_rows, a.rhi[i] - a.rlo[i]);
+    }
+    if (span_rows == 0) return 0;
+    const int n_max = (span_rows + D - 1) / D;           // longest chain of a range
     // Chunking: the resident capacity is `slots` workgroups (256 CUs x workgroups per CU) and a
     // workgroup's cost is its S stored rows plus the 2*LAT warm-up rows.  Pick the chunk count
     // that minimises (dispatch rounds) x (rows per workgroup): usually ONE round with every
@@ -468,8 +491,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
     const int wg_per_cu = NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
-    const int slots = 256 * wg_per_cu;
-    const int64_t nbase = (int64_t)nx * phases;
+    const int slots = std::max(64, 256 * wg_per_cu - rows.reserve);
+    const int64_t nbase = (int64_t)nx * phases * nranges;
     int chunks = 1, S = n_max;
     double best = 1e300;
     for (int c = 1; c <= 4096 && c <= n_max; ++c) {
@@ -493,7 +516,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     a.debug = dbg;
     const int64_t gy = (int64_t)D * chunks;
     if (gy > 65535) WT_FAIL("fused pass: grid too large");
-    dim3 grid(nx, (unsigned)gy), block(NL);
+    dim3 grid(nx, (unsigned)gy, nranges), block(NL);
     ProfScope ps(p->ctx, name);
     hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
@@ -505,18 +528,18 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
 // 4 rows of prefetch.  acc: 0 = plain pass, 1 = also carry the plane sum (p_in -> p_out),
 // 2 = last pass of a sum (adds the smooth plane, streaming store).
 template <int K, int ACC>
-static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns)
+static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns, const FusedRows &rows)
 {
     static const char *names[3][5] = {
         {"wt_fused<d1x3>", "wt_fused<d1x2>", "wt_fused<d8x3>", "wt_fused<d8x2>", "wt_fused<d64x2>"},
         {"wt_fused_acc<d1x3>", "wt_fused_acc<d1x2>", "wt_fused_acc<d8x3>", "wt_fused_acc<d8x2>", "wt_fused_acc<d64x2>"},
         {"wt_fused_sum<d1x3>", "wt_fused_sum<d1x2>", "wt_fused_sum<d8x3>", "wt_fused_sum<d8x2>", "wt_fused_sum<d64x2>"}};
-    if (s0 == 0 && ns == 3) return wt_fused_launch_t<K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0]);
-    if (s0 == 0 && ns == 2) return wt_fused_launch_t<K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1]);
-    if (s0 == 3 && ns == 3) return wt_fused_launch_t<K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2]);
-    if (s0 == 3 && ns == 2) return wt_fused_launch_t<K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3]);
+    if (s0 == 0 && ns == 3) return wt_fused_launch_t<K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0], rows);
+    if (s0 == 0 && ns == 2) return wt_fused_launch_t<K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1], rows);
+    if (s0 == 3 && ns == 3) return wt_fused_launch_t<K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2], rows);
+    if (s0 == 3 && ns == 2) return wt_fused_launch_t<K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3], rows);
     // D = 64 (scales 6-7): taps are 16 / 32 lanes apart
-    if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4]);
+    if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4], rows);
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
@@ -527,7 +550,8 @@ static inline bool wt_fused_has_pass(int s0, int ns)
 
 // acc: see wt_fused_dispatch_acc; p_in / p_out only for acc != 0
 static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns,
-                           int acc = 0, const float *p_in = nullptr, float *p_out = nullptr)
+                           int acc = 0, const float *p_in = nullptr, float *p_out = nullptr,
+                           const FusedRows &rows = FusedRows())
 {
     FusedArgs a{};
     a.in = in;
@@ -537,7 +561,7 @@ static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **ou
     a.p_in = p_in;
     a.p_out = p_out;
     const bool b3 = p->family == WT_B3SPLINE;
-    if (acc == 1) return b3 ? wt_fused_dispatch_acc<5, 1>(p, a, s0, ns) : wt_fused_dispatch_acc<3, 1>(p, a, s0, ns);
-    if (acc == 2) return b3 ? wt_fused_dispatch_acc<5, 2>(p, a, s0, ns) : wt_fused_dispatch_acc<3, 2>(p, a, s0, ns);
-    return b3 ? wt_fused_dispatch_acc<5, 0>(p, a, s0, ns) : wt_fused_dispatch_acc<3, 0>(p, a, s0, ns);
+    if (acc == 1) return b3 ? wt_fused_dispatch_acc<5, 1>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 1>(p, a, s0, ns, rows);
+    if (acc == 2) return b3 ? wt_fused_dispatch_acc<5, 2>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 2>(p, a, s0, ns, rows);
+    return b3 ? wt_fused_dispatch_acc<5, 0>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 0>(p, a, s0, ns, rows);
 }

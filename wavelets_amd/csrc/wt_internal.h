@@ -83,6 +83,10 @@ struct wt_ctx {
     // comm
     int rank = 0, nranks = 1;
     void *comm = nullptr;  // ncclComm_t
+    // second (high-priority) stream for halo exchanges that run beside a pass, and the events that
+    // order it against `stream` (created with the communicator)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_to_comm = nullptr, ev_from_comm = nullptr;
     // small device/host scratch for selects & reductions
     uint32_t *d_hist = nullptr;   // 2048 bins + extras
     double *d_partials = nullptr; // reduction partials
@@ -119,6 +123,7 @@ struct ProfScope {
     wt_ctx *ctx;
     const char *name;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(wt_ctx *c, const char *n);
+    hipStream_t st = nullptr;
+    ProfScope(wt_ctx *c, const char *n, hipStream_t s = nullptr);
     ~ProfScope();
 };
