@@ -237,7 +237,8 @@ def main():
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline figure
     ctx.profile(True)
     ctx.profile_reset()
-    for _ in range(max(3, min(args.steps, 10))):
+    nprof = max(3, min(args.steps, 10))
+    for _ in range(nprof):
         step()
     prof = ctx.profile_entries()
     ctx.profile(False)
@@ -245,12 +246,13 @@ def main():
     kernels = {}
     my_pix = float(nrows) * W
     for name, (calls, ms) in prof.items():
+        # a pass may be launched in several parts (multi-GPU: edge rows, then interior rows): its
+        # algorithmic bytes are per STEP, whatever the number of launches
         bpp = algorithmic_bytes_per_pixel(name)
-        avg_ms = ms / calls
-        kernels[name] = {"calls_per_step": calls // max(3, min(args.steps, 10)),
-                         "avg_ms": round(avg_ms, 4),
+        kernels[name] = {"calls_per_step": calls // nprof,
+                         "avg_ms": round(ms / calls, 4),
                          "algorithmic_GBs": None if bpp is None else
-                         round(bpp * my_pix / (avg_ms * 1e-3) / 1e9, 1)}
+                         round(bpp * my_pix * nprof / (ms * 1e-3) / 1e9, 1)}
     # Dominant kernel = the SOURCE kernel with the largest total time.  The two fused passes are
     # instantiations of one kernel (wt_fused_kernel<..., D=1> and <..., D=8>; rocprof lists them
     # as two rows) and together take ~2/3 of a step, so the roofline entry describes them: per
@@ -264,7 +266,7 @@ def main():
         f = groups.setdefault(key, {"ms": 0.0, "calls": 0, "bytes": 0.0, "members": []})
         f["ms"] += ms
         f["calls"] += c
-        f["bytes"] += bpp * my_pix * c
+        f["bytes"] += bpp * my_pix * nprof
         f["members"].append(n)
     if groups:
         dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -278,7 +280,7 @@ def main():
             if vals and all(v is not None for v in vals):
                 traffic = round(sum(vals) / len(vals))             # HBM bytes per launch
         roofline = {"bound": "hbm", "kernel": dom, "instantiations": sorted(f["members"]),
-                    "launches_per_step": f["calls"] // max(3, min(args.steps, 10)),
+                    "launches_per_step": f["calls"] // nprof,
                     "avg_launch_ms": round(f["ms"] / f["calls"], 4),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
