@@ -50,8 +50,14 @@ enum { WT_TRIANGLE = 0, WT_B3SPLINE = 1 };      /* watroo/wavelets.py:232-287 */
 int wt_abi_version(void);
 const char *wt_last_error(void);
 int wt_device_count(int *count);
-/* process-wide tuning / A-B switches.  "row_kernel" (default 1): single-scale operators use
- * the LDS row kernel where the dilation allows, 0 forces the chain-march kernel (same bits). */
+/* process-wide tuning / A-B switches (every setting produces the same bits).
+ * "row_kernel" (default 1): single-scale operators use the LDS row kernel where the dilation
+ *   allows, 0 forces the chain-march kernel;  "lattice_kernel" (1): lattice kernel for d >= 64.
+ * "overlap" (1): multi-GPU strips run the halo exchange of the next pass beside the interior
+ *   rows of the current one (second stream), 0 = every exchange between the passes;
+ *   "overlap_reserve" (32): workgroup slots the interior launch leaves to the RCCL kernels.
+ * "split_dry" (0): measurement aid - launch the passes of a strip plan split into edge and
+ *   interior rows as "overlap" does, without exchanging (FLAG_NO_EXCHANGE runs). */
 int wt_set_option(const char *name, int value);
 
 /* ---- context ---------------------------------------------------------------------- */
