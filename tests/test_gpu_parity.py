@@ -602,6 +602,23 @@ def test_strip_shaped_wide_image(W, C):
     close(c.sum(axis=0), a, 1e-5 * amax)
 
 
+def test_extremely_wide_rows_take_the_per_scale_kernels(W, C):
+    """Rows beyond ~174 000 pixels: the fused march (31-bit byte offsets within a chunk) declines
+    and the per-scale kernels serve the transform; decompose_sum falls back to the two-call form."""
+    a = rnd((12, 180000), 23)
+    amax = np.abs(a).max()
+    for fam, level in ((W.B3spline, 4), (W.Triangle, 7)):
+        c = W.AtrousTransform(fam)(a, level)
+        ref = C.decompose(a, level, fam.__name__.lower())
+        plan = c._device()
+        for s in range(level + 1):
+            close(plan.download(s), ref[s], 1e-5 * amax)
+        from wavelets_amd import _lib as L
+        plan.upload(L.PLANE_INPUT, a)
+        plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT)
+        close(plan.download(L.PLANE_OUT), a, 2e-5 * amax)
+
+
 def test_large_dilation_scales(W, C):
     """wow-sized dilations (d up to 512) on a 2048x1024 image vs the C oracle."""
     a = rnd((2048, 1024), 9)

@@ -448,7 +448,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static inline bool wt_fused_supported(const wt_plan *) { return true; }
+// The fused march addresses the rows of a chunk with 31-bit byte offsets (fixed store
+// descriptors): the shortest chunk of the widest-dilation pass (D = 64: ~48 steps of 64 rows)
+// must stay below 2 GiB, i.e. rows up to ~174 000 pixels.  Wider images take the per-scale kernels.
+static inline bool wt_fused_supported(const wt_plan *p) { return (int64_t)p->g.P * 4 * 64 * 48 < ((int64_t)1 << 31); }
 
 // Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = workgroup slots the chunk
 // search leaves free (for the RCCL kernels of an exchange running beside the launch).
