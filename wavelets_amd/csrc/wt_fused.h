@@ -164,6 +164,9 @@ __device__ __forceinline__ void wt_bstore4v(__amdgpu_buffer_rsrc_t r, unsigned v
 #ifndef WT_FUSED_W_AUX
 #define WT_FUSED_W_AUX 2
 #endif
+#ifndef WT_FUSED_P_AUX
+#define WT_FUSED_P_AUX 0   // running sum between two passes (re-read by the next pass)
+#endif
 #ifndef WT_FUSED_C_AUX
 #define WT_FUSED_C_AUX 0
 #endif
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
                     pv = pa[kk % PD];
                     pa[kk % PD] = load_acc(k + PD);
                 }
-                wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(rp, at(LAGC), pv);
+                wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), pv);
             }
             koff += step_bytes;
             return;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
             if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
             // the finished reconstruction is a write-once stream; an intermediate sum is re-read
             // by the next pass
-            wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : 0)>(rp, at(LAGC), s);
+            wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
         }
         c1 = n0;
         koff += step_bytes;
