@@ -117,20 +117,12 @@ struct VWin {
 typedef unsigned int wt_v4u __attribute__((ext_vector_type(4)));
 typedef float wt_v4f __attribute__((ext_vector_type(4)));
 
-// Branch-free predicated 16-byte store through a raw buffer descriptor built from wave-uniform
-// values: a row that must not be written gets a zero-length descriptor, a lane that must not
-// write gets an out-of-range offset; the hardware range check drops those stores.  Control
-// flow stays uniform, so the compiler's vmcnt bookkeeping is exact (loads stay in flight
+// Branch-free predicated 16-byte stores through raw buffer descriptors: a row or lane that must
+// not be written gets an out-of-range offset and the hardware range check drops the store.
+// Control flow stays uniform, so the compiler's vmcnt bookkeeping is exact (loads stay in flight
 // across the stores and barriers of several steps).
 // AUX = cache-policy bits of the store (gfx950: 1 = sc0, 2 = nt, 16 = sc1).
-template <int AUX>
-__device__ __forceinline__ void wt_bstore4(uint64_t row_addr, bool row_ok, int row_bytes, unsigned voff, float4 v)
-{
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)row_addr, 0, row_ok ? row_bytes : 0, 0x00020000);
-    wt_v4f t = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
-}
-
+//
 // Store through a descriptor that stays FIXED for the whole march (base = the row the plane
 // stores at step 0, length = the chunk's byte span): the row is selected by the byte offset
 // k * step_bytes folded into voff (one v_add per step shared by all planes), a row or lane that
