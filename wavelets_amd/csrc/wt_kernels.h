@@ -549,14 +549,14 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
 
     WtVert<K, MODE, SMALL_D> vert;
     float4 raw[K];
-    float4 pf0 = load_row(r0 - hw), pf1 = load_row(r0 - hw + 1);
+    // Two rows in flight, in two NAMED registers used in turn (the loop is unrolled by two): a
+    // rotating pair (pf0 = pf1; pf1 = load) makes the compiler copy the load it has just issued
+    // at the end of every iteration, i.e. wait for it at once - no prefetch left.
+    float4 pfa = load_row(r0 - hw), pfb = load_row(r0 - hw + 1);
     // steps t = r0-hw .. r1-1+hw ; step index k selects the LDS buffer
     const int nsteps = (r1 - r0) + 2 * hw;
-    for (int k = 0; k < nsteps; ++k) {
+    auto step = [&](const int k, const float4 cur) {
         const int t = r0 - hw + k;
-        const float4 cur = pf0;
-        pf0 = pf1;
-        pf1 = load_row(t + 2);
         float4 *rowv = rowbuf[k & 1];
         rowv[gl] = cur;
         __syncthreads();
@@ -572,6 +572,18 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
         } else {
             const int r = t - hw;
             vert.emit(raw, a, (int64_t)(q + d * r) * g.P, x, lane_ok);
+        }
+    };
+    for (int k = 0; k < nsteps; k += 2) {
+        {
+            const float4 cur = pfa;
+            pfa = load_row(r0 - hw + k + 2);
+            step(k, cur);
+        }
+        if (k + 1 < nsteps) {                            // workgroup-uniform
+            const float4 cur = pfb;
+            pfb = load_row(r0 - hw + k + 3);
+            step(k + 1, cur);
         }
     }
 }
