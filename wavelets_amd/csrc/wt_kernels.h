@@ -112,23 +112,28 @@ __device__ __forceinline__ float4 wt_load4(const float *row, int xo, int W)
                        row[wt_refl(xo + 3, W)]);
 }
 
-typedef float wt_nt4s __attribute__((ext_vector_type(4)));
+typedef unsigned int wt_su4 __attribute__((ext_vector_type(4)));
+typedef float wt_sf4 __attribute__((ext_vector_type(4)));
+// 16-byte store of pixels x .. x+3 of an image row (row = wave-uniform pointer to the row's first
+// pixel, P = row pitch in floats) through a raw buffer descriptor: a lane that must not write
+// (lane_ok false, or x beyond the row) gets an out-of-range offset and the hardware drops the
+// store.  No exec-mask branch around the store, so the compiler's vmcnt bookkeeping stays exact:
+// behind a branch it has to assume the store may not have been issued and every wait for the
+// next row's loads also waits for this row's stores.  A float4 that straddles W writes into the
+// row's pitch padding (allocated, never read as image data), like the fused passes.
 // nt: streaming (nontemporal) store - the host sets it for planes far larger than the caches
 // (wave-uniform), where write-once outputs only displace useful lines (wow 8192^2: -3 %)
-__device__ __forceinline__ void wt_store4(float *row, int x, int W, float4 v, int nt = 0)
+__device__ __forceinline__ void wt_store4(float *row, int x, int P, float4 v, int nt = 0, bool lane_ok = true)
 {
-    if (x + 3 < W) {
-        if (nt) {
-            wt_nt4s t = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<wt_nt4s *>(row + x));
-        } else {
-            *reinterpret_cast<float4 *>(row + x) = v;
-        }
-    } else {
-        if (x < W) row[x] = v.x;
-        if (x + 1 < W) row[x + 1] = v.y;
-        if (x + 2 < W) row[x + 2] = v.z;
-    }
+    const uint64_t ra = (uint64_t)row;
+    // (the builtin returns int: go through unsigned, or the low word sign-extends into the high one)
+    const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 4, 0x00020000);
+    const unsigned voff = (lane_ok && x >= 0) ? (unsigned)x * 4u : 0xfffffff0u;
+    const wt_sf4 t = {v.x, v.y, v.z, v.w};
+    if (nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_su4, t), r, voff, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_su4, t), r, voff, 0, 0);
 }
 
 __device__ __forceinline__ float wt_sig(float c, float tau, double taud, int soft)
@@ -331,7 +336,7 @@ struct WtVert {
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = wt_var_point(pp[k], mm[k], a.f1, a.f2, a.take_sqrt);
-            if (lane_ok) wt_store4(a.out_c + off, x, g.W, make_float4(v[0], v[1], v[2], v[3]), a.nt);
+            wt_store4(a.out_c + off, x, g.P, make_float4(v[0], v[1], v[2], v[3]), a.nt, lane_ok);
         } else if (MODE == MODE_WOW) {
             // fused wow update: o = conv_s(c^2) (local power), cen[0] = c at this row; result
             // goes to a different plane (the host swaps plane pointers afterwards)
@@ -351,14 +356,12 @@ struct WtVert {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 r4[k] = wt_wow_point(cc[k], pw[k], a.whiten != 0, nn[k], a.tau, tauf, a.soft, a.factor, gg[k]);
-            if (lane_ok) {
-                wt_store4(a.out_c + off, x, g.W, make_float4(r4[0], r4[1], r4[2], r4[3]), a.nt);
-                if (a.gamma) wt_store4(a.gamma + off, x, g.W, make_float4(gg[0], gg[1], gg[2], gg[3]), a.nt);
-            }
-        } else if (lane_ok) {
-            wt_store4(a.out_c + off, x, g.W, o, a.nt);
+            wt_store4(a.out_c + off, x, g.P, make_float4(r4[0], r4[1], r4[2], r4[3]), a.nt, lane_ok);
+            if (a.gamma) wt_store4(a.gamma + off, x, g.P, make_float4(gg[0], gg[1], gg[2], gg[3]), a.nt, lane_ok);
+        } else {
+            wt_store4(a.out_c + off, x, g.P, o, a.nt, lane_ok);
             if (MODE == MODE_DECOMP && a.out_w)
-                wt_store4(a.out_w + off, x, g.W, f4_sub(cen[0], o), a.nt);
+                wt_store4(a.out_w + off, x, g.P, f4_sub(cen[0], o), a.nt, lane_ok);
         }
 #pragma unroll
         for (int j = 0; j < K - 1; ++j) {
@@ -715,8 +718,8 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
             ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
         }
         const int64_t roff = (int64_t)(q + d * r) * g.P;
-        wt_store4(a.out_c + roff, x, g.W, make_float4(o[0], o[1], o[2], o[3]));
-        if (a.out_w) wt_store4(a.out_w + roff, x, g.W, make_float4(ow[0], ow[1], ow[2], ow[3]));
+        wt_store4(a.out_c + roff, x, g.P, make_float4(o[0], o[1], o[2], o[3]));
+        if (a.out_w) wt_store4(a.out_w + roff, x, g.P, make_float4(ow[0], ow[1], ow[2], ow[3]));
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
 #pragma unroll
