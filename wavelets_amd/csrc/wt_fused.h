@@ -36,8 +36,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "wt_internal.h"
 #include "wt_kernels.h"
 
@@ -141,9 +139,6 @@ __device__ __forceinline__ void wt_bstore4v(__amdgpu_buffer_rsrc_t r, unsigned v
 
 // Ablation switches (FusedArgs::debug, env WT_FUSED_DEBUG) are compiled in only with
 // -DWT_FUSED_ABLATION: their loop-invariant branches cost issue slots in every step.
-#ifndef WT_FUSED_STEADY
-#define WT_FUSED_STEADY 0   // 1: predicate-free copy of the step for blocks inside the chunk (spills at 2 waves/SIMD)
-#endif
 #ifdef WT_FUSED_ABLATION
 #define WT_FUSED_DBG(a) ((a).debug)
 #else
@@ -298,14 +293,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
     float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
-    const unsigned chunk_bytes = (unsigned)nsteps * step_bytes + (unsigned)row_bytes;   // < 2^31 (host)
-    auto plane_rsrc = [&](float *base, int lag) -> __amdgpu_buffer_rsrc_t {
+    // Stores: every plane has ONE descriptor for the whole march - base = row r0 of the chain (the
+    // chunk's first stored row), length = the chunk's byte span.  At step k a plane stores row
+    // k - (LAT_IN + LAG) of the chunk, i.e. the lane offset is x*4 + (k - LAT_IN - LAG) * step_bytes:
+    // before the chunk that is negative (wraps to ~4 GiB), after it >= the length - the hardware
+    // range check IS the row predicate, no scalar work per store.  Halo lanes park at 2^31 (the host
+    // keeps a chunk's span incl. warm-up below 2^31, so a parked lane never wraps into range).
+    const unsigned chunk_len = (span - 1u) * step_bytes + (unsigned)row_bytes;
+    auto plane_rsrc = [&](float *base, int) -> __amdgpu_buffer_rsrc_t {
         // Length and flag words pass through an empty asm so that every descriptor owns its four
         // SGPRs: shared words would be copied into place before every store (2 s_mov each).
-        unsigned len = chunk_bytes, flags = 0x00020000;
+        unsigned len = chunk_len, flags = 0x00020000;
         asm volatile("" : "+s"(len), "+s"(flags));
-        return __builtin_amdgcn_make_buffer_rsrc((void *)row_addr0(base, t0 - lag), 0, len, flags);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)row_addr0(base, r0), 0, len, flags);
     };
+    // byte offset of a plane's row at step 0 (negative, as unsigned): -(LAT_IN + LAG) * step_bytes
+    auto lag_off = [&](int lag) -> unsigned { return 0u - (unsigned)(LAT_IN + lag) * step_bytes; };
+    const unsigned o0 = lag_off(LAG0), o1 = lag_off(LAG1), o2 = lag_off(LAG2), oc = lag_off(LAGC);
     const __amdgpu_buffer_rsrc_t rw0 = plane_rsrc(a.out_w[0], LAG0);
     const __amdgpu_buffer_rsrc_t rw1 = plane_rsrc(a.out_w[A1], LAG1);
     const __amdgpu_buffer_rsrc_t rw2 = plane_rsrc(a.out_w[A2], LAG2);
@@ -328,16 +332,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
 
-    // One chain step.  STEADY (compile time): every store of this step is inside the chunk.
-    auto step = [&](auto steady_tag, const int kb, const int kk) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
+    // One chain step.
+    auto step = [&](const int kb, const int kk) {
         const int k = kb + kk;
         const int t = t0 + k;
         // step k stores row t0 + k - LAG of a plane: inside the chunk iff k - (LAT_IN + LAG) < span
-        const unsigned vk = voff + koff;
-        auto at = [&](int lag) -> unsigned {             // lane offset of this step's row, or parked
-            if constexpr (STEADY) return vk;
-            return (((unsigned)(k - LAT_IN - lag) < span) && !(dbg & 1)) ? vk : WT_FUSED_PARKED;
+        const unsigned vk = voff + koff + ((dbg & 1) ? WT_FUSED_PARKED : 0u);
+        auto at = [&](int lag) -> unsigned {             // lane offset of this step's row of a plane
+            return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : oc);
         };
         const float4 cur = pf[kk % PD];
         pf[kk % PD] = load_row(t + PD);
@@ -428,18 +430,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         koff += step_bytes;
     };
 
-    // steady blocks: kb - LAT_IN - LAGC >= 0 and kb + U - 1 - LAT_IN - LAG0 < span
-    [[maybe_unused]] const int kb_lo = LAT_IN + LAGC, kb_hi = LAT_IN + LAG0 + (int)span - U;
     for (int kb = 0; kb < nsteps; kb += U) {
-#if WT_FUSED_STEADY
-        if (kb >= kb_lo && kb <= kb_hi && !dbg) {
 #pragma unroll
-            for (int kk = 0; kk < U; ++kk) step(std::true_type{}, kb, kk);
-            continue;
-        }
-#endif
-#pragma unroll
-        for (int kk = 0; kk < U; ++kk) step(std::false_type{}, kb, kk);
+        for (int kk = 0; kk < U; ++kk) step(kb, kk);
     }
 }
 
