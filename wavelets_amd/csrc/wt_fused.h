@@ -319,15 +319,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     constexpr bool PIN = ACC != 0 && D != 1;
     const __amdgpu_buffer_rsrc_t rp = plane_rsrc(ACC ? a.p_out : a.out_c, LAGC);
     unsigned koff = 0;                                   // k * step_bytes
-    const char *pin0 = PIN ? reinterpret_cast<const char *>(a.p_in + (int64_t)(q + (int64_t)D * r0) * g.P) : nullptr;
-    auto load_acc = [&](int k) -> float4 {               // p_in row of chain element t0 + k - LAG0
-        const int rel = min(max(k - LAT_IN - LAG0, 0), (int)span - 1);
-        return *reinterpret_cast<const float4 *>(pin0 + (size_t)((unsigned)rel * step_bytes) + xoff);
+    // incoming partial sum: the same fixed-descriptor addressing as the stores (row r0 of the chain,
+    // the chunk's byte span) - a row before or after the chunk reads as 0 without touching memory
+    // (its sum is never stored), so there is no clamp and no scalar address arithmetic per step
+    const __amdgpu_buffer_rsrc_t rpin = plane_rsrc(PIN ? const_cast<float *>(a.p_in) : a.out_c, 0);
+    // (halo lanes are parked like their stores: they read nothing)
+    auto load_acc = [&](int k_ahead) -> float4 {         // p_in row of chain element t0 + k - LAG0, k = current step + k_ahead
+        const wt_v4u t = __builtin_amdgcn_raw_buffer_load_b128(rpin, voff + koff + o0 + (unsigned)k_ahead * step_bytes, 0, 0);
+        const wt_v4f f = __builtin_bit_cast(wt_v4f, t);
+        return make_float4(f.x, f.y, f.z, f.w);
     };
     float4 pa[PIN ? PD : 1];
     if constexpr (PIN) {
 #pragma unroll
-        for (int i = 0; i < PD; ++i) pa[i] = load_acc(i);
+        for (int i = 0; i < PD; ++i) pa[i] = load_acc(i);   // koff = 0 here
     }
     const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
                 float4 pv = cur;
                 if constexpr (PIN) {
                     pv = pa[kk % PD];
-                    pa[kk % PD] = load_acc(k + PD);
+                    pa[kk % PD] = load_acc(PD);
                 }
                 wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), pv);
             }
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         float4 pin_cur = zero;
         if constexpr (PIN) {
             pin_cur = pa[kk % PD];
-            pa[kk % PD] = load_acc(k + PD);
+            pa[kk % PD] = load_acc(PD);
         }
         // ACC: the ring slots that come due in this step were written G1 / G2 steps ago - read
         // them before the barrier so the LDS latency hides behind the vertical filters.  Lanes
