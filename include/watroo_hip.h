@@ -55,7 +55,7 @@ int wt_device_count(int *count);
  *   allows, 0 forces the chain-march kernel;  "lattice_kernel" (1): lattice kernel for d >= 64.
  * "overlap" (1): multi-GPU strips run the halo exchange of the next pass beside the interior
  *   rows of the current one (second stream), 0 = every exchange between the passes;
- *   "overlap_reserve" (32): workgroup slots the interior launch leaves to the RCCL kernels.
+ *   "overlap_reserve" (16): compute units the interior launch leaves to the RCCL kernels.
  * "split_dry" (0): measurement aid - launch the passes of a strip plan split into edge and
  *   interior rows as "overlap" does, without exchanging (FLAG_NO_EXCHANGE runs). */
 int wt_set_option(const char *name, int value);

@@ -17,7 +17,7 @@ rng = np.random.default_rng(0)
 plan.upload(L.PLANE_INPUT, rng.standard_normal((nrows, W), dtype=np.float32))
 flags = L.FLAG_FUSED | L.FLAG_NO_EXCHANGE
 ref = None
-for reserve in (None, 0, 32, 64):
+for reserve in (None, 0, 16, 32):
     L.set_option("split_dry", 0 if reserve is None else 1)
     if reserve is not None:
         L.set_option("overlap_reserve", reserve)

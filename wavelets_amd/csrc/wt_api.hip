@@ -802,8 +802,8 @@ static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
 // multi-GPU: run the halo exchange of pass i+1 beside the interior rows of pass i (0 = every
 // exchange on the compute stream, between the passes)
 static int g_opt_overlap = getenv("WT_NO_OVERLAP") ? 0 : 1;
-// workgroup slots the interior launch leaves free for the RCCL kernels of that exchange
-static int g_opt_overlap_reserve = getenv("WT_OVERLAP_RESERVE") ? atoi(getenv("WT_OVERLAP_RESERVE")) : 32;
+// compute units (of 256) the interior launch leaves free for the RCCL kernels of that exchange
+static int g_opt_overlap_reserve = getenv("WT_OVERLAP_RESERVE") ? atoi(getenv("WT_OVERLAP_RESERVE")) : 16;
 // measurement aid: split the passes of a strip plan as the overlapped schedule does, without any
 // exchange (FLAG_NO_EXCHANGE runs on one GPU: what do the edge / interior launches cost?)
 static int g_opt_split_dry = 0;
@@ -814,7 +814,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "row_kernel")) { g_opt_row_kernel = value != 0; return 0; }
     if (!strcmp(name, "lattice_kernel")) { g_opt_lattice = value != 0; return 0; }
     if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
-    if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : value; return 0; }
+    if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }

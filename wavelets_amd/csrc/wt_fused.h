@@ -449,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 // must stay below 2 GiB, i.e. rows up to ~174 000 pixels.  Wider images take the per-scale kernels.
 static inline bool wt_fused_supported(const wt_plan *p) { return (int64_t)p->g.P * 4 * 64 * 48 < ((int64_t)1 << 31); }
 
-// Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = workgroup slots the chunk
+// Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = compute units the chunk
 // search leaves free (for the RCCL kernels of an exchange running beside the launch).
 struct FusedRows {
     int n = 0;
@@ -490,7 +490,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
     const int wg_per_cu = NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
-    const int slots = std::max(64, 256 * wg_per_cu - rows.reserve);
+    const int slots = std::max(64, (256 - rows.reserve) * wg_per_cu);
     const int64_t nbase = (int64_t)nx * phases * nranges;
     int chunks = 1, S = n_max;
     double best = 1e300;
