@@ -1028,3 +1028,25 @@ def test_coefficients_copy_and_pickle(W):
         np.testing.assert_array_equal(o.data, ref)
         o.denoise([5, 3])
         np.testing.assert_array_equal(o.data, c.data)
+
+
+@pytest.mark.parametrize("fam_name,shape", [("b3spline", (300, 517)), ("triangle", (257, 300)), ("b3spline", (1100, 2050))])
+def test_two_pixel_bilateral_kernel_equals_four_pixel_kernel_bitwise(W, fam_name, shape):
+    """wt_bilateral2_kernel (2 pixels per thread, d >= 4) performs the per-pixel operations of
+    wt_bilateral_kernel in the same order: every plane of a bilateral transform is bit-identical
+    whichever kernel serves the scales >= 2 (option "bilateral2")."""
+    from wavelets_amd import _lib as L
+    fam = W.B3spline if fam_name == "b3spline" else W.Triangle
+    a = rnd(shape, 31)
+    out = {}
+    try:
+        for mode in (0, 1):
+            L.set_option("bilateral2", mode)
+            c = W.AtrousTransform(fam, bilateral=1.0)(a, 6)
+            out[mode] = c.data.copy()
+            c2 = W.AtrousTransform(fam, bilateral=[1.0, 2.0, 0.5], bilateral_scaling=True)(a, 5)
+            out[mode + 2] = c2.data.copy()
+    finally:
+        L.set_option("bilateral2", 1)
+    np.testing.assert_array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+    np.testing.assert_array_equal(out[2].view(np.uint32), out[3].view(np.uint32))

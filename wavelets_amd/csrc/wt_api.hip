@@ -799,6 +799,7 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
 // tuning / A-B switches (wt_set_option)
 static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
 static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
+static int g_opt_bilateral2 = getenv("WT_NO_BILATERAL2") ? 0 : 1;   // 2-pixel bilateral kernel for d >= 4
 // multi-GPU: run the halo exchange of pass i+1 beside the interior rows of pass i (0 = every
 // exchange on the compute stream, between the passes)
 static int g_opt_overlap = getenv("WT_NO_OVERLAP") ? 0 : 1;
@@ -813,6 +814,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!name) WT_FAIL("wt_set_option: null name");
     if (!strcmp(name, "row_kernel")) { g_opt_row_kernel = value != 0; return 0; }
     if (!strcmp(name, "lattice_kernel")) { g_opt_lattice = value != 0; return 0; }
+    if (!strcmp(name, "bilateral2")) { g_opt_bilateral2 = value != 0; return 0; }
     if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
     if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
@@ -994,9 +996,17 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
     dim3 grid, block;
+    const bool small = (1 << s) < 4, b3 = p->family == WT_B3SPLINE;
+    if (!small && g_opt_bilateral2) {                    // two pixels per thread: 3-4 waves per SIMD
+        WT_TRY(chain_geometry(p, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64));
+        ProfScope ps(p->ctx, "wt_bilateral2_kernel");
+        if (b3) hipLaunchKernelGGL((wt_bilateral2_kernel<5>), grid, block, 0, p->ctx->stream, a);
+        else hipLaunchKernelGGL((wt_bilateral2_kernel<3>), grid, block, 0, p->ctx->stream, a);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
     WT_TRY(chain_geometry(p, s, a, grid, block));
     ProfScope ps(p->ctx, "wt_bilateral_kernel");
-    const bool small = a.d < 4, b3 = p->family == WT_B3SPLINE;
     if (b3 && small) hipLaunchKernelGGL((wt_bilateral_kernel<5, true>), grid, block, 0, p->ctx->stream, a);
     else if (b3) hipLaunchKernelGGL((wt_bilateral_kernel<5, false>), grid, block, 0, p->ctx->stream, a);
     else if (small) hipLaunchKernelGGL((wt_bilateral_kernel<3, true>), grid, block, 0, p->ctx->stream, a);

@@ -730,6 +730,146 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// K10b  the same bilateral convolution with TWO pixels per thread (d >= 4).  The 4-pixel kernel
+// holds its K x K float4 neighbourhood in ~240 VGPRs: 2 waves per SIMD, and at that occupancy the
+// dependent chain of every tap (difference, square, scale, exp, accumulate) - not the instruction
+// count - sets the pace.  Half the pixels per thread halve the window (K x K float2) and allow
+// 3-4 waves per SIMD.  Per-pixel arithmetic is identical to wt_bilateral_kernel (same operations
+// in the same order, variance included), so the two kernels produce the same bits.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int wt_su2 __attribute__((ext_vector_type(2)));
+typedef float wt_sf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wt_store2(float *row, int x, int P, float2 v)
+{
+    const uint64_t ra = (uint64_t)row;
+    const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 4, 0x00020000);
+    const wt_sf2 t = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), r, (unsigned)x * 4u, 0, 0);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
+{
+    constexpr int hw = K / 2;
+    const Geo g = a.g;
+    int bx, by;
+    wt_xcd_remap(bx, by);
+    const int x = (bx * 64 + threadIdx.x) * 2;
+    if (x >= g.W) return;
+    const int item = by * blockDim.y + threadIdx.y;
+    const int d = a.d;
+    const int q = item % d;
+    const int c = item / d;
+    if (c >= a.chunks || q >= g.nrows) return;
+    const int n_q = (g.nrows - q + d - 1) / d;
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+    const int gy0 = g.row0 + q;
+
+    // operand columns do not depend on the row: pixel pair x + (j - hw) d, reflected per pixel at
+    // the image border; an in-image pair is one aligned 8-byte load (x even, d % 4 == 0)
+    int xa[K], xb[K];
+    unsigned pair = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int xo = x + (j - hw) * d;
+        xa[j] = wt_refl(xo, g.W);
+        xb[j] = wt_refl(xo + 1, g.W);
+        if (xo >= 0 && xo + 1 < g.W) pair |= 1u << j;
+    }
+    float2 win[K][K];
+    auto load_win_row = [&](int r, float2 (&dst)[K]) {
+        const float *row = wt_row(a.in, g, gy0 + d * r);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if ((pair >> j) & 1u) dst[j] = *reinterpret_cast<const float2 *>(row + xa[j]);
+            else dst[j] = make_float2(row[xa[j]], row[xb[j]]);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
+    float2 nxt[K];
+
+    const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
+    for (int r = r0; r < r1; ++r) {
+        load_win_row(min(r + 1, r1 - 1) + hw, nxt);      // software prefetch of the entering row
+        const int64_t roff = (int64_t)(q + d * r) * g.P;
+        const float I[2] = {win[hw][hw].x, win[hw][hw].y};
+        float vv[2];
+        if (a.inline_var) {
+            // row filters, then column filter: the arithmetic of wt_hrow_filter<MODE_VAR> + WtVert
+            float m[2], p[2];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float h[2], h2[2];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float v[2] = {win[i][j].x, win[i][j].y};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float sq = v[k] * v[k];
+                        h[k] = (j == 0) ? wt_tap<K>(0) * v[k] : fmaf(wt_tap<K>(j), v[k], h[k]);
+                        h2[k] = (j == 0) ? wt_tap<K>(0) * sq : fmaf(wt_tap<K>(j), sq, h2[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    m[k] = (i == 0) ? wt_tap<K>(0) * h[k] : fmaf(wt_tap<K>(i), h[k], m[k]);
+                    p[k] = (i == 0) ? wt_tap<K>(0) * h2[k] : fmaf(wt_tap<K>(i), h2[k], p[k]);
+                }
+            }
+            vv[0] = wt_var_point(p[0], m[0], a.f1, a.f2, 0);
+            vv[1] = wt_var_point(p[1], m[1], a.f1, a.f2, 0);
+        } else {
+            vv[0] = a.aux[roff + x];
+            vv[1] = x + 1 < g.W ? a.aux[roff + x + 1] : 1.f;
+        }
+        float norm[2], acc[2], s2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            norm[k] = kc;
+            acc[k] = kc * I[k];
+            s2[k] = -0.72134752044448170368f / vv[k];      // -log2(e) / (2 var)
+        }
+        // taps in the reference order (watroo/wavelets.py:89-91), as in wt_bilateral_kernel
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (i == hw && j == hw) continue;
+                const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
+                const float2 t = win[K - 1 - i][K - 1 - j];
+                const float It[2] = {t.x, t.y};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float diff = I[k] - It[k];
+                    const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, s2[k], lk));
+                    norm[k] += w;
+                    acc[k] = fmaf(It[k], w, acc[k]);
+                }
+            }
+        }
+        float o[2], ow[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            o[k] = acc[k] / norm[k];
+            ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
+        }
+        wt_store2(a.out_c + roff, x, g.P, make_float2(o[0], o[1]));
+        if (a.out_w) wt_store2(a.out_w + roff, x, g.P, make_float2(ow[0], ow[1]));
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) win[i][j] = win[i + 1][j];
+            win[K - 1][j] = nxt[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pointwise kernels over the strip's owned rows: rows are contiguous (pitch P), so they are a
 // flat float4 range of nrows*P/4 elements.  Grid-stride, 16 B per lane.
 // ---------------------------------------------------------------------------------------------
