@@ -1032,9 +1032,9 @@ def test_coefficients_copy_and_pickle(W):
 
 @pytest.mark.parametrize("fam_name,shape", [("b3spline", (300, 517)), ("triangle", (257, 300)), ("b3spline", (1100, 2050))])
 def test_two_pixel_bilateral_kernel_equals_four_pixel_kernel_bitwise(W, fam_name, shape):
-    """wt_bilateral2_kernel (2 pixels per thread, d >= 4) performs the per-pixel operations of
-    wt_bilateral_kernel in the same order: every plane of a bilateral transform is bit-identical
-    whichever kernel serves the scales >= 2 (option "bilateral2")."""
+    """wt_bilateral2_kernel (2 pixels per thread, row filters of the variance cached in an LDS ring)
+    performs the per-pixel operations of wt_bilateral_kernel in the same order: every plane of a
+    bilateral transform is bit-identical whichever kernel runs (option "bilateral2")."""
     from wavelets_amd import _lib as L
     fam = W.B3spline if fam_name == "b3spline" else W.Triangle
     a = rnd(shape, 31)

@@ -799,7 +799,7 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
 // tuning / A-B switches (wt_set_option)
 static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
 static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
-static int g_opt_bilateral2 = getenv("WT_NO_BILATERAL2") ? 0 : 1;   // 2-pixel bilateral kernel for d >= 4
+static int g_opt_bilateral2 = getenv("WT_NO_BILATERAL2") ? 0 : 1;   // 2-pixel bilateral kernel
 // multi-GPU: run the halo exchange of pass i+1 beside the interior rows of pass i (0 = every
 // exchange on the compute stream, between the passes)
 static int g_opt_overlap = getenv("WT_NO_OVERLAP") ? 0 : 1;
@@ -997,7 +997,7 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
     dim3 grid, block;
     const bool small = (1 << s) < 4, b3 = p->family == WT_B3SPLINE;
-    if (!small && g_opt_bilateral2) {                    // two pixels per thread: 3-4 waves per SIMD
+    if (g_opt_bilateral2) {                              // two pixels per thread: 4 waves per SIMD
         WT_TRY(chain_geometry(p, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64));
         ProfScope ps(p->ctx, "wt_bilateral2_kernel");
         if (b3) hipLaunchKernelGGL((wt_bilateral2_kernel<5>), grid, block, 0, p->ctx->stream, a);

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// K10b  the same bilateral convolution with TWO pixels per thread (d >= 4).  The 4-pixel kernel
+// K10b  the same bilateral convolution with TWO pixels per thread (any dilation).  The 4-pixel kernel
 // holds its K x K float4 neighbourhood in ~240 VGPRs: 2 waves per SIMD, and at that occupancy the
 // dependent chain of every tap (difference, square, scale, exp, accumulate) - not the instruction
 // count - sets the pace.  Half the pixels per thread halve the window (K x K float2) and allow
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
     const int gy0 = g.row0 + q;
 
     // operand columns do not depend on the row: pixel pair x + (j - hw) d, reflected per pixel at
-    // the image border; an in-image pair is one aligned 8-byte load (x even, d % 4 == 0)
+    // the image border; an in-image pair at an even pixel is one aligned 8-byte load
     int xa[K], xb[K];
     unsigned pair = 0;
 #pragma unroll
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         const int xo = x + (j - hw) * d;
         xa[j] = wt_refl(xo, g.W);
         xb[j] = wt_refl(xo + 1, g.W);
-        if (xo >= 0 && xo + 1 < g.W) pair |= 1u << j;
+        if (xo >= 0 && xo + 1 < g.W && (xo & 1) == 0) pair |= 1u << j;   // d = 1: odd operands take two 4-byte loads
     }
     float2 win[K][K];
     auto load_win_row = [&](int r, float2 (&dst)[K]) {
@@ -793,6 +793,40 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
     for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
     float2 nxt[K];
 
+    // In-kernel variance: the row filters (h = row-filtered I, h2 = row-filtered I^2) of a window
+    // row are computed ONCE, when the row enters, and parked in a per-thread LDS ring of K slots
+    // (no other thread touches them: no barrier); every step reads the K pairs for the column
+    // filter instead of filtering all K rows again (4/5 of that arithmetic, ~20 % of the kernel's
+    // VALU work; at 4 waves per SIMD the kernel is VALU-bound).  Same operations in the same
+    // order as wt_hrow_filter<MODE_VAR> + WtVert: bit-identical to the separate variance pass.
+    __shared__ float2 hring[K][2][256];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    auto row_filters = [&](const float2 (&wr)[K], float2 &h, float2 &h2) {
+        float hh[2], hh2[2];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float v[2] = {wr[j].x, wr[j].y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float sq = v[k] * v[k];
+                hh[k] = (j == 0) ? wt_tap<K>(0) * v[k] : fmaf(wt_tap<K>(j), v[k], hh[k]);
+                hh2[k] = (j == 0) ? wt_tap<K>(0) * sq : fmaf(wt_tap<K>(j), sq, hh2[k]);
+            }
+        }
+        h = make_float2(hh[0], hh[1]);
+        h2 = make_float2(hh2[0], hh2[1]);
+    };
+    if (a.inline_var) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            float2 h, h2;
+            row_filters(win[i], h, h2);
+            hring[i][0][tid] = h;
+            hring[i][1][tid] = h2;
+        }
+    }
+    int slot0 = 0;                                       // ring slot of window row 0
+
     const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
     for (int r = r0; r < r1; ++r) {
         load_win_row(min(r + 1, r1 - 1) + hw, nxt);      // software prefetch of the entering row
@@ -800,27 +834,33 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         const float I[2] = {win[hw][hw].x, win[hw][hw].y};
         float vv[2];
         if (a.inline_var) {
-            // row filters, then column filter: the arithmetic of wt_hrow_filter<MODE_VAR> + WtVert
+            float2 hn, h2n;
+            row_filters(win[K - 1], hn, h2n);            // the row that entered the window
+            {
+                const int sn = slot0 == 0 ? K - 1 : slot0 - 1;
+                hring[sn][0][tid] = hn;
+                hring[sn][1][tid] = h2n;
+            }
             float m[2], p[2];
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                float h[2], h2[2];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float v[2] = {win[i][j].x, win[i][j].y};
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const float sq = v[k] * v[k];
-                        h[k] = (j == 0) ? wt_tap<K>(0) * v[k] : fmaf(wt_tap<K>(j), v[k], h[k]);
-                        h2[k] = (j == 0) ? wt_tap<K>(0) * sq : fmaf(wt_tap<K>(j), sq, h2[k]);
-                    }
+                float2 h, h2;
+                if (i < K - 1) {
+                    const int si = slot0 + i < K ? slot0 + i : slot0 + i - K;
+                    h = hring[si][0][tid];
+                    h2 = hring[si][1][tid];
+                } else {
+                    h = hn;
+                    h2 = h2n;
                 }
+                const float hk[2] = {h.x, h.y}, h2k[2] = {h2.x, h2.y};
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    m[k] = (i == 0) ? wt_tap<K>(0) * h[k] : fmaf(wt_tap<K>(i), h[k], m[k]);
-                    p[k] = (i == 0) ? wt_tap<K>(0) * h2[k] : fmaf(wt_tap<K>(i), h2[k], p[k]);
+                    m[k] = (i == 0) ? wt_tap<K>(0) * hk[k] : fmaf(wt_tap<K>(i), hk[k], m[k]);
+                    p[k] = (i == 0) ? wt_tap<K>(0) * h2k[k] : fmaf(wt_tap<K>(i), h2k[k], p[k]);
                 }
             }
+            slot0 = slot0 + 1 == K ? 0 : slot0 + 1;
             vv[0] = wt_var_point(p[0], m[0], a.f1, a.f2, 0);
             vv[1] = wt_var_point(p[1], m[1], a.f1, a.f2, 0);
         } else {
