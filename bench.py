@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mpix/s of a-trous decompose + plane sum (B3spline, 6 scales, float32).
+"""Benchmark of the a-trous hot path: Mpix/s, roofline fraction, CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|cfg2|cfg3|cfg5]
 
-N = 1 : the BASELINE.json headline workload - 8192 x 8192 float32, B3spline, 6 scales,
-        decompose (7 planes materialised in HBM) followed by the plane sum; input already
-        resident in HBM when the timed region starts.
-N > 1 : launched by torch.distributed.run, one rank per GPU.  BASELINE config 4: one
-        32768 x 32768 image split into N row strips, halo rows exchanged with the strip
-        neighbours over RCCL (ncclSend/ncclRecv on the compute stream) before every pass.
-        torch.distributed (gloo) is only the launcher plumbing: rendezvous, broadcast of the
-        RCCL unique id, barrier and the MAX over ranks of the timed region.
+--config headline (default; BASELINE.json `metric`)
+    N = 1 : 8192 x 8192 float32 N(0,1), B3spline, 6 scales: decompose (7 planes materialised in
+            HBM) + plane sum; input already resident in HBM when the timed region starts.
+    N > 1 : BASELINE config 4: one 32768 x 32768 image split into N row strips, halo rows
+            exchanged with the strip neighbours over RCCL before every pass.  `python bench.py
+            --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+            itself (as a CHILD process, before anything touches the GPU) when it is not already
+            running under it; torch.distributed (gloo) is only the launcher plumbing:
+            rendezvous, broadcast of the RCCL unique id, barrier, MAX over ranks.
+--config cfg2 | cfg3 | cfg5  (N = 1; the other BASELINE.json configs, same JSON shape)
+    cfg2  4096^2 B3spline L=6 decompose + reconstruct
+    cfg3  8192^2 Triangle L=8 + denoise([5,3,2]) soft threshold + reconstruct
+    cfg5  8192^2 wow(bilateral=1, denoise_coefficients=[5,2])  (B3spline, 11 scales)
 
 One step = one pass of the hot path over the image.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -29,6 +33,16 @@ if ROOT not in sys.path:
 LEVEL = 6
 FAMILY = "b3spline"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy
+VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak (MI355X_MICROARCH.md chip table)
+
+CONFIGS = {
+    # name: (side, family, level, workload text)
+    "headline": (8192, "b3spline", 6, "decompose ({n} planes in HBM) + plane sum"),
+    "cfg2": (4096, "b3spline", 6, "decompose ({n} planes in HBM) + plane sum (BASELINE configs[1])"),
+    "cfg3": (8192, "triangle", 8, "decompose + MAD noise + denoise([5,3,2]) soft + plane sum "
+                                  "(BASELINE configs[2])"),
+    "cfg5": (8192, "b3spline", 11, "wow(bilateral=1, denoise_coefficients=[5,2]) (BASELINE configs[4])"),
+}
 
 
 def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
@@ -40,10 +54,27 @@ def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
     plane (last pass); the accumulate variants additionally the sum's share of the planes they
     fold in: 4*NS, +8 in the last pass (smooth plane read, reconstruction written).  The
     intermediate smooth plane between two passes is NOT algorithmic (it is the price of the
-    two-pass structure).  Shares add up to 32 (decompose) and 64 (decompose + sum) for L = 6."""
+    two-pass structure).  Shares add up to 32 (decompose) and 64 (decompose + sum) for L = 6.
+    cfg3 (108 B/pixel): the MAD select reads plane 0 once (4; the three histogram
+    launches share it), denoise([..3 sigmas..]) is 8 per thresholded plane; fused into the sum
+    kernel those 24 ride on wt_denoise_sum_kernel next to the sum's 4*(L+2).
+    cfg5: per-scale operators - bilateral scale 12 (read c_s, write w_s and c_{s+1}), fused wow
+    update 8 (read c, write c)."""
     if kernel.startswith("wt_plane_sum"):
         return 4.0 * (level + 2)                 # read level+1 planes, write one
-    if kernel.startswith("wt_chain_kernel<decomp>"):
+    if kernel.startswith("wt_denoise_sum"):
+        return 4.0 * (level + 2) + 8.0 * 3       # + RMW of the three thresholded planes
+    if kernel.startswith("wt_hist"):
+        return 4.0 / 3.0                         # three launches share the one compulsory read
+    if kernel.startswith("wt_signif"):
+        return 8.0
+    if kernel.startswith("wt_bilateral"):
+        return 12.0
+    if kernel.startswith(("wt_row_kernel<wow>", "wt_lattice_kernel<wow>", "wt_chain_kernel<wow>",
+                          "wt_wow_kernel")):
+        return 8.0
+    if kernel.startswith(("wt_chain_kernel<decomp>", "wt_row_kernel<decomp>",
+                          "wt_lattice_kernel<decomp>")):
         return 8.0                               # write w_s; read c_0 / write c_L once overall
     if kernel.startswith("wt_fused"):
         tag = kernel[kernel.index("<") + 1:-1]                    # e.g. d8x3
@@ -57,43 +88,87 @@ def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
     return None
 
 
+def whole_path_bytes_per_pixel(config, level):
+    """SURVEY 8(d) per-pixel figure of the whole step."""
+    if config == "cfg3":
+        return 4.0 * (level + 2) + 4.0 + 24.0 + 4.0 * (level + 2)    # 108 for L = 8
+    if config == "cfg5":
+        # per scale: bilateral 12 + whitening update 8; MAD read 4; last-plane update 8; sum 4*(n+2)
+        return 20.0 * level + 4.0 + 8.0 + 4.0 * (level + 2)
+    return 8.0 * (level + 2)
+
+
 def make_strip(nrows, W, seed):
-    """Synthetic N(0,1) float32 strip; tall strips repeat a 2048-row block (generation time)."""
+    """Synthetic N(0,1) float32 strip: np.random.default_rng(seed).standard_normal((nrows, W))
+    (SURVEY 8d), generated in row blocks so that the temporary stays small."""
+    import numpy as np
     rng = np.random.default_rng(seed)
-    block = rng.standard_normal((min(nrows, 2048), W), dtype=np.float32)
-    if nrows <= 2048:
-        return block
-    reps = (nrows + 2047) // 2048
-    return np.ascontiguousarray(np.tile(block, (reps, 1))[:nrows])
+    out = np.empty((nrows, W), dtype=np.float32)
+    for r in range(0, nrows, 1024):
+        rng.standard_normal(dtype=np.float32, out=out[r:r + 1024])
+    return out
 
 
-def cpu_baseline():
+def cpu_baseline(config, side, family, level):
     """The C/OpenMP oracle (a port of the reference algorithm, oracle/atrous_ref.c) timed on
     this host on a bounded sample of the same workload."""
+    import numpy as np
     from oracle import cref
     cref.build()
     cores = cref.usable_cpus()
     threads = min(cores, cref.num_threads())
     cref.set_threads(threads)
-    probe = np.random.default_rng(0).standard_normal((1024, 1024), dtype=np.float32)
-    cref.plane_sum(cref.decompose(probe, LEVEL, FAMILY))      # spawn the OpenMP team
+
+    def run(img):
+        if config == "cfg5":
+            return cref.wow(img, family, bilateral=1, denoise_coefficients=[5, 2])[0]
+        planes = cref.decompose(img, level, family)
+        if config == "cfg3":
+            noise = float(cref.abs_median(planes[0])) / 0.6745 / cref.sigma_e(family)[0]
+            for s, sg in enumerate((5, 3, 2)):
+                cref.denoise_plane(planes[s], sg * noise * cref.sigma_e(family)[s])
+        return cref.plane_sum(planes)
+
+    probe_side = 256 if config == "cfg5" else 1024
+    probe = np.random.default_rng(0).standard_normal((probe_side, probe_side), dtype=np.float32)
+    run(probe)                                                       # spawn the OpenMP team
     t = time.perf_counter()
-    cref.plane_sum(cref.decompose(probe, LEVEL, FAMILY))
+    run(probe)
     per_pix = (time.perf_counter() - t) / probe.size
-    side = 8192
-    while side > 1024 and per_pix * side * side > 15.0:
-        side //= 2
-    img = np.random.default_rng(0).standard_normal((side, side), dtype=np.float32)
+    s = side
+    while s > probe_side and per_pix * s * s > 15.0:
+        s //= 2
+    img = np.random.default_rng(0).standard_normal((s, s), dtype=np.float32)
     reps, t_tot = 0, 0.0
     while reps < 5 and t_tot < 10.0:
         t = time.perf_counter()
-        cref.plane_sum(cref.decompose(img, LEVEL, FAMILY))
+        run(img)
         t_tot += time.perf_counter() - t
         reps += 1
-    return {"value": round(img.size * reps / t_tot / 1e6, 2), "unit": "Mpix/s",
+    what = {"cfg3": f"decompose + MAD + denoise([5,3,2]) + sum, {family} L={level}",
+            "cfg5": "wow(bilateral=1, denoise_coefficients=[5,2]) at this size's own n_scales"}.get(
+        config, f"decompose+sum, {family} L={level}")
+    return {"value": round(img.size * reps / t_tot / 1e6, 3), "unit": "Mpix/s",
             "cores": threads, "kind": "port",
-            "sample": f"{reps} x decompose+sum of {side}x{side} f32 {FAMILY} L={LEVEL} "
+            "sample": f"{reps} x {what} of {s}x{s} f32 "
                       f"(oracle/atrous_ref.c, gcc -O3 -fopenmp, {threads} threads)"}
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child
+    process (never exec: nothing here has touched the GPU yet, and nothing will), forward the
+    child's output (rank 0 prints the one JSON line) and its return code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -101,6 +176,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="headline")
     ap.add_argument("--spinup", type=float, default=0.25,
                     help="seconds of untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--size", type=int, default=0, help="override image side (testing)")
@@ -110,6 +186,9 @@ def main():
                     help="decompose and plane sum as two calls (the sum re-reads the planes) "
                          "instead of wt_decompose_sum")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-build", action="store_true",
+                    help="do not run __graft_entry__.build() (profiled runs: no child process "
+                         "under the profiler's preload)")
     ap.add_argument("--brief", action="store_true", help="one short line (tuning sweeps)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the launcher plumbing (gloo rendezvous, RCCL communicator) even "
@@ -118,6 +197,13 @@ def main():
                     help="testing on a 1-GPU box: all ranks use device 0 and each gets its own "
                          "NCCL_HOSTID, so RCCL treats them as separate hosts (socket transport)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.config != "headline":
+            sys.exit("--config cfg2/cfg3/cfg5 are single-GPU workloads")
+        sys.exit(self_launch(args, sys.argv[1:]))
+
+    import numpy as np
 
     # stdout carries exactly ONE JSON line (rank 0).  Native libraries print banners on fd 1
     # (gloo: "[Gloo] Rank 0 is connected ...", RCCL: ROCm version / hostname / library path), so
@@ -138,10 +224,9 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                     "(one rank per GPU)")
         args.gpus = world
+    if world > 1 and args.config != "headline":
+        sys.exit("--config cfg2/cfg3/cfg5 are single-GPU workloads")
 
     # ORDER MATTERS: torch wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 /
     # librccl).  If libwatroo_hip.so pulls in the system ROCm first and torch is imported
@@ -152,8 +237,8 @@ def main():
     if world > 1 or args.force_dist:
         import torch  # noqa: F401  (before anything loads libwatroo_hip.so)
         import torch.distributed as dist
-    import __graft_entry__ as entry
-    if rank == 0:
+    if rank == 0 and not args.no_build:
+        import __graft_entry__ as entry
         entry.build()
     if dist is not None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -163,6 +248,7 @@ def main():
     from wavelets_amd._lib import PLANE_INPUT, PLANE_OUT
 
     ctx = _lib.Context(local_rank)
+    rccl_ranks = 1
     if dist is not None:
         def bcast(obj, src):
             box = [obj]
@@ -170,30 +256,62 @@ def main():
             return box[0]
         from wavelets_amd.parallel import init_comm
         init_comm(ctx, rank, world, bcast)
+        rccl_ranks = ctx.comm_info()[1]          # what ncclCommCount says, not what we asked for
         if args.force_dist:
             assert ctx.comm_selftest(1 << 20), "RCCL self-test failed"
 
-    side = args.size or (8192 if world == 1 else 32768)
+    config = args.config
+    side, family, level, what = CONFIGS[config]
+    if config == "headline" and world > 1:
+        side = 32768
+    side = args.size or side
     H = W = side
     if args.rows:
         H = args.rows
+    if config == "cfg5":                          # wow's own scale count (utils.py:122)
+        level = int(np.round(np.log2(min(H, W)) - np.log2(5)))
     nrows = H // world
     row0 = rank * nrows
     if rank == world - 1:
         nrows = H - row0
-    fam = _lib.B3SPLINE
-    plan = _lib.Plan(ctx, H, W, fam, LEVEL, row0=row0, nrows=nrows, rank=rank, nranks=world)
-    plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
+    fam = {"b3spline": _lib.B3SPLINE, "triangle": _lib.TRIANGLE}[family]
+    plan = _lib.Plan(ctx, H, W, fam, level, row0=row0, nrows=nrows, rank=rank, nranks=world)
+    if config == "cfg5":
+        # the cfg5 image of tools/bench_configs.py: noise on a smooth structure (pure noise has
+        # no edges for the bilateral weights to act on)
+        img0 = make_strip(nrows, W, seed=0) + 3 * np.sin(np.arange(W, dtype=np.float32) / 50.)[None, :]
+        plan.upload(PLANE_INPUT, img0.astype(np.float32))
+        del img0
+    else:
+        plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
     flags = 0 if args.unfused else _lib.FLAG_FUSED
-
     two_call = args.two_call or args.unfused
 
-    def step():
-        if two_call:
-            plan.decompose(PLANE_INPUT, LEVEL, flags)
-            plan.plane_sum(0, LEVEL + 1, PLANE_OUT)
-        else:       # same outputs (7 planes + reconstruction, bit-identical), sum carried along
-            plan.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, flags)
+    if config in ("headline", "cfg2"):
+        def step():
+            if two_call:
+                plan.decompose(PLANE_INPUT, level, flags)
+                plan.plane_sum(0, level + 1, PLANE_OUT)
+            else:   # same outputs (planes + reconstruction, bit-identical), sum carried along
+                plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+    elif config == "cfg3":
+        import wavelets_amd as WA
+        coefficients = WA.Coefficients(plan, WA.Triangle(2))
+
+        def step():         # Coefficients.denoise([5,3,2]) then np.sum(coefficients, axis=0)
+            plan.decompose(PLANE_INPUT, level, flags)
+            coefficients.noise = None                      # lazy MAD estimate, every step
+            coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
+    else:
+        import wavelets_amd as WA
+        from wavelets_amd import utils as WU
+        transform = WA.AtrousTransform(WA.B3spline, bilateral=[1] * (level + 1))
+        coefficients = WA.Coefficients(plan, WA.B3spline(2), [1] * (level + 1))
+
+        def step():         # utils.wow without its PCIe legs (ref utils.py:148-217)
+            transform._run(plan, level)
+            coefficients.noise = None
+            WU._wow_device(coefficients, level, [], True, [5, 2], True, False, 3.2, None, None, 0)
 
     def fence():
         ctx.sync()
@@ -207,7 +325,7 @@ def main():
     if dist is None:
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < args.spinup:
-            for _ in range(20):
+            for _ in range(20 if config in ("headline", "cfg2") else 2):
                 step()
             ctx.sync()
     elif args.spinup > 0:
@@ -245,28 +363,34 @@ def main():
     roofline = None
     kernels = {}
     my_pix = float(nrows) * W
+    def algo_bytes(name, calls):
+        """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
+        fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
+        its bytes are per STEP; every other kernel's are per launch."""
+        bpp = algorithmic_bytes_per_pixel(name, level)
+        if bpp is None:
+            return None
+        return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)
+
     for name, (calls, ms) in prof.items():
-        # a pass may be launched in several parts (multi-GPU: edge rows, then interior rows): its
-        # algorithmic bytes are per STEP, whatever the number of launches
-        bpp = algorithmic_bytes_per_pixel(name)
+        ab = algo_bytes(name, calls)
         kernels[name] = {"calls_per_step": calls // nprof,
                          "avg_ms": round(ms / calls, 4),
-                         "algorithmic_GBs": None if bpp is None else
-                         round(bpp * my_pix * nprof / (ms * 1e-3) / 1e9, 1)}
-    # Dominant kernel = the SOURCE kernel with the largest total time.  The two fused passes are
+                         "algorithmic_GBs": None if ab is None else round(ab / (ms * 1e-3) / 1e9, 1)}
+    # Dominant kernel = the SOURCE kernel with the largest total time.  The fused passes are
     # instantiations of one kernel (wt_fused_kernel<..., D=1> and <..., D=8>; rocprof lists them
-    # as two rows) and together take ~2/3 of a step, so the roofline entry describes them: per
-    # launch algorithmic bytes / average launch duration over both instantiations.
+    # as two rows), so the roofline entry describes them together: per launch algorithmic bytes /
+    # average launch duration over the instantiations.
     groups = {}
     for n, (c, ms) in prof.items():
-        bpp = algorithmic_bytes_per_pixel(n)
-        if bpp is None:
+        ab = algo_bytes(n, c)
+        if ab is None:
             continue
         key = "wt_fused_kernel" if n.startswith("wt_fused") else n.split("<")[0]
         f = groups.setdefault(key, {"ms": 0.0, "calls": 0, "bytes": 0.0, "members": []})
         f["ms"] += ms
         f["calls"] += c
-        f["bytes"] += bpp * my_pix * nprof
+        f["bytes"] += ab
         f["members"].append(n)
     if groups:
         dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -284,31 +408,51 @@ def main():
                     "avg_launch_ms": round(f["ms"] / f["calls"], 4),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
+        if dom.startswith("wt_bilateral"):
+            # the bilateral operator is VALU / transcendental bound - K*K-1 taps of
+            # (sub, mul, fma into the exponent, v_exp, two fmas) + variance + normalisation per
+            # pixel and scale: ~10 flop per tap + 40.  HBM stays the `bound` the schema knows;
+            # the vector-ALU fraction is reported beside it.
+            taps = 24 if family == "b3spline" else 8
+            flops = (10.0 * taps + 40.0) * my_pix * f["calls"]
+            roofline["valu"] = {"algorithmic_flop_per_pixel_scale": 10.0 * taps + 40.0,
+                                "achieved_TFLOPs": round(flops / (f["ms"] * 1e-3) / 1e12, 1),
+                                "peak_TFLOPs": VALU_PEAK_TFLOPS,
+                                "frac": round(flops / (f["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
 
     if rank == 0:
-        whole_job_GBs = 8.0 * (LEVEL + 2) * H * W * args.steps / elapsed / 1e9
+        bpp_whole = whole_path_bytes_per_pixel(config, level)
+        whole_job_GBs = bpp_whole * H * W * args.steps / elapsed / 1e9
+        metric = {"headline": f"Mpix/s decompose+sum, {H}x{W} f32 B3spline 6 scales; %HBM roofline"
+                              if (world > 1 or side != 8192) else
+                              "Mpix/s decompose+sum, 8192^2 f32 B3spline 6 scales; %HBM roofline",
+                  "cfg2": "Mpix/s decompose+sum, 4096^2 f32 B3spline 6 scales; %HBM roofline",
+                  "cfg3": "Mpix/s decompose+denoise([5,3,2])+sum, 8192^2 f32 Triangle 8 scales; %HBM roofline",
+                  "cfg5": "Mpix/s wow(bilateral=1, denoise_coefficients=[5,2]), 8192^2 f32"}[config]
         out = {
-            "metric": "Mpix/s decompose+sum, 8192^2 f32 B3spline 6 scales; %HBM roofline",
+            "metric": metric,
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{H}x{W} float32 N(0,1), {FAMILY} L={LEVEL}, decompose "
-                                   f"({LEVEL + 1} planes in HBM) + plane sum; device-resident"
+            "config": {"workload": f"{H}x{W} float32 np.random.default_rng(seed).standard_normal, "
+                                   f"{family} L={level}, " + what.format(n=level + 1)
+                                   + "; device-resident"
                                    + ("" if world == 1 else f"; {world} row strips, RCCL halo "
                                       "exchange per pass"),
-                       "image": [H, W], "levels": LEVEL, "family": FAMILY,
+                       "name": config, "image": [H, W], "levels": level, "family": family,
                        "fused": not args.unfused, "sum_in_passes": not two_call,
-                       "schedule": _lib.schedule(fam, LEVEL, not args.unfused),
+                       "schedule": _lib.schedule(fam, level, not args.unfused),
                        "parallelism": f"strips{world}"},
+            "rccl_ranks": rccl_ranks,
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "whole_path": {"algorithmic_GBs": round(whole_job_GBs, 1),
                            "frac_of_hbm_peak": round(whole_job_GBs / (HBM_PEAK_GBS * world), 4),
-                           "bytes_per_pixel": 8 * (LEVEL + 2)},
+                           "bytes_per_pixel": bpp_whole},
             "roofline": roofline,
             "kernels": kernels,
         }
-        if world == 1:
+        if world == 1 and config in ("headline", "cfg2"):
             # PCIe-inclusive rate (host numpy in, reconstruction out as a numpy array) - never
             # `value`.  First call: the result's page-locked block is allocated; later calls
             # reuse it from the host pool (wavelets_amd/_lib.py _HostPool), which is the steady
@@ -324,13 +468,15 @@ def main():
                 del recon
             out["pcie_inclusive_first_call_mpix_s"] = round(rates[0], 1)
             out["pcie_inclusive_mpix_s"] = round(max(rates[1:]), 1)
-            if not args.no_cpu and not args.brief:
-                out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu and not args.brief:
+            out["cpu_baseline"] = cpu_baseline(config, side, family, level)
         if args.brief:
             emit(f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
                 f"{k}={v['avg_ms']}" for k, v in kernels.items()))
         else:
             emit(json.dumps(out))
+    if config in ("cfg3", "cfg5"):
+        coefficients._plan = None                 # the plan is ours, not the pool's
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

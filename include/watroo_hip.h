@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 2
+#define WT_ABI_VERSION 3
 
 typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
 typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */
@@ -57,6 +57,8 @@ int wt_device_count(int *count);
  * "overlap" (1): multi-GPU strips run the halo exchange of the next pass beside the interior
  *   rows of the current one (second stream), 0 = every exchange between the passes;
  *   "overlap_reserve" (16): compute units the interior launch leaves to the RCCL kernels.
+ * "fused_fast" (1): fused passes use the single-bounce / aligned-group addressing where the image
+ *   allows (W % 4 == 0, halo <= image); 0 forces the generic (multi-bounce, gather) addressing.
  * "split_dry" (0): measurement aid - launch the passes of a strip plan split into edge and
  *   interior rows as "overlap" does, without exchanging (FLAG_NO_EXCHANGE runs). */
 int wt_set_option(const char *name, int value);
@@ -80,6 +82,9 @@ int wt_profile_entry(wt_ctx *ctx, int i, char *name64, int64_t *calls, double *t
 /* 128-byte ncclUniqueId; rank 0 creates it, the launcher broadcasts it out of band. */
 int wt_comm_unique_id(void *id128);
 int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *id128);
+/* rank / size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount);
+ * 0 / 1 without a communicator.  bench.py prints the size as "rccl_ranks". */
+int wt_ctx_comm_info(wt_ctx *ctx, int *rank, int *nranks);
 /* test hook: nranks==1 periodic self exchange through RCCL send/recv (plumbing check). */
 int wt_comm_selftest(wt_ctx *ctx, int64_t nfloats, int *ok);
 

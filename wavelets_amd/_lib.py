@@ -52,6 +52,7 @@ SIGNATURES = {
                                     _c.POINTER(_c.c_double)]),
     "wt_comm_unique_id": (_c.c_int, [_vp]),
     "wt_ctx_comm_init": (_c.c_int, [_vp, _c.c_int, _c.c_int, _vp]),
+    "wt_ctx_comm_info": (_c.c_int, [_vp, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "wt_comm_selftest": (_c.c_int, [_vp, _i64, _c.POINTER(_c.c_int)]),
     "wt_plan_create": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _c.POINTER(_vp)]),
     "wt_plan_create_strip": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _i64, _i64, _i64,
@@ -128,7 +129,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = res, args
-            if L.wt_abi_version() != 2:
+            if L.wt_abi_version() != 3:
                 raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
             _lib = L
     return _lib
@@ -217,6 +218,12 @@ class Context:
         buf = _c.create_string_buffer(unique_id, 128)
         check(load().wt_ctx_comm_init(self._h, rank, nranks, buf))
         self.rank, self.nranks = rank, nranks
+
+    def comm_info(self):
+        """(rank, size) as the RCCL communicator reports them; (0, 1) without one."""
+        r, n = _c.c_int(0), _c.c_int(1)
+        check(load().wt_ctx_comm_info(self._h, _c.byref(r), _c.byref(n)))
+        return r.value, n.value
 
     def comm_selftest(self, nfloats=1 << 20):
         ok = _c.c_int(0)

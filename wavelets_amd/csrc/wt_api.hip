@@ -124,6 +124,8 @@ struct RcclApi {
     int (*GetUniqueId)(void *) = nullptr;
     void *CommInitRank = nullptr;  // ncclCommInitRank(comm*, nranks, ncclUniqueId by value, rank)
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*CommUserRank)(void *, int *) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -155,6 +157,8 @@ static int rccl_load()
     SYM(GetUniqueId, "ncclGetUniqueId");
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
     SYM(GroupStart, "ncclGroupStart");
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(Send, "ncclSend");
@@ -207,6 +211,20 @@ extern "C" int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *i
         WT_HIP(hipEventCreateWithFlags(&ctx->ev_to_comm, hipEventDisableTiming));
         WT_HIP(hipEventCreateWithFlags(&ctx->ev_from_comm, hipEventDisableTiming));
     }
+    return 0;
+}
+
+// What the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what the caller
+// passed to wt_ctx_comm_init: bench.py reports it as `rccl_ranks`.  No communicator: 0 / 1.
+extern "C" int wt_ctx_comm_info(wt_ctx *ctx, int *rank, int *nranks)
+{
+    WtGuard guard_(ctx_of(ctx));
+    if (!ctx || !rank || !nranks) WT_FAIL("wt_ctx_comm_info: null pointer");
+    *rank = 0;
+    *nranks = 1;
+    if (!ctx->comm) return 0;
+    WT_NCCL(g_rccl.CommCount(ctx->comm, nranks));
+    WT_NCCL(g_rccl.CommUserRank(ctx->comm, rank));
     return 0;
 }
 
@@ -411,10 +429,12 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
     // mapping of row-marching kernels
     static const int64_t pitch_pad = getenv("WT_PITCH_PAD") ? std::max<int64_t>(0, atoll(getenv("WT_PITCH_PAD")) / 4 * 4) : 0;
     const int64_t P = (W + 3) / 4 * 4 + pitch_pad;
-    if ((nrows + 2 * halo) * P >= ((int64_t)1 << 31)) {
-        // kernels index pixels with 64-bit offsets but rows/cols with int32
-        if (nrows + 2 * halo >= ((int64_t)1 << 30)) WT_FAIL("wt_plan_create: strip too tall");
-    }
+    // Kernels index rows / columns with int32 and pixels with 64-bit offsets, but the flat pointwise
+    // kernels count float4 groups in int64 and the tests cover planes up to 2^30 pixels (32768^2):
+    // larger strips are refused rather than run unverified.
+    if ((nrows + 2 * halo) * P > ((int64_t)1 << 31))
+        WT_FAIL("wt_plan_create: a strip of %lld x %lld pixels (incl. margins) exceeds 2^31 per plane; split it into more strips",
+                (long long)(nrows + 2 * halo), (long long)P);
     wt_plan *p = new wt_plan();
     p->ctx = ctx;
     p->g = Geo{(int)W, (int)P, (int)H, (int)row0, (int)nrows, (int)halo, 0};
@@ -730,8 +750,8 @@ extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
     WT_HIP(hipMalloc(&b, nfloats * 4));
     std::vector<float> h(nfloats), r(nfloats, 0.f);
     for (int64_t i = 0; i < nfloats; ++i) h[i] = (float)(i % 977) * 0.5f + (float)c->rank;
-    WT_HIP(hipMemcpy(a, h.data(), nfloats * 4, hipMemcpyHostToDevice));
-    WT_HIP(hipMemset(b, 0, nfloats * 4));
+    WT_HIP(hipMemcpyAsync(a, h.data(), nfloats * 4, hipMemcpyHostToDevice, c->stream));
+    WT_HIP(hipMemsetAsync(b, 0, nfloats * 4, c->stream));   // ordered before the Recv into b
     // ring: send to (rank+1)%n, receive from (rank-1+n)%n  (self when n == 1)
     const int to = (c->rank + 1) % c->nranks, from = (c->rank + c->nranks - 1) % c->nranks;
     WT_NCCL(g_rccl.GroupStart());
@@ -741,8 +761,8 @@ extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
     // all-reduce of a tiny vector
     WT_HIP(hipMemsetAsync(c->d_hist, 0, 16, c->stream));
     WT_NCCL(g_rccl.AllReduce(c->d_hist, c->d_hist, 4, NCCL_UINT32, NCCL_SUM, c->comm, c->stream));
+    WT_HIP(hipMemcpyAsync(r.data(), b, nfloats * 4, hipMemcpyDeviceToHost, c->stream));
     WT_HIP(hipStreamSynchronize(c->stream));
-    WT_HIP(hipMemcpy(r.data(), b, nfloats * 4, hipMemcpyDeviceToHost));
     int good = 1;
     for (int64_t i = 0; i < nfloats; ++i)
         if (r[i] != (float)(i % 977) * 0.5f + (float)from) { good = 0; break; }
@@ -818,6 +838,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
     if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
+    if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }
 

@@ -186,7 +186,7 @@ __device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk,
 // a-1 produced in step j-1, so the NS vertical filters, the NS LDS row writes, ONE barrier and
 // the NS horizontal filters of a step are mutually independent (one s_barrier per row instead
 // of NS, 4*NS LDS reads in flight together).  LDS rows are double-buffered by step parity.
-template <int K, int NS, int D, int NW, int PDREQ, int ACC>
+template <int K, int NS, int D, int NW, int PDREQ, int ACC, bool FAST>
 #ifndef WT_FUSED_WPS4_K3
 #define WT_FUSED_WPS4_K3 3   // 3-tap family: 148 VGPRs, three 4-wave workgroups per CU (0.345 -> 0.32 ms)
 #endif
@@ -239,12 +239,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     const bool lane_store = (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
     const unsigned voff = lane_store ? (unsigned)x * 4u : WT_FUSED_PARKED;
     const int row_bytes = g.P * 4;
-    // Every lane issues ONE aligned in-bounds dwordx4 per row; lanes whose 4 pixels are not
-    // all inside the image (reflected halo at the image border, ragged right edge) patch the
-    // value with a reflected gather under a wave-uniform branch (border waves only).
+    // Every lane issues ONE aligned in-bounds dwordx4 per row.
+    // FAST (host: W % 4 == 0, W >= HX, H >= D * (LAT_IN + 1) - every image the benchmarks name):
+    //   the reflection of an aligned 4-pixel group that lies outside the image is an aligned group
+    //   read backwards, so a border lane loads that group like any other lane and reverses the
+    //   four values when the row is CONSUMED (wave-uniform branch around four v_cndmask: no load
+    //   sits behind a branch, every workgroup runs the same instruction stream), and a row index
+    //   reflects at most once (two s_max / s_min instead of a modulo behind a branch).
+    // generic: lanes whose 4 pixels are not all inside the image (reflected halo at the image
+    //   border, ragged right edge) patch the value with a reflected gather under a wave-uniform
+    //   branch (border waves only); rows reflect any number of times.
     const bool lane_interior = (x >= 0) && (x + 3 < g.W);
     const bool wave_has_edge = !__all(lane_interior);
-    const int xc = min(max(x, 0), g.P - 4);
+    const bool lane_rev = FAST && !lane_interior;
+    const int xg = x < 0 ? -4 - x : (x >= g.W ? 2 * g.W - 4 - x : x);   // FAST: the group this lane loads
+    const int xc = FAST ? min(max(xg, 0), g.W - 4) : min(max(x, 0), g.P - 4);
     const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + 2, g.W),
               xi3 = wt_refl(x + 3, g.W);
     const int gy0 = g.row0 + q;                          // global row of chain element 0
@@ -252,15 +261,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     const int dbg = WT_FUSED_DBG(a);
     const int t_last = r1 - 1 + LAT_IN;                  // last input row any stored output needs
     const unsigned xoff = (unsigned)xc * 4u;             // byte offset of this lane's aligned load
+    const int H2m1 = 2 * g.H - 1;
     auto load_row = [&](int t) -> float4 {
         // steps past t_last only flush the pipeline / unroll padding: keep the address in range.
         // Uniform row pointer + 32-bit lane offset: one global_load_dwordx4 with an SGPR base.
-        const float *row = wt_row(a.in, g, gy0 + D * ((dbg & 2) ? r0 : min(t, t_last)));
-        float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(row) + xoff);
-        if (wave_has_edge) {
-            if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
+        if constexpr (FAST) {
+            const int gy = gy0 + D * ((dbg & 2) ? r0 : min(t, t_last));
+            const int up = max(gy, ~gy);                 // -1 - gy above the image
+            const int ry = min(up, H2m1 - up);           // 2H - 1 - gy below it
+            const float *row = a.in + (int64_t)(ry - g.row0) * g.P;
+            return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(row) + xoff);
+        } else {
+            const float *row = wt_row(a.in, g, gy0 + D * ((dbg & 2) ? r0 : min(t, t_last)));
+            float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(row) + xoff);
+            if (wave_has_edge) {
+                if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
+            }
+            return v;
         }
-        return v;
     };
     // Output rows advance by one chain step (D image rows) per iteration.  Every plane has ONE
     // descriptor for the whole march, based at the row it stores at step 0 (row t0 - LAG of the
@@ -334,6 +352,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 #pragma unroll
         for (int i = 0; i < PD; ++i) pa[i] = load_acc(i);   // koff = 0 here
     }
+    // The compiler sizes every `s_waitcnt vmcnt(N)` of the loop from the FEWEST vector-memory
+    // operations that can lie between a prefetch and its use on any path into that point - and on
+    // the path from here the PD prefetches would be back to back, while in the steady state a
+    // step's stores sit between them.  Without the padding below the first PD steps of every trip
+    // through the unrolled body wait with vmcnt(2..15), i.e. for the STORES of the previous steps
+    // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
+    // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
+    // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
+#ifndef WT_FUSED_NO_VMPAD
+    {
+        constexpr int ST = NS + 1 + (ACC ? 1 : 0);          // stores per step
+#pragma unroll
+        for (int i = 0; i < PD * ST; ++i) wt_bstore4v<0>(rc, WT_FUSED_PARKED + 16u * i, zero);   // distinct: not merged
+    }
+#endif
     const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
 
@@ -346,8 +379,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         auto at = [&](int lag) -> unsigned {             // lane offset of this step's row of a plane
             return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : oc);
         };
-        const float4 cur = pf[kk % PD];
+        float4 cur = pf[kk % PD];
         pf[kk % PD] = load_row(t + PD);
+        if constexpr (FAST) {
+            // The fence pins the reversal to THIS step: without it the (w, z) swap is scheduled
+            // right behind the load it reads (same basic block), and the wave waits for every row
+            // in the step that issued it - no prefetch left.
+            asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w));
+            if (wave_has_edge) {
+                if (lane_rev) cur = make_float4(cur.w, cur.z, cur.y, cur.x);
+            }
+        }
         float4 (*buf)[NL] = vbuf[kk & 1];
 #ifdef WT_FUSED_ABLATION
         if (dbg & 4) {   // ablation: same loads / stores / addresses, no filtering at all
@@ -433,6 +475,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         }
         c1 = n0;
         koff += step_bytes;
+#ifndef WT_FUSED_NO_SCHEDBAR
+        // Keep the scheduler from interleaving consecutive steps: with the branch-free FAST loads
+        // the unrolled body is one basic block, and free motion across steps costs 30 more VGPRs
+        // (spills) and turns every wait into vmcnt(0).
+        if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
+#endif
     };
 
     for (int kb = 0; kb < nsteps; kb += U) {
@@ -451,6 +499,9 @@ static inline bool wt_fused_supported(const wt_plan *p) { return (int64_t)p->g.P
 
 // Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = compute units the chunk
 // search leaves free (for the RCCL kernels of an exchange running beside the launch).
+// A/B switch (wt_set_option "fused_fast"): 0 forces the generic addressing of the fused passes
+static int g_opt_fused_fast = getenv("WT_FUSED_NO_FAST") ? 0 : 1;
+
 struct FusedRows {
     int n = 0;
     int lo[2] = {0, 0}, hi[2] = {0, 0};
@@ -460,6 +511,7 @@ struct FusedRows {
 template <int K, int NS, int D, int NW, int PD, int ACC>
 static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name, const FusedRows &rows)
 {
+
     constexpr int hw = K / 2;
     constexpr int LAT = hw * ((1 << NS) - 1) + (NS - 1);
     constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
@@ -517,7 +569,10 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     if (gy > 65535) WT_FAIL("fused pass: grid too large");
     dim3 grid(nx, (unsigned)gy, nranges), block(NL);
     ProfScope ps(p->ctx, name);
-    hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC>), grid, block, 0, p->ctx->stream, a);
+    // fast addressing: aligned groups reflect onto aligned groups and no index reflects twice
+    const bool fast = g_opt_fused_fast && g.W % 4 == 0 && g.W >= HX && g.H >= D * (hw * ((1 << NS) - 1) + 1);
+    if (fast) hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
+    else hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }

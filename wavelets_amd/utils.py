@@ -171,6 +171,19 @@ def wow(data,
     else:
         coefficients = data
 
+    plan = _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients,
+                       soft_threshold, preserve_variance, gamma, gamma_min, gamma_max, h)
+    nplanes = len(coefficients)
+    recon = coefficients._from_plane(plan.download(PLANE_OUT))
+    coefficients._refresh_host(range(nplanes))
+    return recon, coefficients
+
+
+def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients, soft_threshold,
+                preserve_variance, gamma, gamma_min, gamma_max, h):
+    """The device-resident part of wow (ref:157-217): per-scale loop, plane sum, gamma blend.
+    Leaves the whitened planes on the plan and the image in PLANE_OUT; returns the plan.
+    (bench.py --config cfg5 times exactly this behind the transform, without the PCIe legs.)"""
     plan = coefficients._device()
     npix = float(plan.H) * float(plan.W)
 
@@ -206,9 +219,7 @@ def wow(data,
                 gamma_max = hi
         plan.gamma_blend(PLANE_OUT, _GAMMA_PLANE, gamma_min, gamma_max, 1 / gamma, h)
 
-    recon = coefficients._from_plane(plan.download(PLANE_OUT))
-    coefficients._refresh_host(range(nplanes))
-    return recon, coefficients
+    return plan
 
 
 def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
