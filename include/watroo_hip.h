@@ -42,7 +42,7 @@ enum { WT_TRIANGLE = 0, WT_B3SPLINE = 1 };      /* watroo/wavelets.py:232-287 */
 
 #define WT_PLANE_INPUT (-1)
 #define WT_PLANE_OUT (-2)
-#define WT_NUM_SCRATCH 16
+#define WT_NUM_SCRATCH 32
 #define WT_PLANE_SCRATCH(i) (-3 - (i))
 #define WT_PLANE_NONE (-1000)
 

@@ -15,6 +15,17 @@
  *   orc_abs_median  np.median(np.abs(data[0])) - watroo/wavelets.py:127
  *   orc_denoise     watroo/wavelets.py:129-149 (scalar noise; NumPy-2 promotion: ratio and
  *                   erf evaluated in double, product rounded back to float)
+ *   orc_variance    watroo/wavelets.py:24-32 (sdev_loc, variance=True) times the two factors of
+ *                   :434-436 (sigma_bilateral**2, then s+1 with bilateral_scaling)
+ *   orc_bilateral   watroo/wavelets.py:74-105 (atrous_convolution with bilateral_variance; the
+ *                   numexpr expression of :97 in float: sub, square, negate, divide by the
+ *                   variance, halve, expf, times the tap).  expf is libm's (<= 1 ulp) where the
+ *                   numpy oracle uses numpy's own float exp and the reference numexpr's VML: this
+ *                   is the one function here that is NOT bit-identical to atrous_numpy.py
+ *                   (agreement ~1e-6 relative, tested)
+ *   orc_decompose_bilateral  watroo/wavelets.py:408-444 with bilateral
+ *   orc_clip_sqrt / orc_scale_div / orc_scale / orc_axpy1   the pointwise steps of
+ *                   watroo/utils.py:195-196, :203, :201 (utils.wow)
  */
 #include <math.h>
 #include <stdint.h>
@@ -155,5 +166,140 @@ int orc_denoise(float *plane, long npix, double tau, double wgt, int soft)
         else sig = fabs((double)plane[i]) > tau ? 1.0 : 0.0;
         plane[i] = (float)((double)plane[i] * (wgt * sig));
     }
+    return 0;
+}
+
+/* sdev_loc(image, variance=True) * f1 (* f2): conv(I^2) - conv(I)^2, <= 0 -> 1e-20 */
+int orc_variance(const float *restrict in, float *restrict out, long H, long W, int family, int s, float f1,
+                 float f2, int use_f2)
+{
+    const size_t n = (size_t)H * W;
+    float *m = (float *)malloc(n * sizeof(float));
+    if (!m) return 1;
+    int rc = orc_smooth(in, m, H, W, family, s, 0);
+    if (!rc) rc = orc_smooth(in, out, H, W, family, s, 1);
+    if (rc) { free(m); return rc; }
+#pragma omp parallel for schedule(dynamic, 65536)
+    for (long i = 0; i < (long)n; i++) {
+        float m2 = m[i] * m[i];
+        float v = out[i] - m2;
+        if (v <= 0.f) v = 1e-20f;
+        v = v * f1;
+        if (use_f2) v = v * f2;
+        out[i] = v;
+    }
+    free(m);
+    return 0;
+}
+
+/* atrous_convolution(image, kernel, bilateral_variance=var, s): out may not alias in / var */
+int orc_bilateral(const float *restrict in, const float *restrict var, float *restrict out, long H, long W,
+                  int family, int s)
+{
+    const int K = family ? 5 : 3, hw = K / 2;
+    const float *t = family ? TAPS_B3 : TAPS_TRI;
+    const long d = 1L << s;
+    float k2[5][5];
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < K; j++) k2[i][j] = (float)((double)t[i] * (double)t[j]);
+    long *cx = (long *)malloc(sizeof(long) * (size_t)W * K);
+    if (!cx) return 1;
+    for (int j = 0; j < K; j++)
+        for (long x = 0; x < W; x++) cx[j * W + x] = reflect(x + (long)(K - 1 - j - hw) * d, W);
+#pragma omp parallel
+    {
+        float *norm = (float *)malloc(sizeof(float) * (size_t)W);
+#pragma omp for schedule(dynamic, 4)
+        for (long y = 0; y < H; y++) {
+            float *restrict o = out + y * W;
+            const float *restrict c = in + y * W;
+            const float *restrict v = var + y * W;
+            const float kc = k2[hw][hw];
+            for (long x = 0; x < W; x++) { o[x] = kc * c[x]; norm[x] = kc; }
+            for (int i = 0; i < K; i++) {
+                const float *restrict r = in + reflect(y + (long)(K - 1 - i - hw) * d, H) * W;
+                for (int j = 0; j < K; j++) {
+                    if (i == hw && j == hw) continue;
+                    const float k = k2[i][j];
+                    const long *ix = cx + j * W;
+                    for (long x = 0; x < W; x++) {
+                        const float sh = r[ix[x]];
+                        float df = c[x] - sh;
+                        float e = df * df;
+                        e = -e;
+                        e = e / v[x];
+                        e = e / 2.0f;
+                        float w = k * expf(e);
+                        norm[x] = norm[x] + w;
+                        float p = sh * w;
+                        o[x] = o[x] + p;
+                    }
+                }
+            }
+            for (long x = 0; x < W; x++) o[x] = o[x] / norm[x];
+        }
+        free(norm);
+    }
+    free(cx);
+    return 0;
+}
+
+/* atrous_standard with bilateral: sigma_b[level] (already padded), planes as orc_decompose */
+int orc_decompose_bilateral(const float *in, float *planes, long H, long W, int family, int level,
+                            const double *sigma_b, int bilateral_scaling)
+{
+    const size_t n = (size_t)H * W;
+    memcpy(planes, in, n * sizeof(float));
+    float *var = (float *)malloc(n * sizeof(float));
+    if (!var) return 1;
+    for (int s = 0; s < level; s++) {
+        float *cs = planes + (size_t)s * n, *cn = planes + (size_t)(s + 1) * n;
+        /* variance = sdev_loc(...) * sb**2 ; variance *= s + 1  - python scalars are weak: float32 */
+        int rc = orc_variance(cs, var, H, W, family, s, (float)(sigma_b[s] * sigma_b[s]), (float)(s + 1),
+                              bilateral_scaling);
+        if (!rc) rc = orc_bilateral(cs, var, cn, H, W, family, s);
+        if (rc) { free(var); return rc; }
+#pragma omp parallel for schedule(dynamic, 65536)
+        for (long i = 0; i < (long)n; i++) cs[i] = cs[i] - cn[i];
+    }
+    free(var);
+    return 0;
+}
+
+/* local_power[local_power <= 0] = 1e-15; sqrt in place  (utils.py:195-196) */
+int orc_clip_sqrt(float *p, long n)
+{
+#pragma omp parallel for schedule(dynamic, 65536)
+    for (long i = 0; i < n; i++) {
+        float v = p[i];
+        if (v <= 0.f) v = 1e-15f;
+        p[i] = sqrtf(v);
+    }
+    return 0;
+}
+
+/* c *= factor / local_power  (utils.py:203: the float32 array factor/local_power, then the product) */
+int orc_scale_div(float *c, const float *lp, float factor, long n)
+{
+#pragma omp parallel for schedule(dynamic, 65536)
+    for (long i = 0; i < n; i++) {
+        float q = factor / lp[i];
+        c[i] = c[i] * q;
+    }
+    return 0;
+}
+
+int orc_scale(float *c, float factor, long n)
+{
+#pragma omp parallel for schedule(dynamic, 65536)
+    for (long i = 0; i < n; i++) c[i] = c[i] * factor;
+    return 0;
+}
+
+/* acc += c  (gamma_scaled, utils.py:201) */
+int orc_axpy1(float *acc, const float *c, long n)
+{
+#pragma omp parallel for schedule(dynamic, 65536)
+    for (long i = 0; i < n; i++) acc[i] = acc[i] + c[i];
     return 0;
 }

@@ -313,6 +313,31 @@ def g13_richardson_lucy_fft():
     save("g13_rl_fft", "hard(numpy fft; transform via cv2 stand-in)", **out)
 
 
+def g17_rl_fft_odd_height():
+    """richardson_lucy(fft=True) on an ODD-height image: the reference rolls the padded PSF by
+    H // 2 twice (utils.py:246-250), which for odd H leaves the PSF centre one row above the
+    origin - the circular products are shifted by one row against the even-height case.
+    (Odd widths are not valid in the reference: irfft2 returns W - 1 columns.)"""
+    rng = np.random.default_rng(1717)
+    data = (rng.uniform(0.5, 1.5, (33, 40)) + 4 * np.exp(-((np.arange(40) - 17.) ** 2) / 18.)[None, :]).astype(np.float32)
+    psf = rng.uniform(0.2, 1.0, (5, 7)).astype(np.float32)
+    psf /= psf.sum()
+    thin = rng.uniform(0.2, 1.0, (1, 4)).astype(np.float32)       # anchor falls outside a 1-row PSF
+    thin /= thin.sum()
+    out = {"data": data, "psf": psf, "psf_thin": thin}
+    out["rl_fft_odd"] = richardson_lucy(data.copy(), psf, iterations=3, fft=True, denoise_coefficients=(4, 2))
+    out["rl_fft_odd_thin"] = richardson_lucy(data.copy(), thin, iterations=2, fft=True, denoise_coefficients=(4, 2))
+    H, W = data.shape
+    for tag, k in (("", psf), ("_thin", thin)):
+        pad = np.zeros_like(data)
+        kh, kw = k.shape
+        pad[H // 2 - kh // 2:H // 2 - kh // 2 + kh, W // 2 - kw // 2:W // 2 - kw // 2 + kw] = k
+        f = np.fft.rfft2(np.roll(pad, (H // 2, W // 2), axis=(0, 1)))
+        out["circ_conv" + tag] = np.fft.irfft2(np.fft.rfft2(data) * f)
+        out["circ_corr" + tag] = np.fft.irfft2(np.fft.rfft2(data) * f.conj())
+    save("g17_rl_fft_odd", "hard(numpy fft; transform via cv2 stand-in)", **out)
+
+
 def g14_wow_denoise_nd():
     """wow / denoise on 1-D signals and (Z, Y, X) cubes (the reference is ndim-generic)."""
     out = {}
@@ -481,3 +506,7 @@ if __name__ == "__main__":
         g10_enhance()
         g11_one_dimensional()
         g12_three_dimensional()
+        g14_wow_denoise_nd()
+        g15_custom_scaling_function()
+        g16_bilateral_nd()
+        g17_rl_fft_odd_height()

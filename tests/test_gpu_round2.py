@@ -154,3 +154,164 @@ def test_bench_self_launches_two_ranks_on_the_shared_gpu():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
     assert out["config"]["image"] == [2048, 2048] and "2048x2048" in out["metric"]
     assert out["roofline"]["frac"] > 0
+
+
+# --------------------------------------------------------------------------- cfg 5 at real dilations
+def _structured(shape, seed):
+    """noise on a smooth structure: gives the range weights of the bilateral filter edges to act on"""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape, dtype=np.float32)
+            + 3 * np.sin(np.arange(shape[1], dtype=np.float32) / 50.)[None, :]).astype(np.float32)
+
+
+def _wclose(got, ref, what):
+    """wow tolerance of tests/test_gpu_parity.py: rtol 1e-4 + atol 1e-4 * max|ref| (the whitening
+    divides by a local power that can be small)"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    tol = 1e-4 * max(1.0, float(np.abs(ref).max())) + 1e-4 * np.abs(ref)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())} of {bad.size} beyond tolerance, worst "
+                           f"{float(np.abs(got - ref).max()):.3e} (max|ref| {float(np.abs(ref).max()):.3e})")
+
+
+@pytest.fixture(scope="module")
+def WA(L):
+    import wavelets_amd
+    return wavelets_amd
+
+
+def test_bilateral_transform_8_scales_vs_numpy_oracle(WA):
+    """AtrousTransform(bilateral=1)(a, 8) at 1024 x 2048: wt_bilateral2_kernel at d = 1 .. 128
+    meets the (pinned) numpy oracle for the first time beyond d = 8."""
+    from oracle import atrous_numpy as O
+    a = _structured((1024, 2048), 41)
+    got = WA.AtrousTransform(WA.B3spline, bilateral=1)(a, 8).data
+    ref = O.atrous_standard(a, 8, "b3spline", bilateral=1)
+    tol = 2e-5 * float(np.abs(a).max())
+    for s in range(9):
+        close(got[s], ref[s], (5 if s else 1) * tol)     # errors of c_s accumulate into later planes
+
+
+@pytest.mark.parametrize("kw", [dict(denoise_coefficients=[5, 2]),
+                                dict(bilateral=1, denoise_coefficients=[5, 2])],
+                         ids=["plain", "bilateral"])
+def test_wow_8_scales_vs_oracles(WA, C, kw):
+    """wow at 1024 x 2048 (n_scales = 8: the row kernel's fused wow update at d = 16, 32 and the
+    lattice kernel's at d = 64, 128) against atrous_numpy.wow and the C-backed restatement."""
+    from oracle import atrous_numpy as O
+    a = _structured((1024, 2048), 42)
+    recon, coef = WA.wow(a.copy(), **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    assert coef.data.shape[0] == 9
+    ref_r, ref_c = O.wow(a.copy(), "b3spline", **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    _wclose(coef.data, ref_c.data, "planes vs numpy oracle")
+    _wclose(recon, ref_r, "image vs numpy oracle")
+    c_r, c_p = C.wow(a.copy(), "b3spline", **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    _wclose(coef.data, c_p, "planes vs C oracle")
+    _wclose(recon, c_r, "image vs C oracle")
+    np.testing.assert_allclose(coef.noise, ref_c.noise, rtol=1e-4)
+
+
+def test_cfg5_8192_wow_bilateral_11_scales_vs_c_oracle(WA, C):
+    """BASELINE config 5 at full size: 8192^2, wow(bilateral=1, denoise_coefficients=[5,2]) ->
+    n_scales = 11 (bilateral kernel at d = 1 .. 1024, row<wow> d <= 32, lattice<wow> d >= 64)
+    against the C/OpenMP oracle (oracle/atrous_ref.c: bit-identical to the numpy oracle except
+    expf, tests/test_oracle_c.py)."""
+    a = _structured((8192, 8192), 43)
+    recon, coef = WA.wow(a, bilateral=1, denoise_coefficients=[5, 2])
+    plan = coef._device()
+    assert len(coef) == 12
+    c_r, c_p = C.wow(a, "b3spline", bilateral=1, denoise_coefficients=[5, 2])
+    _wclose(recon, c_r, "image")
+    for s in range(12):
+        _wclose(plan.download(s), c_p[s], f"plane {s}")
+
+
+def test_default_wow_8192_vs_c_oracle(WA, C):
+    """wow(a, denoise_coefficients=[5,2]) at 8192^2, 11 scales, no bilateral: fused passes for scales
+    0-7, lattice<decomp> above, the whitening update at every dilation."""
+    a = _structured((8192, 8192), 44)
+    recon, coef = WA.wow(a, denoise_coefficients=[5, 2])
+    plan = coef._device()
+    c_r, c_p = C.wow(a, "b3spline", denoise_coefficients=[5, 2])
+    _wclose(recon, c_r, "image")
+    for s in range(12):
+        _wclose(plan.download(s), c_p[s], f"plane {s}")
+
+
+# --------------------------------------------------------------------------- ADVICE r1 items
+@pytest.mark.parametrize("tag,iters", [("", 3), ("_thin", 2)])
+def test_richardson_lucy_fft_on_an_odd_height_image(WA, tag, iters):
+    """g17 (reference output): odd image heights shift the circular products by one row
+    (utils.py:246-250); the row anchor of a one-row PSF then lies outside the kernel."""
+    from conftest import load_golden
+    g = load_golden("g17_rl_fft_odd")
+    got = WA.richardson_lucy(g["data"].copy(), g["psf" + tag], iterations=iters, fft=True,
+                             denoise_coefficients=(4, 2))
+    ref = g["rl_fft_odd" + tag]
+    np.testing.assert_allclose(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
+    with pytest.raises(ValueError, match="even image width"):
+        WA.richardson_lucy(np.ones((32, 33), np.float32), g["psf"], fft=True)
+
+
+def test_richardson_lucy_any_number_of_scales_and_uniform_init(WA):
+    """ref utils.py:222-224 takes any number of denoise coefficients (round 1 stopped at 5); with
+    uniform_init the noise of every iteration is the residual's own MAD estimate (ref:262,131)."""
+    from oracle import atrous_numpy as O
+    rng = np.random.default_rng(5)
+    data = (rng.uniform(0.5, 1.5, (96, 128)) + 4 * np.exp(-((np.arange(128) - 60.) ** 2) / 50.)[None, :]).astype(np.float32)
+    psf = np.outer(np.hanning(7), np.hanning(5)).astype(np.float32) + 0.05
+    psf /= psf.sum()
+    for kw in (dict(denoise_coefficients=(5, 4, 3, 2, 1, 1, 1), iterations=2),
+               dict(denoise_coefficients=(4, 2), iterations=3, uniform_init=True)):
+        got = WA.richardson_lucy(data.copy(), psf, **kw)
+        ref = O.richardson_lucy(data.copy(), psf, **kw)
+        np.testing.assert_allclose(got, ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-4)
+
+
+def test_negative_sigma_follows_the_reference(WA):
+    """ref wavelets.py:137-141: erf(|w / tau|) does not care about the sign of tau, and
+    |w| > tau with a negative tau is always true."""
+    from oracle import atrous_numpy as O
+    a = rnd((64, 80), 3)
+    for soft in (True, False):
+        c = WA.AtrousTransform(WA.B3spline)(a, 3)
+        c.noise = 1.0
+        oc = O.Coeffs(O.atrous_standard(a, 3), "b3spline")
+        oc.noise = 1.0
+        np.testing.assert_allclose(c.significance(-3, 1, soft_threshold=soft).astype(np.float32),
+                                   np.asarray(oc.significance(-3, 1, soft_threshold=soft), np.float32),
+                                   atol=1e-6)
+        c.denoise([-3, 2], soft_threshold=soft)
+        oc.denoise([-3, 2], soft_threshold=soft)
+        np.testing.assert_allclose(c.data, oc.data, atol=1e-5 * np.abs(a).max())
+
+
+def test_with_sum_keyword_carries_the_synthesis_through_the_passes(WA):
+    """AtrousTransform(...)(a, L, with_sum=True): wt_decompose_sum behind the public API; the sum is
+    served by np.sum(c, axis=0) without another pass, bit-identical, and dropped as soon as a
+    plane changes."""
+    from wavelets_amd import _lib as L
+    a = rnd((1100, 2100), 77)
+    T = WA.AtrousTransform(WA.B3spline)
+    plain = T(a, 6)
+    ref_planes = np.array(plain.data, copy=True)
+    ref_sum = np.sum(plain, axis=0)
+    ctx = L.default_context()
+    c = T(a, 6, with_sum=True)
+    assert c._sum_valid
+    ctx.profile(True)
+    ctx.profile_reset()
+    got = np.sum(c, axis=0)
+    ent = ctx.profile_entries()
+    ctx.profile(False)
+    assert not any(k.startswith("wt_plane_sum") for k in ent), ent       # no second pass
+    np.testing.assert_array_equal(got, ref_sum)
+    np.testing.assert_array_equal(c.data, ref_planes)
+    c.denoise([5, 3])                                                     # planes change: sum is stale
+    assert not c._sum_valid
+    plain.denoise([5, 3])
+    np.testing.assert_array_equal(np.sum(c, axis=0), np.sum(plain, axis=0))
+    # bilateral transforms have no fused passes: the keyword is accepted and changes nothing
+    cb = WA.AtrousTransform(WA.B3spline, bilateral=1)(a[:200, :300], 3, with_sum=True)
+    assert not cb._sum_valid
+    np.testing.assert_array_equal(np.sum(cb, axis=0), cb.data.sum(axis=0))

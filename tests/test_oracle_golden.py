@@ -257,6 +257,24 @@ def test_periodic_products_even_psf_anchor():
     close(O.filter2d_periodic(d, k, (kh // 2, kw // 2)), g["circ_corr_even"], tol)
 
 
+@pytest.mark.parametrize("tag", ["", "_thin"])
+def test_periodic_products_and_rl_on_an_odd_height_image(tag):
+    """g17: for an odd image height the reference's two rolls by H // 2 leave the PSF centre one
+    row above the origin (utils.py:246-250): row anchors k-1-k//2-1 (forward), k//2+1 (backward),
+    which may fall outside a thin PSF (np.roll-based oracle: any anchor works)."""
+    g = load_golden("g17_rl_fft_odd")
+    d, k = g["data"], g["psf" + tag]
+    assert d.shape[0] % 2 == 1
+    kh, kw = k.shape
+    tol = 1e-5 * np.abs(d).max()
+    close(O.filter2d_periodic(d, k[::-1, ::-1], (kh - 1 - kh // 2 - 1, kw - 1 - kw // 2)),
+          g["circ_conv" + tag], tol)
+    close(O.filter2d_periodic(d, k, (kh // 2 + 1, kw // 2)), g["circ_corr" + tag], tol)
+    ref = g["rl_fft_odd" + tag]
+    got = O.richardson_lucy(d.copy(), k, iterations=2 if tag else 3, fft=True, denoise_coefficients=(4, 2))
+    close(got, ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-4)
+
+
 def test_filter2d_even_kernel_anchor():
     g = load_golden("g9_richardson_lucy")
     close(O.filter2d_reflect(g["data"], g["psf_even"]), g["filter_even"],

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WATROO_HIP_LIB", os.path.join(_HERE, "libwatroo_hip.s
 
 TRIANGLE, B3SPLINE = 0, 1
 PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
-NUM_SCRATCH = 16
+NUM_SCRATCH = 32
 FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE = 1, 2, 4
 
 

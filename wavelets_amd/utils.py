@@ -185,6 +185,7 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
     Leaves the whitened planes on the plan and the image in PLANE_OUT; returns the plan.
     (bench.py --config cfg5 times exactly this behind the transform, without the PCIe legs.)"""
     plan = coefficients._device()
+    coefficients._sum_valid = False
     npix = float(plan.H) * float(plan.W)
 
     use_gamma = h > 0
@@ -246,7 +247,7 @@ def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sd
             factor = np.float32(w * power_norm / local_power)             # ref:203
             plan.wow_update(s, PLANE_NONE, 0.0, soft_threshold, PLANE_NONE, factor, gplane)
         else:
-            t = coefficients._tau(d, s)                                   # ref:199
+            t = coefficients._tau(d, s, soft_threshold)                   # ref:199
             tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
             factor = np.float32(w * power_norm)
             if whitening and h < 1 and coefficients._ndim == 3:           # ref:193-196 on a cube
@@ -262,6 +263,19 @@ def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sd
                 plan.wow_scale(s, s, tau, soft_threshold, noise_plane, factor, gplane)
             else:
                 plan.wow_update(s, PLANE_NONE, tau, soft_threshold, noise_plane, factor, gplane)
+
+
+def _periodic_operand(kernel, ay, ax):
+    """(kernel, filter2d keywords) of a periodic correlation anchored at row ay, which may fall
+    just outside the kernel (odd image heights, one-row PSFs): zero rows are added until the
+    anchor lies inside - wt_filter2d_ex wants 0 <= ay < kh."""
+    kh = kernel.shape[0]
+    if ay < 0:
+        kernel = np.concatenate([np.zeros((-ay, kernel.shape[1]), np.float32), kernel])
+        ay = 0
+    elif ay >= kh:
+        kernel = np.concatenate([kernel, np.zeros((ay - kh + 1, kernel.shape[1]), np.float32)])
+    return np.ascontiguousarray(kernel), dict(anchor=(ay, ax), periodic=True)
 
 
 def richardson_lucy(data, psf,
@@ -283,9 +297,9 @@ def richardson_lucy(data, psf,
     sf = B3spline(2)                                                     # ref:229 default transform
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
     DATA, PSI, PHI, RES, CONV = (PLANE_SCRATCH(i) for i in (6, 7, 8, 9, 10))
-    MRS = [PLANE_SCRATCH(11 + s) for s in range(level)]
-    if level > 5:
-        raise ValueError("richardson_lucy supports at most 5 denoise coefficients")
+    if level > _lib.NUM_SCRATCH - 16:            # one support plane per scale (scratch 16 ..)
+        raise ValueError(f"richardson_lucy: at most {_lib.NUM_SCRATCH - 16} denoise coefficients")
+    MRS = [PLANE_SCRATCH(16 + s) for s in range(level)]
     plan.upload(DATA, img)
     plan.decompose(DATA, level)                                          # ref:230
     coefficients = Coefficients(plan, sf)
@@ -302,26 +316,33 @@ def richardson_lucy(data, psf,
     kh, kw = psf.shape
     # fft=True: psi (*) psf circular with the PSF centre psf.shape // 2 at the origin (ref:246-250)
     # = periodic correlation with the flipped PSF anchored at k - 1 - k // 2; the second product
-    # with conj(fft_psf) (ref:284) = periodic correlation with the PSF anchored at k // 2
-    fwd = dict(anchor=(kh - 1 - kh // 2, kw - 1 - kw // 2), periodic=True) if fft else {}
-    bwd = dict(anchor=(kh // 2, kw // 2), periodic=True) if fft else {}
+    # with conj(fft_psf) (ref:284) = periodic correlation with the PSF anchored at k // 2.  For an
+    # ODD image height the reference's two rolls by H // 2 leave the PSF centre one row above the
+    # origin, which moves the row anchors by one (g17_rl_fft_odd.npz); odd widths are not valid
+    # in the reference (irfft2 returns W - 1 columns).
+    if fft and img.shape[1] % 2:
+        raise ValueError("richardson_lucy(fft=True) needs an even image width (numpy.fft.irfft2 "
+                         "returns W - 1 columns in the reference)")
+    e = img.shape[0] % 2
+    fwd_k, fwd = _periodic_operand(psf_flipped, kh - 1 - kh // 2 - e, kw - 1 - kw // 2) if fft \
+        else (psf_flipped, {})
+    bwd_k, bwd = _periodic_operand(psf, kh // 2 + e, kw // 2) if fft else (psf, {})
+    data_noise = coefficients.noise       # None with uniform_init: every iteration then estimates
     for iteration in range(iterations):                                  # ref:252
-        plan.filter2d(PSI, PHI, psf_flipped, **fwd)                      # ref:255-257
+        plan.filter2d(PSI, PHI, fwd_k, **fwd)                            # ref:255-257
         plan.binary("sub", DATA, PHI, RES)                               # ref:259
         plan.decompose(RES, level)                                       # ref:261
-        res_coefficients = Coefficients.__new__(Coefficients)            # same plan, no release
-        res_coefficients.scaling_function, res_coefficients.bilateral = sf, None
-        res_coefficients._plan, res_coefficients._host = plan, None
-        res_coefficients._nplanes, res_coefficients._noise_uploaded = level + 1, None
-        res_coefficients.noise = coefficients.noise                      # ref:262
+        # ref:262: a fresh Coefficients per iteration inherits the data's noise; when that is None
+        # its lazy MAD estimate (ref:131-132) comes from the RESIDUAL's plane 0 - the planes the
+        # plan holds right now.  One owner of the plan throughout: `coefficients`.
+        coefficients.noise = data_noise
         for s, c in enumerate(denoise_coefficients):                     # ref:263-276
-            t = res_coefficients._tau(c, s)
+            t = coefficients._tau(c, s, soft)
             tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
             plan.mrs_update(s, MRS[s], tau, soft, noise_plane, persistent_mrs,
                             1.0 / (iteration + 1))
-        res_coefficients._plan = None                                    # keep the plan out of the pool
         plan.plane_sum(0, level + 1, RES)                                # ref:278
         plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
-        plan.filter2d(RES, CONV, psf, **bwd)                             # ref:284-286
+        plan.filter2d(RES, CONV, bwd_k, **bwd)                           # ref:284-286
         plan.binary("mul", PSI, CONV, PSI)                               # ref:288
     return plan.download(PSI)

@@ -299,6 +299,7 @@ class Coefficients:
         self._plan = None
         self._host = None
         self._noise_uploaded = None
+        self._sum_valid = False     # PLANE_OUT holds np.sum(planes, axis=0) of the CURRENT planes
         # logical shape of one plane: (N,), (H, W) or (Z, Y, X); the engine stores it as a 2-D
         # image: 1 x N, H x W or (Z*Y) x X
         if isinstance(data, Plan):
@@ -385,6 +386,7 @@ class Coefficients:
         if self._host is not None:
             for s in range(self._nplanes):
                 self._plan.upload(s, self._as_plane(self._host[s]))
+            self._sum_valid = False          # a user-owned mirror may have been edited
         return self._plan
 
     def _refresh_host(self, planes):
@@ -417,7 +419,7 @@ class Coefficients:
     def _noise_from_device(self):
         return self._plan.abs_median(0) / 0.6745 / self.sigma_e[0]
 
-    def _tau(self, sigma, scale):
+    def _tau(self, sigma, scale, soft=True):
         """(tau, noise_plane) or None when the significance is identically one
         (sigma == 0, ref:142-143; scalar noise == 0, ref:133-135).  Runs inside a device
         operation (planes already in sync)."""
@@ -428,19 +430,27 @@ class Coefficients:
         if type(self.noise) is not np.ndarray:
             if self.noise == 0:
                 return None
-            return float(sigma * self.noise * self.sigma_e[scale]), PLANE_NONE
+            tau = float(sigma * self.noise * self.sigma_e[scale])
+            if tau < 0:
+                # ref:137-141 with a negative threshold: erf(|w / tau|) is erf(|w| / |tau|), and
+                # |w| > tau is always true (significance one)
+                return (-tau, PLANE_NONE) if soft else None
+            return tau, PLANE_NONE
         plan = self._plan
         if self._noise_uploaded is not self.noise:
             plan.upload(_NOISE_PLANE, np.broadcast_to(
                 self._as_plane(np.asarray(self.noise, np.float32)), plan.shape))
             self._noise_uploaded = self.noise
-        return float(sigma * self.sigma_e[scale]), _NOISE_PLANE
+        tau = float(sigma * self.sigma_e[scale])
+        if tau < 0 and not soft:
+            return None
+        return abs(tau), _NOISE_PLANE
 
     def significance(self, sigma, scale, soft_threshold=True):
         """erf(|w|/tau) (soft) or |w| > tau (hard, bool), tau = sigma*noise*sigma_e[scale]
         (ref:129-143).  Returns a host ndarray like the reference."""
         plan = self._device()
-        t = self._tau(sigma, scale)
+        t = self._tau(sigma, scale, soft_threshold)
         if t is None:
             return np.ones(self._img_shape(), np.float32)
         plan.significance(scale, _TMP_PLANE, t[0], soft_threshold, t[1])
@@ -453,9 +463,10 @@ class Coefficients:
         if weights is None:
             weights = (1,) * len(sigma)
         plan = self._device()
+        self._sum_valid = False
         touched = []
         for scl, (_, sig, wgt) in enumerate(zip(range(self._nplanes), sigma, weights)):
-            t = self._tau(sig, scl)
+            t = self._tau(sig, scl, soft_threshold)
             if t is None:
                 if wgt != 1:
                     plan.wow_update(scl, PLANE_NONE, 0.0, True, PLANE_NONE, wgt, PLANE_NONE)
@@ -471,9 +482,10 @@ class Coefficients:
         if weights is None:
             weights = (1,) * len(sigma)
         plan = self._device()
+        self._sum_valid = False              # PLANE_OUT becomes the DENOISED sum
         taus, wgts, noise_plane = [], [], PLANE_NONE
         for scl, (_, sig, wgt) in enumerate(zip(range(self._nplanes), sigma, weights)):
-            t = self._tau(sig, scl)
+            t = self._tau(sig, scl, soft_threshold)
             taus.append(0.0 if t is None else t[0])
             wgts.append(wgt)
             if t is not None and t[1] != PLANE_NONE:
@@ -490,7 +502,9 @@ class Coefficients:
         reduction over axis 0).  Any other reduction falls back to numpy on the mirror."""
         if axis == 0 and dtype is None and not kwargs:
             plan = self._device()
-            plan.plane_sum(0, self._nplanes, PLANE_OUT)
+            if not self._sum_valid:           # with_sum=True transforms carried it along already
+                plan.plane_sum(0, self._nplanes, PLANE_OUT)
+                self._sum_valid = self._host is None
             res = self._from_plane(plan.download(PLANE_OUT))
             if out is None:
                 return res
@@ -516,8 +530,15 @@ class AtrousTransform:
         self.bilateral = bilateral
         self.bilateral_scaling = bilateral_scaling
 
-    def __call__(self, arr, level, recursive=False):
-        """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328)."""
+    def __call__(self, arr, level, recursive=False, *, with_sum=False):
+        """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328).
+
+        ``with_sum=True`` (keyword-only, not in the reference) asks the transform to carry the
+        synthesis ``np.sum(coefficients, axis=0)`` through its fused passes (wt_decompose_sum: the
+        planes are written as usual but not re-read).  The sum is kept on the device next to the
+        planes and handed out by ``np.sum(coefficients, axis=0)`` / ``coefficients.sum(axis=0)``
+        as long as no plane has been modified since; it is bit-identical to summing afterwards.
+        Without the keyword nothing extra is computed."""
         if _is_1d(arr):
             return self._call_1d(arr, level, recursive)
         if np.ndim(arr) == 3:
@@ -529,8 +550,14 @@ class AtrousTransform:
         plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                             _family_of(scaling_function), level)
         plan.upload(PLANE_INPUT, img)
-        self._run(plan, level)
-        return Coefficients(plan, scaling_function, self.bilateral)
+        summed = bool(with_sum) and self.bilateral is None and not plan.custom
+        if summed:
+            plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, FLAG_FUSED)     # ref:432,442 + utils.py:98
+        else:
+            self._run(plan, level)
+        coefficients = Coefficients(plan, scaling_function, self.bilateral)
+        coefficients._sum_valid = summed
+        return coefficients
 
     # the reference's two algorithm entry points return the stacked planes as an ndarray
     # (ref:330-406, 408-444); kept for code that calls them directly
