@@ -298,10 +298,17 @@ def main():
         import wavelets_amd as WA
         coefficients = WA.Coefficients(plan, WA.Triangle(2))
 
-        def step():         # Coefficients.denoise([5,3,2]) then np.sum(coefficients, axis=0)
-            plan.decompose(PLANE_INPUT, level, flags)
+        from wavelets_amd.wavelets import _decompose_denoise_sum
+        transform = WA.AtrousTransform(WA.Triangle)
+
+        def step():         # transform, Coefficients.denoise([5,3,2]), np.sum(coefficients, axis=0)
             coefficients.noise = None                      # lazy MAD estimate, every step
-            coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
+            if two_call:
+                plan.decompose(PLANE_INPUT, level, flags)
+                coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
+            else:           # the same three results with the threshold step between the passes
+                _decompose_denoise_sum(transform, plan, level, coefficients, [5, 3, 2],
+                                       soft_threshold=True, write_back=True)
     else:
         import wavelets_amd as WA
         from wavelets_amd import utils as WU

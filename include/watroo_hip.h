@@ -168,6 +168,13 @@ int wt_decompose_pass(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags
  * 4*(L+2) + 8*passes - 4 B/pixel of traffic instead of 8*(L+2).  Bit-identical to the two-call
  * form.  Schedules that contain single-scale passes run as the two calls. */
 int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
+/* *ok = 1 when wt_decompose_sum(plan, ., level, ., bit0) runs as accumulate passes (else it is the
+ * two-call form).  The host uses it to interleave Coefficients.denoise with the passes:
+ * wt_decompose_pass for the passes that produce the thresholded planes, wt_abs_median,
+ * wt_denoise_sum over those planes into the sum plane, wt_decompose_pass_sum (first = 0) for the
+ * rest - the same bits as transform, denoise, sum (watroo/utils.py:95-98) with the planes read
+ * once less. */
+int wt_plan_fused_ok(wt_plan *plan, int level, int *ok);
 /* one pass of that (fused passes only): `first` = the sum starts with this pass's first detail
  * plane, `last` = the smooth plane `nxt` is added and the sum is complete. */
 int wt_decompose_pass_sum(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags,

@@ -315,3 +315,37 @@ def test_with_sum_keyword_carries_the_synthesis_through_the_passes(WA):
     cb = WA.AtrousTransform(WA.B3spline, bilateral=1)(a[:200, :300], 3, with_sum=True)
     assert not cb._sum_valid
     np.testing.assert_array_equal(np.sum(cb, axis=0), cb.data.sum(axis=0))
+
+
+@pytest.mark.parametrize("fam,level,sigma,weights", [
+    ("triangle", 8, [5, 3, 2], None),                       # BASELINE config 3: passes (0,3) | (3,3) (6,2)
+    ("b3spline", 6, [5, 3], [.5, 2]),                       # thresholded planes inside the first pass
+    ("b3spline", 6, [5, 3, 2, 1], None),                    # reaches into the second pass: both first
+    ("b3spline", 8, [0, 0, 0, 0, 3], None),                 # leading zeros
+    ("triangle", 5, [4, 2], None),                          # schedule (0,3) (3,2)
+])
+@pytest.mark.parametrize("soft", [True, False])
+def test_denoise_between_the_passes_is_bitwise_transform_denoise_sum(WA, L, fam, level, sigma, weights, soft):
+    """_decompose_denoise_sum (threshold step between the fused passes, the rest of the passes
+    carry the sum) == AtrousTransform -> Coefficients.denoise -> np.sum, planes and image."""
+    from wavelets_amd.wavelets import _decompose_denoise_sum
+    cls = {"b3spline": WA.B3spline, "triangle": WA.Triangle}[fam]
+    a = rnd((700, 1100), 91)
+    ref = WA.AtrousTransform(cls)(a, level)
+    ref.denoise(list(sigma), weights=weights, soft_threshold=soft)
+    ref_planes = np.array(ref.data, copy=True)
+    ref_sum = np.sum(ref, axis=0)
+    for write_back in (True, False):
+        plan = L.acquire_plan(L.default_context(), 700, 1100, cls._family, level)
+        plan.upload(L.PLANE_INPUT, a)
+        c = WA.Coefficients(plan, cls(2))
+        T = WA.AtrousTransform(cls)
+        _decompose_denoise_sum(T, plan, level, c, list(sigma), weights, soft, write_back)
+        np.testing.assert_array_equal(plan.download(L.PLANE_OUT), ref_sum)
+        np.testing.assert_allclose(c.noise, ref.noise, rtol=0)
+        if write_back:
+            np.testing.assert_array_equal(c.data, ref_planes)
+    # the public route: denoise(a, sigmas padded with zeros) == the reference call sequence
+    pad = list(sigma) + [0] * (level - len(sigma))
+    if weights is None:
+        np.testing.assert_array_equal(WA.denoise(a, pad, cls, soft_threshold=soft), ref_sum)

@@ -16,7 +16,7 @@ __device__ __forceinline__ void ntstore(float4 o, float4 *p) { vf4 v = {o.x, o.y
 
 // NWR planes written, NRD row loads per step (NRD = 2: the second load reads the row D/2 above -
 // the "every phase loads both parities" variant), NT: nontemporal stores to planes 0..2
-template <int PD, int NWR, int NRD, int NT>
+template <int PD, int NWR, int NRD, int NT, int PERM = 0>
 __global__ __launch_bounds__(256) void march(Ptrs in, Ptrs out, int W4, int H, int nstrips, int D, int S, int chunks)
 {
     const int strip = blockIdx.x % nstrips;
@@ -27,7 +27,10 @@ __global__ __launch_bounds__(256) void march(Ptrs in, Ptrs out, int W4, int H, i
     const int r0 = c * S, r1 = min(r0 + S, n_q);
     if (r0 >= r1) return;
     const long col = (long)strip * 256 + threadIdx.x;
-    auto row = [&](int r) -> long { return (long)(q + D * min(r, r1 - 1)) * W4 + col; };
+    // PERM: chunk-interleaved row layout - logical row y = j*S + k lives at physical row k*chunks + j,
+    // so the rows that the `chunks` workgroups of a column strip touch in the same step are adjacent
+    auto phys = [&](int y) -> long { return PERM ? (long)(y % S) * chunks + y / S : (long)y; };
+    auto row = [&](int r) -> long { return phys(q + D * min(r, r1 - 1)) * W4 + col; };
     float4 pf[PD], pg[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) { pf[i] = in.p[0][row(r0 + i)]; if (NRD > 1) pg[i] = in.p[0][max(row(r0 + i) - (long)(D / 2) * W4, col)]; }
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void march(Ptrs in, Ptrs out, int W4, int H, i
             float4 cur = pf[k];
             pf[k] = in.p[0][row(rr + PD)];
             if (NRD > 1) { cur.x += pg[k].x; pg[k] = in.p[0][max(row(rr + PD) - (long)(D / 2) * W4, col)]; }
-            const long o = (long)(q + D * rr) * W4 + col;
+            const long o = phys(q + D * rr) * W4 + col;
 #pragma unroll
             for (int w = 0; w < NWR; ++w) {
                 if (NT && w < 3) ntstore(cur, &out.p[w][o]); else out.p[w][o] = cur;
@@ -83,6 +86,10 @@ int main(int argc, char **argv)
                 printf("D %2d  WGs %4d  S %4d  W%d R%d nt%d : %.4f ms  %5.0f GB/s\n", D, grid, S, NWR, NRD, NT, ms, (1.0 + NWR) * bytes / ms / 1e6); \
             }
             GO(5, 1, 1) GO(5, 1, 0)
+            if (D == 1 && side % (chunks * 1) == 0 && S * chunks == side) {
+                double ms = timeit([&] { hipLaunchKernelGGL((march<4, 5, 1, 1, 1>), dim3(grid), dim3(256), 0, 0, in, out, W4, side, nstrips, D, S, chunks); });
+                printf("D %2d  WGs %4d  S %4d  W5 R1 nt1 PERMUTED rows : %.4f ms  %5.0f GB/s\n", D, grid, S, ms, 6.0 * bytes / ms / 1e6);
+            }
             if (wgs == 512) { GO(4, 1, 1) if (D > 1) GO(5, 2, 1) }
         }
     }

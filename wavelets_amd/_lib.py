@@ -78,6 +78,7 @@ SIGNATURES = {
     "wt_decompose_pass": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose_pass_sum": (_c.c_int, [_vp] + [_c.c_int] * 8),
+    "wt_plan_fused_ok": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_int)]),
     "wt_atrous_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float,
@@ -455,6 +456,12 @@ class Plan:
     def decompose_pass_sum(self, cur, nxt, s0, ns, flags, sum_plane, first, last):
         check(load().wt_decompose_pass_sum(self._h, cur, nxt, s0, ns, flags, sum_plane,
                                            int(first), int(last)))
+
+    def fused_ok(self, level):
+        """True when decompose_sum(level) runs as accumulate passes (wt_plan_fused_ok)."""
+        ok = _c.c_int(0)
+        check(load().wt_plan_fused_ok(self._h, level, _c.byref(ok)))
+        return bool(ok.value)
 
     def decompose_pass(self, cur, nxt, s0, ns, flags=FLAG_FUSED):
         check(load().wt_decompose_pass(self._h, cur, nxt, s0, ns, flags))

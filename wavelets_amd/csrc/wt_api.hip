@@ -1194,6 +1194,23 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
     return run_schedule(p, src, level, flags, tr, np, true, dst);
 }
 
+// Would wt_decompose_sum(plan, ., level, ., FLAG_FUSED) run as accumulate passes (every pass of the
+// schedule has a fused kernel, symmetric border, built-in taps, rows short enough)?  Host logic.
+extern "C" int wt_plan_fused_ok(wt_plan *p, int level, int *ok)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !ok) WT_FAIL("wt_plan_fused_ok: null pointer");
+    *ok = 0;
+    if (level <= 0 || level > p->max_level || p->g.border || p->ntaps || !wt_fused_supported(p)) return 0;
+    int32_t tr[3 * 32];
+    int np = 0;
+    WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
+    for (int i = 0; i < np; ++i)
+        if (!wt_fused_has_pass(tr[3 * i], tr[3 * i + 1])) return 0;
+    *ok = 1;
+    return 0;
+}
+
 extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
 {
     WtGuard guard_(ctx_of(p));

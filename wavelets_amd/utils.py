@@ -12,7 +12,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
-from .wavelets import (AtrousTransform, B3spline, Coefficients, _family_of, _to_f32_image,
+from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of,
+                       _to_f32_image,
                        generalized_anscombe,
                        PLANE_INPUT)
 
@@ -93,12 +94,13 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     plan.upload(PLANE_INPUT, img)
     if anscombe:
         plan.anscombe(PLANE_INPUT, PLANE_INPUT)                           # ref:93-94
-    transform._run(plan, level)                                           # ref:95
     coefficients = Coefficients(plan, sf, bilateral)
     coefficients.noise = noise                                            # ref:96
-    # ref:97-98 in one pass over the planes; the thresholded planes themselves are not
-    # returned by denoise(), so they are not written back
-    coefficients._denoise_sum(weights, soft_threshold=soft_threshold, write_back=False)
+    # ref:95, 97-98: transform, threshold and sum interleaved (trailing zero sigmas - scales that
+    # are transformed but not thresholded - ride on the accumulate passes); the thresholded planes
+    # themselves are not returned by denoise(), so they are not written back
+    _decompose_denoise_sum(transform, plan, level, coefficients, weights,
+                           soft_threshold=soft_threshold, write_back=False)
     if anscombe:
         plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)                 # ref:99-100
     return plan.download(PLANE_OUT)

@@ -513,6 +513,55 @@ class Coefficients:
         return np.sum(self.data, axis=axis, dtype=dtype, out=out, **kwargs)
 
 
+def _decompose_denoise_sum(transform, plan, level, coefficients, sigma, weights=None,
+                           soft_threshold=True, write_back=False):
+    """Transform (ref:95 / 408-444), ``Coefficients.denoise(sigma, weights)`` (ref:145-149) and
+    ``np.sum(coefficients, axis=0)`` (utils.py:98) of the image in ``plan``'s input plane, with the
+    threshold step placed BETWEEN the fused passes: the passes that produce the planes to be
+    thresholded run first, the MAD noise estimate reads plane 0 (final by then, ref:131-132), one
+    kernel thresholds those planes and starts the sum with them (wt_denoise_sum), and the remaining
+    passes carry the sum along (wt_decompose_pass_sum) instead of the sum re-reading every plane.
+    Same operations in the same order as transform -> denoise -> sum: identical bits.  Falls back
+    to exactly that sequence when the schedule is not all fused passes or every plane is
+    thresholded.  Result in PLANE_OUT; ``write_back`` also stores the thresholded planes."""
+    if weights is None:
+        weights = (1,) * len(sigma)
+    entries = list(zip(range(level + 1), sigma, weights))                 # zip truncation, ref:148
+    n_den = max([scl + 1 for scl, sig, wgt in entries if sig != 0 or wgt != 1], default=0)
+    sched = _lib.schedule(plan.family, level, True) if not plan.custom else []
+    k, covered = 0, 0
+    if transform.bilateral is None and not plan.custom and level > 0 and plan.fused_ok(level):
+        while k < len(sched) and (covered < n_den or k == 0):
+            covered += sched[k][1]
+            k += 1
+    if k == 0 or k == len(sched):
+        transform._run(plan, level)
+        coefficients._denoise_sum(sigma, weights, soft_threshold, write_back)
+        return plan
+    coefficients._sum_valid = False
+    cur = PLANE_INPUT
+    for i in range(k):
+        nxt = PLANE_SCRATCH(i & 1)
+        plan.decompose_pass(cur, nxt, sched[i][0], sched[i][1])
+        cur = nxt
+    taus, wgts, noise_plane = [], [], PLANE_NONE
+    for scl, sig, wgt in entries[:covered]:
+        t = coefficients._tau(sig, scl, soft_threshold)
+        taus.append(0.0 if t is None else t[0])
+        wgts.append(wgt)
+        if t is not None and t[1] != PLANE_NONE:
+            noise_plane = t[1]
+    plan.denoise_sum(covered, taus, wgts, soft_threshold, noise_plane, write_back)
+    for i in range(k, len(sched)):
+        last = i == len(sched) - 1
+        nxt = level if last else PLANE_SCRATCH(i & 1)
+        plan.decompose_pass_sum(cur, nxt, sched[i][0], sched[i][1], FLAG_FUSED, PLANE_OUT,
+                                first=False, last=last)
+        cur = nxt
+    coefficients._sum_valid = bool(write_back) and coefficients._host is None
+    return plan
+
+
 def _rebuild_coefficients(data, scaling_function, bilateral, noise):
     c = Coefficients(data, scaling_function, bilateral)
     c.noise = noise
