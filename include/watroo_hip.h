@@ -109,8 +109,9 @@ int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int
  * cv2.BORDER_REFLECT; 1 = symmetric reflection inside each polyphase component of the
  * operator's dilation - the rule atrous_recursive applies to its sub-arrays
  * (watroo/wavelets.py:354-390); 2 = scipy 'mirror' (reflection without edge duplication), the
- * border of the 1-D branch (watroo/wavelets.py:66-69; a 1-D signal is a 1 x N image).
- * Modes 1 and 2: per-scale kernels only, single GPU. */
+ * border of the 1-D branch (watroo/wavelets.py:66-69; a 1-D signal is a 1 x N image); 3 = 'mirror'
+ * inside each polyphase component (atrous_recursive on a 1-D signal).
+ * Modes 1-3: per-scale kernels only (the bilateral and 3-D operators accept 0 and 1), single GPU. */
 int wt_plan_set_border(wt_plan *plan, int border);
 /* User-defined scaling function (a subclass of AbstractScalingFunction with its own
  * coefficients_1d, watroo/wavelets.py:152-229): `ntaps` odd 1-D taps (<= 15) replace the plan's
@@ -127,6 +128,11 @@ int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int6
  * a host round trip (tools/check_large.py builds and checks a 32768^2 image this way). */
 int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t y0,
                    int64_t x0);
+/* general form: dst[dy:dy+rows, dx:dx+cols] = src[sy:sy+rows, sx:sx+cols] (local rows, same
+ * device) - the crop of a padded CUBE back to its (Z, Y, X) block is one window per z slice
+ * (atrous_recursive on 3-D data, watroo/wavelets.py:394-406). */
+int wt_copy_window(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t sy,
+                   int64_t sx, int64_t dy, int64_t dx, int64_t rows, int64_t cols);
 /* device pointer of a plane's local row 0 (for zero-copy interop / virtual-strip tests) */
 int wt_plane_ptr(wt_plan *plan, int plane, void **dev_ptr);
 

@@ -338,6 +338,27 @@ def g17_rl_fft_odd_height():
     save("g17_rl_fft_odd", "hard(numpy fft; transform via cv2 stand-in)", **out)
 
 
+def g18_recursive_nd_bilateral():
+    """recursive=True beyond the 2-D plain case (wavelets.py:330-406): with bilateral filtering,
+    on 1-D signals (scipy 'mirror' border inside every sub-array) and on cubes."""
+    out = {}
+    a2 = img((40, 52), 181)
+    out["img2"] = a2
+    out["rec2_b1"] = AtrousTransform(B3spline, bilateral=1)(a2, 3, recursive=True).data
+    out["rec2_blist"] = AtrousTransform(Triangle, bilateral=[1.5, .7], bilateral_scaling=True)(a2, 3, recursive=True).data
+    a1 = img((1, 200), 182)[0]
+    out["sig1"] = a1
+    out["rec1_b3"] = AtrousTransform(B3spline)(a1, 4, recursive=True).data
+    out["rec1_tri"] = AtrousTransform(Triangle)(a1, 3, recursive=True).data
+    out["rec1_b1"] = AtrousTransform(B3spline, bilateral=1)(a1, 3, recursive=True).data
+    a3 = np.random.default_rng(183).standard_normal((10, 12, 14)).astype(np.float32)
+    out["cube"] = a3
+    out["rec3_tri"] = AtrousTransform(Triangle)(a3, 2, recursive=True).data
+    out["rec3_b3"] = AtrousTransform(B3spline)(a3, 2, recursive=True).data
+    out["rec3_b1"] = AtrousTransform(Triangle, bilateral=1)(a3, 2, recursive=True).data
+    save("g18_recursive_nd", "1-D plain: hard (numpy + scipy); others: semantic(cv2 stand-in)", **out)
+
+
 def g14_wow_denoise_nd():
     """wow / denoise on 1-D signals and (Z, Y, X) cubes (the reference is ndim-generic)."""
     out = {}
@@ -510,3 +531,4 @@ if __name__ == "__main__":
         g15_custom_scaling_function()
         g16_bilateral_nd()
         g17_rl_fft_odd_height()
+        g18_recursive_nd_bilateral()

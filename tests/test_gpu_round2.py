@@ -349,3 +349,29 @@ def test_denoise_between_the_passes_is_bitwise_transform_denoise_sum(WA, L, fam,
     pad = list(sigma) + [0] * (level - len(sigma))
     if weights is None:
         np.testing.assert_array_equal(WA.denoise(a, pad, cls, soft_threshold=soft), ref_sum)
+
+
+def test_recursive_algorithm_on_signals_cubes_and_with_bilateral(WA):
+    """recursive=True (wavelets.py:330-406) beyond the plain 2-D case of round 1: g18 holds the
+    reference's output for bilateral 2-D, 1-D (plain / bilateral) and 3-D (plain / bilateral)."""
+    from conftest import load_golden
+    g = load_golden("g18_recursive_nd")
+    cases = [("rec2_b1", "img2", 3, WA.B3spline, 1, False, 1e-4),
+             ("rec2_blist", "img2", 3, WA.Triangle, [1.5, .7], True, 1e-4),
+             ("rec1_b3", "sig1", 4, WA.B3spline, None, False, 1e-5),
+             ("rec1_tri", "sig1", 3, WA.Triangle, None, False, 1e-5),
+             ("rec1_b1", "sig1", 3, WA.B3spline, 1, False, 1e-4),
+             ("rec3_tri", "cube", 2, WA.Triangle, None, False, 1e-5),
+             ("rec3_b3", "cube", 2, WA.B3spline, None, False, 1e-5),
+             ("rec3_b1", "cube", 2, WA.Triangle, 1, False, 1e-4)]
+    for name, src, level, cls, bil, scaling, rel in cases:
+        a = g[src]
+        bl = list(bil) if isinstance(bil, list) else bil
+        c = WA.AtrousTransform(cls, bilateral=bl, bilateral_scaling=scaling)(a, level, recursive=True)
+        assert c.data.shape == g[name].shape, name
+        close(c.data, g[name], rel * float(np.abs(a).max()))
+        # and it differs from the standard algorithm near the borders only where the reference does
+    a = rnd((300,), 7)
+    std = WA.AtrousTransform(WA.B3spline)(a, 4).data
+    rec = WA.AtrousTransform(WA.B3spline)(a, 4, recursive=True).data
+    np.testing.assert_allclose(rec[:, 64:-64], std[:, 64:-64], atol=1e-5 * np.abs(a).max())

@@ -391,3 +391,23 @@ def test_bilateral_nd_vs_reference(tag):
     for fam in FAMS:
         close(O.atrous_standard_nd(a, 3, fam, 1), g[f"{tag}_{fam}_b1_L3"], tol)
         close(O.atrous_standard_nd(a, 2, fam, [2.0, 0.7], True), g[f"{tag}_{fam}_blist_scaling_L2"], tol)
+
+
+def test_recursive_algorithm_nd_and_bilateral_vs_reference():
+    """g18: atrous_recursive on signals / cubes and with bilateral filtering (wavelets.py:330-406);
+    the oracle's generic restatement against the reference's output."""
+    g = load_golden("g18_recursive_nd")
+    cases = [("rec2_b1", "img2", 3, "b3spline", 1, False),
+             ("rec2_blist", "img2", 3, "triangle", [1.5, .7], True),
+             ("rec1_b3", "sig1", 4, "b3spline", None, False),
+             ("rec1_tri", "sig1", 3, "triangle", None, False),
+             ("rec1_b1", "sig1", 3, "b3spline", 1, False),
+             ("rec3_tri", "cube", 2, "triangle", None, False),
+             ("rec3_b3", "cube", 2, "b3spline", None, False),
+             ("rec3_b1", "cube", 2, "triangle", 1, False)]
+    for name, src, level, fam, bil, scaling in cases:
+        got = O.atrous_recursive_nd(g[src], level, fam, bil, scaling)
+        close(got, g[name], atol=3e-6 * np.abs(g[src]).max())
+    # the 2-D plain case agrees with the dedicated restatement
+    a = g["img2"]
+    np.testing.assert_array_equal(O.atrous_recursive_nd(a, 3, "b3spline"), O.atrous_recursive(a, 3, "b3spline"))

@@ -14,7 +14,9 @@ is what this script verifies: every rank compares its strip of
   * the 7 planes and the reconstruction of wt_decompose_sum (fused passes, B3spline L = 6),
   * the planes of the per-scale (unfused) schedule and of Triangle L = 8,
   * the global MAD noise (all-reduced radix-select histograms), denoise([5,3,2]) + plane sum,
-  * wt_reduce's {sum, sum^2, min, max}
+  * wt_reduce's {sum, sum^2, min, max},
+  * StripTransform.wow (plain and bilateral=1, denoise_coefficients=[5,2], 5 scales: halos of every
+    scale's own plane, all-reduced median / moments) and StripTransform.denoise_sum
 
 BIT FOR BIT with an unsharded plan computed on the same GPU by the same rank.
 Where the devices differ (a real multi-GPU node) pass --own-gpu: rank r uses device LOCAL_RANK.
@@ -53,7 +55,9 @@ def main():
     from wavelets_amd.parallel import init_comm, StripTransform
     from wavelets_amd.wavelets import B3spline, Triangle
 
-    ctx = L.Context(local_rank if args.own_gpu else 0)
+    dev = local_rank if args.own_gpu else 0
+    os.environ["WATROO_HIP_DEVICE"] = str(dev)     # the unsharded reference (default context) on the same GPU
+    ctx = L.Context(dev)
 
     def bcast(obj, src):
         box = [obj]
@@ -115,6 +119,44 @@ def main():
         same(f"{tag} denoised sum", st.sum(), whole.download(L.PLANE_OUT)[r0:r0 + n])
         st.plan.close()
         whole.close()
+
+    # ---- sharded wow / denoise_sum against the unsharded public API on the same GPU
+    import wavelets_amd as WA
+    n_scales = 5
+    if (2 << (n_scales - 1)) <= H // world:
+        simg = (img + 2 * np.sin(np.arange(W, dtype=np.float32) / 9.)[None, :]).astype(np.float32)
+        for kw in (dict(denoise_coefficients=[5, 2]), dict(bilateral=1, denoise_coefficients=[5, 2]),
+                   dict(h=.5, gamma=2, denoise_coefficients=[5, 2], preserve_variance=True)):
+            tag = "wow " + ",".join(f"{k}={v}" for k, v in kw.items())
+            ref_img, ref_c = WA.wow(simg.copy(), n_scales=n_scales,
+                                    **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+            st = StripTransform(ctx, H, W, n_scales, B3spline)
+            r0, n = st.row0, st.nrows
+            st.upload(simg[r0:r0 + n])
+            got = st.wow(**{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+            # detail planes: no global moment enters unless preserve_variance -> bit for bit; the
+            # last plane and the image carry std / rms / min / max from fp64 partial sums that are
+            # folded per rank before the all-reduce: equal to the fp32 rounding of those scalars
+            exact = "preserve_variance" not in kw
+            for s in range(n_scales):
+                if exact:
+                    same(f"{tag} plane {s}", st.plane(s), ref_c.data[s][r0:r0 + n])
+                else:
+                    checks.append((f"{tag} plane {s}", bool(np.allclose(st.plane(s), ref_c.data[s][r0:r0 + n], rtol=2e-6, atol=0))))
+            checks.append((f"{tag} smooth plane", bool(np.allclose(st.plane(n_scales), ref_c.data[n_scales][r0:r0 + n], rtol=2e-6, atol=0))))
+            checks.append((f"{tag} image", bool(np.allclose(got, ref_img[r0:r0 + n], rtol=2e-6, atol=2e-6 * float(np.abs(ref_img).max())))))
+            same(f"{tag} noise", np.float64(st.noise), np.float64(ref_c.noise))
+            st.plan.close()
+        st = StripTransform(ctx, H, W, 4, Triangle)
+        r0, n = st.row0, st.nrows
+        st.upload(simg[r0:r0 + n])
+        st.decompose()
+        c = WA.AtrousTransform(Triangle)(simg, 4)
+        c.denoise([4, 2], weights=[.5, 2])
+        same("denoise_sum", st.denoise_sum([4, 2], weights=[.5, 2]), np.sum(c, axis=0)[r0:r0 + n])
+        for s in range(5):
+            same(f"denoise_sum plane {s}", st.plane(s), c.data[s][r0:r0 + n])
+        st.plan.close()
 
     ctx.sync()
     bad = [n for n, ok in checks if not ok]

@@ -65,6 +65,7 @@ SIGNATURES = {
     "wt_plan_set_taps": (_c.c_int, [_vp, _fp, _c.c_int]),
     "wt_crop_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
     "wt_paste_plane": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64]),
+    "wt_copy_window": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int] + [_i64] * 6),
     "wt_plane_ptr": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_vp)]),
     "wt_host_alloc": (_c.c_int, [_vp, _c.c_size_t, _c.POINTER(_vp)]),
     "wt_host_free": (_c.c_int, [_vp]),
@@ -423,6 +424,11 @@ class Plan:
 
     def crop_from(self, src_plan, src_plane, dst_plane, y0, x0):
         check(load().wt_crop_plane(src_plan._h, src_plane, self._h, dst_plane, y0, x0))
+
+    def copy_window_from(self, src_plan, src_plane, dst_plane, sy, sx, dy, dx, rows, cols):
+        """self[dst_plane][dy:dy+rows, dx:dx+cols] = src_plan[src_plane][sy:sy+rows, sx:sx+cols]"""
+        check(load().wt_copy_window(src_plan._h, src_plane, self._h, dst_plane, sy, sx, dy, dx,
+                                    rows, cols))
 
     def paste_into(self, dst_plan, src_plane, dst_plane, y0, x0):
         check(load().wt_paste_plane(self._h, src_plane, dst_plan._h, dst_plane, y0, x0))

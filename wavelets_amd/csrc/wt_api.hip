@@ -492,7 +492,7 @@ extern "C" int wt_plan_set_border(wt_plan *p, int border)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_plan_set_border: null plan");
-    if (border < 0 || border > 2) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
+    if (border < 0 || border > 3) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
     if (border && p->nranks > 1) WT_FAIL("wt_plan_set_border: non-default borders are single-GPU only");
     p->g.border = border;
     return 0;
@@ -561,6 +561,26 @@ extern "C" int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst
     WT_TRY(plane_base(dst, dst_plane, &d_));
     WT_HIP(hipMemcpy2DAsync(d_ + (size_t)y0 * dst->g.P + x0, (size_t)dst->g.P * 4, s_, (size_t)src->g.P * 4,
                             (size_t)src->g.W * 4, (size_t)src->g.nrows, hipMemcpyDeviceToDevice, src->ctx->stream));
+    if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
+    return 0;
+}
+
+// dst[dy:dy+rows, dx:dx+cols] = src[sy:sy+rows, sx:sx+cols]  (local rows; same device)
+extern "C" int wt_copy_window(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t sy, int64_t sx,
+                              int64_t dy, int64_t dx, int64_t rows, int64_t cols)
+{
+    WtGuard guard_(ctx_of(src), ctx_of(dst));
+    if (!src || !dst) WT_FAIL("wt_copy_window: null plan");
+    if (src->ctx->device != dst->ctx->device) WT_FAIL("wt_copy_window: plans on different devices");
+    if (rows < 1 || cols < 1 || sy < 0 || sx < 0 || dy < 0 || dx < 0 || sy + rows > src->g.nrows || sx + cols > src->g.W ||
+        dy + rows > dst->g.nrows || dx + cols > dst->g.W)
+        WT_FAIL("wt_copy_window: window outside a plane");
+    float *s_ = nullptr, *d_ = nullptr;
+    WT_TRY(plane_base(src, src_plane, &s_));
+    WT_TRY(plane_base(dst, dst_plane, &d_));
+    if (s_ == d_) WT_FAIL("wt_copy_window: source and destination are the same plane");
+    WT_HIP(hipMemcpy2DAsync(d_ + (size_t)dy * dst->g.P + dx, (size_t)dst->g.P * 4, s_ + (size_t)sy * src->g.P + sx,
+                            (size_t)src->g.P * 4, (size_t)cols * 4, (size_t)rows, hipMemcpyDeviceToDevice, src->ctx->stream));
     if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
     return 0;
 }
@@ -1011,7 +1031,7 @@ extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, 
 static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s,
                             float f1 = 1.f, float f2 = 1.f)
 {
-    if (p->g.border) WT_FAIL("bilateral kernels implement the symmetric border only");
+    if (p->g.border != 0 && p->g.border != 1) WT_FAIL("bilateral kernels implement the symmetric border (whole image or polyphase) only");
     if (p->ntaps) WT_FAIL("bilateral kernels are not available with user-defined taps");
     ChainArgs a{};
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
@@ -1450,16 +1470,17 @@ static int conv3d_planes(wt_plan *p, float *in, float *tmp, float *out, int s, i
     const int64_t n4 = plan_n4(p);
     ProfScope ps(p->ctx, "wt_zfilter_kernel");
     if (p->family == WT_B3SPLINE)
-        hipLaunchKernelGGL((wt_zfilter_kernel<5>), dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, tmp, out, n4, whole.P / 4, Y, depth, 1 << s);
+        hipLaunchKernelGGL((wt_zfilter_kernel<5>), dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, tmp, out, n4, whole.P / 4, Y, depth, 1 << s, whole.border);
     else
-        hipLaunchKernelGGL((wt_zfilter_kernel<3>), dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, tmp, out, n4, whole.P / 4, Y, depth, 1 << s);
+        hipLaunchKernelGGL((wt_zfilter_kernel<3>), dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, tmp, out, n4, whole.P / 4, Y, depth, 1 << s, whole.border);
     WT_HIP(hipGetLastError());
     return 0;
 }
 
 static int check3d(const wt_plan *p, int depth, int s, const char *who)
 {
-    if (p->nranks != 1 || p->g.border) WT_FAIL("%s: single-GPU plans with the symmetric border only", who);
+    if (p->nranks != 1 || (p->g.border != 0 && p->g.border != 1))
+        WT_FAIL("%s: single-GPU plans with the symmetric border (whole cube or polyphase) only", who);
     if (p->ntaps) WT_FAIL("%s: not available with user-defined taps", who);
     if (depth < 1 || p->g.H % depth) WT_FAIL("%s: plan height %d is not a multiple of depth %d", who, p->g.H, depth);
     if (s < 0 || s > 20) WT_FAIL("%s: scale %d out of range", who, s);
@@ -1522,10 +1543,10 @@ extern "C" int wt_bilateral3d_conv(wt_plan *p, int src, int var, int dst, int s,
     ProfScope ps(p->ctx, "wt_bilateral3d_kernel");
     if (p->family == WT_B3SPLINE)
         hipLaunchKernelGGL((wt_bilateral3d_kernel<5>), grid, block, 0, p->ctx->stream, (const float *)in, (const float *)v, out,
-                           p->g.W, p->g.P, Y, depth, 1 << s);
+                           p->g.W, p->g.P, Y, depth, 1 << s, p->g.border);
     else
         hipLaunchKernelGGL((wt_bilateral3d_kernel<3>), grid, block, 0, p->ctx->stream, (const float *)in, (const float *)v, out,
-                           p->g.W, p->g.P, Y, depth, 1 << s);
+                           p->g.W, p->g.P, Y, depth, 1 << s, p->g.border);
     WT_HIP(hipGetLastError());
     return 0;
 }

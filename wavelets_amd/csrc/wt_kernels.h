@@ -41,6 +41,15 @@ __device__ __forceinline__ int wt_refl_b(int i, int n, int d, int border)
     if (o < 0) o += d;
     const int j = (i - o) / d;
     const int n_o = (n - o + d - 1) / d;
+    if (border == 3) {
+        // 'mirror' inside the residue class: the 1-D branch of convolution() applied to the
+        // sub-arrays of atrous_recursive (watroo/wavelets.py:66-69 under :354-390)
+        if (n_o == 1) return o;
+        const int p = 2 * n_o - 2;
+        int m = j % p;
+        if (m < 0) m += p;
+        return o + d * (m < n_o ? m : p - m);
+    }
     return o + d * wt_refl(j, n_o);
 }
 
@@ -80,6 +89,20 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b)
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b)
 {
     return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// a / b for the two divisions of the bilateral kernels (b = the weight sum in [k_c, 1], or a
+// variance >= 1e-20): v_rcp_f32, one Newton step on the reciprocal and one residual correction of
+// the quotient - 6 instructions instead of the ~10 of the IEEE sequence (v_div_scale x2, v_rcp,
+// 4 fma, v_div_fmas, v_div_fixup), the same result except for rare 1-ulp cases (no scaling is
+// needed: neither operand is near the ends of the exponent range).  Bilateral outputs are a
+// stated-tolerance path (2e-5 * max|input|), not a bit-exact one.
+__device__ __forceinline__ float wt_div_nr(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
 }
 
 // Row pointer for GLOBAL row gy (any integer): reflect on the global image, then map into
@@ -635,10 +658,10 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
     //   d <  4: pixels x - 4 + 4 j .. +3        (3 float4 per row: e[12] of wt_hrow)
     float4 win[K][NX];
     auto load_win_row = [&](int r, float4 (&dst)[NX]) {
-        const float *row = wt_row(a.in, g, gy0 + d * r);
+        const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
 #pragma unroll
         for (int j = 0; j < NX; ++j)
-            dst[j] = wt_load4(row, SMALL_D ? x - 4 + 4 * j : x + (j - hw) * d, g.W);
+            dst[j] = wt_load4_b(row, SMALL_D ? x - 4 + 4 * j : x + (j - hw) * d, g.W, d, g.border);
     };
 #pragma unroll
     for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
         for (int k = 0; k < 4; ++k) {
             norm[k] = kc;
             acc[k] = kc * I[k];
-            s2[k] = -0.72134752044448170368f / vv[k];      // -log2(e) / (2 var)
+            s2[k] = wt_div_nr(-0.72134752044448170368f, vv[k]);   // -log2(e) / (2 var)
         }
         // taps in the reference order (watroo/wavelets.py:89-91): kernel index (i, j) pairs with
         // the shift (K-1-i-hw, K-1-j-hw) * d
@@ -714,7 +737,7 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
         float o[4], ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            o[k] = acc[k] / norm[k];
+            o[k] = wt_div_nr(acc[k], norm[k]);
             ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
         }
         const int64_t roff = (int64_t)(q + d * r) * g.P;
@@ -776,13 +799,13 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int xo = x + (j - hw) * d;
-        xa[j] = wt_refl(xo, g.W);
-        xb[j] = wt_refl(xo + 1, g.W);
+        xa[j] = wt_refl_b(xo, g.W, d, g.border);
+        xb[j] = wt_refl_b(xo + 1, g.W, d, g.border);
         if (xo >= 0 && xo + 1 < g.W && (xo & 1) == 0) pair |= 1u << j;   // d = 1: odd operands take two 4-byte loads
     }
     float2 win[K][K];
     auto load_win_row = [&](int r, float2 (&dst)[K]) {
-        const float *row = wt_row(a.in, g, gy0 + d * r);
+        const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if ((pair >> j) & 1u) dst[j] = *reinterpret_cast<const float2 *>(row + xa[j]);
@@ -867,13 +890,15 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
             vv[0] = a.aux[roff + x];
             vv[1] = x + 1 < g.W ? a.aux[roff + x + 1] : 1.f;
         }
-        float norm[2], acc[2], s2[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            norm[k] = kc;
-            acc[k] = kc * I[k];
-            s2[k] = -0.72134752044448170368f / vv[k];      // -log2(e) / (2 var)
-        }
+        // The two pixels of a thread are a register PAIR throughout the tap loop: difference,
+        // square, exponent (one v_pk_fma with the tap's log2 weight as the addend), and the two
+        // accumulations are packed-FP32 instructions; only the exponentials are per pixel.  Same
+        // operations in the same order as the four-pixel kernel: identical bits.
+        typedef float wt_p2 __attribute__((ext_vector_type(2)));
+        const wt_p2 Iv = {I[0], I[1]};
+        wt_p2 norm = {kc, kc};
+        wt_p2 acc = kc * Iv;
+        const wt_p2 s2 = {wt_div_nr(-0.72134752044448170368f, vv[0]), wt_div_nr(-0.72134752044448170368f, vv[1])};   // -log2(e) / (2 var)
         // taps in the reference order (watroo/wavelets.py:89-91), as in wt_bilateral_kernel
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -881,21 +906,19 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
             for (int j = 0; j < K; ++j) {
                 if (i == hw && j == hw) continue;
                 const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
-                const float2 t = win[K - 1 - i][K - 1 - j];
-                const float It[2] = {t.x, t.y};
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float diff = I[k] - It[k];
-                    const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, s2[k], lk));
-                    norm[k] += w;
-                    acc[k] = fmaf(It[k], w, acc[k]);
-                }
+                const float2 t2 = win[K - 1 - i][K - 1 - j];
+                const wt_p2 t = {t2.x, t2.y};
+                const wt_p2 diff = Iv - t;
+                const wt_p2 ex = __builtin_elementwise_fma(diff * diff, s2, (wt_p2){lk, lk});
+                const wt_p2 w = {__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+                norm += w;
+                acc = __builtin_elementwise_fma(t, w, acc);
             }
         }
         float o[2], ow[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            o[k] = acc[k] / norm[k];
+            o[k] = wt_div_nr(acc[k], norm[k]);
             ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
         }
         wt_store2(a.out_c + roff, x, g.P, make_float2(o[0], o[1]));
@@ -1123,7 +1146,7 @@ __global__ __launch_bounds__(256) void wt_anscombe_kernel(const float *src, floa
 // the tuned kernels serve, and the cost is the K^3 transcendental evaluations either way.
 template <int K>
 __global__ __launch_bounds__(256) void wt_bilateral3d_kernel(const float *in, const float *var, float *out,
-                                                             int X, int P, int Y, int Z, int d)
+                                                             int X, int P, int Y, int Z, int d, int border)
 {
     constexpr int hw = K / 2;
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -1137,16 +1160,16 @@ __global__ __launch_bounds__(256) void wt_bilateral3d_kernel(const float *in, co
         float den = wt_tap<K>(hw) * wt_tap<K>(hw) * wt_tap<K>(hw);
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
-            const int zz = wt_refl(z + (i - hw) * d, Z);
+            const int zz = wt_refl_b(z + (i - hw) * d, Z, d, border);
 #pragma unroll 1
             for (int j = 0; j < K; ++j) {
-                const int yy = wt_refl(y + (j - hw) * d, Y);
+                const int yy = wt_refl_b(y + (j - hw) * d, Y, d, border);
                 const float kzy = wt_tap<K>(i) * wt_tap<K>(j);
                 const float *r = in + ((int64_t)zz * Y + yy) * P;
 #pragma unroll
                 for (int l = 0; l < K; ++l) {
                     if (i == hw && j == hw && l == hw) continue;
-                    const float It = r[wt_refl(x + (l - hw) * d, X)];
+                    const float It = r[wt_refl_b(x + (l - hw) * d, X, d, border)];
                     const float dl = I - It;
                     const float w = kzy * wt_tap<K>(l) * __expf(dl * dl * m);
                     num = fmaf(w, It, num);
@@ -1334,7 +1357,7 @@ __global__ __launch_bounds__(256) void wt_mrs_kernel(float *c, float *mrs, const
 // BORDER_REFLECT).  The cube is stored as a (Z*Y) x X image, so axis 0 is rows Y apart.
 template <int K>
 __global__ __launch_bounds__(256) void wt_zfilter_kernel(const float *in, float *out, int64_t n4,
-                                                         int P4, int Y, int Z, int d)
+                                                         int P4, int Y, int Z, int d, int border)
 {
     constexpr int hw = K / 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
@@ -1344,7 +1367,7 @@ __global__ __launch_bounds__(256) void wt_zfilter_kernel(const float *in, float 
         float4 acc;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int zz = wt_refl(z + (j - hw) * d, Z);
+            const int zz = wt_refl_b(z + (j - hw) * d, Z, d, border);
             const float4 v = reinterpret_cast<const float4 *>(in)[((int64_t)zz * Y + y) * P4 + c4];
             acc = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, acc);
         }

@@ -17,7 +17,9 @@ import numpy as np
 
 from . import _lib
 from ._lib import PLANE_INPUT, PLANE_OUT, PLANE_NONE, FLAG_FUSED, Plan, Context
-from .wavelets import B3spline, _family_of
+import copy
+
+from .wavelets import AtrousTransform, B3spline, Coefficients, _family_of
 
 __all__ = ["partition_rows", "init_comm", "StripTransform"]
 
@@ -53,9 +55,13 @@ def init_comm(ctx, rank, nranks, bcast):
 class StripTransform:
     """The a-trous transform of one row strip of a global H x W image on this rank's GPU.
 
-    Mirrors ``AtrousTransform`` + ``Coefficients`` for the sharded case (non-bilateral):
+    Mirrors ``AtrousTransform`` + ``Coefficients`` + ``utils.wow`` for the sharded case:
     ``decompose`` -> planes in HBM, ``get_noise``/``denoise`` (global MAD via all-reduced
-    histograms), ``sum`` -> this rank's rows of the reconstruction."""
+    histograms), ``sum`` -> this rank's rows of the reconstruction, ``denoise_sum`` and ``wow``
+    (every dilated operator - the bilateral transform's variance and
+    range-weighted convolution, the local power conv_s(c^2) - exchanges hw * 2**s rows of ITS OWN
+    input plane with the strip neighbours first; np.std / np.mean / min / max become all-reduced
+    fp64 moments inside wt_reduce)."""
 
     def __init__(self, ctx, H, W, level, scaling_function_class=B3spline, rank=None,
                  nranks=None, fused=True):
@@ -116,3 +122,51 @@ class StripTransform:
 
     def plane(self, s):
         return self.plan.download(s)
+
+    # -- sharded applications (watroo/utils.py:83-102, 105-219) -------------------------------
+    def _coefficients(self, bilateral=None):
+        """A Coefficients view of this strip's plan (global scalars are all-reduced by the
+        library); the view never owns the plan."""
+        c = Coefficients(self.plan, self.scaling_function, bilateral)
+        c.noise = self.noise
+        return c
+
+    def denoise_sum(self, sigma, weights=None, soft_threshold=True, write_back=True, out=None):
+        """Coefficients.denoise(sigma, weights) fused with the plane sum (wt_denoise_sum); returns
+        this rank's rows of the sum."""
+        c = self._coefficients()
+        try:
+            c._denoise_sum(sigma, weights, soft_threshold, write_back)
+            self.noise = c.noise
+        finally:
+            c._plan = None
+        return self.plan.download(PLANE_OUT, out)
+
+    def wow(self, weights=[], whitening=True, denoise_coefficients=[], noise=None, bilateral=None,
+            bilateral_scaling=False, soft_threshold=True, preserve_variance=False, gamma=3.2,
+            gamma_min=None, gamma_max=None, h=0, out=None):
+        """utils.wow (watroo/utils.py:105-219) of the strip uploaded with ``upload``: the number
+        of scales is this transform's ``level`` (the reference derives it from the image size,
+        ref:122; sharded, every scale's halo hw * 2**s must fit a strip).  Returns this rank's
+        rows of the enhanced image; the whitened planes stay on the plan (``plane(s)``)."""
+        from .utils import _wow_device
+        n_scales = self.level
+        if bilateral is None:                                             # ref:140-146
+            sigma_bilateral = None
+        else:
+            sigma_bilateral = copy.copy(bilateral) if type(bilateral) is list \
+                else [bilateral, ] * (n_scales + 1)
+            if len(sigma_bilateral) <= n_scales:
+                sigma_bilateral.extend([1, ] * (n_scales - len(sigma_bilateral) + 1))
+        transform = AtrousTransform(type(self.scaling_function), bilateral=sigma_bilateral,
+                                    bilateral_scaling=bilateral_scaling)
+        transform._run(self.plan, n_scales, flags=FLAG_FUSED if self.fused else 0)   # ref:148-151
+        c = self._coefficients(sigma_bilateral)
+        c.noise = noise
+        try:
+            _wow_device(c, n_scales, weights, whitening, denoise_coefficients, soft_threshold,
+                        preserve_variance, gamma, gamma_min, gamma_max, h)
+            self.noise = c.noise
+        finally:
+            c._plan = None
+        return self.plan.download(PLANE_OUT, out)

@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of,
-                       _to_f32_image,
+                       _result_dtype, _to_f32_image,
                        generalized_anscombe,
                        PLANE_INPUT)
 
@@ -48,7 +48,7 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     img = np.asarray(args[0])
     channels = [0, 1, 2] if img.ndim == 3 else [Ellipsis]                 # ref:47-50
     if out is None:
-        out = _lib.host_empty(img.shape)
+        out = _lib.host_empty(img.shape) if _result_dtype(img) == np.float32 else np.empty(img.shape, np.float64)
     weights = prepare_params(weights, img.ndim)
     denoise = prepare_params(denoise, img.ndim)
     atrous = AtrousTransform(**kwargs)
@@ -85,7 +85,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
         plan = coefficients._denoise_sum(weights, soft_threshold=soft_threshold, write_back=False)
         if anscombe:
             plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)
-        return coefficients._from_plane(plan.download(PLANE_OUT))
+        return coefficients._from_plane(plan.download(PLANE_OUT)).astype(_result_dtype(data), copy=False)
     img = _to_f32_image(data, "data")
     level = len(weights)
     transform = AtrousTransform(scaling_function, bilateral=bilateral)
@@ -103,7 +103,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
                            soft_threshold=soft_threshold, write_back=False)
     if anscombe:
         plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)                 # ref:99-100
-    return plan.download(PLANE_OUT)
+    return plan.download(PLANE_OUT).astype(_result_dtype(data), copy=False)
 
 
 def _pad_list(values, n, fill):
@@ -176,7 +176,7 @@ def wow(data,
     plan = _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients,
                        soft_threshold, preserve_variance, gamma, gamma_min, gamma_max, h)
     nplanes = len(coefficients)
-    recon = coefficients._from_plane(plan.download(PLANE_OUT))
+    recon = coefficients._from_plane(plan.download(PLANE_OUT)).astype(coefficients._dtype, copy=False)
     coefficients._refresh_host(range(nplanes))
     return recon, coefficients
 
@@ -347,4 +347,5 @@ def richardson_lucy(data, psf,
         plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
         plan.filter2d(RES, CONV, bwd_k, **bwd)                           # ref:284-286
         plan.binary("mul", PSI, CONV, PSI)                               # ref:288
-    return plan.download(PSI)
+    # psi is float32 by construction with uniform_init (ref:233), else np.sum of the data's planes
+    return plan.download(PSI).astype(np.float32 if uniform_init else _result_dtype(data), copy=False)

@@ -4,10 +4,15 @@ Same public names, argument meaning and error behaviour as the reference module
 (/root/reference/watroo/wavelets.py, cited as ``ref:LINE``), but the arithmetic runs in
 ``libwatroo_hip.so`` on the GPU and coefficient planes stay resident in HBM.
 
-Scope: 2-D images, float32 compute.  float64 / integer inputs are
-converted to float32 (the reference keeps float64, ref:297,319-320); 1-D signals run as
-1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes as (Z*Y) x X images
-(per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no CPU fallback.
+Scope: float32 COMPUTE.  dtype policy: the
+reference keeps float64 inputs in float64 and promotes int / big-endian inputs to float64
+(ref:297,319-320; the README examples are float64).  Here such inputs are converted to float32
+on upload, every kernel runs in float32, and the containers and results handed back carry the
+dtype the reference would return (float64 for float64 / promoted inputs, float32 for float32) -
+same types for downstream code, float32 precision (about 1e-7 relative; the parity tests state
+it).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
+as (Z*Y) x X images (per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no
+CPU fallback.
 """
 import copy
 
@@ -177,6 +182,20 @@ def _to_f32_image(arr, what="arr"):
     return np.ascontiguousarray(arr, dtype=np.float32)
 
 
+_RECAST = [np.dtype(t) for t in (np.int32, np.int64, '>f4', '>f8', 'int16', 'uint16', 'int32', 'uint32')]
+
+
+def _result_dtype(arr):
+    """dtype of what the reference hands back for this input: float64 stays float64 and the
+    types of ref:297 are recast to float64 (ref:319-320); everything else is served as float32
+    (the engine's compute type)."""
+    dt = np.asarray(arr).dtype
+    return np.dtype(np.float64) if (dt == np.float64 or dt in _RECAST) else np.dtype(np.float32)
+
+
+_SOFT_SIG_DTYPE = np.float64 if int(np.__version__.split(".")[0]) >= 2 else np.float32   # NEP 50
+
+
 # ------------------------------------------------------------------------------------------
 # pointwise / single-operator entry points
 # ------------------------------------------------------------------------------------------
@@ -193,7 +212,7 @@ def generalized_anscombe(signal, alpha=1, g=0, sigma=0, inverse=False):
     try:
         plan.upload(PLANE_INPUT, img)
         plan.anscombe(PLANE_INPUT, PLANE_OUT, alpha, g, sigma, inverse)
-        return plan.download(PLANE_OUT).reshape(shape)
+        return plan.download(PLANE_OUT).reshape(shape).astype(_result_dtype(arr), copy=False)
     finally:
         release_plan(plan)
 
@@ -225,7 +244,7 @@ def convolution(arr, scaling_function, s=0, output=None):
         else:
             plan.smooth(PLANE_INPUT, PLANE_OUT, s)
         res = plan.download(PLANE_OUT)
-        res = res.reshape(np.shape(arr))
+        res = res.reshape(np.shape(arr)).astype(_result_dtype(arr), copy=False)
     finally:
         release_plan(plan)
     if output is None:
@@ -292,7 +311,7 @@ class Coefficients:
     it and afterwards refreshes it in place, so references held by the caller stay valid.
     """
 
-    def __init__(self, data, scaling_function, bilateral=None, _shape=None):
+    def __init__(self, data, scaling_function, bilateral=None, _shape=None, _dtype=None):
         self.scaling_function = scaling_function
         self.bilateral = bilateral
         self.noise = None
@@ -315,9 +334,14 @@ class Coefficients:
             data = np.asarray(data)
             if data.ndim not in (2, 3, 4):
                 raise ValueError("Unsupported number of dimensions")
-            self._host = np.ascontiguousarray(data, dtype=np.float32)
+            if _dtype is None:
+                _dtype = _result_dtype(data)
+            self._host = np.ascontiguousarray(data, dtype=_dtype)
             self._nplanes = self._host.shape[0]
             self._shape = tuple(self._host.shape[1:])
+        # dtype of the host mirror and of every array handed back (the planes on the device and all
+        # arithmetic are float32): what the reference would return for the transform's input
+        self._dtype = np.dtype(np.float32 if _dtype is None else _dtype)
         self._ndim = len(self._shape)
 
     def __del__(self):
@@ -362,15 +386,17 @@ class Coefficients:
     @property
     def data(self):
         if self._host is None:
-            host = _lib.host_empty((self._nplanes,) + self._img_shape(), self._plan.ctx)
-            for s in range(self._nplanes):
-                self._plan.download(s, self._as_plane(host[s]))
+            if self._dtype == np.float32:
+                host = _lib.host_empty((self._nplanes,) + self._img_shape(), self._plan.ctx)
+            else:
+                host = np.empty((self._nplanes,) + self._img_shape(), self._dtype)
             self._host = host
+            self._refresh_host(range(self._nplanes))
         return self._host
 
     @data.setter
     def data(self, value):
-        value = np.ascontiguousarray(value, dtype=np.float32)
+        value = np.ascontiguousarray(value, dtype=self._dtype)
         if value.ndim != self._ndim + 1 or value.shape[0] != self._nplanes:
             raise ValueError("Coefficients.data must keep its (level+1, ...) shape")
         self._host = value
@@ -392,7 +418,10 @@ class Coefficients:
     def _refresh_host(self, planes):
         if self._host is not None:
             for s in planes:
-                self._plan.download(s, self._as_plane(self._host[s]))
+                if self._host.dtype == np.float32:
+                    self._plan.download(s, self._as_plane(self._host[s]))
+                else:                        # float64 mirror of float32 planes
+                    self._as_plane(self._host[s])[...] = self._plan.download(s)
 
     # -- reference interface -----------------------------------------------------------
     def __len__(self):
@@ -452,10 +481,13 @@ class Coefficients:
         plan = self._device()
         t = self._tau(sigma, scale, soft_threshold)
         if t is None:
-            return np.ones(self._img_shape(), np.float32)
+            return np.ones(self._img_shape(), self._dtype)                # ones_like(data[0]), ref:135,143
         plan.significance(scale, _TMP_PLANE, t[0], soft_threshold, t[1])
         sig = self._from_plane(plan.download(_TMP_PLANE))
-        return sig if soft_threshold else sig.astype(bool)
+        # ref:137-141: bool for the hard threshold; the soft one divides by numpy float64 scalars,
+        # which under NumPy 2 (NEP 50) makes the ratio - and erf of it - float64 for any data
+        return sig.astype(_SOFT_SIG_DTYPE if self._dtype == np.float32 else self._dtype, copy=False) \
+            if soft_threshold else sig.astype(bool)
 
     def denoise(self, sigma, weights=None, soft_threshold=True):
         """In-place ``w_s *= weights[s] * significance(sigma[s], s)`` for the first
@@ -505,7 +537,7 @@ class Coefficients:
             if not self._sum_valid:           # with_sum=True transforms carried it along already
                 plan.plane_sum(0, self._nplanes, PLANE_OUT)
                 self._sum_valid = self._host is None
-            res = self._from_plane(plan.download(PLANE_OUT))
+            res = self._from_plane(plan.download(PLANE_OUT)).astype(self._dtype, copy=False)
             if out is None:
                 return res
             out[...] = res
@@ -595,7 +627,7 @@ class AtrousTransform:
         img = _to_f32_image(arr)
         scaling_function = self.scaling_function_class(img.ndim)
         if recursive:
-            return self._recursive(img, level, scaling_function)
+            return self._recursive(img, level, scaling_function, _result_dtype(arr))
         plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                             _family_of(scaling_function), level)
         plan.upload(PLANE_INPUT, img)
@@ -604,7 +636,7 @@ class AtrousTransform:
             plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, FLAG_FUSED)     # ref:432,442 + utils.py:98
         else:
             self._run(plan, level)
-        coefficients = Coefficients(plan, scaling_function, self.bilateral)
+        coefficients = Coefficients(plan, scaling_function, self.bilateral, _dtype=_result_dtype(arr))
         coefficients._sum_valid = summed
         return coefficients
 
@@ -617,19 +649,19 @@ class AtrousTransform:
         return other
 
     def atrous_standard(self, arr, level, scaling_function):
-        """(level + 1, ...) float32 ndarray of planes, standard algorithm (ref:408-444)."""
+        """(level + 1, ...) ndarray of planes, standard algorithm (ref:408-444)."""
         return self._as_class(scaling_function)(arr, level, recursive=False).data
 
     def atrous_recursive(self, arr, level, scaling_function):
-        """(level + 1, ...) float32 ndarray of planes, recursive algorithm (ref:330-406)."""
+        """(level + 1, ...) ndarray of planes, recursive algorithm (ref:330-406)."""
         return self._as_class(scaling_function)(arr, level, recursive=True).data
 
     def _call_1d(self, arr, level, recursive):
         """1-D signals (ref:65-69, 'mirror' border): run as a 1 x N image with the engine's
         mirror border rule and the per-scale kernels."""
         if recursive:
-            raise NotImplementedError("recursive=True on 1-D signals is not implemented in the "
-                                      "HIP engine")
+            return self._recursive(np.asarray(arr), level, self.scaling_function_class(1),
+                                   _result_dtype(arr))
         row = _to_f32_row(arr)
         scaling_function = self.scaling_function_class(1)
         plan = acquire_plan(default_context(), 1, row.shape[1], _family_of(scaling_function, 1), level)
@@ -638,7 +670,7 @@ class AtrousTransform:
             plan.set_border(2)
             plan.decompose(PLANE_INPUT, level, 0)
             plan.set_border(0)
-            return Coefficients(plan, scaling_function, None)
+            return Coefficients(plan, scaling_function, None, _dtype=_result_dtype(arr))
         # Bilateral (ref:433-440 on a 1-D signal): the variance comes from convolution()'s 1-D
         # branch ('mirror' border, ref:24-32 over :65-69), the range-weighted convolution pads
         # symmetrically (ref:77).  On a 1 x N image the 2-D bilateral kernel reduces to the 1-D
@@ -660,14 +692,14 @@ class AtrousTransform:
             cur = nxt
         if level == 0:
             plan.copy(PLANE_INPUT, 0)
-        return Coefficients(plan, scaling_function, self.bilateral)
+        return Coefficients(plan, scaling_function, self.bilateral, _dtype=_result_dtype(arr))
 
     def _call_3d(self, arr, level, recursive):
         """(Z, Y, X) cubes (ref:46-64): per-slice 2-D filter then the same filter along axis 0;
         the cube lives on the GPU as a (Z*Y) x X image."""
         if recursive:
-            raise NotImplementedError("recursive=True on cubes is not implemented in the HIP "
-                                      "engine")
+            return self._recursive(np.asarray(arr), level, self.scaling_function_class(3),
+                                   _result_dtype(arr))
         cube = np.ascontiguousarray(arr, dtype=np.float32)
         Z, Y, X = cube.shape
         scaling_function = self.scaling_function_class(3)
@@ -679,7 +711,7 @@ class AtrousTransform:
         plan.upload(PLANE_INPUT, cube.reshape(Z * Y, X))
         if self.bilateral is None:
             plan.decompose3d(PLANE_INPUT, level, Z)
-            return Coefficients(plan, scaling_function, None, _shape=(Z, Y, X))
+            return Coefficients(plan, scaling_function, None, _shape=(Z, Y, X), _dtype=_result_dtype(arr))
         # bilateral (ref:433-440 on a cube): 3-D variance, then the K^3 range-weighted kernel
         sb = self._sigma_bilateral(level)
         cur = PLANE_INPUT
@@ -692,36 +724,73 @@ class AtrousTransform:
             cur = nxt
         if level == 0:
             plan.copy(PLANE_INPUT, 0)
-        return Coefficients(plan, scaling_function, self.bilateral, _shape=(Z, Y, X))
+        return Coefficients(plan, scaling_function, self.bilateral, _shape=(Z, Y, X), _dtype=_result_dtype(arr))
 
-    def _recursive(self, img, level, scaling_function):
-        """The reference's recursive algorithm (ref:330-406) on the GPU.  It pads once by
-        hw*2**(level-1) (ref:394-395), filters every polyphase sub-array on its own with a
-        symmetric border (ref:354-390) and crops (ref:405-406) - which differs from the
-        standard algorithm near the borders from scale 3 on.  Here: the padded image is
-        transformed by the per-scale kernels under the plan's polyphase border rule
-        (wt_plan_set_border) and the planes are cropped on the device."""
-        if self.bilateral is not None:
-            raise NotImplementedError("recursive=True with bilateral filtering is not "
-                                      "implemented in the HIP engine")
+    def _recursive(self, arr, level, scaling_function, dtype=np.float32):
+        """The reference's recursive algorithm (ref:330-406) on the GPU, for signals, images and
+        cubes, with or without bilateral filtering.  It pads once by hw*2**(level-1) on every axis
+        (ref:394-395), filters every polyphase sub-array on its own with the base operator of its
+        dimensionality (ref:354-390) and crops (ref:405-406) - which differs from the standard
+        algorithm near the borders from scale 3 on.  Here: the padded array is transformed by the
+        per-scale kernels under the plan's POLYPHASE border rule (an out-of-range index reflects
+        inside its own residue class modulo the dilation: wt_plan_set_border 1, or 3 for the
+        'mirror' border of the 1-D convolution) and the planes are cropped on the device."""
         if level < 1:
             raise ValueError("recursive=True needs level >= 1")
+        arr = np.asarray(arr, dtype=np.float32)
+        nd = arr.ndim
         ctx = default_context()
-        fam = _family_of(scaling_function)
+        fam = _family_of(scaling_function, nd)
+        custom = isinstance(fam, tuple)
+        if custom and (nd == 3 or self.bilateral is not None):
+            raise NotImplementedError("recursive 3-D / bilateral transforms with a user-defined "
+                                      "scaling function are not implemented in the HIP engine")
         pad = (len(scaling_function.coefficients_1d) // 2) * 2 ** (level - 1)
-        padded = np.pad(img, pad, mode='symmetric')
-        big = acquire_plan(ctx, padded.shape[0], padded.shape[1], fam, level)
-        plan = acquire_plan(ctx, img.shape[0], img.shape[1], fam, level)
+        padded = np.pad(arr, pad, mode='symmetric')
+        shape2 = {1: lambda a: (1, a.shape[0]), 2: lambda a: a.shape,
+                  3: lambda a: (a.shape[0] * a.shape[1], a.shape[2])}[nd]
+        big = acquire_plan(ctx, *shape2(padded), fam, level)
+        plan = acquire_plan(ctx, *shape2(arr), fam, level)
+        sym, conv_border = 1, (3 if nd == 1 else 1)   # symmetric / convolution() border, per sub-array
         try:
-            big.set_border(1)
-            big.upload(PLANE_INPUT, padded)
-            big.decompose(PLANE_INPUT, level, 0)          # one kernel per scale
-            for s in range(level + 1):
-                plan.crop_from(big, s, s, pad, pad)
+            big.upload(PLANE_INPUT, padded.reshape(shape2(padded)))
+            if self.bilateral is None:
+                big.set_border(conv_border)
+                if nd == 3:
+                    big.decompose3d(PLANE_INPUT, level, padded.shape[0])
+                else:
+                    big.decompose(PLANE_INPUT, level, 0)      # one kernel per scale
+            else:
+                sb = self._sigma_bilateral(level)
+                cur = PLANE_INPUT
+                for s in range(level):
+                    nxt = level if s == level - 1 else PLANE_SCRATCH(s & 1)
+                    f1 = float(sb[s]) ** 2
+                    f2 = float(s + 1) if self.bilateral_scaling else 1.0
+                    if nd == 3:
+                        big.set_border(sym)
+                        big.local_variance3d(cur, _TMP_PLANE, s, padded.shape[0], f1, f2)
+                        big.bilateral3d_conv(cur, _TMP_PLANE, nxt, s, padded.shape[0])
+                    else:
+                        big.set_border(conv_border)           # ref:375: sdev_loc over convolution()
+                        big.local_variance(cur, _TMP_PLANE, s, f1, f2)
+                        big.set_border(sym)                   # ref:378: mode='symmetric'
+                        big.bilateral_conv(cur, _TMP_PLANE, nxt, s)
+                    big.binary("sub", cur, nxt, s)            # ref:402-403
+                    cur = nxt
+            for s in range(level + 1):                        # ref:405-406
+                if nd == 3:
+                    Z, Y, X = arr.shape
+                    Yp = padded.shape[1]
+                    for z in range(Z):
+                        plan.copy_window_from(big, s, s, (z + pad) * Yp + pad, pad, z * Y, 0, Y, X)
+                else:
+                    plan.crop_from(big, s, s, 0 if nd == 1 else pad, pad)
         finally:
             big.set_border(0)
             release_plan(big)
-        return Coefficients(plan, scaling_function, None)
+        return Coefficients(plan, scaling_function, self.bilateral,
+                            _shape=arr.shape if nd == 3 else None, _dtype=dtype)
 
     def _run(self, plan, level, src=PLANE_INPUT, flags=FLAG_FUSED):
         if self.bilateral is not None and plan.custom:
