@@ -232,8 +232,12 @@ def test_recursive_algorithm(W, O):
         assert got.data.shape == ref.shape
         close(got.data, ref, 1e-5 * np.abs(b).max())
         close(got.sum(axis=0), b, 1e-5 * np.abs(b).max())
-    with pytest.raises(NotImplementedError):
-        W.AtrousTransform(bilateral=1)(a, 3, recursive=True)
+    # recursive + bilateral, 1-D and 3-D (NotImplementedError in round 1): oracle at other sizes
+    for arr, L, fam, bil in ((rnd((70, 90), 62), 4, "b3spline", 1), (rnd((333,), 63), 5, "triangle", None),
+                             (rnd((9, 20, 22), 64), 2, "b3spline", None)):
+        got = W.AtrousTransform(cls_of(W, fam), bilateral=bil)(arr, L, recursive=True)
+        ref = O.atrous_recursive_nd(arr, L, fam, bil)
+        close(got.data, ref, (1e-4 if bil else 1e-5) * np.abs(arr).max())
 
 
 def test_reference_wow_smoke_tests(W):

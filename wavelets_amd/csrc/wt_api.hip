@@ -376,14 +376,108 @@ extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, i
     return 0;
 }
 
+// One plane of `need` bytes as a contiguous virtual range over shuffled physical chunks (see
+// plan_alloc).  Returns non-zero without leaving a mapping behind if any step fails.
+static int vmm_plane_alloc(wt_plan *p, size_t need, int scatter, void **out)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = p->ctx->device;
+    if (!p->vmm_gran) {
+        size_t g = 0;
+        if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) return 1;
+        p->vmm_gran = std::max<size_t>(g, (size_t)2 << 20);
+    }
+    const size_t g = p->vmm_gran;
+    const size_t nchunks = (need + g - 1) / g;
+    const size_t size = nchunks * g;
+    if (p->vmm_pool.size() < nchunks) {        // refill: chunks for `scatter` planes, shuffled
+        const size_t add = nchunks * (size_t)scatter;
+        std::vector<hipMemGenericAllocationHandle_t> fresh;
+        fresh.reserve(add);
+        for (size_t i = 0; i < add; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, g, &prop, 0) != hipSuccess) break;     // out of memory: use what we got
+            fresh.push_back(h);
+            p->vmm_handles.push_back(h);
+        }
+        uint64_t st = 0x9e3779b97f4a7c15ull;
+        for (size_t i = fresh.size(); i > 1; --i) {                     // Fisher-Yates, xorshift stream
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            std::swap(fresh[i - 1], fresh[st % i]);
+        }
+        p->vmm_pool.insert(p->vmm_pool.end(), fresh.begin(), fresh.end());
+        if (p->vmm_pool.size() < nchunks) return 1;
+    }
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) return 1;
+    size_t mapped = 0;
+    for (; mapped < nchunks; ++mapped)
+        if (hipMemMap((char *)va + mapped * g, g, 0, p->vmm_pool[p->vmm_pool.size() - 1 - mapped], 0) != hipSuccess) break;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (mapped < nchunks || hipMemSetAccess(va, size, &acc, 1) != hipSuccess) {
+        if (mapped) (void)hipMemUnmap(va, mapped * g);
+        (void)hipMemAddressFree(va, size);
+        return 1;
+    }
+    p->vmm_pool.resize(p->vmm_pool.size() - nchunks);
+    p->vmm_planes.push_back({va, size});
+    *out = va;
+    return 0;
+}
+
 static int plan_alloc(wt_plan *p, float **slot)
 {
     if (*slot) return 0;
     WT_HIP(hipSetDevice(p->ctx->device));
-    void *raw = nullptr;
     const size_t skew_max = p->skew_floats * 16;
-    WT_HIP(hipMalloc(&raw, (p->plane_floats + skew_max) * sizeof(float)));
-    p->raw_allocs.push_back(raw);
+    const size_t need = (p->plane_floats + skew_max) * sizeof(float);
+    // WT_ARENA=n (experiment): the first n planes of a plan are carved from ONE allocation, so that
+    // their relative placement (and with it the HBM channel / bank relation between the planes a
+    // pass writes side by side) does not depend on what the allocator hands out per call
+    static const int arena_planes = getenv("WT_ARENA") ? atoi(getenv("WT_ARENA")) : 0;
+    void *raw = nullptr;
+    if (arena_planes > 0) {
+        static const size_t arena_pad = getenv("WT_ARENA_PAD") ? (size_t)atoll(getenv("WT_ARENA_PAD")) / 16 * 16 : 0;
+        const size_t stride = (need + 4095) / 4096 * 4096 + arena_pad;
+        if (!p->arena) {
+            WT_HIP(hipMalloc(&p->arena, stride * (size_t)arena_planes));
+            p->raw_allocs.push_back(p->arena);
+            p->arena_left = arena_planes;
+            p->arena_stride = stride;
+        }
+        if (p->arena_left > 0) {
+            raw = (char *)p->arena + (size_t)(arena_planes - p->arena_left) * p->arena_stride;
+            p->arena_left--;
+        }
+    }
+    // Planes whose physical memory is NOT one contiguous run (default; WT_SCATTER=0 restores plain
+    // hipMalloc, WT_SCATTER=c sets the group size).  Measured on MI355X (profiles/r02_d): the same
+    // binary runs the headline step in 0.61-0.66 ms when the planes' 2-MiB pages are scattered and in
+    // 0.76 ms when the planes lie physically back to back (one arena - or a freshly booted box, whose
+    // allocator hands out consecutive blocks: the "slow hosts" of round 1).  The passes write the
+    // same pixel of 5 planes side by side; with planes a power of two apart those addresses differ
+    // only in bits the HBM channel / bank hash folds away, and the streams fight over the same banks.
+    // So: physical chunks of the allocation granularity (2 MiB) are created in groups worth
+    // `scatter` planes and dealt to the planes in a shuffled order (fixed seed); each plane stays one
+    // contiguous VIRTUAL range (hipMemAddressReserve / hipMemMap).  Small planes (< 8 MiB) stay on
+    // hipMalloc: nothing to gain, and a map call per chunk to lose.
+    static const int scatter = getenv("WT_SCATTER") ? atoi(getenv("WT_SCATTER")) : 4;
+    static bool vmm_ok = true;           // cleared when the virtual-memory API is not usable here
+    if (!raw && scatter > 0 && vmm_ok && need >= ((size_t)8 << 20)) {
+        if (vmm_plane_alloc(p, need, scatter, &raw)) {
+            (void)hipGetLastError();     // e.g. hipErrorNotSupported: plain hipMalloc from now on
+            vmm_ok = false;
+            raw = nullptr;
+        }
+    }
+    if (!raw) {
+        WT_HIP(hipMalloc(&raw, need));
+        p->raw_allocs.push_back(raw);
+    }
     *slot = (float *)raw + p->skew_floats * (size_t)(p->n_allocs % 16);
     p->n_allocs++;
     return 0;
@@ -475,6 +569,11 @@ extern "C" int wt_plan_destroy(wt_plan *p)
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     for (void *q : p->raw_allocs) (void)hipFree(q);
+    for (auto &v : p->vmm_planes) {
+        (void)hipMemUnmap(v.va, v.size);
+        (void)hipMemAddressFree(v.va, v.size);
+    }
+    for (auto h : p->vmm_handles) (void)hipMemRelease(h);
     delete p;
     return 0;
 }
@@ -495,6 +594,48 @@ extern "C" int wt_plan_set_border(wt_plan *p, int border)
     if (border < 0 || border > 3) WT_FAIL("wt_plan_set_border: unknown border mode %d", border);
     if (border && p->nranks > 1) WT_FAIL("wt_plan_set_border: non-default borders are single-GPU only");
     p->g.border = border;
+    return 0;
+}
+
+// Planes built from scattered physical chunks (plan_alloc): the memcpy engines refuse ranges that
+// span several mapped handles, so host transfers bounce through a hipMalloc'ed plane and every
+// device-to-device copy of plane data is a kernel.
+static bool is_vmm(const wt_plan *p, const float *b)
+{
+    for (auto &v : p->vmm_planes)
+        if ((const char *)b >= (const char *)v.va && (const char *)b < (const char *)v.va + v.size) return true;
+    return false;
+}
+static int vmm_stage(wt_plan *p, float **stage)
+{
+    if (!p->vmm_stage) {
+        void *raw = nullptr;
+        WT_HIP(hipMalloc(&raw, p->plane_floats * sizeof(float)));
+        p->raw_allocs.push_back(raw);
+        p->vmm_stage = (float *)raw;
+    }
+    *stage = p->vmm_stage + (size_t)p->g.halo * p->g.P;
+    return 0;
+}
+static int vmm_copy(wt_plan *p, float *dst, const float *src)
+{
+    const int64_t n4 = (int64_t)p->g.nrows * p->g.P / 4;
+    hipLaunchKernelGGL(wt_copy_kernel, dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, p->ctx->stream, dst, src, n4);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+// rows x cols floats, device to device, on `st`
+static int copy2d(wt_plan *a, wt_plan *b, float *dst, size_t dpitch, const float *src, size_t spitch, size_t cols,
+                  size_t rows, hipStream_t st)
+{
+    if (rows == 0 || cols == 0) return 0;
+    if (is_vmm(a, dst) || is_vmm(a, src) || is_vmm(b, dst) || is_vmm(b, src)) {
+        dim3 grid((unsigned)std::min<size_t>((cols + 255) / 256, 64), (unsigned)std::min<size_t>(rows, 4096));
+        hipLaunchKernelGGL(wt_copy2d_kernel, grid, dim3(256), 0, st, dst, (int64_t)dpitch, src, (int64_t)spitch, (int)cols, (int)rows);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
+    WT_HIP(hipMemcpy2DAsync(dst, dpitch * 4, src, spitch * 4, cols * 4, rows, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -543,8 +684,8 @@ extern "C" int wt_crop_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_
     float *s_ = nullptr, *d_ = nullptr;
     WT_TRY(plane_base(src, src_plane, &s_));
     WT_TRY(plane_base(dst, dst_plane, &d_));
-    WT_HIP(hipMemcpy2DAsync(d_, (size_t)dst->g.P * 4, s_ + (size_t)y0 * src->g.P + x0, (size_t)src->g.P * 4,
-                            (size_t)dst->g.W * 4, (size_t)dst->g.nrows, hipMemcpyDeviceToDevice, src->ctx->stream));
+    WT_TRY(copy2d(src, dst, d_, (size_t)dst->g.P, s_ + (size_t)y0 * src->g.P + x0, (size_t)src->g.P, (size_t)dst->g.W,
+                  (size_t)dst->g.nrows, src->ctx->stream));
     if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
     return 0;
 }
@@ -559,8 +700,8 @@ extern "C" int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst
     float *s_ = nullptr, *d_ = nullptr;
     WT_TRY(plane_base(src, src_plane, &s_));
     WT_TRY(plane_base(dst, dst_plane, &d_));
-    WT_HIP(hipMemcpy2DAsync(d_ + (size_t)y0 * dst->g.P + x0, (size_t)dst->g.P * 4, s_, (size_t)src->g.P * 4,
-                            (size_t)src->g.W * 4, (size_t)src->g.nrows, hipMemcpyDeviceToDevice, src->ctx->stream));
+    WT_TRY(copy2d(src, dst, d_ + (size_t)y0 * dst->g.P + x0, (size_t)dst->g.P, s_, (size_t)src->g.P, (size_t)src->g.W,
+                  (size_t)src->g.nrows, src->ctx->stream));
     if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
     return 0;
 }
@@ -579,8 +720,8 @@ extern "C" int wt_copy_window(wt_plan *src, int src_plane, wt_plan *dst, int dst
     WT_TRY(plane_base(src, src_plane, &s_));
     WT_TRY(plane_base(dst, dst_plane, &d_));
     if (s_ == d_) WT_FAIL("wt_copy_window: source and destination are the same plane");
-    WT_HIP(hipMemcpy2DAsync(d_ + (size_t)dy * dst->g.P + dx, (size_t)dst->g.P * 4, s_ + (size_t)sy * src->g.P + sx,
-                            (size_t)src->g.P * 4, (size_t)cols * 4, (size_t)rows, hipMemcpyDeviceToDevice, src->ctx->stream));
+    WT_TRY(copy2d(src, dst, d_ + (size_t)dy * dst->g.P + dx, (size_t)dst->g.P, s_ + (size_t)sy * src->g.P + sx,
+                  (size_t)src->g.P, (size_t)cols, (size_t)rows, src->ctx->stream));
     if (dst->ctx->stream != src->ctx->stream) WT_HIP(hipStreamSynchronize(src->ctx->stream));
     return 0;
 }
@@ -644,9 +785,12 @@ extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
     const size_t span = ((size_t)(p->g.nrows - 1) * (size_t)host_stride + (size_t)p->g.W) * 4;
+    float *target = b;
+    if (is_vmm(p, b)) WT_TRY(vmm_stage(p, &target));
     const bool pinned = try_pin(host, span);
-    hipError_t e = hipMemcpy2DAsync(b, (size_t)p->g.P * 4, host, (size_t)host_stride * 4, (size_t)p->g.W * 4,
+    hipError_t e = hipMemcpy2DAsync(target, (size_t)p->g.P * 4, host, (size_t)host_stride * 4, (size_t)p->g.W * 4,
                                     (size_t)p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess && target != b) e = vmm_copy(p, b, target) ? hipErrorUnknown : hipSuccess;
     if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
     if (pinned) (void)hipHostUnregister(const_cast<float *>(host));
     WT_HIP(e);
@@ -662,6 +806,12 @@ extern "C" int wt_download(wt_plan *p, int plane, float *host, int64_t host_stri
     WT_TRY(plane_base(p, plane, &b));
     const size_t span = ((size_t)(p->g.nrows - 1) * (size_t)host_stride + (size_t)p->g.W) * 4;
     const bool pinned = try_pin(host, span);
+    if (is_vmm(p, b)) {
+        float *stage = nullptr;
+        WT_TRY(vmm_stage(p, &stage));
+        WT_TRY(vmm_copy(p, stage, b));
+        b = stage;
+    }
     hipError_t e = hipMemcpy2DAsync(host, (size_t)host_stride * 4, b, (size_t)p->g.P * 4, (size_t)p->g.W * 4,
                                     (size_t)p->g.nrows, hipMemcpyDeviceToHost, p->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
@@ -681,6 +831,7 @@ extern "C" int wt_copy_plane(wt_plan *p, int src, int dst)
     WT_TRY(plane_base(p, src, &s));
     WT_TRY(plane_base(p, dst, &d));
     if (s == d) return 0;
+    if (is_vmm(p, s) || is_vmm(p, d)) return vmm_copy(p, d, s);
     WT_HIP(hipMemcpyAsync(d, s, (size_t)p->g.nrows * p->g.P * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
     return 0;
 }
@@ -716,8 +867,9 @@ extern "C" int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane,
     const size_t P = (size_t)upper->g.P, bytes = (size_t)rows * P * 4;
     hipStream_t st = upper->ctx->stream;
     // upper's last rows -> lower's top margin ; lower's first rows -> upper's bottom margin
-    WT_HIP(hipMemcpyAsync(l - (size_t)rows * P, u + (size_t)(upper->g.nrows - rows) * P, bytes, hipMemcpyDeviceToDevice, st));
-    WT_HIP(hipMemcpyAsync(u + (size_t)upper->g.nrows * P, l, bytes, hipMemcpyDeviceToDevice, st));
+    (void)bytes;
+    WT_TRY(copy2d(upper, lower, l - (size_t)rows * P, P, u + (size_t)(upper->g.nrows - rows) * P, P, P, (size_t)rows, st));
+    WT_TRY(copy2d(upper, lower, u + (size_t)upper->g.nrows * P, P, l, P, P, (size_t)rows, st));
     if (lower->ctx->stream != st) WT_HIP(hipStreamSynchronize(st));
     return 0;
 }

@@ -36,6 +36,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wt_internal.h"
 #include "wt_kernels.h"
 
@@ -360,18 +362,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
     // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
     // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
-#ifndef WT_FUSED_NO_VMPAD
-    {
-        constexpr int ST = NS + 1 + (ACC ? 1 : 0);          // stores per step
-#pragma unroll
-        for (int i = 0; i < PD * ST; ++i) wt_bstore4v<0>(rc, WT_FUSED_PARKED + 16u * i, zero);   // distinct: not merged
-    }
-#endif
     const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
 
     // One chain step.
-    auto step = [&](const int kb, const int kk) {
+    auto step = [&](const int kb, const int kk, auto stores_tag) {
+        constexpr bool ST_ON = decltype(stores_tag)::value;   // false: the peeled first U steps, where no plane stores yet
         const int k = kb + kk;
         const int t = t0 + k;
         // step k stores row t0 + k - LAG of a plane: inside the chunk iff k - (LAT_IN + LAG) < span
@@ -437,19 +433,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         __syncthreads();
         const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
         const float4 d0 = f4_sub(cen0, n0);
-        wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
-        if constexpr (NS == 1) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
+        if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
+        if constexpr (ST_ON && (NS == 1)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
         float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
         if constexpr (NS > 1) {
             n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
             d1 = f4_sub(cen1, n1);
-            wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
-            if constexpr (NS == 2) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
+            if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
+            if constexpr (ST_ON && (NS == 2)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
             if constexpr (NS > 2) {
                 n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
                 d2 = f4_sub(cen2, n2);
-                wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
-                wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
+                if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
+                if constexpr (ST_ON) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
             }
             c2 = n1;
         }
@@ -471,7 +467,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
             if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
             // the finished reconstruction is a write-once stream; an intermediate sum is re-read
             // by the next pass
-            wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
+            if constexpr (ST_ON) wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
         }
         c1 = n0;
         koff += step_bytes;
@@ -483,10 +479,49 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
 #endif
     };
 
-    for (int kb = 0; kb < nsteps; kb += U) {
+    // The register rotation fixes the unroll factor at U steps, not the trip count: leave the
+    // body at the last step that stores anything (a loop EXIT, not a skipped step - nothing
+    // rejoins inside the loop, so the vmcnt bookkeeping of the steps stays exact).  S = 147 at
+    // 8192^2 would otherwise march 192 steps instead of 177.
+#ifndef WT_FUSED_NO_EARLY_EXIT
+    const int nexact = (r1 - r0) + LAT + LAT_IN;
+#else
+    const int nexact = nsteps;
+#endif
+    int kb0 = 0;
+#ifdef WT_FUSED_PEEL
+    // No plane stores before step LAT_IN + LAG0 >= U: the first trip through the body runs a copy
+    // of the steps WITHOUT store instructions (every one of them would be parked - dropped by the
+    // range check, but issued, addressed and counted: 9 % of a chunk's store instructions).
+    if constexpr (LAT_IN + LAG0 >= U) {
 #pragma unroll
-        for (int kk = 0; kk < U; ++kk) step(kb, kk);
+        for (int kk = 0; kk < U; ++kk) step(0, kk, std::false_type{});
+        kb0 = U;
     }
+#endif
+    // The compiler sizes every `s_waitcnt vmcnt(N)` of the loop from the FEWEST vector-memory
+    // operations that can lie between a prefetch and its use on any path into that point - and on
+    // the path from here the PD prefetches would be back to back, while in the steady state a
+    // step's stores sit between them.  Without the padding below the first PD steps of every trip
+    // through the unrolled body wait with vmcnt(2..15), i.e. for the STORES of the previous steps
+    // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
+    // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
+    // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
+#ifndef WT_FUSED_NO_VMPAD
+    {
+        constexpr int ST = NS + 1 + (ACC ? 1 : 0);          // stores per step
+#pragma unroll
+        for (int i = 0; i < PD * ST; ++i) wt_bstore4v<0>(rc, WT_FUSED_PARKED + 16u * i, zero);   // distinct: not merged
+    }
+#endif
+    for (int kb = kb0; kb < nsteps; kb += U) {
+#pragma unroll
+        for (int kk = 0; kk < U; ++kk) {
+            if (kb + kk >= nexact) goto done;
+            step(kb, kk, std::true_type{});
+        }
+    }
+done:;
 }
 
 // ---------------------------------------------------------------------------------------------

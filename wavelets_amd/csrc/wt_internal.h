@@ -113,6 +113,17 @@ struct wt_plan {
     std::vector<void *> raw_allocs;         // what hipFree gets
     size_t skew_floats = 0;
     int n_allocs = 0;
+    void *arena = nullptr;                  // WT_ARENA experiment: planes carved from one allocation
+    int arena_left = 0;
+    size_t arena_stride = 0;
+    // scattered planes (hipMem* virtual memory management): every plane is a contiguous VIRTUAL range
+    // mapped onto physical chunks taken from a shuffled pool (see plan_alloc)
+    struct VmmPlane { void *va; size_t size; };
+    std::vector<VmmPlane> vmm_planes;
+    std::vector<hipMemGenericAllocationHandle_t> vmm_pool;   // created, not yet mapped
+    std::vector<hipMemGenericAllocationHandle_t> vmm_handles; // everything to release
+    size_t vmm_gran = 0;
+    float *vmm_stage = nullptr;             // hipMalloc'ed bounce plane: hipMemcpy2D does not cross mapped chunks
     // user-defined scaling function (wt_plan_set_taps): odd number of 1-D taps, 0 = built-in family
     int ntaps = 0;
     float taps[WT_MAX_CUSTOM_TAPS] = {0};
