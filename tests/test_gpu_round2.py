@@ -375,3 +375,24 @@ def test_recursive_algorithm_on_signals_cubes_and_with_bilateral(WA):
     std = WA.AtrousTransform(WA.B3spline)(a, 4).data
     rec = WA.AtrousTransform(WA.B3spline)(a, 4, recursive=True).data
     np.testing.assert_allclose(rec[:, 64:-64], std[:, 64:-64], atol=1e-5 * np.abs(a).max())
+
+
+@pytest.mark.parametrize("shape,kind", [((2048, 1030), "normal"), ((1025, 1027), "normal"), ((1500, 1400), "ties"),
+                                        ((2048, 2048), "flat"), ((1200, 1000), "two_values"), ((4096, 4096), "normal")])
+def test_exact_median_of_large_planes(L, shape, kind):
+    """planes of >= 2^20 pixels (round 1 tested up to 512^2): the three-pass radix select ==
+    np.median of |plane| exactly - odd and even counts, ties, bins that hold most of the plane."""
+    rng = np.random.default_rng(hash(kind) % 1000 + shape[0])
+    a = rng.standard_normal(shape, dtype=np.float32)
+    if kind == "ties":
+        a = np.round(a * 8) / 8
+    elif kind == "flat":
+        a = np.full(shape, 2.5, np.float32)
+        a[::7, ::5] = -2.5000002
+    elif kind == "two_values":
+        a = np.where(rng.random(shape) < 0.5, np.float32(1.0), np.float32(1.0000001)).astype(np.float32)
+    plan = L.Plan(L.default_context(), shape[0], shape[1], L.B3SPLINE, 0)
+    plan.upload(0, a)
+    got = plan.abs_median(0)
+    assert got == np.median(np.abs(a)), (got, np.median(np.abs(a)))
+    plan.close()
