@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def scope_name(kernel):
     """rocprof kernel name -> ProfScope name of wt_api.hip / wt_fused.h"""
-    m = re.match(r"void wt_fused_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)
+    m = re.match(r"void wt_fused_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel)
     if m:
         _, ns, d, _, _, acc = map(int, m.groups())
         return f"{('wt_fused', 'wt_fused_acc', 'wt_fused_sum')[acc]}<d{d}x{ns}>"

@@ -405,7 +405,9 @@ __global__ __launch_bounds__(256) void wt_chain_kernel(ChainArgs a)
     wt_xcd_remap(bx, by);
     const int x = (bx * 64 + threadIdx.x) * 4;
     if (x >= g.W) return;
-    const int item = by * blockDim.y + threadIdx.y;
+    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
+    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
+    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
     const int d = a.d;
     const int q = item % d;   // chain phase (local row offset)
     const int c = item / d;   // chunk along the chain
@@ -458,7 +460,9 @@ __global__ __launch_bounds__(256, 2) void wt_lattice_kernel(ChainArgs a)
     const int gi = t / p4, ph = t - gi * p4;
     const int x0 = 4 * ph + d * C * gi;          // first lattice column of this thread
     if (x0 >= g.W) return;
-    const int item = by * blockDim.y + threadIdx.y;
+    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
+    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
+    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
     const int q = item % d;
     const int c = item / d;
     if (c >= a.chunks || q >= g.nrows) return;
@@ -575,10 +579,18 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
 
     WtVert<K, MODE, SMALL_D> vert;
     float4 raw[K];
-    // Two rows in flight, in two NAMED registers used in turn (the loop is unrolled by two): a
-    // rotating pair (pf0 = pf1; pf1 = load) makes the compiler copy the load it has just issued
-    // at the end of every iteration, i.e. wait for it at once - no prefetch left.
+    // WT_ROW_PD rows in flight, in NAMED registers used in turn (the loop is unrolled by that many):
+    // a rotating array (pf0 = pf1; pf1 = load) makes the compiler copy the load it has just issued
+    // at the end of every iteration, i.e. wait for it at once - no prefetch left.  Four rows: the
+    // kernel sits at s_waitcnt / s_barrier for 72 % of its wave cycles with two (SQ_WAIT_ANY,
+    // profiles/r02_e), i.e. it is latency-bound at 16 waves per CU.
+#ifndef WT_ROW_PD
+#define WT_ROW_PD 4
+#endif
     float4 pfa = load_row(r0 - hw), pfb = load_row(r0 - hw + 1);
+#if WT_ROW_PD == 4
+    float4 pfc = load_row(r0 - hw + 2), pfd = load_row(r0 - hw + 3);
+#endif
     // steps t = r0-hw .. r1-1+hw ; step index k selects the LDS buffer
     const int nsteps = (r1 - r0) + 2 * hw;
     auto step = [&](const int k, const float4 cur) {
@@ -600,17 +612,29 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
             vert.emit(raw, a, (int64_t)(q + d * r) * g.P, x, lane_ok);
         }
     };
-    for (int k = 0; k < nsteps; k += 2) {
+    for (int k = 0; k < nsteps; k += WT_ROW_PD) {
         {
             const float4 cur = pfa;
-            pfa = load_row(r0 - hw + k + 2);
+            pfa = load_row(r0 - hw + k + WT_ROW_PD);
             step(k, cur);
         }
         if (k + 1 < nsteps) {                            // workgroup-uniform
             const float4 cur = pfb;
-            pfb = load_row(r0 - hw + k + 3);
+            pfb = load_row(r0 - hw + k + 1 + WT_ROW_PD);
             step(k + 1, cur);
         }
+#if WT_ROW_PD == 4
+        if (k + 2 < nsteps) {
+            const float4 cur = pfc;
+            pfc = load_row(r0 - hw + k + 2 + WT_ROW_PD);
+            step(k + 2, cur);
+        }
+        if (k + 3 < nsteps) {
+            const float4 cur = pfd;
+            pfd = load_row(r0 - hw + k + 3 + WT_ROW_PD);
+            step(k + 3, cur);
+        }
+#endif
     }
 }
 
@@ -641,7 +665,9 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
     wt_xcd_remap(bx, by);
     const int x = (bx * 64 + threadIdx.x) * 4;
     if (x >= g.W) return;
-    const int item = by * blockDim.y + threadIdx.y;
+    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
+    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
+    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
     const int d = a.d;
     const int q = item % d;
     const int c = item / d;
@@ -781,7 +807,9 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
     wt_xcd_remap(bx, by);
     const int x = (bx * 64 + threadIdx.x) * 2;
     if (x >= g.W) return;
-    const int item = by * blockDim.y + threadIdx.y;
+    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
+    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
+    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
     const int d = a.d;
     const int q = item % d;
     const int c = item / d;
@@ -808,8 +836,10 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if ((pair >> j) & 1u) dst[j] = *reinterpret_cast<const float2 *>(row + xa[j]);
-            else dst[j] = make_float2(row[xa[j]], row[xb[j]]);
+            const char *rb = reinterpret_cast<const char *>(row);        // SGPR base + 32-bit lane offset
+            if ((pair >> j) & 1u) dst[j] = *reinterpret_cast<const float2 *>(rb + (unsigned)xa[j] * 4u);
+            else dst[j] = make_float2(*reinterpret_cast<const float *>(rb + (unsigned)xa[j] * 4u),
+                                      *reinterpret_cast<const float *>(rb + (unsigned)xb[j] * 4u));
         }
     };
 #pragma unroll
