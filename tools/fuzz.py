@@ -3,7 +3,9 @@
 
 Random (H, W, level, family) images: fused / per-scale (row + chain kernels) / chain-only
 schedules against the C oracle; virtual row strips against the unsharded result (bitwise);
-recursive=True against the numpy oracle.  Prints one line per failure and a summary.
+recursive=True against the numpy oracle; the fused passes' fast addressing against the generic
+one (bitwise); and - round 2 - the bilateral transform and wow() (plain / bilateral, random keyword
+combinations, up to 9 scales) against the C-backed oracle.  Prints one line per failure and a summary.
 
     python tools/fuzz.py [n_cases] [seed]
 """
@@ -104,6 +106,47 @@ def main():
                 print(f"FAIL {tag}: {k} strips decompose_pass_sum reconstruction != unsharded")
             for p in plans:
                 p.close()
+        # fast vs generic addressing of the fused passes (bitwise)
+        if Wd % 4 == 0:
+            outs = {}
+            for mode in (1, 0):
+                L.set_option("fused_fast", mode)
+                plan = L.Plan(ctx, H, Wd, FAM[fam], level)
+                plan.upload(L.PLANE_INPUT, a)
+                plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, L.FLAG_FUSED)
+                outs[mode] = np.concatenate([planes(plan, level + 1), plan.download(L.PLANE_OUT)[None]])
+                plan.close()
+            L.set_option("fused_fast", 1)
+            if not np.array_equal(outs[0], outs[1]):
+                fails += 1
+                print(f"FAIL {tag}: fast addressing != generic addressing")
+        # bilateral transform and wow against the C-backed oracle (expf vs v_exp_f32: stated tolerance)
+        if case % 3 == 0 and H >= 24 and Wd >= 24 and H * Wd <= 1500000:
+            cls = W.B3spline if fam == "b3spline" else W.Triangle
+            b = (a + 3 * np.sin(np.arange(Wd, dtype=np.float32) / 11.)[None, :]).astype(np.float32)
+            lev = max(1, min(level, int(np.log2(min(H, Wd))) - 2, len(cls(2).sigma_e(bilateral=1)) - 1))
+            sb = float(rng.uniform(0.5, 2.0))
+            got_b = W.AtrousTransform(cls, bilateral=sb)(b, lev).data
+            ref_b = cref.decompose_bilateral(b, lev, fam, sb)
+            e = float(np.abs(got_b - ref_b).max())
+            if not e <= 1e-4 * float(np.abs(b).max()):
+                fails += 1
+                print(f"FAIL {tag}: bilateral transform L={lev} sigma_b={sb:.2f} max err {e:.3e}")
+            kw = dict(denoise_coefficients=[5, 2][:int(rng.integers(0, 3))])
+            if rng.integers(0, 2):
+                kw["bilateral"] = 1
+            if rng.integers(0, 3) == 0:
+                kw["h"], kw["gamma"] = 0.5, 2.0
+            if rng.integers(0, 3) == 0:
+                kw["preserve_variance"] = True
+            cp = lambda d: {k: (list(v) if isinstance(v, list) else v) for k, v in d.items()}
+            rec_w, coef_w = W.wow(b.copy(), cls, **cp(kw))
+            ref_r, ref_p = cref.wow(b.copy(), fam, **cp(kw))
+            bad = np.abs(coef_w.data - ref_p) > 2e-4 * max(1.0, float(np.abs(ref_p).max())) + 2e-4 * np.abs(ref_p)
+            badr = np.abs(rec_w - ref_r) > 2e-4 * max(1.0, float(np.abs(ref_r).max())) + 2e-4 * np.abs(ref_r)
+            if coef_w.data.shape != ref_p.shape or bad.any() or badr.any():
+                fails += 1
+                print(f"FAIL {tag}: wow({kw}) {int(bad.sum())} plane / {int(badr.sum())} image pixels beyond tolerance")
         if case % 5 == 0 and H * Wd < 400000 and level <= 6:
             r = W.AtrousTransform(W.B3spline if fam == "b3spline" else W.Triangle)(a, level, recursive=True)
             e = float(np.abs(r.data - O.atrous_recursive(a, level, fam)).max())

@@ -472,7 +472,11 @@ static int plan_alloc(wt_plan *p, float **slot)
     // hipMalloc: nothing to gain, and a map call per chunk to lose.
     static const int scatter = getenv("WT_SCATTER") ? atoi(getenv("WT_SCATTER")) : 4;
     static bool vmm_ok = true;           // cleared when the virtual-memory API is not usable here
-    if (!raw && scatter > 0 && vmm_ok && need >= ((size_t)8 << 20)) {
+    // Strip plans keep plain hipMalloc unless WT_SCATTER_STRIPS=1: RCCL reads and writes the planes
+    // of a strip, and its xGMI transport has never run on mapped memory here (the socket transport
+    // of the one-GPU rank test has, green) - the one multi-GPU measurement must not hinge on it.
+    static const int scatter_strips = getenv("WT_SCATTER_STRIPS") ? atoi(getenv("WT_SCATTER_STRIPS")) : 0;
+    if (!raw && scatter > 0 && vmm_ok && need >= ((size_t)8 << 20) && (p->nranks == 1 || scatter_strips)) {
         if (vmm_plane_alloc(p, need, scatter, &raw)) {
             (void)hipGetLastError();     // e.g. hipErrorNotSupported: plain hipMalloc from now on
             vmm_ok = false;
