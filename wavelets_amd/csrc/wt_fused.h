@@ -577,25 +577,46 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
     const int wg_per_cu = NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
-    const int slots = std::max(64, (256 - rows.reserve) * wg_per_cu);
     const int64_t nbase = (int64_t)nx * phases * nranges;
     int chunks = 1, S = n_max;
     double best = 1e300;
-    for (int c = 1; c <= 4096 && c <= n_max; ++c) {
-        const int Sc = (n_max + c - 1) / c;
-        const int cc = (n_max + Sc - 1) / Sc;                    // chunks actually needed
-        const int64_t rounds = (nbase * cc + slots - 1) / slots;
-        // the kernel addresses the rows of a chunk with 31-bit byte offsets
-        if ((int64_t)(Sc + 2 * LAT + 2 * UMAX + 1) * D * g.P * 4 >= ((int64_t)1 << 31)) continue;
-        // more than one round: keep the warm-up <= ~50 % of a chunk.  A grid that fits in one
-        // round anyway (small images: the chip is not full) is latency-bound by the steps of
-        // ONE workgroup, so shorter chunks win even if most of their steps are warm-up.
-        if (c > 1 && Sc < std::min(n_max, rounds > 1 ? 2 * LAT : 4)) break;
-        if (rounds_env && rounds > rounds_env) break;
-        const double cost = (double)rounds * (Sc + 2 * LAT + 8);
-        if (cost < best) { best = cost; chunks = cc; S = Sc; }
+    auto search = [&](int slots) {
+        chunks = 1; S = n_max; best = 1e300;
+        for (int c = 1; c <= 4096 && c <= n_max; ++c) {
+            const int Sc = (n_max + c - 1) / c;
+            const int cc = (n_max + Sc - 1) / Sc;                    // chunks actually needed
+            const int64_t rounds = (nbase * cc + slots - 1) / slots;
+            // the kernel addresses the rows of a chunk with 31-bit byte offsets
+            if ((int64_t)(Sc + 2 * LAT + 2 * UMAX + 1) * D * g.P * 4 >= ((int64_t)1 << 31)) continue;
+            // more than one round: keep the warm-up <= ~50 % of a chunk.  A grid that fits in one
+            // round anyway (small images: the chip is not full) is latency-bound by the steps of
+            // ONE workgroup, so shorter chunks win even if most of their steps are warm-up.
+            if (c > 1 && Sc < std::min(n_max, rounds > 1 ? 2 * LAT : 4)) break;
+            if (rounds_env && rounds > rounds_env) break;
+            const double cost = (double)rounds * (Sc + 2 * LAT + 8);
+            if (cost < best) { best = cost; chunks = cc; S = Sc; }
+        }
+    };
+    search(std::max(64, (256 - rows.reserve) * wg_per_cu));
+    // Large images, D = 1: ONE workgroup per CU with chunks twice as long.  The pass is bound by
+    // its memory pattern, not by latency (section 3.1 of DESIGN.md), so the second workgroup per CU
+    // buys nothing, while half as many chunks halve the warm-up share and the number of isolated
+    // write fronts: 8192^2 0.297 -> 0.277 ms, 6144^2 -8 %, 12288^2 -8 %, 16384^2 -5 %
+    // (profiles/r02_f_chunks.txt).  At 4096^2 (chunks of 81 rows) it is 3 % slower: the planes sit in
+    // the Infinity Cache there and latency matters again - hence the threshold on the chunk length.
+    static const int wpc1_env = getenv("WT_FUSED_WPC1") ? atoi(getenv("WT_FUSED_WPC1")) : -1;   // -1 auto, 0 off, 1 force
+    if (D == 1 && NW == 4 && wg_per_cu > 1 && wpc1_env != 0) {
+        const int c2 = chunks, S2 = S;
+        const double b2 = best;
+        search(std::max(64, 256 - rows.reserve));
+        if (best == 1e300 || (wpc1_env < 0 && S < 128)) { chunks = c2; S = S2; best = b2; }
     }
     if (best == 1e300) WT_FAIL("fused pass: no chunking keeps a chunk's byte span below 2 GiB");
+    static const int chunks_env = getenv("WT_FUSED_CHUNKS") ? atoi(getenv("WT_FUSED_CHUNKS")) : 0;   // experiments (D = 1 passes)
+    if (D == 1 && chunks_env > 0 && chunks_env <= n_max) {
+        S = (n_max + chunks_env - 1) / chunks_env;
+        chunks = (n_max + S - 1) / S;
+    }
     a.S = S;
     a.chunks = chunks;
     static const int dbg = getenv("WT_FUSED_DEBUG") ? atoi(getenv("WT_FUSED_DEBUG")) : 0;
