@@ -242,6 +242,11 @@ extern "C" int wt_ctx_create(int device, wt_ctx **out)
     WT_HIP(hipSetDevice(device));
     wt_ctx *c = new wt_ctx();
     c->device = device;
+    {
+        int cus = 0;      // the chunk searches size their grids to the compute units of THIS device
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+        else (void)hipGetLastError();
+    }
     WT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     WT_HIP(hipEventCreate(&c->t0));
     WT_HIP(hipEventCreate(&c->t1));
@@ -1039,7 +1044,7 @@ static int launch_row_t(wt_plan *p, ChainArgs a, int HX, const char *name)
     const int phases = std::min(d, g.nrows);
     const int n_max = (g.nrows + d - 1) / d;
     // one to two rounds of resident workgroups (16 waves per CU at <= 128 VGPRs)
-    const int slots = 256 * (16 / NW) * 2;
+    const int slots = p->ctx->num_cus * (16 / NW) * 2;
     int chunks = std::max(1, slots / std::max(1, nx * phases));
     int S = (n_max + chunks - 1) / chunks;
     S = std::max(S, std::min(n_max, 16));

@@ -597,7 +597,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
             if (cost < best) { best = cost; chunks = cc; S = Sc; }
         }
     };
-    search(std::max(64, (256 - rows.reserve) * wg_per_cu));
+    const int cus = p->ctx->num_cus;
+    search(std::max(64, (cus - rows.reserve) * wg_per_cu));
     // Large images, D = 1: ONE workgroup per CU with chunks twice as long.  The pass is bound by
     // its memory pattern, not by latency (section 3.1 of DESIGN.md), so the second workgroup per CU
     // buys nothing, while half as many chunks halve the warm-up share and the number of isolated
@@ -608,7 +609,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     if (D == 1 && NW == 4 && wg_per_cu > 1 && wpc1_env != 0) {
         const int c2 = chunks, S2 = S;
         const double b2 = best;
-        search(std::max(64, 256 - rows.reserve));
+        search(std::max(64, cus - rows.reserve));
         if (best == 1e300 || (wpc1_env < 0 && S < 128)) { chunks = c2; S = S2; best = b2; }
     }
     if (best == 1e300) WT_FAIL("fused pass: no chunking keeps a chunk's byte span below 2 GiB");

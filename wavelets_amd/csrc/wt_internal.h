@@ -72,6 +72,7 @@ struct wt_ctx {
     // calls from several host threads are serialised per context (ctypes releases the GIL)
     std::recursive_mutex mu;
     int device = 0;
+    int num_cus = 256;                      // hipDeviceAttributeMultiprocessorCount (MI355X: 256)
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // profiling
