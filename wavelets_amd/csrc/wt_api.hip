@@ -1852,37 +1852,24 @@ extern "C" int wt_reduce(wt_plan *p, int plane, double out[4])
     return 0;
 }
 
-// one histogram pass; returns the bin holding rank k (0-based among the elements matching the
-// prefix), the number of matching elements below that bin, and the bin's population
-static int select_pass(wt_plan *p, const float *b, uint32_t prefix_mask, uint32_t prefix_val, int shift,
-                       uint32_t bin_mask, int64_t k, uint32_t *bin, int64_t *below, int64_t *in_bin)
+// One histogram pass of the radix select + the device-side step that folds the selected bin into
+// the state (no host round trip: the three passes chain on the stream).
+static int select_pass(wt_plan *p, const float *b, WtSelectState *st, uint32_t prefix_mask, int shift, uint32_t bin_mask, int last)
 {
     wt_ctx *c = p->ctx;
-    WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
     {
         ProfScope ps(c, "wt_hist_kernel");
         hipLaunchKernelGGL(wt_hist_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, b, p->g.nrows, p->g.P / 4, p->g.W,
-                           prefix_mask, prefix_val, shift, bin_mask, c->d_hist);
+                           prefix_mask, (const WtSelectState *)st, shift, bin_mask, c->d_hist);
     }
     WT_HIP(hipGetLastError());
     if (p->nranks > 1) {
         if (!c->comm) WT_FAIL("wt_abs_median: multi-rank plan without communicator");
         WT_NCCL(g_rccl.AllReduce(c->d_hist, c->d_hist, WT_HIST_BINS, NCCL_UINT32, NCCL_SUM, c->comm, c->stream));
     }
-    WT_HIP(hipMemcpyAsync(c->h_pinned, c->d_hist, WT_HIST_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    WT_HIP(hipStreamSynchronize(c->stream));
-    const uint32_t *h = (const uint32_t *)c->h_pinned;
-    int64_t cum = 0;
-    for (uint32_t i = 0; i <= bin_mask; ++i) {
-        if (k < cum + (int64_t)h[i]) {
-            *bin = i;
-            *below = cum;
-            *in_bin = h[i];
-            return 0;
-        }
-        cum += h[i];
-    }
-    WT_FAIL("wt_abs_median: rank %lld not found (NaN input?)", (long long)k);
+    hipLaunchKernelGGL(wt_select_step_kernel, dim3(1), dim3(256), 0, c->stream, c->d_hist, st, (int)bin_mask + 1, shift, last);
+    WT_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
@@ -1894,16 +1881,21 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
     WT_TRY(plane_base(p, plane, &b));
     const int64_t N = (int64_t)p->g.H * p->g.W;   // global element count
     const int64_t klo = (N - 1) / 2;
-    uint32_t b1, b2, b3;
-    int64_t below, inb, k = klo, cum_le = 0;
-    WT_TRY(select_pass(p, b, 0u, 0u, 20, 0x7ffu, k, &b1, &below, &inb));
-    k -= below; cum_le += below;
-    WT_TRY(select_pass(p, b, 0x7ff00000u, b1 << 20, 10, 0x3ffu, k, &b2, &below, &inb));
-    k -= below; cum_le += below;
-    const uint32_t pre21 = (b1 << 20) | (b2 << 10);
-    WT_TRY(select_pass(p, b, 0x7ffffc00u, pre21, 0, 0x3ffu, k, &b3, &below, &inb));
-    cum_le += below + inb;                        // elements <= v_lo
-    const uint32_t ulo = pre21 | b3;
+    // state on the device (behind the histogram and the upper-median word); initialised from pinned memory
+    WtSelectState *st = (WtSelectState *)(c->d_hist + WT_HIST_BINS + 4);
+    WtSelectState *hst = (WtSelectState *)c->h_pinned;
+    hst->k = (unsigned long long)klo; hst->cum_le = 0; hst->prefix = 0; hst->failed = 0;
+    WT_HIP(hipMemcpyAsync(st, hst, sizeof(WtSelectState), hipMemcpyHostToDevice, c->stream));
+    WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+    WT_TRY(select_pass(p, b, st, 0u, 20, 0x7ffu, 0));
+    WT_TRY(select_pass(p, b, st, 0x7ff00000u, 10, 0x3ffu, 0));
+    WT_TRY(select_pass(p, b, st, 0x7ffffc00u, 0, 0x3ffu, 1));
+    WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(WtSelectState), hipMemcpyDeviceToHost, c->stream));
+    WT_HIP(hipStreamSynchronize(c->stream));                 // the one host round trip of the select
+    const WtSelectState res_st = *(const WtSelectState *)((const char *)c->h_pinned + 64);
+    if (res_st.failed) WT_FAIL("wt_abs_median: rank %lld not found (NaN input?)", (long long)klo);
+    const int64_t cum_le = (int64_t)res_st.cum_le;           // elements <= v_lo
+    const uint32_t ulo = res_st.prefix;
     uint32_t uhi = ulo;
     if ((N & 1) == 0 && cum_le < klo + 2) {
         // the upper median is the smallest element strictly greater than v_lo

@@ -1436,11 +1436,59 @@ __global__ __launch_bounds__(256) void wt_fill_kernel(float *dst, int64_t n4, fl
 // non-empty bin per block.  Pixels in the pitch padding (x >= W) are masked.
 // ---------------------------------------------------------------------------------------------
 #define WT_HIST_BINS 2048
+// Selection state kept on the device between the passes of the radix select (wt_abs_median): the
+// passes chain on the stream without a host round trip; the host reads the state once at the end.
+struct WtSelectState {
+    unsigned long long k;        // rank still to find among the elements matching `prefix`
+    unsigned long long cum_le;   // elements below the selected bins so far (+ the last bin's population at the end)
+    uint32_t prefix;             // bits fixed so far
+    uint32_t failed;             // rank not found (NaN input)
+};
+
+// After a histogram pass: find the bin that holds rank k, fold it into the prefix, clear the bins.
+__global__ __launch_bounds__(256) void wt_select_step_kernel(uint32_t *hist, WtSelectState *st, int nbins, int shift, int last)
+{
+    __shared__ unsigned long long part[256];
+    __shared__ int found_bin;
+    const int per = (nbins + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    unsigned long long s = 0;
+    for (int i = 0; i < per && b0 + i < nbins; ++i) s += hist[b0 + i];
+    part[threadIdx.x] = s;
+    if (threadIdx.x == 0) found_bin = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long k = st->k;
+        unsigned long long cum = 0;
+        int t = 0;
+        for (; t < 256; ++t) {                      // the thread group that holds rank k
+            if (k < cum + part[t]) break;
+            cum += part[t];
+        }
+        if (t < 256) {
+            for (int i = t * per; i < nbins && i < (t + 1) * per; ++i) {
+                if (k < cum + hist[i]) {
+                    found_bin = i;
+                    st->k = k - cum;
+                    st->cum_le += cum + (last ? hist[i] : 0);
+                    st->prefix |= (uint32_t)i << shift;
+                    break;
+                }
+                cum += hist[i];
+            }
+        }
+        if (found_bin < 0) st->failed = 1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;     // ready for the next pass
+}
+
 __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows, int P4, int W,
-                                                      uint32_t prefix_mask, uint32_t prefix_val,
+                                                      uint32_t prefix_mask, const WtSelectState *st,
                                                       int shift, uint32_t bin_mask,
                                                       uint32_t *hist)
 {
+    const uint32_t prefix_val = st->prefix & prefix_mask;      // wave-uniform scalar load
     __shared__ uint32_t lh[WT_HIST_BINS];
     for (int i = threadIdx.x; i < WT_HIST_BINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
