@@ -116,8 +116,14 @@ int wt_plan_set_border(wt_plan *plan, int border);
 /* User-defined scaling function (a subclass of AbstractScalingFunction with its own
  * coefficients_1d, watroo/wavelets.py:152-229): `ntaps` odd 1-D taps (<= 15) replace the plan's
  * built-in family for wt_decompose / wt_decompose_pass (one scale) / wt_atrous_scale /
- * wt_smooth, which then run generic separable kernels (no fused passes); the other operators
- * (variance, bilateral, fused wow update, 3-D) fail.  ntaps = 0 restores the family.  Single GPU. */
+ * wt_smooth / wt_local_variance / wt_bilateral_conv / wt_decompose_bilateral and the 3-D
+ * operators, which then run generic kernels (no fused passes; scratch planes 12, 13 and 15 are
+ * used internally); the fused wow update fails.  ntaps = 0 restores the family.  Single GPU.
+ * Orientation: taps are applied like cv2.filter2D applies its kernel (correlation, tap j at
+ * offset (j - ntaps/2) * 2^s; watroo/wavelets.py:39-45).  The range-weighted operator is a true
+ * convolution in the reference (kernel index i at offset (ntaps/2 - i) * 2^s, :87-91) and
+ * applies the same taps accordingly.  A caller that stored the taps reversed - to get scipy's
+ * convolution for a 1-D signal (:65-69) - passes flag bit3 to the bilateral entry points. */
 int wt_plan_set_taps(wt_plan *plan, const float *taps, int ntaps);
 /* dst plane <- window of a (larger) source plan's plane starting at (y0, x0); device copy.
  * (atrous_recursive pads by hw*2^(level-1) and crops at the end, watroo/wavelets.py:394-406) */
@@ -162,7 +168,8 @@ int wt_halo_exchange(wt_plan *plan, int plane, int64_t rows);
  * planes[0..level-1] <- detail, planes[level] <- smooth, from plane `src` (left intact).
  * flags: bit0 = allow fused multi-scale passes (default path), bit1 = skip halo exchange
  * (caller did it / virtual strips), bit2 (bilateral only) = materialise the variance plane
- * with a separate kernel instead of forming it inside the bilateral kernel. */
+ * with a separate kernel instead of forming it inside the bilateral kernel, bit3 (bilateral with
+ * user-defined taps only) = the plan's taps are stored reversed (see wt_plan_set_taps). */
 int wt_decompose(wt_plan *plan, int src, int level, int flags);
 /* one pass of the schedule (wt_schedule): scales [s0,s0+ns) from plane `cur` (c_{s0}) into
  * detail planes s0..s0+ns-1 and plane `nxt` (c_{s0+ns}); exchanges the pass halo first. */
@@ -197,7 +204,7 @@ int wt_smooth(wt_plan *plan, int src, int dst, int s, int square_input, int flag
 int wt_local_variance(wt_plan *plan, int src, int dst, int s, float f1, float f2,
                       int take_sqrt, int flags);
 /* atrous_convolution(image, kernel, bilateral_variance, s, 'symmetric')
- * (watroo/wavelets.py:74-105; numexpr expression :97). */
+ * (watroo/wavelets.py:74-105; numexpr expression :97).  flags: bit1, bit3 as for wt_decompose. */
 int wt_bilateral_conv(wt_plan *plan, int src, int var, int dst, int s, int flags);
 /* atrous_standard with bilateral (watroo/wavelets.py:421-442): sigma_b[level] */
 int wt_decompose_bilateral(wt_plan *plan, int src, int level, const double *sigma_b,

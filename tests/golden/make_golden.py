@@ -359,6 +359,54 @@ def g18_recursive_nd_bilateral():
     save("g18_recursive_nd", "1-D plain: hard (numpy + scipy); others: semantic(cv2 stand-in)", **out)
 
 
+def g19_custom_bilateral_nd():
+    """User-defined scaling functions beyond the plain 1-D / 2-D transform: bilateral filtering
+    (2-D, 1-D, 3-D), 3-D cubes, sdev_loc, atrous_convolution with the class's own kernel and the
+    recursive algorithm.  The asymmetric taps pin every orientation: cv2.filter2D correlates
+    (wavelets.py:39-63), scipy convolves (:65-69), the tap loop of atrous_convolution convolves
+    (:87-91)."""
+    from watroo.wavelets import AbstractScalingFunction, sdev_loc, atrous_convolution
+
+    class Binomial7(AbstractScalingFunction):
+        coefficients_1d = np.array([1, 6, 15, 20, 15, 6, 1]) / 64
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('binomial7', *args, **kwargs)
+
+    class Skew5(AbstractScalingFunction):
+        coefficients_1d = np.array([0.05, 0.25, 0.4, 0.2, 0.1])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('skew5', *args, **kwargs)
+
+    out = {}
+    a = img((45, 57), 191) + np.linspace(0, 3, 57, dtype=np.float32)[None, :]
+    sig = img((180,), 192) + 2 * np.sin(np.arange(180, dtype=np.float32) / 7.)
+    cube = img((8, 14, 16), 193) + np.linspace(0, 2, 16, dtype=np.float32)[None, None, :]
+    var = (0.5 + np.abs(img((45, 57), 194))).astype(np.float32)
+    out["img"], out["sig"], out["cube"], out["var"] = a.astype(np.float32), sig.astype(np.float32), \
+        cube.astype(np.float32), var
+    a, sig, cube = out["img"], out["sig"], out["cube"]
+    for name, cls in (("bin7", Binomial7), ("skew5", Skew5)):
+        out[f"{name}_taps"] = cls.coefficients_1d
+        out[f"{name}_b2d_L3"] = AtrousTransform(cls, bilateral=1)(a, 3).data
+        out[f"{name}_b2d_list_L2"] = AtrousTransform(cls, bilateral=[1.5, .7],
+                                                     bilateral_scaling=True)(a, 2).data
+        out[f"{name}_b1d_L3"] = AtrousTransform(cls, bilateral=1)(sig, 3).data
+        out[f"{name}_c3d_L2"] = AtrousTransform(cls)(cube, 2).data
+        out[f"{name}_b3d_L2"] = AtrousTransform(cls, bilateral=1)(cube, 2).data
+        out[f"{name}_conv3d_s1"] = convolution(cube, cls(3), s=1)
+        out[f"{name}_sdev_s1"] = sdev_loc(a, cls(2), s=1)
+        out[f"{name}_var_s0"] = sdev_loc(a, cls(2), s=0, variance=True)
+        k2 = cls(2).kernel.astype(np.float32)
+        out[f"{name}_ac_var_s1"] = atrous_convolution(a, k2, var, s=1)
+        out[f"{name}_ac_plain_s2"] = atrous_convolution(a, k2, None, s=2)
+        out[f"{name}_rec2_b1_L2"] = AtrousTransform(cls, bilateral=1)(a, 2, recursive=True).data
+        out[f"{name}_rec1_b1_L2"] = AtrousTransform(cls, bilateral=1)(sig, 2, recursive=True).data
+        out[f"{name}_rec3_L2"] = AtrousTransform(cls)(cube, 2, recursive=True).data
+    save("g19_custom_bilateral_nd", "bilateral taps: hard (numpy); smoothing: semantic(cv2 stand-in), 1-D scipy", **out)
+
+
 def g14_wow_denoise_nd():
     """wow / denoise on 1-D signals and (Z, Y, X) cubes (the reference is ndim-generic)."""
     out = {}
@@ -532,3 +580,4 @@ if __name__ == "__main__":
         g16_bilateral_nd()
         g17_rl_fft_odd_height()
         g18_recursive_nd_bilateral()
+        g19_custom_bilateral_nd()

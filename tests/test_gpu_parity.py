@@ -945,10 +945,6 @@ def test_custom_scaling_function_vs_golden(W, name):
     class Retapped(W.B3spline):
         coefficients_1d = g[f"{name}_taps"]
     close(W.AtrousTransform(Retapped)(a, 3).data, g[f"{name}_coef_2d_L3"], tol)
-    with pytest.raises(NotImplementedError):
-        W.AtrousTransform(Custom, bilateral=1)(a, 2)
-    with pytest.raises(NotImplementedError):
-        W.AtrousTransform(Custom)(np.zeros((4, 5, 6), np.float32), 1)
 
 
 def test_plain_c_client_of_the_abi():

@@ -396,3 +396,41 @@ def test_exact_median_of_large_planes(L, shape, kind):
     got = plan.abs_median(0)
     assert got == np.median(np.abs(a)), (got, np.median(np.abs(a)))
     plan.close()
+
+
+@pytest.mark.parametrize("name", ["bin7", "skew5"])
+def test_custom_taps_bilateral_nd_vs_golden(WA, name):
+    W = WA
+    """g19 (the reference's output): user-defined taps through the bilateral operator (2-D, 1-D,
+    3-D), on cubes, in sdev_loc, in atrous_convolution with the class's own kernel and in the
+    recursive algorithm.  skew5 is asymmetric: it pins the orientation of every branch."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g19_custom_bilateral_nd.npz"))
+    a, sig, cube, var = g["img"], g["sig"], g["cube"], g["var"]
+
+    class Custom(W.AbstractScalingFunction):
+        coefficients_1d = g[f"{name}_taps"]
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(name, *args, **kwargs)
+
+    tol = 2e-5 * float(np.abs(a).max())
+    T = W.AtrousTransform
+    close(T(Custom, bilateral=1)(a, 3).data, g[f"{name}_b2d_L3"], tol)
+    close(T(Custom, bilateral=[1.5, .7], bilateral_scaling=True)(a, 2).data, g[f"{name}_b2d_list_L2"], tol)
+    close(T(Custom, bilateral=1)(sig, 3).data, g[f"{name}_b1d_L3"], tol)
+    close(T(Custom)(cube, 2).data, g[f"{name}_c3d_L2"], tol)
+    close(T(Custom, bilateral=1)(cube, 2).data, g[f"{name}_b3d_L2"], tol)
+    close(W.convolution(cube, Custom(3), s=1), g[f"{name}_conv3d_s1"], tol)
+    close(W.sdev_loc(a, Custom(2), s=1), g[f"{name}_sdev_s1"], 5e-5)
+    close(W.sdev_loc(a, Custom(2), s=0, variance=True), g[f"{name}_var_s0"], 5e-5)
+    k2 = Custom(2).kernel.astype(np.float32)
+    close(W.atrous_convolution(a, k2, var, s=1), g[f"{name}_ac_var_s1"], tol)
+    close(W.atrous_convolution(a, k2, None, s=2), g[f"{name}_ac_plain_s2"], tol)
+    close(T(Custom, bilateral=1)(a, 2, recursive=True).data, g[f"{name}_rec2_b1_L2"], tol)
+    close(T(Custom, bilateral=1)(sig, 2, recursive=True).data, g[f"{name}_rec1_b1_L2"], tol)
+    close(T(Custom)(cube, 2, recursive=True).data, g[f"{name}_rec3_L2"], tol)
+    # a non-separable kernel has no 1-D taps: loud failure, not a wrong answer
+    bad = k2.copy()
+    bad[0, 1] *= 1.5
+    with pytest.raises(NotImplementedError):
+        W.atrous_convolution(a, bad, var, s=0)

@@ -411,3 +411,28 @@ def test_recursive_algorithm_nd_and_bilateral_vs_reference():
     # the 2-D plain case agrees with the dedicated restatement
     a = g["img2"]
     np.testing.assert_array_equal(O.atrous_recursive_nd(a, 3, "b3spline"), O.atrous_recursive(a, 3, "b3spline"))
+
+
+@pytest.mark.parametrize("name", ["bin7", "skew5"])
+def test_custom_taps_bilateral_nd_vs_reference(name):
+    """g19: user-defined taps through the bilateral operator (2-D, 1-D, 3-D), 3-D cubes, sdev_loc,
+    atrous_convolution with the class's kernel and the recursive algorithm; the asymmetric taps
+    pin the orientation of every branch (filter2D correlates, scipy and the tap loop convolve)."""
+    g = load_golden("g19_custom_bilateral_nd")
+    a, sig, cube, var = g["img"], g["sig"], g["cube"], g["var"]
+    fam = O.CustomFamily(g[f"{name}_taps"], {})
+    tol = 3e-6 * np.abs(a).max()
+    close(O.atrous_standard(a, 3, fam, 1), g[f"{name}_b2d_L3"], tol)
+    close(O.atrous_standard(a, 2, fam, [1.5, .7], True), g[f"{name}_b2d_list_L2"], tol)
+    close(O.atrous_standard_nd(sig, 3, fam, 1), g[f"{name}_b1d_L3"], tol)
+    close(O.atrous_standard_nd(cube, 2, fam), g[f"{name}_c3d_L2"], tol)
+    close(O.atrous_standard_nd(cube, 2, fam, 1), g[f"{name}_b3d_L2"], tol)
+    close(O.convolution_3d(cube, fam, 1), g[f"{name}_conv3d_s1"], tol)
+    close(O.sdev_loc(a, fam, 1), g[f"{name}_sdev_s1"], 2e-5)
+    close(O.sdev_loc(a, fam, 0, variance=True), g[f"{name}_var_s0"], 2e-5)
+    k2 = O.kernel_2d(fam, np.float32)
+    close(O.atrous_convolution(a, k2, var, 1), g[f"{name}_ac_var_s1"], tol)
+    close(O.atrous_convolution(a, k2, None, 2), g[f"{name}_ac_plain_s2"], tol)
+    close(O.atrous_recursive_nd(a, 2, fam, 1), g[f"{name}_rec2_b1_L2"], tol)
+    close(O.atrous_recursive_nd(sig, 2, fam, 1), g[f"{name}_rec1_b1_L2"], tol)
+    close(O.atrous_recursive_nd(cube, 2, fam), g[f"{name}_rec3_L2"], tol)

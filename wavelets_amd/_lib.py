@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("WATROO_HIP_LIB", os.path.join(_HERE, "libwatroo_hip.s
 TRIANGLE, B3SPLINE = 0, 1
 PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
 NUM_SCRATCH = 32
-FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE = 1, 2, 4
+FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE, FLAG_TAPS_REVERSED = 1, 2, 4, 8
 
 
 def PLANE_SCRATCH(i):

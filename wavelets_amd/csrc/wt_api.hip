@@ -668,6 +668,14 @@ extern "C" int wt_plan_set_taps(wt_plan *p, const float *taps, int ntaps)
     return 0;
 }
 
+static CustomTaps plan_taps(const wt_plan *p)
+{
+    CustomTaps t{};
+    t.n = p->ntaps;
+    for (int i = 0; i < p->ntaps; ++i) t.k[i] = p->taps[i];
+    return t;
+}
+
 // separable filter with the plan's run-time taps: rows into scratch 15, then columns (+ detail)
 static int launch_custom(wt_plan *p, const float *in, float *out_c, float *out_w, int s, int square, const char *name)
 {
@@ -676,14 +684,32 @@ static int launch_custom(wt_plan *p, const float *in, float *out_c, float *out_w
     WT_TRY(plane_base(p, WT_PLANE_SCRATCH(15), &tmp));
     if (in == tmp || out_c == tmp || out_w == tmp) WT_FAIL("%s: scratch plane 15 is used internally for user-defined taps", name);
     if (out_c == in || out_w == in) WT_FAIL("%s: in-place operation", name);
-    CustomTaps t{};
-    t.n = p->ntaps;
-    for (int i = 0; i < p->ntaps; ++i) t.k[i] = p->taps[i];
+    const CustomTaps t = plan_taps(p);
     const int d = 1 << s;
     dim3 grid((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)), block(256);
     ProfScope ps(p->ctx, "wt_custom_kernels");
     hipLaunchKernelGGL(wt_custom_rows_kernel, grid, block, 0, p->ctx->stream, in, tmp, p->g, d, t, square);
     hipLaunchKernelGGL(wt_custom_cols_kernel, grid, block, 0, p->ctx->stream, (const float *)tmp, in, out_c, out_w, p->g, d, t);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+static inline int64_t plan_n4(const wt_plan *p);
+static inline int flat_grid(int64_t n4);
+// sdev_loc (watroo/wavelets.py:24-32) with run-time taps: both moments through the generic
+// separable kernels (mean in scratch 13), then the clip / sqrt / factors
+static int launch_custom_variance(wt_plan *p, const float *in, float *out, int s, float f1, float f2, int take_sqrt,
+                                  const char *name)
+{
+    float *mean = nullptr;
+    WT_TRY(plane_base(p, WT_PLANE_SCRATCH(13), &mean));
+    if (in == mean || out == mean) WT_FAIL("%s: scratch plane 13 is used internally for user-defined taps", name);
+    WT_TRY(launch_custom(p, in, mean, nullptr, s, 0, name));
+    WT_TRY(launch_custom(p, in, out, nullptr, s, 1, name));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_var_moments_kernel");
+    hipLaunchKernelGGL(wt_var_moments_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, (const float *)mean,
+                       (const float *)out, out, n4, f1, f2, take_sqrt);
     WT_HIP(hipGetLastError());
     return 0;
 }
@@ -1090,7 +1116,8 @@ static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
     if (p->ntaps) {      // user-defined scaling function: generic separable kernels
         if (MODE == MODE_SMOOTH || MODE == MODE_SMOOTH_SQ || MODE == MODE_DECOMP)
             return launch_custom(p, a.in, a.out_c, MODE == MODE_DECOMP ? a.out_w : nullptr, s, MODE == MODE_SMOOTH_SQ, name);
-        WT_FAIL("%s: not available with user-defined taps (smooth / decompose only)", name);
+        if (MODE == MODE_VAR) return launch_custom_variance(p, a.in, a.out_c, s, a.f1, a.f2, a.take_sqrt, name);
+        WT_FAIL("%s: not available with user-defined taps", name);
     }
     const bool no_row = !g_opt_row_kernel;
     const int hw = family_taps(p->family) / 2;
@@ -1195,10 +1222,25 @@ extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, 
 
 // var == nullptr: the kernel forms the variance itself (times f1, f2) from its register window
 static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s,
-                            float f1 = 1.f, float f2 = 1.f)
+                            float f1 = 1.f, float f2 = 1.f, int rev = 0)
 {
     if (p->g.border != 0 && p->g.border != 1) WT_FAIL("bilateral kernels implement the symmetric border (whole image or polyphase) only");
-    if (p->ntaps) WT_FAIL("bilateral kernels are not available with user-defined taps");
+    if (p->ntaps) {      // user-defined scaling function: generic kernel, variance plane in scratch 12
+        if (s < 0 || s > 24) WT_FAIL("wt_bilateral_conv: scale %d out of range", s);
+        if (!var) {
+            float *v = nullptr;
+            WT_TRY(plane_base(p, WT_PLANE_SCRATCH(12), &v));
+            if (in == v || out == v || out_w == v) WT_FAIL("wt_decompose_bilateral: scratch plane 12 is used internally for user-defined taps");
+            WT_TRY(launch_custom_variance(p, in, v, s, f1, f2, 0, "wt_decompose_bilateral"));
+            var = v;
+        }
+        dim3 grid((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)), block(256);
+        ProfScope ps(p->ctx, "wt_bilateral_custom_kernel");
+        hipLaunchKernelGGL(wt_bilateral_custom_kernel, grid, block, 0, p->ctx->stream, in, var, out, out_w, p->g, p->g.H, 0,
+                           1 << s, plan_taps(p), rev);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
     ChainArgs a{};
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
@@ -1233,7 +1275,7 @@ extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, i
     WT_TRY(plane_base(p, var, &v));
     WT_TRY(plane_base(p, dst, &o));
     WT_TRY(maybe_exchange(p, src, scale_halo(p, s), flags));
-    return launch_bilateral(p, in, v, o, nullptr, s);
+    return launch_bilateral(p, in, v, o, nullptr, s, 1.f, 1.f, (flags & 8) != 0);
 }
 
 // =============================================================================================
@@ -1435,9 +1477,9 @@ extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const doub
         const float f2 = bilateral_scaling ? (float)(s + 1) : 1.f;
         if (flags & 4) {   // two-kernel form (variance plane materialised), kept for A/B tests
             WT_TRY(launch_chain<MODE_VAR>(p, in, var, nullptr, s, f1, f2, 0, "wt_chain_kernel<variance>"));
-            WT_TRY(launch_bilateral(p, in, var, oc, ow, s));
+            WT_TRY(launch_bilateral(p, in, var, oc, ow, s, 1.f, 1.f, (flags & 8) != 0));
         } else {
-            WT_TRY(launch_bilateral(p, in, nullptr, oc, ow, s, f1, f2));
+            WT_TRY(launch_bilateral(p, in, nullptr, oc, ow, s, f1, f2, (flags & 8) != 0));
         }
         cur = nxt;
     }
@@ -1623,6 +1665,21 @@ static int conv3d_planes(wt_plan *p, float *in, float *tmp, float *out, int s, i
 {
     const Geo whole = p->g;
     const int Y = whole.H / depth;
+    if (p->ntaps) {      // user-defined taps: rows -> scratch 15, axis 1 -> scratch 12, axis 0 -> out
+        float *t2 = nullptr;
+        WT_TRY(plane_base(p, WT_PLANE_SCRATCH(12), &t2));
+        if (in == t2 || out == t2 || tmp == t2) WT_FAIL("3-D filter: scratch plane 12 is used internally for user-defined taps");
+        const CustomTaps t = plan_taps(p);
+        dim3 grid((whole.W + 255) / 256, (unsigned)std::min(whole.H, 32768)), block(256);
+        ProfScope ps(p->ctx, "wt_custom_kernels");
+        hipLaunchKernelGGL(wt_custom_rows_kernel, grid, block, 0, p->ctx->stream, (const float *)in, tmp, whole, 1 << s, t, 0);
+        hipLaunchKernelGGL(wt_custom_axis_kernel, grid, block, 0, p->ctx->stream, (const float *)tmp, t2, whole.W, whole.P, Y, depth,
+                           1 << s, whole.border, t, 1);
+        hipLaunchKernelGGL(wt_custom_axis_kernel, grid, block, 0, p->ctx->stream, (const float *)t2, out, whole.W, whole.P, Y, depth,
+                           1 << s, whole.border, t, 0);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
     // per-slice 2-D filter: the single-scale kernels run on each Y x X slice as its own image
     p->g.H = Y;
     p->g.nrows = Y;
@@ -1647,7 +1704,6 @@ static int check3d(const wt_plan *p, int depth, int s, const char *who)
 {
     if (p->nranks != 1 || (p->g.border != 0 && p->g.border != 1))
         WT_FAIL("%s: single-GPU plans with the symmetric border (whole cube or polyphase) only", who);
-    if (p->ntaps) WT_FAIL("%s: not available with user-defined taps", who);
     if (depth < 1 || p->g.H % depth) WT_FAIL("%s: plan height %d is not a multiple of depth %d", who, p->g.H, depth);
     if (s < 0 || s > 20) WT_FAIL("%s: scale %d out of range", who, s);
     return 0;
@@ -1706,6 +1762,13 @@ extern "C" int wt_bilateral3d_conv(wt_plan *p, int src, int var, int dst, int s,
     WT_TRY(plane_base(p, dst, &out));
     const int Y = p->g.H / depth;
     dim3 grid((p->g.W + 255) / 256, (unsigned)std::min(p->g.H, 32768)), block(256);
+    if (p->ntaps) {
+        ProfScope ps(p->ctx, "wt_bilateral_custom_kernel");
+        hipLaunchKernelGGL(wt_bilateral_custom_kernel, grid, block, 0, p->ctx->stream, (const float *)in, (const float *)v, out,
+                           (float *)nullptr, p->g, Y, depth, 1 << s, plan_taps(p), 0);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
     ProfScope ps(p->ctx, "wt_bilateral3d_kernel");
     if (p->family == WT_B3SPLINE)
         hipLaunchKernelGGL((wt_bilateral3d_kernel<5>), grid, block, 0, p->ctx->stream, (const float *)in, (const float *)v, out,

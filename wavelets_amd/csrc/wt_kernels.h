@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(256) void wt_bilateral3d_kernel(const float *in, co
 // variance plane from the two smoothed moments (sdev_loc, watroo/wavelets.py:24-32, with the
 // factors of :434-436): dst = max(meansq - mean^2 -> 1e-20 if <= 0) * f1 * f2
 __global__ __launch_bounds__(256) void wt_var_moments_kernel(const float *mean, const float *meansq, float *dst,
-                                                             int64_t n4, float f1, float f2)
+                                                             int64_t n4, float f1, float f2, int take_sqrt = 0)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(256) void wt_var_moments_kernel(const float *mean, 
         const float m[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
         float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = wt_var_point(q[k], m[k], f1, f2, 0);
+        for (int k = 0; k < 4; ++k) v[k] = wt_var_point(q[k], m[k], f1, f2, take_sqrt);
         reinterpret_cast<float4 *>(dst)[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
@@ -1271,6 +1271,78 @@ __global__ __launch_bounds__(256) void wt_custom_cols_kernel(const float *tmp, c
         const int64_t o = (int64_t)y * g.P + x;
         if (out_w) out_w[o] = in[o] - acc;
         out_c[o] = acc;
+    }
+}
+
+// filter along axis 0 (axis == 0) or axis 1 (axis == 1, inside every slice) of a (Z, Y, X) cube
+// stored as a (Z*Y) x X image, run-time taps: the second half of the per-slice 2-D filter and the
+// third pass of convolution()'s 3-D branch (watroo/wavelets.py:46-63) for user-defined scaling
+// functions
+__global__ __launch_bounds__(256) void wt_custom_axis_kernel(const float *in, float *out, int W, int P, int Y,
+                                                             int Z, int d, int border, CustomTaps t, int axis)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int hw = t.n / 2;
+    for (int row = blockIdx.y; row < Z * Y; row += gridDim.y) {
+        const int z = row / Y, y = row - z * Y;
+        float acc = 0.f;
+        for (int j = 0; j < t.n; ++j) {
+            const int zz = axis == 0 ? wt_refl_b(z + (j - hw) * d, Z, d, border) : z;
+            const int yy = axis == 1 ? wt_refl_b(y + (j - hw) * d, Y, d, border) : y;
+            const float v = in[((int64_t)zz * Y + yy) * P + x];
+            acc = j == 0 ? t.k[0] * v : fmaf(t.k[j], v, acc);
+        }
+        out[(int64_t)row * P + x] = acc;
+    }
+}
+
+// atrous_convolution(image, kernel, bilateral_variance, s) with run-time taps
+// (watroo/wavelets.py:74-105): K^2 taps on an image (Z == 0; rows [g.row0, g.row0 + g.nrows) of
+// it) or K^3 on a (Z, Y, X) cube.  The reference's tap loop is a TRUE CONVOLUTION - kernel index
+// i pairs with the sample at offset (hw - i) * d (:87-91) - while the plan stores the taps in
+// cv2.filter2D's correlation order, so tap i is t.k[i] here; `rev` = the plan's taps are stored
+// reversed (plans of 1-D signals, whose smoothing is scipy's convolution).  Taps are visited in
+// the reference's order (row-major kernel index).  One sample per thread.
+__global__ __launch_bounds__(256) void wt_bilateral_custom_kernel(const float *in, const float *var, float *out_c,
+                                                                  float *out_w, Geo g, int Y, int Z, int d,
+                                                                  CustomTaps t, int rev)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int n = t.n, hw = n / 2;
+    const bool cube = Z > 0;
+    const int nrows = cube ? Z * Y : g.nrows;
+    const int H = cube ? Y : g.H;
+    const float kc = t.k[hw];
+    for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+        const int z = cube ? row / Y : 0;
+        const int y = cube ? row - z * Y : g.row0 + row;
+        const int64_t o = (int64_t)row * g.P + x;
+        const float I = in[o];
+        const float m = -0.5f / var[o];
+        float den = cube ? kc * kc * kc : kc * kc;
+        float num = den * I;
+        for (int iz = 0; iz < (cube ? n : 1); ++iz) {
+            const int zz = cube ? wt_refl_b(z + (hw - iz) * d, Z, d, g.border) : 0;
+            const float kz = cube ? t.k[rev ? n - 1 - iz : iz] : 1.f;
+            for (int iy = 0; iy < n; ++iy) {
+                const int yy = wt_refl_b(y + (hw - iy) * d, H, d, g.border);
+                const float kzy = kz * t.k[rev ? n - 1 - iy : iy];
+                const float *r = in + (cube ? ((int64_t)zz * Y + yy) : (int64_t)(yy - g.row0)) * g.P;
+                for (int ix = 0; ix < n; ++ix) {
+                    if (ix == hw && iy == hw && (!cube || iz == hw)) continue;
+                    const float It = r[wt_refl_b(x + (hw - ix) * d, g.W, d, g.border)];
+                    const float dl = I - It;
+                    const float w = kzy * t.k[rev ? n - 1 - ix : ix] * __expf(dl * dl * m);
+                    num = fmaf(w, It, num);
+                    den += w;
+                }
+            }
+        }
+        const float c = num / den;
+        if (out_w) out_w[o] = I - c;
+        out_c[o] = c;
     }
 }
 

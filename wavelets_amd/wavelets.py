@@ -231,9 +231,6 @@ def convolution(arr, scaling_function, s=0, output=None):
     else:
         img = _to_f32_row(arr) if one_d else _to_f32_image(arr)
     fam = _family_of(scaling_function, 1 if one_d else 2)
-    if three_d and isinstance(fam, tuple):
-        raise NotImplementedError("3-D convolution with a user-defined scaling function is not "
-                                  "implemented in the HIP engine")
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
     try:
         if one_d:
@@ -269,7 +266,9 @@ def sdev_loc(image, scaling_function, s=0, variance=False):
 def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmetric",
                        output=None):
     """Dilated convolution, optionally range-weighted by ``bilateral_variance`` (ref:74-105).
-    ``kernel`` must be the 2-D Triangle or B3spline kernel; ``mode`` must be 'symmetric'."""
+    ``kernel`` must be a SEPARABLE 2-D kernel - the outer product of an odd number (<= 15) of 1-D
+    taps with itself, which every AbstractScalingFunction kernel is (ref:170-173); ``mode`` must
+    be 'symmetric'."""
     if mode != "symmetric":
         raise NotImplementedError("the HIP engine implements mode='symmetric' only")
     img = _to_f32_image(image, "image")
@@ -279,8 +278,24 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
         k = cls(2).kernel
         if kernel.shape == k.shape and np.allclose(kernel, k, rtol=1e-6, atol=0):
             fam = cls._family
+    flags = 0
     if fam is None:
-        raise NotImplementedError("kernel must be the 2-D Triangle or B3spline kernel")
+        # kernel = outer(t, t): t = centre row / sqrt(centre).  The reference's tap loop is a true
+        # convolution (ref:87-91) and the engine correlates: the plan gets the taps reversed and
+        # the range-weighted kernel is told so (wt_bilateral_conv flag bit 3).
+        k64 = np.asarray(kernel, dtype=np.float64)
+        ok = k64.ndim == 2 and k64.shape[0] == k64.shape[1] and k64.shape[0] % 2 == 1 \
+            and k64.shape[0] <= 15 and k64[k64.shape[0] // 2, k64.shape[0] // 2] > 0
+        if ok:
+            hw = k64.shape[0] // 2
+            taps = k64[hw] / np.sqrt(k64[hw, hw])
+            ok = np.allclose(np.multiply.outer(taps, taps), k64, rtol=1e-6,
+                             atol=1e-7 * np.abs(k64).max())
+        if not ok:
+            raise NotImplementedError("kernel must be the outer product of an odd number (<= 15) "
+                                      "of 1-D taps with itself")
+        fam = tuple(float(t) for t in taps[::-1])
+        flags = _lib.FLAG_TAPS_REVERSED
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
     try:
         plan.upload(PLANE_INPUT, img)
@@ -289,7 +304,7 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
         else:
             var = np.broadcast_to(np.asarray(bilateral_variance, np.float32), img.shape)
             plan.upload(_TMP_PLANE, var)
-            plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s)
+            plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s, flags)
         res = plan.download(PLANE_OUT)
     finally:
         release_plan(plan)
@@ -676,9 +691,7 @@ class AtrousTransform:
         # symmetrically (ref:77).  On a 1 x N image the 2-D bilateral kernel reduces to the 1-D
         # one: the taps of the other axis all reflect onto the same row, carry weight e = 1 and
         # factor out of numerator and denominator.
-        if plan.custom:
-            raise NotImplementedError("bilateral filtering with a user-defined scaling function "
-                                      "is not implemented in the HIP engine")
+        # (user-defined taps: the plan of a 1-D signal holds them reversed, see _family_of)
         sb = self._sigma_bilateral(level)
         cur = PLANE_INPUT
         for s in range(level):
@@ -687,7 +700,7 @@ class AtrousTransform:
             plan.local_variance(cur, _TMP_PLANE, s, float(sb[s]) ** 2,
                                 float(s + 1) if self.bilateral_scaling else 1.0)
             plan.set_border(0)
-            plan.bilateral_conv(cur, _TMP_PLANE, nxt, s)
+            plan.bilateral_conv(cur, _TMP_PLANE, nxt, s, _lib.FLAG_TAPS_REVERSED)
             plan.binary("sub", cur, nxt, s)                                # ref:442
             cur = nxt
         if level == 0:
@@ -704,9 +717,6 @@ class AtrousTransform:
         Z, Y, X = cube.shape
         scaling_function = self.scaling_function_class(3)
         fam = _family_of(scaling_function)
-        if isinstance(fam, tuple):
-            raise NotImplementedError("3-D transforms with a user-defined scaling function are "
-                                      "not implemented in the HIP engine")
         plan = acquire_plan(default_context(), Z * Y, X, fam, level)
         plan.upload(PLANE_INPUT, cube.reshape(Z * Y, X))
         if self.bilateral is None:
@@ -741,10 +751,6 @@ class AtrousTransform:
         nd = arr.ndim
         ctx = default_context()
         fam = _family_of(scaling_function, nd)
-        custom = isinstance(fam, tuple)
-        if custom and (nd == 3 or self.bilateral is not None):
-            raise NotImplementedError("recursive 3-D / bilateral transforms with a user-defined "
-                                      "scaling function are not implemented in the HIP engine")
         pad = (len(scaling_function.coefficients_1d) // 2) * 2 ** (level - 1)
         padded = np.pad(arr, pad, mode='symmetric')
         shape2 = {1: lambda a: (1, a.shape[0]), 2: lambda a: a.shape,
@@ -775,7 +781,8 @@ class AtrousTransform:
                         big.set_border(conv_border)           # ref:375: sdev_loc over convolution()
                         big.local_variance(cur, _TMP_PLANE, s, f1, f2)
                         big.set_border(sym)                   # ref:378: mode='symmetric'
-                        big.bilateral_conv(cur, _TMP_PLANE, nxt, s)
+                        big.bilateral_conv(cur, _TMP_PLANE, nxt, s,
+                                           _lib.FLAG_TAPS_REVERSED if nd == 1 else 0)
                     big.binary("sub", cur, nxt, s)            # ref:402-403
                     cur = nxt
             for s in range(level + 1):                        # ref:405-406
@@ -793,9 +800,6 @@ class AtrousTransform:
                             _shape=arr.shape if nd == 3 else None, _dtype=dtype)
 
     def _run(self, plan, level, src=PLANE_INPUT, flags=FLAG_FUSED):
-        if self.bilateral is not None and plan.custom:
-            raise NotImplementedError("bilateral filtering with a user-defined scaling function "
-                                      "is not implemented in the HIP engine")
         if self.bilateral is None:
             plan.decompose(src, level, flags)                              # ref:432,442
         else:
