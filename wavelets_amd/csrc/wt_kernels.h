@@ -1518,40 +1518,45 @@ struct WtSelectState {
 };
 
 // After a histogram pass: find the bin that holds rank k, fold it into the prefix, clear the bins.
+// One block: every thread sums its run of bins, a block-wide scan of the 256 partial sums finds the
+// one thread whose run holds the rank, and that thread walks its (<= 8) bins.
 __global__ __launch_bounds__(256) void wt_select_step_kernel(uint32_t *hist, WtSelectState *st, int nbins, int shift, int last)
 {
     __shared__ unsigned long long part[256];
-    __shared__ int found_bin;
-    const int per = (nbins + 255) / 256;
+    const int per = (nbins + 255) / 256;                 // <= WT_HIST_BINS / 256 = 8
     const int b0 = threadIdx.x * per;
+    uint32_t h[WT_HIST_BINS / 256];
     unsigned long long s = 0;
-    for (int i = 0; i < per && b0 + i < nbins; ++i) s += hist[b0 + i];
-    part[threadIdx.x] = s;
-    if (threadIdx.x == 0) found_bin = -1;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long k = st->k;
-        unsigned long long cum = 0;
-        int t = 0;
-        for (; t < 256; ++t) {                      // the thread group that holds rank k
-            if (k < cum + part[t]) break;
-            cum += part[t];
-        }
-        if (t < 256) {
-            for (int i = t * per; i < nbins && i < (t + 1) * per; ++i) {
-                if (k < cum + hist[i]) {
-                    found_bin = i;
-                    st->k = k - cum;
-                    st->cum_le += cum + (last ? hist[i] : 0);
-                    st->prefix |= (uint32_t)i << shift;
-                    break;
-                }
-                cum += hist[i];
-            }
-        }
-        if (found_bin < 0) st->failed = 1;
+#pragma unroll
+    for (int i = 0; i < WT_HIST_BINS / 256; ++i) {
+        h[i] = (i < per && b0 + i < nbins) ? hist[b0 + i] : 0u;
+        s += h[i];
     }
+    const unsigned long long k = st->k, cum_le = st->cum_le;
+    const uint32_t prefix = st->prefix;
+    part[threadIdx.x] = s;
     __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {            // inclusive scan
+        const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long incl = part[threadIdx.x];
+    unsigned long long cum = incl - s;
+    if (k >= cum && k < incl) {                          // exactly one thread
+#pragma unroll
+        for (int i = 0; i < WT_HIST_BINS / 256; ++i) {
+            if (k < cum + h[i]) {
+                st->k = k - cum;
+                st->cum_le = cum_le + cum + (last ? h[i] : 0);
+                st->prefix = prefix | ((uint32_t)(b0 + i) << shift);
+                break;
+            }
+            cum += h[i];
+        }
+    }
+    if (threadIdx.x == 255 && k >= incl) st->failed = 1;  // rank beyond the population (NaN input)
     for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;     // ready for the next pass
 }
 
