@@ -169,10 +169,16 @@ int wt_halo_exchange(wt_plan *plan, int plane, int64_t rows);
  * flags: bit0 = allow fused multi-scale passes (default path), bit1 = skip halo exchange
  * (caller did it / virtual strips), bit2 (bilateral only) = materialise the variance plane
  * with a separate kernel instead of forming it inside the bilateral kernel, bit3 (bilateral with
- * user-defined taps only) = the plan's taps are stored reversed (see wt_plan_set_taps). */
+ * user-defined taps only) = the plan's taps are stored reversed (see wt_plan_set_taps), bit4
+ * (wt_decompose / wt_decompose_pass whose first pass is a fused pass from scale 0) = that pass
+ * also histograms the first radix level of |w_0| as it produces the plane
+ * (np.median(np.abs(data[0])), watroo/wavelets.py:127): a wt_abs_median(plan, 0, .) that follows
+ * before anything else touches plane 0 reads the plane twice instead of three times.  Same
+ * result; costs nothing measurable. */
 int wt_decompose(wt_plan *plan, int src, int level, int flags);
 /* one pass of the schedule (wt_schedule): scales [s0,s0+ns) from plane `cur` (c_{s0}) into
- * detail planes s0..s0+ns-1 and plane `nxt` (c_{s0+ns}); exchanges the pass halo first. */
+ * detail planes s0..s0+ns-1 and plane `nxt` (c_{s0+ns}); exchanges the pass halo first.
+ * flags bit4: as for wt_decompose. */
 int wt_decompose_pass(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags);
 /* wt_decompose followed by wt_plane_sum(0, level+1, dst) - the transform and its synthesis
  * np.sum(coefficients, axis=0) (watroo/wavelets.py:408-444 then watroo/utils.py:98,205) - in the

@@ -323,6 +323,7 @@ def test_with_sum_keyword_carries_the_synthesis_through_the_passes(WA):
     ("b3spline", 6, [5, 3, 2, 1], None),                    # reaches into the second pass: both first
     ("b3spline", 8, [0, 0, 0, 0, 3], None),                 # leading zeros
     ("triangle", 5, [4, 2], None),                          # schedule (0,3) (3,2)
+    ("b3spline", 6, [0, 3], [2., 1.]),                      # lazy noise AFTER plane 0 was rescaled (ref:131-132,149)
 ])
 @pytest.mark.parametrize("soft", [True, False])
 def test_denoise_between_the_passes_is_bitwise_transform_denoise_sum(WA, L, fam, level, sigma, weights, soft):
@@ -330,13 +331,18 @@ def test_denoise_between_the_passes_is_bitwise_transform_denoise_sum(WA, L, fam,
     carry the sum) == AtrousTransform -> Coefficients.denoise -> np.sum, planes and image."""
     from wavelets_amd.wavelets import _decompose_denoise_sum
     cls = {"b3spline": WA.B3spline, "triangle": WA.Triangle}[fam]
-    a = rnd((700, 1100), 91)
+    # 700 x 1100: fast addressing; 333 x 1001: ragged width, generic addressing (the first pass
+    # histograms |w_0| for the noise estimate in both)
+    H, Wd = (700, 1100) if soft else (333, 1001)
+    a = rnd((H, Wd), 91)
     ref = WA.AtrousTransform(cls)(a, level)
     ref.denoise(list(sigma), weights=weights, soft_threshold=soft)
     ref_planes = np.array(ref.data, copy=True)
     ref_sum = np.sum(ref, axis=0)
+    if sigma[0] == 0 and weights is not None:                # the corner really is one
+        assert abs(ref.noise / (WA.AtrousTransform(cls)(a, level).get_noise() * weights[0]) - 1) < 1e-6
     for write_back in (True, False):
-        plan = L.acquire_plan(L.default_context(), 700, 1100, cls._family, level)
+        plan = L.acquire_plan(L.default_context(), H, Wd, cls._family, level)
         plan.upload(L.PLANE_INPUT, a)
         c = WA.Coefficients(plan, cls(2))
         T = WA.AtrousTransform(cls)
@@ -434,3 +440,33 @@ def test_custom_taps_bilateral_nd_vs_golden(WA, name):
     bad[0, 1] *= 1.5
     with pytest.raises(NotImplementedError):
         W.atrous_convolution(a, bad, var, s=0)
+
+
+def test_noise_estimate_from_the_first_pass_histogram(WA):
+    """The first fused pass of a plain transform histograms |w_0| as it writes the plane
+    (wt_decompose flag bit4) and the next wt_abs_median of that plane starts from those bins.
+    The estimate must stay np.median(|data[0]|) (ref:126-127) exactly - with the marker, after the
+    plane has been modified, and with transforms of other images in between."""
+    def mad(c):
+        return np.median(np.abs(c.data[0])) / 0.6745 / c.sigma_e[0]
+
+    T = WA.AtrousTransform(WA.B3spline)
+    for shape, seed in (((700, 1100), 5), ((333, 1001), 6), ((2048, 4096), 7)):
+        a = rnd(shape, seed)
+        c = T(a, 4)
+        n = c.get_noise()                                   # marker path
+        assert n == mad(c)
+        assert c.get_noise() == n                           # marker consumed: the full select agrees
+        # plane 0 modified on the device: the estimate follows the plane, not the stale bins
+        c2 = T(a, 4)
+        c2.denoise([3.0])
+        assert c2.noise == n
+        c2.noise = None
+        assert c2.get_noise() == mad(c2) and c2.get_noise() != n
+        # the bins belong to the LAST transform only
+        ca, cb = T(a, 3), T(a[::-1].copy() * 2, 3)
+        assert ca.get_noise() == mad(ca)
+        assert cb.get_noise() == mad(cb)
+        # triangle family, level 2 (a two-scale first pass)
+        ct = WA.AtrousTransform(WA.Triangle)(a, 2)
+        assert ct.get_noise() == mad(ct)

@@ -18,6 +18,7 @@ TRIANGLE, B3SPLINE = 0, 1
 PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
 NUM_SCRATCH = 32
 FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE, FLAG_TAPS_REVERSED = 1, 2, 4, 8
+FLAG_MEDIAN_HIST = 16     # wt_decompose_pass: the pass histograms |w_0| for the next wt_abs_median
 
 
 def PLANE_SCRATCH(i):

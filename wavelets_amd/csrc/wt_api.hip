@@ -506,6 +506,7 @@ static int plane_base(wt_plan *p, int id, float **base)
     else if (id == WT_PLANE_OUT) slot = &p->out;
     else if (id <= WT_PLANE_SCRATCH(0) && id > WT_PLANE_SCRATCH(WT_NUM_SCRATCH)) slot = &p->scratch[-3 - id];
     else WT_FAIL("invalid plane id %d (max_level %d)", id, p->max_level);
+    if (p->ctx->prehist_plan == p && p->ctx->prehist_plane == id) p->ctx->prehist_plan = nullptr;   // plane touched
     WT_TRY(plan_alloc(p, slot));
     *base = *slot + (size_t)p->g.halo * p->g.P;
     return 0;
@@ -580,6 +581,7 @@ extern "C" int wt_plan_destroy(wt_plan *p)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) return 0;
+    if (p->ctx->prehist_plan == p) p->ctx->prehist_plan = nullptr;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     for (void *q : p->raw_allocs) (void)hipFree(q);
@@ -1285,6 +1287,27 @@ extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, i
 // planes s0..s0+ns-1 and plane `nxt` (= c_{s0+ns}).
 // acc / p_sum: 0 = plain pass; 1 / 2 = the pass also carries the plane sum in plane `p_sum`
 // (2 = last pass of the schedule: the smooth plane is added too) - fused passes only.
+// flag bit4: the fused first pass of a plain decomposition also histograms |w_0| (first radix level
+// of wt_abs_median's select).  begin: clear the bins once per entry point (a pass may be several
+// launches); end: leave the marker if the histogram variant really ran.
+static int prehist_begin(wt_plan *p, int flags)
+{
+    p->ctx->prehist_ran = false;
+    if (flags & 16) {
+        p->ctx->prehist_plan = nullptr;                  // the bins are about to be cleared
+        WT_HIP(hipMemsetAsync(p->ctx->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), p->ctx->stream));
+    }
+    return 0;
+}
+static void prehist_end(wt_plan *p)
+{
+    if (p->ctx->prehist_ran) {
+        p->ctx->prehist_plan = p;
+        p->ctx->prehist_plane = 0;
+    }
+    p->ctx->prehist_ran = false;
+}
+
 static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int flags, int acc, bool first_of_sum,
                                int p_sum, const FusedRows &rows = FusedRows())
 {
@@ -1315,13 +1338,23 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
     if (acc && first_of_sum != (s0 == 0))
         WT_FAIL("wt_decompose_pass_sum: first must be set for the pass that starts at scale 0 and only for it (got first=%d, s0=%d)", (int)first_of_sum, s0);
     if (acc) WT_TRY(plane_base(p, p_sum, &ps));
+    if (acc == 0 && (flags & 16) && s0 == 0) {
+        // plain first pass that also histograms the first radix level of |w_0| for wt_abs_median
+        // (the caller cleared the bins: a pass may be several launches)
+        p->ctx->prehist_ran = true;
+        return wt_fused_launch(p, in, oc, ow, s0, ns, 3, nullptr, nullptr, rows, p->ctx->d_hist);
+    }
     return wt_fused_launch(p, in, oc, ow, s0, ns, acc, first_of_sum ? nullptr : ps, ps, rows);
 }
 
 extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, int flags)
 {
     WtGuard guard_(ctx_of(p));
-    return decompose_pass_impl(p, cur, nxt, s0, ns, flags, 0, false, WT_PLANE_NONE);
+    if (!p) WT_FAIL("wt_decompose_pass: null plan");
+    WT_TRY(prehist_begin(p, flags));
+    WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags, 0, false, WT_PLANE_NONE));
+    prehist_end(p);
+    return 0;
 }
 
 extern "C" int wt_decompose_pass_sum(wt_plan *p, int cur, int nxt, int s0, int ns, int flags, int sum_plane, int first,
@@ -1451,7 +1484,10 @@ extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
     int np = 0;
     if (p->ntaps) flags &= ~1;          // user-defined taps: one generic pass per scale
     WT_TRY(wt_schedule(p->family, level, (flags & 1) && wt_fused_supported(p), tr, 32, &np));
-    return run_schedule(p, src, level, flags, tr, np, false, WT_PLANE_NONE);
+    WT_TRY(prehist_begin(p, flags));
+    WT_TRY(run_schedule(p, src, level, flags, tr, np, false, WT_PLANE_NONE));
+    prehist_end(p);
+    return 0;
 }
 
 extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const double *sigma_b, int bilateral_scaling, int flags)
@@ -1917,10 +1953,11 @@ extern "C" int wt_reduce(wt_plan *p, int plane, double out[4])
 
 // One histogram pass of the radix select + the device-side step that folds the selected bin into
 // the state (no host round trip: the three passes chain on the stream).
-static int select_pass(wt_plan *p, const float *b, WtSelectState *st, uint32_t prefix_mask, int shift, uint32_t bin_mask, int last)
+static int select_pass(wt_plan *p, const float *b, WtSelectState *st, uint32_t prefix_mask, int shift, uint32_t bin_mask, int last,
+                       bool have_hist = false)
 {
     wt_ctx *c = p->ctx;
-    {
+    if (!have_hist) {
         ProfScope ps(c, "wt_hist_kernel");
         hipLaunchKernelGGL(wt_hist_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, b, p->g.nrows, p->g.P / 4, p->g.W,
                            prefix_mask, (const WtSelectState *)st, shift, bin_mask, c->d_hist);
@@ -1940,6 +1977,10 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
     WtGuard guard_(ctx_of(p));
     if (!p || !median) WT_FAIL("wt_abs_median: null pointer");
     wt_ctx *c = p->ctx;
+    // a fused pass has histogrammed the first level of this plane (flag bit4 of wt_decompose /
+    // wt_decompose_pass) and nothing has touched the plane or the bins since: one pass less over it
+    const bool pre = c->prehist_plan == p && c->prehist_plane == plane;
+    c->prehist_plan = nullptr;
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
     const int64_t N = (int64_t)p->g.H * p->g.W;   // global element count
@@ -1949,8 +1990,8 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
     WtSelectState *hst = (WtSelectState *)c->h_pinned;
     hst->k = (unsigned long long)klo; hst->cum_le = 0; hst->prefix = 0; hst->failed = 0;
     WT_HIP(hipMemcpyAsync(st, hst, sizeof(WtSelectState), hipMemcpyHostToDevice, c->stream));
-    WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
-    WT_TRY(select_pass(p, b, st, 0u, 20, 0x7ffu, 0));
+    if (!pre) WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+    WT_TRY(select_pass(p, b, st, 0u, 20, 0x7ffu, 0, pre));
     WT_TRY(select_pass(p, b, st, 0x7ff00000u, 10, 0x3ffu, 0));
     WT_TRY(select_pass(p, b, st, 0x7ffffc00u, 0, 0x3ffu, 1));
     WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(WtSelectState), hipMemcpyDeviceToHost, c->stream));

@@ -61,6 +61,9 @@ struct FusedArgs {
     // a whole pass is the single range [0, nrows).  Splitting a pass into its edge rows and its
     // interior lets the halo exchange of the NEXT pass overlap with the interior (multi-GPU).
     int rlo[2], rhi[2];
+    // ACC == 3 (plain pass + first level of the exact-median select): 2048-bin histogram of the top
+    // 11 magnitude bits of the first detail plane's stored pixels, added to these global bins
+    uint32_t *hist;
     int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
@@ -195,8 +198,14 @@ template <int K, int NS, int D, int NW, int PDREQ, int ACC, bool FAST>
 #ifndef WT_FUSED_WPS4
 #define WT_FUSED_WPS4 2   // waves per SIMD requested for the 4-wave workgroup variant
 #endif
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : 2)) void wt_fused_kernel(FusedArgs a)
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 3) ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : 2)) void wt_fused_kernel(FusedArgs a)
 {
+    // ACC: 0 = plain pass; 1 / 2 = the pass carries the plane sum (2: last pass, adds the smooth
+    // plane); 3 = plain pass that also histograms |w_{s0}| (first level of wt_abs_median's select:
+    // Coefficients.get_noise reads plane 0 once less)
+    constexpr bool SUM = ACC == 1 || ACC == 2;
+    constexpr bool HIST = ACC == 3;
+    static_assert(!HIST || D == 1, "the histogram variant exists for the first pass only");
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
     constexpr int LAT_IN = hw * ((1 << NS) - 1);         // rows of input beyond a stored row
@@ -218,7 +227,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
     constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0;
     constexpr int NV = NL - HX / 2;
-    __shared__ float4 ring[ACC ? (G1 + G2) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
+    __shared__ float4 ring[SUM ? (G1 + G2) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
+
+    __shared__ uint32_t lh[HIST ? WT_HIST_BINS : 1];
+    if constexpr (HIST) {                                // (before the early exits: all waves pass the barrier)
+        for (int i = threadIdx.x; i < WT_HIST_BINS; i += NL) lh[i] = 0;
+        __syncthreads();
+    }
 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
@@ -336,8 +351,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     const __amdgpu_buffer_rsrc_t rc = plane_rsrc(a.out_c, LAGC);
     // ---- ACC state.  The first pass of a sum (D = 1, s0 = 0) has no incoming partial sum, every
     // later pass has one: decided at compile time (the host checks first == (s0 == 0)).
-    constexpr bool PIN = ACC != 0 && D != 1;
-    const __amdgpu_buffer_rsrc_t rp = plane_rsrc(ACC ? a.p_out : a.out_c, LAGC);
+    constexpr bool PIN = SUM && D != 1;
+    const __amdgpu_buffer_rsrc_t rp = plane_rsrc(SUM ? a.p_out : a.out_c, LAGC);
     unsigned koff = 0;                                   // k * step_bytes
     // incoming partial sum: the same fixed-descriptor addressing as the stores (row r0 of the chain,
     // the chunk's byte span) - a row before or after the chunk reads as 0 without touching memory
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
             if constexpr (NS > 1) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), cur);
             if constexpr (NS > 2) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), cur);
             wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), cur);
-            if constexpr (ACC != 0) {
+            if constexpr (SUM) {
                 float4 pv = cur;
                 if constexpr (PIN) {
                     pv = pa[kk % PD];
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         // without stored pixels share the spare slot NV of each ring row (their sums are never
         // stored), which keeps the ring traffic free of exec-mask branches.
         float4 old1 = zero, old2 = zero;
-        if constexpr (ACC != 0 && NS > 1) {
+        if constexpr (SUM && NS > 1) {
             old1 = ring[i1 * (NV + 1) + li];
             if constexpr (NS > 2) old2 = ring[(G1 + i2) * (NV + 1) + li];
         }
@@ -434,6 +449,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
         const float4 d0 = f4_sub(cen0, n0);
         if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
+        if constexpr (HIST) {
+            // the same predicate as the store of this row: chunk row k - (LAT_IN + LAG0) in [0, span)
+            // (wave-uniform) and a lane that owns stored pixels
+            if ((unsigned)(k - (LAT_IN + LAG0)) < span && lane_store) {
+                const uint32_t b[4] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z),
+                                       __float_as_uint(d0.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (FAST || x + j < g.W) atomicAdd(&lh[(b[j] & 0x7fffffffu) >> 20], 1u);
+            }
+        }
         if constexpr (ST_ON && (NS == 1)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
         float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
         if constexpr (NS > 1) {
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
             }
             c2 = n1;
         }
-        if constexpr (ACC != 0) {
+        if constexpr (SUM) {
             // plane-order sum of image row rho: ((p_in + w_s0) + w_s0+1) + w_s0+2 (+ c): the
             // partial sum of a row is parked in the ring until the next scale's detail row of the
             // same image row appears (G1, then G2 steps later)
@@ -509,7 +535,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
     // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
 #ifndef WT_FUSED_NO_VMPAD
     {
-        constexpr int ST = NS + 1 + (ACC ? 1 : 0);          // stores per step
+        constexpr int ST = NS + 1 + (SUM ? 1 : 0);          // stores per step
 #pragma unroll
         for (int i = 0; i < PD * ST; ++i) wt_bstore4v<0>(rc, WT_FUSED_PARKED + 16u * i, zero);   // distinct: not merged
     }
@@ -522,6 +548,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_
         }
     }
 done:;
+    if constexpr (HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < WT_HIST_BINS; i += NL)
+            if (lh[i]) atomicAdd(&a.hist[i], lh[i]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -575,7 +606,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // that minimises (dispatch rounds) x (rows per workgroup): usually ONE round with every
     // slot filled; when the x-strips x phases alone under-fill the chip (tall narrow-ish strips:
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
-    const int wg_per_cu = NW == 4 ? (K == 3 && ACC == 0 ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
+    const int wg_per_cu = NW == 4 ? (K == 3 && (ACC == 0 || ACC == 3) ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
     const int64_t nbase = (int64_t)nx * phases * nranges;
     int chunks = 1, S = n_max;
@@ -641,16 +672,19 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
 template <int K, int ACC>
 static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns, const FusedRows &rows)
 {
-    static const char *names[3][5] = {
+    static const char *names[4][5] = {
         {"wt_fused<d1x3>", "wt_fused<d1x2>", "wt_fused<d8x3>", "wt_fused<d8x2>", "wt_fused<d64x2>"},
         {"wt_fused_acc<d1x3>", "wt_fused_acc<d1x2>", "wt_fused_acc<d8x3>", "wt_fused_acc<d8x2>", "wt_fused_acc<d64x2>"},
-        {"wt_fused_sum<d1x3>", "wt_fused_sum<d1x2>", "wt_fused_sum<d8x3>", "wt_fused_sum<d8x2>", "wt_fused_sum<d64x2>"}};
+        {"wt_fused_sum<d1x3>", "wt_fused_sum<d1x2>", "wt_fused_sum<d8x3>", "wt_fused_sum<d8x2>", "wt_fused_sum<d64x2>"},
+        {"wt_fused_hist<d1x3>", "wt_fused_hist<d1x2>", "", "", ""}};
     if (s0 == 0 && ns == 3) return wt_fused_launch_t<K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0], rows);
     if (s0 == 0 && ns == 2) return wt_fused_launch_t<K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1], rows);
-    if (s0 == 3 && ns == 3) return wt_fused_launch_t<K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2], rows);
-    if (s0 == 3 && ns == 2) return wt_fused_launch_t<K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3], rows);
-    // D = 64 (scales 6-7): taps are 16 / 32 lanes apart
-    if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4], rows);
+    if constexpr (ACC != 3) {
+        if (s0 == 3 && ns == 3) return wt_fused_launch_t<K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2], rows);
+        if (s0 == 3 && ns == 2) return wt_fused_launch_t<K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3], rows);
+        // D = 64 (scales 6-7): taps are 16 / 32 lanes apart
+        if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4], rows);
+    }
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
@@ -662,7 +696,7 @@ static inline bool wt_fused_has_pass(int s0, int ns)
 // acc: see wt_fused_dispatch_acc; p_in / p_out only for acc != 0
 static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns,
                            int acc = 0, const float *p_in = nullptr, float *p_out = nullptr,
-                           const FusedRows &rows = FusedRows())
+                           const FusedRows &rows = FusedRows(), uint32_t *hist = nullptr)
 {
     FusedArgs a{};
     a.in = in;
@@ -671,7 +705,9 @@ static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **ou
     a.g = p->g;
     a.p_in = p_in;
     a.p_out = p_out;
+    a.hist = hist;
     const bool b3 = p->family == WT_B3SPLINE;
+    if (acc == 3) return b3 ? wt_fused_dispatch_acc<5, 3>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 3>(p, a, s0, ns, rows);
     if (acc == 1) return b3 ? wt_fused_dispatch_acc<5, 1>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 1>(p, a, s0, ns, rows);
     if (acc == 2) return b3 ? wt_fused_dispatch_acc<5, 2>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 2>(p, a, s0, ns, rows);
     return b3 ? wt_fused_dispatch_acc<5, 0>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 0>(p, a, s0, ns, rows);

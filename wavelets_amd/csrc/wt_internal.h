@@ -94,6 +94,13 @@ struct wt_ctx {
     int partial_blocks = 0;
     void *h_pinned = nullptr;     // 64 KiB pinned host scratch
     float *d_psf = nullptr;       // PSF taps of wt_filter2d (<= 4096 floats)
+    // Marker a fused first pass leaves when it has histogrammed the first radix level of |plane| of
+    // `prehist_plan` into d_hist (flag bit4 of wt_decompose / wt_decompose_pass).  wt_abs_median of
+    // that plane then skips its first pass over the plane.  Dropped by any access to the plane
+    // through plane_base (conservative: reads too), by any wt_abs_median and with the plan.
+    struct wt_plan *prehist_plan = nullptr;
+    int prehist_plane = 0;
+    bool prehist_ran = false;     // set by the launch of the histogram variant (per entry point)
 };
 
 #define WT_MAX_CUSTOM_TAPS 15

@@ -523,11 +523,26 @@ class Coefficients:
             touched.append(scl)
         self._refresh_host(touched)
 
+    def _lazy_noise_after_rescale(self, sigma, weights):
+        """The reference estimates the noise lazily, at the first non-zero threshold (ref:131-132),
+        from plane 0 AS IT IS THEN: with sigma[0] == 0 and weights[0] != 1 that plane has already
+        been rescaled (ref:149).  The fused forms take all thresholds first, so they leave this
+        corner to the plane-by-plane ``denoise``."""
+        pairs = list(zip(range(self._nplanes), sigma, weights))
+        return self.noise is None and len(pairs) > 1 and pairs[0][1] == 0 and pairs[0][2] != 1 \
+            and any(sig != 0 for _, sig, _ in pairs[1:])
+
     def _denoise_sum(self, sigma, weights=None, soft_threshold=True, write_back=True):
         """denoise(sigma, weights) fused with the plane sum: one pass over the planes
         (wt_denoise_sum).  Same lazy-noise / truncation rules as ``denoise``."""
         if weights is None:
             weights = (1,) * len(sigma)
+        if self._lazy_noise_after_rescale(sigma, weights):
+            self.denoise(sigma, weights, soft_threshold)                  # the reference's order
+            plan = self._plan
+            plan.plane_sum(0, self._nplanes, PLANE_OUT)
+            self._sum_valid = self._host is None
+            return plan
         plan = self._device()
         self._sum_valid = False              # PLANE_OUT becomes the DENOISED sum
         taus, wgts, noise_plane = [], [], PLANE_NONE
@@ -581,15 +596,23 @@ def _decompose_denoise_sum(transform, plan, level, coefficients, sigma, weights=
         while k < len(sched) and (covered < n_den or k == 0):
             covered += sched[k][1]
             k += 1
-    if k == 0 or k == len(sched):
+    if k == 0 or k == len(sched) or coefficients._lazy_noise_after_rescale(sigma, weights):
         transform._run(plan, level)
         coefficients._denoise_sum(sigma, weights, soft_threshold, write_back)
         return plan
     coefficients._sum_valid = False
     cur = PLANE_INPUT
+    # the MAD noise estimate (lazy in the reference, ref:131-132) will be needed iff some threshold
+    # is non-zero and no noise was given: then the first pass histograms |w_0| as it produces it
+    # and the estimate is taken right behind it (plane 0 is final by then)
+    want_noise = coefficients.noise is None and any(sig != 0 for _, sig, _ in entries[:covered])
     for i in range(k):
         nxt = PLANE_SCRATCH(i & 1)
-        plan.decompose_pass(cur, nxt, sched[i][0], sched[i][1])
+        first = i == 0 and want_noise
+        plan.decompose_pass(cur, nxt, sched[i][0], sched[i][1],
+                            FLAG_FUSED | (_lib.FLAG_MEDIAN_HIST if first else 0))
+        if first:
+            coefficients.noise = coefficients._noise_from_device()
         cur = nxt
     taus, wgts, noise_plane = [], [], PLANE_NONE
     for scl, sig, wgt in entries[:covered]:
@@ -801,7 +824,8 @@ class AtrousTransform:
 
     def _run(self, plan, level, src=PLANE_INPUT, flags=FLAG_FUSED):
         if self.bilateral is None:
-            plan.decompose(src, level, flags)                              # ref:432,442
+            # (the first fused pass also histograms |w_0| for a get_noise() that may follow)
+            plan.decompose(src, level, flags | (_lib.FLAG_MEDIAN_HIST if flags & FLAG_FUSED else 0))   # ref:432,442
         else:
             sb = self._sigma_bilateral(level)
             plan.decompose_bilateral(src, level, sb, self.bilateral_scaling, flags & ~FLAG_FUSED)
