@@ -640,7 +640,11 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     if (D == 1 && NW == 4 && wg_per_cu > 1 && wpc1_env != 0) {
         const int c2 = chunks, S2 = S;
         const double b2 = best;
-        search(std::max(64, cus - rows.reserve));
+        // (an interior launch beside a halo exchange, rows.reserve > 0: with one 4-wave workgroup
+        // per CU half of every CU's register file and LDS stays free for the RCCL kernels, so no CU
+        // is set aside - setting 16 aside costs a whole chunk per strip, 7-10 % of the pass at
+        // 32768 columns: 36 strips x 7 chunks = 252 workgroups fit 256 CUs, 6 chunks do not fill 240)
+        search(std::max(64, cus));
         if (best == 1e300 || (wpc1_env < 0 && S < 128)) { chunks = c2; S = S2; best = b2; }
     }
     if (best == 1e300) WT_FAIL("fused pass: no chunking keeps a chunk's byte span below 2 GiB");
