@@ -45,7 +45,7 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
+def algorithmic_bytes_per_pixel(kernel, level=LEVEL, interleaved=False):
     """Compulsory HBM bytes per pixel attributed to one launch of `kernel`.
 
     SURVEY 8(d): decompose = 4*(L+2) (read the input, write L+1 planes), sum = 4*(L+2) (read
@@ -55,17 +55,21 @@ def algorithmic_bytes_per_pixel(kernel, level=LEVEL):
     fold in: 4*NS, +8 in the last pass (smooth plane read, reconstruction written).  The
     intermediate smooth plane between two passes is NOT algorithmic (it is the price of the
     two-pass structure).  Shares add up to 32 (decompose) and 64 (decompose + sum) for L = 6.
-    cfg3 (108 B/pixel): the MAD select reads plane 0 once (4; the three histogram
+    cfg3 (108 B/pixel): the MAD select reads plane 0 once (4; the histogram
     launches share it), denoise([..3 sigmas..]) is 8 per thresholded plane; fused into the sum
-    kernel those 24 ride on wt_denoise_sum_kernel next to the sum's 4*(L+2).
+    kernel those 24 ride on wt_denoise_sum_kernel next to its share of the sum: all 4*(L+2) when
+    it sums every plane, 4 per thresholded plane when the threshold step runs between the fused
+    passes (`interleaved`: the accumulate passes behind it are charged the rest of the sum).
     cfg5: per-scale operators - bilateral scale 12 (read c_s, write w_s and c_{s+1}), fused wow
     update 8 (read c, write c)."""
     if kernel.startswith("wt_plane_sum"):
         return 4.0 * (level + 2)                 # read level+1 planes, write one
     if kernel.startswith("wt_denoise_sum"):
-        return 4.0 * (level + 2) + 8.0 * 3       # + RMW of the three thresholded planes
+        return (4.0 * 3 if interleaved else 4.0 * (level + 2)) + 8.0 * 3   # + RMW of the three thresholded planes
     if kernel.startswith("wt_hist"):
-        return 4.0 / 3.0                         # three launches share the one compulsory read
+        # the launches of a select share the one compulsory read (two when the first level rides
+        # on the transform's first pass, three otherwise)
+        return 4.0 / (2.0 if interleaved else 3.0)
     if kernel.startswith("wt_signif"):
         return 8.0
     if kernel.startswith("wt_bilateral"):
@@ -374,7 +378,8 @@ def main():
         """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
         fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
         its bytes are per STEP; every other kernel's are per launch."""
-        bpp = algorithmic_bytes_per_pixel(name, level)
+        bpp = algorithmic_bytes_per_pixel(name, level, interleaved=any(
+            k.startswith("wt_fused_hist") for k in prof))
         if bpp is None:
             return None
         return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)
