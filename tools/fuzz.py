@@ -147,6 +147,31 @@ def main():
             if coef_w.data.shape != ref_p.shape or bad.any() or badr.any():
                 fails += 1
                 print(f"FAIL {tag}: wow({kw}) {int(bad.sum())} plane / {int(badr.sum())} image pixels beyond tolerance")
+        # MAD noise estimate + denoise (the first fused pass histograms |w_0|; threshold step between
+        # the passes) against np.median / the C oracle's planes
+        if H * Wd >= 2:
+            cls = W.B3spline if fam == "b3spline" else W.Triangle
+            lev = min(level, len(cls(2).sigma_e()) - 1)
+            c = W.AtrousTransform(cls)(a, lev)
+            n_got = c.get_noise()
+            n_ref = np.median(np.abs(ref[0])) / 0.6745 / cls(2).sigma_e()[0]
+            planes0 = c.data[0]
+            n_own = np.median(np.abs(planes0)) / 0.6745 / cls(2).sigma_e()[0]
+            if n_got != n_own or not abs(n_got - n_ref) <= 2e-5 * max(abs(n_ref), 1e-30) + 1e-6:
+                fails += 1
+                print(f"FAIL {tag}: get_noise {n_got!r} vs own plane {n_own!r} vs oracle {n_ref!r}")
+            nsig = int(rng.integers(1, lev + 1))
+            sig = [float(x) for x in rng.choice([0., 1., 2., 3., 5.], nsig)]
+            soft = bool(rng.integers(0, 2))
+            got_d = W.denoise(a, sig, cls, soft_threshold=soft)
+            cd = O.Coeffs(cref.decompose(a, len(sig), fam), fam)
+            cd.denoise(sig, soft_threshold=soft)
+            ref_d = np.sum(cd.data, axis=0)
+            bad = np.abs(got_d - ref_d) > 3e-5 * max(1.0, float(np.abs(a).max()))
+            # a hard threshold may flip for coefficients within rounding of tau
+            if bad.sum() > (0 if soft else max(2, a.size // 20000)):
+                fails += 1
+                print(f"FAIL {tag}: denoise(sigma={sig}, soft={soft}) {int(bad.sum())} pixels beyond tolerance")
         if case % 5 == 0 and H * Wd < 400000 and level <= 6:
             r = W.AtrousTransform(W.B3spline if fam == "b3spline" else W.Triangle)(a, level, recursive=True)
             e = float(np.abs(r.data - O.atrous_recursive(a, level, fam)).max())
