@@ -114,6 +114,63 @@ __device__ __forceinline__ float4 wt_hfilter_lds(const float4 *vrow, int gl, flo
     }
 }
 
+// Experiment (-DWT_FUSED_WAVEAUTO, D = 1 passes): WAVE-AUTONOMOUS horizontal taps.  Every wave
+// covers its own 256 pixels including 4 halo lanes per side (the cumulative x halo of three scales
+// at D = 1 is 14 px), neighbouring lanes' values come through DPP wave shifts, there is no LDS row
+// and no barrier.  Same taps in the same order as wt_hfilter_lds: identical bits on the lanes
+// that store.  DESIGN.md 3.1 has the measurement.
+#ifdef WT_FUSED_WAVEAUTO
+#define WT_FUSED_WA 1
+#else
+#define WT_FUSED_WA 0
+#endif
+__device__ __forceinline__ float wt_dpp_from_prev(float v)   // lane i <- lane i-1 (wave_shr:1)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wt_dpp_from_next(float v)   // lane i <- lane i+1 (wave_shl:1)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float4 wt_dpp4_prev(float4 v)
+{
+    return make_float4(wt_dpp_from_prev(v.x), wt_dpp_from_prev(v.y), wt_dpp_from_prev(v.z), wt_dpp_from_prev(v.w));
+}
+__device__ __forceinline__ float4 wt_dpp4_next(float4 v)
+{
+    return make_float4(wt_dpp_from_next(v.x), wt_dpp_from_next(v.y), wt_dpp_from_next(v.z), wt_dpp_from_next(v.w));
+}
+template <int K, int SHIFT_PX>
+__device__ __forceinline__ float4 wt_hfilter_dpp(float4 own)
+{
+    constexpr int hw = K / 2;
+    static_assert(SHIFT_PX == 1 || SHIFT_PX == 2 || SHIFT_PX == 4, "D = 1 passes only");
+    const float4 L = wt_dpp4_prev(own), R = wt_dpp4_next(own);
+    if constexpr (SHIFT_PX == 4) {
+        float4 nb[5] = {own, own, own, own, own};       // lanes -2 .. +2
+        nb[1] = L; nb[3] = R;
+        if constexpr (hw == 2) { nb[0] = wt_dpp4_prev(L); nb[4] = wt_dpp4_next(R); }
+        float4 acc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float4 v = nb[2 + j - hw];
+            acc = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, acc);
+        }
+        return acc;
+    } else {
+        const float e[12] = {L.x, L.y, L.z, L.w, own.x, own.y, own.z, own.w, R.x, R.y, R.z, R.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float acc = wt_tap<K>(0) * e[4 + k - hw * SHIFT_PX];
+#pragma unroll
+            for (int j = 1; j < K; ++j) acc = fmaf(wt_tap<K>(j), e[4 + k + (j - hw) * SHIFT_PX], acc);
+            o[k] = acc;
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // vertical window of scale A: 2^A interleaved sub-chains, K-1 stored rows each
 template <int K, int A>
 struct VWin {
@@ -238,7 +295,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
     const int X0 = blockIdx.x * a.Vx;                    // first valid pixel of this x-strip
-    const int x = X0 - HX + 4 * gl;                      // this lane's first pixel (may be < 0)
+    constexpr bool WA = WT_FUSED_WA && D == 1;           // wave-autonomous horizontal taps (experiment)
+    const int wa_ln = gl & 63, wa_vw = a.Vx / NW;        // lane in the wave; stored pixels per wave
+    const int x = WA ? X0 + (gl >> 6) * wa_vw - 16 + 4 * wa_ln
+                     : X0 - HX + 4 * gl;                 // this lane's first pixel (may be < 0)
     const int item = blockIdx.y;
     const int q = item % D;                              // chain phase
     const int chunk = item / D;
@@ -253,7 +313,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
 
     // lanes that own stored pixels; a float4 that straddles W writes into the row's pitch
     // padding (allocated, never read as image data)
-    const bool lane_store = (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
+    const bool lane_store = WA ? (wa_ln >= 4 && 4 * (wa_ln - 4) < wa_vw && x < g.W)
+                               : (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
     const unsigned voff = lane_store ? (unsigned)x * 4u : WT_FUSED_PARKED;
     const int row_bytes = g.P * 4;
     // Every lane issues ONE aligned in-bounds dwordx4 per row.
@@ -436,17 +497,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         }
         float4 cen0, cen1, cen2, v0, v1, v2;
         v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
-        buf[0][gl] = v0;
+        if constexpr (!WA) buf[0][gl] = v0;
         if constexpr (NS > 1) {
             v1 = wt_fused_vstage<K, A1>(w1, kk, c1, cen1);
-            buf[A1][gl] = v1;
+            if constexpr (!WA) buf[A1][gl] = v1;
         }
         if constexpr (NS > 2) {
             v2 = wt_fused_vstage<K, A2>(w2, kk, c2, cen2);
-            buf[A2][gl] = v2;
+            if constexpr (!WA) buf[A2][gl] = v2;
         }
-        __syncthreads();
-        const float4 n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
+        if constexpr (!WA) __syncthreads();
+        float4 n0;
+        if constexpr (WA) n0 = wt_hfilter_dpp<K, (D <= 4 ? D : 4)>(v0);
+        else n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
         const float4 d0 = f4_sub(cen0, n0);
         if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
         if constexpr (HIST) {
@@ -463,12 +526,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         if constexpr (ST_ON && (NS == 1)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
         float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
         if constexpr (NS > 1) {
-            n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
+            if constexpr (WA) n1 = wt_hfilter_dpp<K, ((D << A1) <= 4 ? (D << A1) : 4)>(v1);
+            else n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
             d1 = f4_sub(cen1, n1);
             if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
             if constexpr (ST_ON && (NS == 2)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
             if constexpr (NS > 2) {
-                n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
+                if constexpr (WA) n2 = wt_hfilter_dpp<K, ((D << A2) <= 4 ? (D << A2) : 4)>(v2);
+                else n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
                 d2 = f4_sub(cen2, n2);
                 if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
                 if constexpr (ST_ON) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
@@ -582,7 +647,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     constexpr int LAT = hw * ((1 << NS) - 1) + (NS - 1);
     constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
     constexpr int NL = NW * 64;
-    constexpr int VXMAX = NL * 4 - 2 * HX;               // widest valid strip per WG
+    constexpr int VXMAX = (WT_FUSED_WA && D == 1) ? NW * 56 * 4     // 56 storing lanes per wave
+                                                  : NL * 4 - 2 * HX; // widest valid strip per WG
     constexpr int UMAX = (K - 1) << (NS - 1);
     static_assert(VXMAX >= 64, "workgroup too narrow for this halo");
     const Geo &g = p->g;
