@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 3
+#define WT_ABI_VERSION 4
 
 typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
 typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */
@@ -287,6 +287,44 @@ int wt_mrs_update(wt_plan *plan, int plane, int mrs_plane, double tau, int soft,
 /* generalized_anscombe (watroo/wavelets.py:14-21) */
 int wt_anscombe(wt_plan *plan, int src, int dst, float alpha, float g, float sigma,
                 int inverse);
+
+/* ---- float64 engine ------------------------------------------------------------------------
+ * The reference computes float64 inputs in float64 and promotes int / big-endian inputs to
+ * float64 (watroo/wavelets.py:297,319-320).  A wt_plan64 holds double planes (same plane ids as a
+ * wt_plan: 0..max_level, WT_PLANE_INPUT, WT_PLANE_OUT, 8 scratch planes; scratch 5-7 are used
+ * internally) and runs the standard decomposition without bilateral filtering and the
+ * Coefficients operators in double arithmetic on generic kernels with the given 1-D taps
+ * (cv2.filter2D's correlation order).  Single GPU, whole images.  `depth`: 0 = an H x W image (a
+ * 1 x N image is a signal: no column pass; its 'mirror' border is border mode 2), Z > 0 = a
+ * (Z, Y, X) cube stored as a (Z*Y) x X image (watroo/wavelets.py:46-63). */
+typedef struct wt_plan64 wt_plan64;
+int wt64_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int max_level, const double *taps,
+                     int ntaps, wt_plan64 **plan);
+int wt64_plan_destroy(wt_plan64 *plan);
+int wt64_plan_set_border(wt_plan64 *plan, int border);
+int wt64_upload(wt_plan64 *plan, int plane, const double *host, int64_t host_pitch);
+int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
+/* AtrousTransform.atrous_standard (watroo/wavelets.py:408-444) */
+int wt64_decompose(wt_plan64 *plan, int src, int level, int depth);
+/* convolution(arr, scaling_function, s) (watroo/wavelets.py:35-69); square_input: of src*src */
+int wt64_smooth(wt_plan64 *plan, int src, int dst, int s, int square_input, int depth);
+/* sdev_loc (watroo/wavelets.py:24-32) times f1 then f2; images */
+int wt64_local_variance(wt_plan64 *plan, int src, int dst, int s, double f1, double f2,
+                        int take_sqrt);
+/* np.median(np.abs(plane)) (watroo/wavelets.py:127): exact 63-bit radix select */
+int wt64_abs_median(wt_plan64 *plan, int plane, double *median);
+/* mode 0: dst = Coefficients.significance (watroo/wavelets.py:129-143); mode 1: dst = src * (wgt *
+ * significance) (Coefficients.denoise with dst = src, :145-149).  tau <= 0: significance one;
+ * noise_plane: per-pixel noise map multiplying tau, or WT_PLANE_NONE */
+int wt64_significance(wt_plan64 *plan, int src, int dst, double tau, double wgt, int soft,
+                      int noise_plane, int mode);
+/* np.sum(planes[first..first+count), axis=0) in plane order (watroo/utils.py:98) */
+int wt64_plane_sum(wt_plan64 *plan, int first, int count, int dst);
+/* dst = a OP b: 0 add, 1 sub, 2 mul, 3 div */
+int wt64_binary(wt_plan64 *plan, int op, int a, int b, int dst);
+/* generalized_anscombe (watroo/wavelets.py:14-21) */
+int wt64_anscombe(wt_plan64 *plan, int src, int dst, double alpha, double g, double sigma,
+                  int inverse);
 
 #ifdef __cplusplus
 }

@@ -407,6 +407,71 @@ def g19_custom_bilateral_nd():
     save("g19_custom_bilateral_nd", "bilateral taps: hard (numpy); smoothing: semantic(cv2 stand-in), 1-D scipy", **out)
 
 
+def g20_float64():
+    """float64 and integer inputs: the reference computes them in float64 (wavelets.py:297,
+    319-320).  Pins the float64 engine at double-precision tolerance."""
+    from watroo.wavelets import AbstractScalingFunction, sdev_loc
+    from watroo.utils import enhance
+
+    class Skew5(AbstractScalingFunction):
+        coefficients_1d = np.array([0.05, 0.25, 0.4, 0.2, 0.1])
+        sigma_e_1d = np.array([0.7, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.9, 0.2, 0.09, 0.04, 0.02, 0.01])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('skew5', *args, **kwargs)
+
+    rng = np.random.default_rng(201)
+    out = {}
+    a = rng.standard_normal((45, 57)) * 1e3 + 1e5 + 50 * np.sin(np.arange(57) / 5.)[None, :]   # large offset: float32 would lose it
+    sig = rng.standard_normal(200) + 1e4
+    cube = rng.standard_normal((8, 12, 14))
+    pos = np.abs(rng.standard_normal((30, 34))) * 20 + 5
+    ints = rng.integers(0, 60000, (40, 36)).astype(np.int32)
+    u16 = rng.integers(0, 65535, (33, 29)).astype(np.uint16)
+    out.update(img=a, sig=sig, cube=cube, pos=pos, ints=ints, u16=u16)
+    assert a.dtype == np.float64
+    for fam, cls in FAM.items():
+        out[f"{fam}_coef2_L3"] = AtrousTransform(cls)(a, 3).data
+        out[f"{fam}_coef2_L5"] = AtrousTransform(cls)(a, 5).data
+        out[f"{fam}_coef1_L3"] = AtrousTransform(cls)(sig, 3).data
+        out[f"{fam}_coef3_L2"] = AtrousTransform(cls)(cube, 2).data
+        out[f"{fam}_ints_L3"] = AtrousTransform(cls)(ints, 3).data
+        out[f"{fam}_conv2_s2"] = convolution(a, cls(2), s=2)
+        out[f"{fam}_conv1_s1"] = convolution(sig, cls(1), s=1)
+        out[f"{fam}_conv3_s1"] = convolution(cube, cls(3), s=1)
+        out[f"{fam}_sdev_s1"] = sdev_loc(a, cls(2), s=1)
+        out[f"{fam}_var_s0"] = sdev_loc(a, cls(2), s=0, variance=True)
+        out[f"{fam}_den2"] = denoise(a.copy(), [5, 3], cls)
+        out[f"{fam}_den2_hard"] = denoise(a.copy(), [3, 2, 1], cls, soft_threshold=False)
+        out[f"{fam}_den1"] = denoise(sig.copy(), [4, 2], cls)
+        out[f"{fam}_den3"] = denoise(cube.copy(), [4, 2], cls)
+    out["u16_coef_L2"] = AtrousTransform(B3spline)(u16, 2).data
+    c = AtrousTransform(B3spline)(a, 4)
+    assert c.data.dtype == np.float64
+    out["noise"] = np.float64(c.get_noise())
+    out["sig_soft_s1"] = c.significance(3.0, 1)
+    out["sig_hard_s0"] = c.significance(2.0, 0, soft_threshold=False)
+    c.denoise([5, 3, 2], weights=[1, .5, 2])
+    out["den_planes"] = c.data
+    cm = AtrousTransform(Triangle)(a, 3)
+    cm.noise = (1 + np.abs(rng.standard_normal(a.shape))) * 900.0            # per-pixel noise map
+    out["noise_map"] = cm.noise
+    cm.denoise([3, 2])
+    out["den_planes_noise_map"] = cm.data
+    out["den_pos_anscombe"] = denoise(pos.copy(), [4, 2], anscombe=True)
+    out["ans_pos"] = generalized_anscombe(pos)
+    out["ans_pos_inv"] = generalized_anscombe(out["ans_pos"], inverse=True)
+    out["enh"] = enhance(a.copy(), weights=[.5, 2, 1], denoise=[4, 2])
+    out["skew5_coef2_L2"] = AtrousTransform(Skew5)(a, 2).data
+    out["skew5_coef1_L2"] = AtrousTransform(Skew5)(sig, 2).data
+    out["skew5_den2"] = denoise(a.copy(), [4, 2], Skew5)
+    for k, v in out.items():
+        if k not in ("ints", "u16", "sig_hard_s0", "noise"):
+            assert np.asarray(v).dtype == np.float64, (k, np.asarray(v).dtype)
+    save("g20_float64", "1-D: hard (numpy + scipy); 2-D / 3-D: semantic(cv2 stand-in), float64", **out)
+
+
 def g14_wow_denoise_nd():
     """wow / denoise on 1-D signals and (Z, Y, X) cubes (the reference is ndim-generic)."""
     out = {}
@@ -581,3 +646,4 @@ if __name__ == "__main__":
         g17_rl_fft_odd_height()
         g18_recursive_nd_bilateral()
         g19_custom_bilateral_nd()
+        g20_float64()

@@ -22,7 +22,7 @@ def built():
 def header_symbols():
     txt = open(os.path.join(ROOT, "include", "watroo_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(wt_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(wt(?:64)?_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libwatroo_hip.so lacks {n}"
     assert sorted(_lib.SIGNATURES) == names       # python binding covers the whole header
-    assert _lib.load().wt_abi_version() == 3
+    assert _lib.load().wt_abi_version() == 4
 
 
 def test_schedule_host_logic():

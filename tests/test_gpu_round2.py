@@ -470,3 +470,88 @@ def test_noise_estimate_from_the_first_pass_histogram(WA):
         # triangle family, level 2 (a two-scale first pass)
         ct = WA.AtrousTransform(WA.Triangle)(a, 2)
         assert ct.get_noise() == mad(ct)
+
+
+def test_float64_engine_vs_golden(WA):
+    """g20 (the reference's own float64 output): float64 and integer inputs are computed in float64
+    (ref wavelets.py:297,319-320) on the float64 engine (wt_plan64) - standard transform of images,
+    signals and cubes, Coefficients operators, denoise / enhance, convolution, sdev_loc, Anscombe,
+    user-defined taps.  Tolerance: double-precision rounding (1e-12 relative; the image carries an
+    offset of 1e5 with unit-scale structure that float32 arithmetic cannot hold)."""
+    from conftest import load_golden
+    from wavelets_amd import _lib as L
+    g = load_golden("g20_float64")
+    a, sig, cube, pos, ints, u16 = (g[k] for k in ("img", "sig", "cube", "pos", "ints", "u16"))
+    amax = float(np.abs(a).max())
+    tol = 1e-12 * amax
+    for fam, cls in (("b3spline", WA.B3spline), ("triangle", WA.Triangle)):
+        T = WA.AtrousTransform(cls)
+        c = T(a, 3)
+        assert isinstance(c._plan, L.Plan64) and c.data.dtype == np.float64
+        close(c.data, g[f"{fam}_coef2_L3"], tol)
+        close(T(a, 5).data, g[f"{fam}_coef2_L5"], tol)
+        close(T(sig, 3).data, g[f"{fam}_coef1_L3"], 1e-12 * float(np.abs(sig).max()))
+        close(T(cube, 2).data, g[f"{fam}_coef3_L2"], 1e-13)
+        ci = T(ints, 3)
+        assert ci.data.dtype == np.float64
+        close(ci.data, g[f"{fam}_ints_L3"], 1e-10)
+        close(WA.convolution(a, cls(2), s=2), g[f"{fam}_conv2_s2"], tol)
+        close(WA.convolution(sig, cls(1), s=1), g[f"{fam}_conv1_s1"], 1e-12 * float(np.abs(sig).max()))
+        close(WA.convolution(cube, cls(3), s=1), g[f"{fam}_conv3_s1"], 1e-13)
+        # sdev_loc: a variance of ~1e6 out of second moments of ~1e10: cancellation, both sides
+        close(WA.sdev_loc(a, cls(2), s=1), g[f"{fam}_sdev_s1"], 1e-6)
+        close(WA.sdev_loc(a, cls(2), s=0, variance=True), g[f"{fam}_var_s0"], 1e-3)
+        close(WA.denoise(a.copy(), [5, 3], cls), g[f"{fam}_den2"], 10 * tol)
+        got = WA.denoise(a.copy(), [3, 2, 1], cls, soft_threshold=False)
+        assert (np.abs(got - g[f"{fam}_den2_hard"]) > 10 * tol).sum() <= 2      # threshold ties
+        close(WA.denoise(sig.copy(), [4, 2], cls), g[f"{fam}_den1"], 1e-11 * float(np.abs(sig).max()))
+        close(WA.denoise(cube.copy(), [4, 2], cls), g[f"{fam}_den3"], 1e-12)
+    close(WA.AtrousTransform(WA.B3spline)(u16, 2).data, g["u16_coef_L2"], 1e-10)
+    c = WA.AtrousTransform(WA.B3spline)(a, 4)
+    assert c.get_noise() == np.median(np.abs(c.data[0])) / 0.6745 / c.sigma_e[0]     # exact select
+    assert abs(c.get_noise() - g["noise"]) <= 1e-11 * g["noise"]
+    s1 = c.significance(3.0, 1)
+    assert s1.dtype == np.float64
+    close(s1, g["sig_soft_s1"], 1e-11)
+    h0 = c.significance(2.0, 0, soft_threshold=False)
+    assert h0.dtype == bool and (h0 != g["sig_hard_s0"]).sum() <= 1
+    c.denoise([5, 3, 2], weights=[1, .5, 2])
+    close(c.data, g["den_planes"], 20 * tol)
+    close(np.sum(c, axis=0), g["den_planes"].sum(axis=0), 20 * tol)
+    cm = WA.AtrousTransform(WA.Triangle)(a, 3)
+    cm.noise = g["noise_map"]
+    cm.denoise([3, 2])
+    close(cm.data, g["den_planes_noise_map"], 20 * tol)
+    close(WA.denoise(pos.copy(), [4, 2], anscombe=True), g["den_pos_anscombe"], 1e-11 * float(pos.max()))
+    close(WA.generalized_anscombe(pos), g["ans_pos"], 1e-12)
+    close(WA.generalized_anscombe(g["ans_pos"], inverse=True), g["ans_pos_inv"], 1e-11)
+    from wavelets_amd.utils import enhance
+    close(enhance(a.copy(), weights=[.5, 2, 1], denoise=[4, 2]), g["enh"], 20 * tol)
+
+    class Skew5(WA.AbstractScalingFunction):
+        coefficients_1d = np.array([0.05, 0.25, 0.4, 0.2, 0.1])
+        sigma_e_1d = np.array([0.7, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.9, 0.2, 0.09, 0.04, 0.02, 0.01])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('skew5', *args, **kwargs)
+
+    close(WA.AtrousTransform(Skew5)(a, 2).data, g["skew5_coef2_L2"], tol)
+    close(WA.AtrousTransform(Skew5)(sig, 2).data, g["skew5_coef1_L2"], 1e-12 * float(np.abs(sig).max()))
+    close(WA.denoise(a.copy(), [4, 2], Skew5), g["skew5_den2"], 10 * tol)
+    # operators of the float32 engine on a float64 object: float64 containers, float32 precision
+    cw = WA.AtrousTransform(WA.B3spline)(a - 1e5, 3)
+    r, c2 = WA.wow(cw)
+    assert c2 is cw and r.dtype == np.float64 and cw.data.dtype == np.float64
+    assert isinstance(cw._plan, L.Plan)
+    r_ref, _ = WA.wow((a - 1e5).astype(np.float32), n_scales=3)
+    close(r, r_ref, 1e-4 * float(np.abs(r_ref).max()))
+    # median on an even and an odd number of samples, ties and zeros, in float64
+    for shape in ((64, 64), (63, 65), (1, 7)):
+        z = np.random.default_rng(3).standard_normal(shape)
+        z[::3] = 0.0
+        z[1::5] = z[0, 0]
+        p64 = L.Plan64(L.default_context(), shape[0], shape[1], (1.0,), 0)
+        p64.upload(0, z)
+        assert p64.abs_median(0) == np.median(np.abs(z))
+        p64.close()

@@ -436,3 +436,29 @@ def test_custom_taps_bilateral_nd_vs_reference(name):
     close(O.atrous_recursive_nd(a, 2, fam, 1), g[f"{name}_rec2_b1_L2"], tol)
     close(O.atrous_recursive_nd(sig, 2, fam, 1), g[f"{name}_rec1_b1_L2"], tol)
     close(O.atrous_recursive_nd(cube, 2, fam), g[f"{name}_rec3_L2"], tol)
+
+
+def test_float64_and_integer_inputs_vs_reference():
+    """g20: the reference computes float64 / integer inputs in float64 (wavelets.py:297,319-320);
+    the oracle is dtype-generic and must follow to double-precision rounding."""
+    g = load_golden("g20_float64")
+    a, sig, cube, ints = g["img"], g["sig"], g["cube"], g["ints"]
+    assert a.dtype == np.float64 and ints.dtype == np.int32
+    tol = 1e-12 * np.abs(a).max()
+    for fam in FAMS:
+        got = O.atrous_standard(a, 3, fam)
+        assert got.dtype == np.float64
+        close(got, g[f"{fam}_coef2_L3"], tol)
+        close(O.atrous_standard(a, 5, fam), g[f"{fam}_coef2_L5"], tol)
+        close(O.atrous_standard_nd(sig, 3, fam), g[f"{fam}_coef1_L3"], 1e-12 * np.abs(sig).max())
+        close(O.atrous_standard_nd(cube, 2, fam), g[f"{fam}_coef3_L2"], 1e-13)
+        gi = O.atrous_standard(ints, 3, fam)
+        assert gi.dtype == np.float64
+        close(gi, g[f"{fam}_ints_L3"], 1e-10)
+        close(O.convolution(a, fam, 2), g[f"{fam}_conv2_s2"], tol)
+        close(O.denoise(a.copy(), [5, 3], fam), g[f"{fam}_den2"], tol)
+        close(O.denoise(sig.copy(), [4, 2], fam), g[f"{fam}_den1"], 1e-12 * np.abs(sig).max())
+    c = O.Coeffs(O.atrous_standard(a, 4, "b3spline"), "b3spline")
+    assert abs(c.get_noise() - g["noise"]) <= 1e-12 * g["noise"]
+    close(c.significance(3.0, 1), g["sig_soft_s1"], 1e-12)
+    close(O.generalized_anscombe(g["pos"]), g["ans_pos"], 1e-12)

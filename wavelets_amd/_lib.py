@@ -113,6 +113,24 @@ SIGNATURES = {
                                  _c.c_int, _c.c_float]),
     "wt_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                _c.c_int]),
+    # float64 engine (wt_plan64)
+    "wt64_plan_create": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.POINTER(_c.c_double), _c.c_int,
+                                    _c.POINTER(_vp)]),
+    "wt64_plan_destroy": (_c.c_int, [_vp]),
+    "wt64_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
+    "wt64_upload": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double), _i64]),
+    "wt64_download": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double), _i64]),
+    "wt64_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
+                                       _c.c_double, _c.c_int]),
+    "wt64_abs_median": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
+    "wt64_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int,
+                                     _c.c_int, _c.c_int]),
+    "wt64_plane_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
+                                 _c.c_int]),
 }
 
 _lib = None
@@ -132,7 +150,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = res, args
-            if L.wt_abi_version() != 3:
+            if L.wt_abi_version() != 4:
                 raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
             _lib = L
     return _lib
@@ -245,7 +263,7 @@ def _shutdown():
     _host_pool.close()
     objs = list(_live)
     for o in objs:
-        if isinstance(o, Plan):
+        if isinstance(o, (Plan, Plan64)):
             o.close()
     for o in objs:
         if isinstance(o, Context):
@@ -570,10 +588,134 @@ _pool = []            # [(key, plan)] most recently released last
 
 
 def _plan_bytes(plan):
-    return (plan.nrows + 2 * plan.halo) * plan.pitch * 4 * (plan.max_level + 1 + 2 + 4)
+    return (plan.nrows + 2 * plan.halo) * plan.pitch * (8 if isinstance(plan, Plan64) else 4) * (plan.max_level + 1 + 2 + 4)
 
 
 _pool_lock = threading.RLock()      # plan pool and default contexts are shared by host threads
+
+
+_dp = _c.POINTER(_c.c_double)
+
+
+class Plan64:
+    """Double-precision planes of one image: wt_plan64, the float64 engine (the reference computes
+    float64 / promoted inputs in float64, ref wavelets.py:297,319-320).  Same plane ids and, for the
+    operators it has, the same method names as ``Plan``; taps are always given (the built-in
+    families pass theirs).  Standard decomposition without bilateral filtering, Coefficients
+    operators, convolution, sdev_loc, Anscombe."""
+
+    dtype = np.float64
+    custom = True            # generic kernels with run-time taps: no fused passes
+    rank, nranks, row0, halo = 0, 1, 0, 0
+
+    def __init__(self, ctx, H, W, taps, max_level):
+        self._h = _vp()
+        self.ctx = ctx
+        self.family = tuple(float(t) for t in taps)
+        arr = (_c.c_double * len(self.family))(*self.family)
+        check(load().wt64_plan_create(ctx._h, H, W, max_level, arr, len(self.family),
+                                      _c.byref(self._h)))
+        self.H, self.W, self.nrows, self.max_level = H, W, H, max_level
+        self.pitch = (W + 1) // 2 * 2
+        _live.add(self)
+
+    def close(self):
+        if self._h:
+            load().wt64_plan_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def shape(self):
+        return (self.H, self.W)
+
+    def upload(self, plane, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        if host.shape != self.shape:
+            raise ValueError(f"image shape {host.shape} != plan shape {self.shape}")
+        check(load().wt64_upload(self._h, plane, host.ctypes.data_as(_dp), host.shape[1]))
+
+    def download(self, plane, out=None):
+        if out is None:
+            out = np.empty(self.shape, np.float64)
+        assert out.dtype == np.float64 and out.shape == self.shape and out.strides[1] == 8
+        check(load().wt64_download(self._h, plane, out.ctypes.data_as(_dp), out.strides[0] // 8))
+        return out
+
+    def set_border(self, border):
+        check(load().wt64_plan_set_border(self._h, int(border)))
+
+    def fused_ok(self, level):
+        return False
+
+    def decompose(self, src, level, flags=0):
+        check(load().wt64_decompose(self._h, src, level, 0))
+
+    def decompose3d(self, src, level, depth):
+        check(load().wt64_decompose(self._h, src, level, depth))
+
+    def smooth(self, src, dst, s, square_input=False, flags=0):
+        check(load().wt64_smooth(self._h, src, dst, s, int(square_input), 0))
+
+    def smooth3d(self, src, dst, s, depth):
+        check(load().wt64_smooth(self._h, src, dst, s, 0, depth))
+
+    def local_variance(self, src, dst, s, f1=1.0, f2=1.0, take_sqrt=False, flags=0):
+        check(load().wt64_local_variance(self._h, src, dst, s, f1, f2, int(take_sqrt)))
+
+    def abs_median(self, plane):
+        m = _c.c_double(0)
+        check(load().wt64_abs_median(self._h, plane, _c.byref(m)))
+        return np.float64(m.value)
+
+    def significance(self, src, dst, tau, soft=True, noise_plane=PLANE_NONE):
+        check(load().wt64_significance(self._h, src, dst, tau, 1.0, int(soft), noise_plane, 0))
+
+    def denoise(self, plane, tau, weight=1.0, soft=True, noise_plane=PLANE_NONE):
+        check(load().wt64_significance(self._h, plane, plane, tau, weight, int(soft), noise_plane, 1))
+
+    def wow_update(self, plane, power_plane, tau, soft, noise_plane, factor, gamma_plane):
+        """Only the form Coefficients.denoise needs: plane *= factor * significance."""
+        if power_plane != PLANE_NONE or gamma_plane != PLANE_NONE:
+            raise NotImplementedError("float64 plans implement the plain threshold update only")
+        check(load().wt64_significance(self._h, plane, plane, tau, float(factor), int(soft),
+                                       noise_plane, 1))
+
+    def denoise_sum(self, n, taus, wgts, soft, noise_plane=PLANE_NONE, write_back=True, dst=PLANE_OUT):
+        """Coefficients.denoise over the first len(taus) planes, then the plane sum (two steps
+        here; the planes are always written back)."""
+        for s, (tau, wgt) in enumerate(zip(taus, wgts)):
+            if tau > 0 or wgt != 1:
+                self.denoise(s, tau, wgt, soft, noise_plane)
+        self.plane_sum(0, n, dst)
+
+    def plane_sum(self, first, count, dst=PLANE_OUT):
+        check(load().wt64_plane_sum(self._h, first, count, dst))
+
+    def binary(self, op, a, b, dst):
+        code = {"add": 0, "sub": 1, "mul": 2, "div": 3}[op]
+        check(load().wt64_binary(self._h, code, a, b, dst))
+
+    def anscombe(self, src, dst, alpha=1, g=0, sigma=0, inverse=False):
+        check(load().wt64_anscombe(self._h, src, dst, alpha, g, sigma, int(inverse)))
+
+
+def acquire_plan64(ctx, H, W, taps, max_level):
+    """Pooled float64 plan (same pool and eviction rule as the float32 plans)."""
+    taps = tuple(float(t) for t in taps)
+    key = (id(ctx), H, W, ("f64",) + taps, max_level)
+    with _pool_lock:
+        for i in range(len(_pool) - 1, -1, -1):
+            if _pool[i][0] == key:
+                plan = _pool.pop(i)[1]
+                plan.set_border(0)
+                return plan
+    return Plan64(ctx, H, W, taps, max_level)
 
 
 def acquire_plan(ctx, H, W, family, max_level):
@@ -593,8 +735,9 @@ def release_plan(plan):
     if plan is None or not plan._h or plan.nranks != 1:
         return
     evicted = []
+    fam = ("f64",) + plan.family if isinstance(plan, Plan64) else plan.family
     with _pool_lock:
-        _pool.append(((id(plan.ctx), plan.H, plan.W, plan.family, plan.max_level), plan))
+        _pool.append(((id(plan.ctx), plan.H, plan.W, fam, plan.max_level), plan))
         total = sum(_plan_bytes(p) for _, p in _pool)
         while _pool and (total > _POOL_MAX_BYTES or len(_pool) > 8):
             _, old = _pool.pop(0)

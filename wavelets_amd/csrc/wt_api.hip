@@ -250,7 +250,7 @@ extern "C" int wt_ctx_create(int device, wt_ctx **out)
     WT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     WT_HIP(hipEventCreate(&c->t0));
     WT_HIP(hipEventCreate(&c->t1));
-    WT_HIP(hipMalloc(&c->d_hist, (WT_HIST_BINS + 16) * sizeof(uint32_t)));
+    WT_HIP(hipMalloc(&c->d_hist, (WT_HIST_BINS + 64) * sizeof(uint32_t)));   // bins, float32 select state (+4), float64 state (+16), 64-bit result (+32)
     WT_HIP(hipMalloc(&c->d_partials, (kPartialBlocks * 4 + 8) * sizeof(double)));
     c->partial_blocks = kPartialBlocks;
     WT_HIP(hipHostMalloc(&c->h_pinned, 65536, hipHostMallocDefault));
@@ -2023,3 +2023,5 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
     *median = (N & 1) ? lo : (lo + hi) / 2.0f;
     return 0;
 }
+
+#include "wt_f64.h"

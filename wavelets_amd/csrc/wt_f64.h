@@ -1,0 +1,550 @@
+// float64 engine: the standard decomposition and the Coefficients operators in double precision.
+//
+// The reference keeps float64 inputs in float64 and promotes int / big-endian inputs to float64
+// (watroo/wavelets.py:297,319-320; the README examples are float64).  The tuned engine above is
+// float32; this one serves the same path - AtrousTransform (standard algorithm, no bilateral
+// filtering; signals, images and cubes), Coefficients.get_noise / significance / denoise, the plane
+// sum, convolution(), sdev_loc() and the Anscombe transform - with double planes and double
+// arithmetic, on generic one-sample-per-thread kernels with run-time taps (the built-in families
+// pass theirs).  HBM-bound work at 8 B per sample; nothing here is tuned like the float32 path.
+// Included at the end of wt_api.hip (one translation unit).
+#pragma once
+
+#define WT64_NUM_SCRATCH 8
+#define WT64_MAX_TAPS 15
+
+struct wt_plan64 {
+    wt_ctx *ctx = nullptr;
+    Geo g{};                                   // P = pitch in doubles (even)
+    int max_level = 0;
+    double taps[WT64_MAX_TAPS] = {0};
+    int ntaps = 0;
+    std::vector<double *> coef;
+    double *input = nullptr, *out = nullptr;
+    double *scratch[WT64_NUM_SCRATCH] = {nullptr};
+    std::vector<void *> allocs;
+};
+
+struct Taps64 {
+    double k[WT64_MAX_TAPS];
+    int n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// dilated filter along x: tmp[y][x] = sum_j k_j * in[y][R(x + (j - hw) d)]   (correlation order, like
+// cv2.filter2D, watroo/wavelets.py:39-45); square: filter in^2 (sdev_loc, :26)
+__global__ __launch_bounds__(256) void wt64_rows_kernel(const double *in, double *tmp, Geo g, int d, Taps64 t, int square)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < g.nrows; y += gridDim.y) {
+        const double *row = in + (int64_t)y * g.P;
+        double acc = 0.0;
+        for (int j = 0; j < t.n; ++j) {
+            double v = row[wt_refl_b(x + (j - hw) * d, g.W, d, g.border)];
+            if (square) v *= v;
+            acc = j == 0 ? t.k[0] * v : fma(t.k[j], v, acc);
+        }
+        tmp[(int64_t)y * g.P + x] = acc;
+    }
+}
+
+// dilated filter along axis 1 (inside every slice: axis == 1) or axis 0 (across slices) of a
+// (Z, Y, X) cube stored as a (Z*Y) x X image; an image is the cube with Z = 1
+// (watroo/wavelets.py:35-63).  out_w != nullptr: also the detail plane cen - result (:442).
+__global__ __launch_bounds__(256) void wt64_axis_kernel(const double *in, double *out, const double *cen, double *out_w,
+                                                        int W, int P, int Y, int Z, int d, int border, Taps64 t, int axis)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int hw = t.n / 2;
+    for (int row = blockIdx.y; row < Z * Y; row += gridDim.y) {
+        const int z = row / Y, y = row - z * Y;
+        double acc = 0.0;
+        for (int j = 0; j < t.n; ++j) {
+            const int zz = axis == 0 ? wt_refl_b(z + (j - hw) * d, Z, d, border) : z;
+            const int yy = axis == 1 ? wt_refl_b(y + (j - hw) * d, Y, d, border) : y;
+            const double v = in[((int64_t)zz * Y + yy) * P + x];
+            acc = j == 0 ? t.k[0] * v : fma(t.k[j], v, acc);
+        }
+        const int64_t o = (int64_t)row * P + x;
+        if (out_w) out_w[o] = cen[o] - acc;
+        out[o] = acc;
+    }
+}
+
+// pointwise: 0 add, 1 sub, 2 mul, 3 div
+__global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const double *b, double *dst, int W, int P, int nrows, int op)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        const double u = a[o], v = b[o];
+        dst[o] = op == 0 ? u + v : op == 1 ? u - v : op == 2 ? u * v : u / v;
+    }
+}
+
+// Coefficients.significance / denoise (watroo/wavelets.py:129-149): mode 0: dst = significance;
+// mode 1: dst = c * (wgt * significance).  tau <= 0: significance one.  noise: optional per-pixel map
+// that multiplies tau (:133).
+__global__ __launch_bounds__(256) void wt64_signif_kernel(const double *c, const double *noise, double *dst, int W, int P, int nrows,
+                                                          double tau, double wgt, int soft, int mode)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        const double v = c[o];
+        double sg = 1.0;
+        if (tau > 0.0) {
+            const double tt = noise ? tau * noise[o] : tau;
+            sg = soft ? erf(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
+        }
+        dst[o] = mode ? v * (wgt * sg) : sg;
+    }
+}
+
+struct Sum64Args {
+    const double *p[32];
+    int n;
+};
+// np.sum(planes, axis=0) in plane order (watroo/utils.py:98)
+__global__ __launch_bounds__(256) void wt64_plane_sum_kernel(Sum64Args a, double *dst, int W, int P, int nrows)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        double acc = a.p[0][o];
+        for (int k = 1; k < a.n; ++k) acc += a.p[k][o];
+        dst[o] = acc;
+    }
+}
+
+// generalized_anscombe (watroo/wavelets.py:14-21)
+__global__ __launch_bounds__(256) void wt64_anscombe_kernel(const double *src, double *dst, int W, int P, int nrows, double alpha,
+                                                            double g, double sigma, int inverse)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        const double v = src[o];
+        double r;
+        if (inverse) {
+            const double h = alpha * v / 2.0;
+            r = (h * h + alpha * g - sigma * sigma - 3.0 * alpha / 8.0) / alpha;
+        } else {
+            double dum = alpha * v + 3.0 * alpha * alpha / 8.0 + sigma * sigma - alpha * g;
+            if (dum <= 0.0) dum = 0.0;
+            r = 2.0 * sqrt(dum) / alpha;
+        }
+        dst[o] = r;
+    }
+}
+
+// sdev_loc (watroo/wavelets.py:24-32) from the two smoothed moments
+__global__ __launch_bounds__(256) void wt64_var_kernel(const double *mean, const double *meansq, double *dst, int W, int P, int nrows,
+                                                       double f1, double f2, int take_sqrt)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        double v = meansq[o] - mean[o] * mean[o];
+        if (v <= 0.0) v = 1e-20;
+        if (take_sqrt) v = sqrt(v);
+        dst[o] = (v * f1) * f2;
+    }
+}
+
+// Exact median of |x| (np.median(np.abs(data[0])), watroo/wavelets.py:127): non-negative doubles
+// order like their bit patterns; radix select over 63 bits, 11 bits per pass (LDS-privatised bins),
+// selection state on the device like the float32 select.
+struct Select64State {
+    unsigned long long k, cum_le, prefix;
+    uint32_t failed, pad;
+};
+
+__global__ __launch_bounds__(256) void wt64_hist_kernel(const double *p, int nrows, int P, int W, unsigned long long prefix_mask,
+                                                        const Select64State *st, int shift, uint32_t bin_mask, uint32_t *hist)
+{
+    const unsigned long long prefix_val = st->prefix & prefix_mask;
+    __shared__ uint32_t lh[WT_HIST_BINS];
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const double *row = p + (int64_t)r * P;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const unsigned long long w = (unsigned long long)__double_as_longlong(row[x]) & 0x7fffffffffffffffull;
+            if ((w & prefix_mask) == prefix_val) atomicAdd(&lh[(uint32_t)(w >> shift) & bin_mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+__global__ __launch_bounds__(256) void wt64_select_step_kernel(uint32_t *hist, Select64State *st, int nbins, int shift, int last)
+{
+    __shared__ unsigned long long part[256];
+    const int per = (nbins + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    uint32_t h[WT_HIST_BINS / 256];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int i = 0; i < WT_HIST_BINS / 256; ++i) {
+        h[i] = (i < per && b0 + i < nbins) ? hist[b0 + i] : 0u;
+        s += h[i];
+    }
+    const unsigned long long k = st->k, cum_le = st->cum_le, prefix = st->prefix;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long incl = part[threadIdx.x];
+    unsigned long long cum = incl - s;
+    if (k >= cum && k < incl) {
+#pragma unroll
+        for (int i = 0; i < WT_HIST_BINS / 256; ++i) {
+            if (k < cum + h[i]) {
+                st->k = k - cum;
+                st->cum_le = cum_le + cum + (last ? h[i] : 0);
+                st->prefix = prefix | ((unsigned long long)(b0 + i) << shift);
+                break;
+            }
+            cum += h[i];
+        }
+    }
+    if (threadIdx.x == 255 && k >= incl) st->failed = 1;
+    for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void wt64_min_greater_kernel(const double *p, int nrows, int P, int W, unsigned long long than,
+                                                               unsigned long long *result)
+{
+    unsigned long long best = ~0ull;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const double *row = p + (int64_t)r * P;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const unsigned long long w = (unsigned long long)__double_as_longlong(row[x]) & 0x7fffffffffffffffull;
+            if (w > than && w < best) best = w;
+        }
+    }
+    if (best != ~0ull) atomicMin(result, best);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int plan64_base(wt_plan64 *p, int id, double **base)
+{
+    double **slot = nullptr;
+    if (id >= 0 && id <= p->max_level) slot = &p->coef[id];
+    else if (id == WT_PLANE_INPUT) slot = &p->input;
+    else if (id == WT_PLANE_OUT) slot = &p->out;
+    else if (id <= WT_PLANE_SCRATCH(0) && id > WT_PLANE_SCRATCH(WT64_NUM_SCRATCH)) slot = &p->scratch[-3 - id];
+    else WT_FAIL("float64 plan: invalid plane id %d (max_level %d)", id, p->max_level);
+    if (!*slot) {
+        void *q = nullptr;
+        WT_HIP(hipSetDevice(p->ctx->device));
+        WT_HIP(hipMalloc(&q, (size_t)p->g.nrows * p->g.P * sizeof(double)));
+        p->allocs.push_back(q);
+        *slot = (double *)q;
+    }
+    *base = *slot;
+    return 0;
+}
+
+static inline wt_ctx *ctx_of(wt_plan64 *p) { return p ? p->ctx : nullptr; }
+static inline dim3 grid64(const wt_plan64 *p) { return dim3((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)); }
+static Taps64 taps64(const wt_plan64 *p)
+{
+    Taps64 t{};
+    t.n = p->ntaps;
+    for (int i = 0; i < p->ntaps; ++i) t.k[i] = p->taps[i];
+    return t;
+}
+
+extern "C" int wt64_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int max_level, const double *taps, int ntaps, wt_plan64 **out)
+{
+    WtGuard guard_(ctx);
+    if (!ctx || !out || !taps) WT_FAIL("wt64_plan_create: null pointer");
+    if (H < 1 || W < 1 || H > (1 << 30) || W > (1 << 30)) WT_FAIL("wt64_plan_create: bad image size %lld x %lld", (long long)H, (long long)W);
+    if (max_level < 0 || max_level > 30) WT_FAIL("wt64_plan_create: max_level %d out of range", max_level);
+    if (ntaps < 1 || ntaps > WT64_MAX_TAPS || !(ntaps & 1)) WT_FAIL("wt64_plan_create: %d taps unsupported (odd, 1..%d)", ntaps, WT64_MAX_TAPS);
+    if ((int64_t)H * ((W + 1) / 2 * 2) > ((int64_t)1 << 31) - 1) WT_FAIL("wt64_plan_create: planes beyond 2^31 samples are not supported in float64");
+    wt_plan64 *p = new wt_plan64();
+    p->ctx = ctx;
+    p->g.W = (int)W;
+    p->g.P = (int)((W + 1) / 2 * 2);
+    p->g.H = (int)H;
+    p->g.row0 = 0;
+    p->g.nrows = (int)H;
+    p->g.halo = 0;
+    p->g.border = 0;
+    p->max_level = max_level;
+    p->coef.assign(max_level + 1, nullptr);
+    p->ntaps = ntaps;
+    for (int i = 0; i < ntaps; ++i) p->taps[i] = taps[i];
+    *out = p;
+    return 0;
+}
+
+extern "C" int wt64_plan_destroy(wt_plan64 *p)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) return 0;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (void *q : p->allocs) (void)hipFree(q);
+    delete p;
+    return 0;
+}
+
+/* 0 = symmetric, 2 = 'mirror' (1-D signals: a 1 x N image), as wt_plan_set_border */
+extern "C" int wt64_plan_set_border(wt_plan64 *p, int border)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_plan_set_border: null plan");
+    if (border != 0 && border != 2) WT_FAIL("wt64_plan_set_border: border %d unsupported (0 symmetric, 2 mirror)", border);
+    p->g.border = border;
+    return 0;
+}
+
+extern "C" int wt64_upload(wt_plan64 *p, int plane, const double *host, int64_t host_pitch)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !host) WT_FAIL("wt64_upload: null pointer");
+    double *b = nullptr;
+    WT_TRY(plan64_base(p, plane, &b));
+    WT_HIP(hipMemcpy2DAsync(b, (size_t)p->g.P * 8, host, (size_t)host_pitch * 8, (size_t)p->g.W * 8, p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream));
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+}
+
+extern "C" int wt64_download(wt_plan64 *p, int plane, double *host, int64_t host_pitch)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !host) WT_FAIL("wt64_download: null pointer");
+    double *b = nullptr;
+    WT_TRY(plan64_base(p, plane, &b));
+    WT_HIP(hipMemcpy2DAsync(host, (size_t)host_pitch * 8, b, (size_t)p->g.P * 8, (size_t)p->g.W * 8, p->g.nrows, hipMemcpyDeviceToHost, p->ctx->stream));
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+}
+
+// conv_s of a plane: rows -> scratch 7, axis 1 (-> scratch 6 when an axis-0 pass follows), axis 0.
+// depth = 0: an image (or a 1 x N signal: no column pass); depth = Z > 0: a (Z, Y, X) cube.
+static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, int s, int square, int depth)
+{
+    if (s < 0 || s > 24) WT_FAIL("float64 plan: scale %d out of range", s);
+    if (depth < 0 || (depth > 0 && p->g.H % depth)) WT_FAIL("float64 plan: height %d is not a multiple of depth %d", p->g.H, depth);
+    double *t1 = nullptr, *t2 = nullptr;
+    WT_TRY(plan64_base(p, WT_PLANE_SCRATCH(7), &t1));
+    WT_TRY(plan64_base(p, WT_PLANE_SCRATCH(6), &t2));
+    if (in == t1 || in == t2 || out == t1 || out == t2 || out_w == t1 || out_w == t2)
+        WT_FAIL("float64 plan: scratch planes 6 and 7 are used internally by the filters");
+    if (out == in || out_w == in) WT_FAIL("float64 plan: in-place filtering");
+    const Taps64 t = taps64(p);
+    const int d = 1 << s;
+    const Geo g = p->g;
+    const dim3 grid = grid64(p), block(256);
+    const int Z = depth > 0 ? depth : 1, Y = g.H / Z;
+    const bool cols = Y > 1, deep = Z > 1;
+    double *r_out = (cols || deep) ? t1 : out;
+    hipLaunchKernelGGL(wt64_rows_kernel, grid, block, 0, p->ctx->stream, in, r_out, g, d, t, square);
+    if (!cols && !deep) {
+        if (out_w) hipLaunchKernelGGL(wt64_binary_kernel, grid, block, 0, p->ctx->stream, in, (const double *)out, out_w, g.W, g.P, g.nrows, 1);
+    } else if (cols) {
+        double *c_out = deep ? t2 : out;
+        hipLaunchKernelGGL(wt64_axis_kernel, grid, block, 0, p->ctx->stream, (const double *)t1, c_out, in, deep ? (double *)nullptr : out_w,
+                           g.W, g.P, Y, Z, d, g.border, t, 1);
+        if (deep)
+            hipLaunchKernelGGL(wt64_axis_kernel, grid, block, 0, p->ctx->stream, (const double *)t2, out, in, out_w, g.W, g.P, Y, Z, d, g.border, t, 0);
+    } else {
+        hipLaunchKernelGGL(wt64_axis_kernel, grid, block, 0, p->ctx->stream, (const double *)t1, out, in, out_w, g.W, g.P, Y, Z, d, g.border, t, 0);
+    }
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* convolution(arr, scaling_function, s) in float64 (watroo/wavelets.py:35-69); square_input as wt_smooth */
+extern "C" int wt64_smooth(wt_plan64 *p, int src, int dst, int s, int square_input, int depth)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_smooth: null plan");
+    double *in = nullptr, *o = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    WT_TRY(plan64_base(p, dst, &o));
+    return smooth64(p, in, o, nullptr, s, square_input, depth);
+}
+
+/* AtrousTransform.atrous_standard in float64 (watroo/wavelets.py:408-444): planes 0..level-1 detail,
+ * plane level smooth, from plane src (left intact).  depth as above. */
+extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_decompose: null plan");
+    if (level < 0 || level > p->max_level) WT_FAIL("wt64_decompose: level %d exceeds plan max_level %d", level, p->max_level);
+    if (src >= 0 && src <= level) WT_FAIL("wt64_decompose: src plane %d is one of the output planes", src);
+    if (src == WT_PLANE_SCRATCH(0) || src == WT_PLANE_SCRATCH(1)) WT_FAIL("wt64_decompose: scratch planes 0/1 are used internally");
+    double *in = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    if (level == 0) {
+        double *o = nullptr;
+        WT_TRY(plan64_base(p, 0, &o));
+        WT_HIP(hipMemcpyAsync(o, in, (size_t)p->g.nrows * p->g.P * 8, hipMemcpyDeviceToDevice, p->ctx->stream));
+        return 0;
+    }
+    int cur = src;
+    for (int s = 0; s < level; ++s) {
+        const int nxt = (s == level - 1) ? level : WT_PLANE_SCRATCH(s & 1);
+        double *ci = nullptr, *co = nullptr, *w = nullptr;
+        WT_TRY(plan64_base(p, cur, &ci));
+        WT_TRY(plan64_base(p, nxt, &co));
+        WT_TRY(plan64_base(p, s, &w));
+        WT_TRY(smooth64(p, ci, co, w, s, 0, depth));
+        cur = nxt;
+    }
+    return 0;
+}
+
+/* sdev_loc(image, sf, s, variance) (watroo/wavelets.py:24-32), times f1 then f2; images only */
+extern "C" int wt64_local_variance(wt_plan64 *p, int src, int dst, int s, double f1, double f2, int take_sqrt)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_local_variance: null plan");
+    if (src == dst) WT_FAIL("wt64_local_variance: src and dst must differ");
+    double *in = nullptr, *o = nullptr, *mean = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    WT_TRY(plan64_base(p, dst, &o));
+    WT_TRY(plan64_base(p, WT_PLANE_SCRATCH(5), &mean));
+    if (in == mean || o == mean) WT_FAIL("wt64_local_variance: scratch plane 5 is used internally");
+    WT_TRY(smooth64(p, in, mean, nullptr, s, 0, 0));
+    WT_TRY(smooth64(p, in, o, nullptr, s, 1, 0));
+    hipLaunchKernelGGL(wt64_var_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)mean, (const double *)o, o, p->g.W, p->g.P, p->g.nrows,
+                       f1, f2, take_sqrt);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt64_binary(wt_plan64 *p, int op, int a, int b, int dst)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_binary: null plan");
+    if (op < 0 || op > 3) WT_FAIL("wt64_binary: unknown op %d", op);
+    double *pa = nullptr, *pb = nullptr, *pd = nullptr;
+    WT_TRY(plan64_base(p, a, &pa));
+    WT_TRY(plan64_base(p, b, &pb));
+    WT_TRY(plan64_base(p, dst, &pd));
+    hipLaunchKernelGGL(wt64_binary_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)pa, (const double *)pb, pd, p->g.W, p->g.P, p->g.nrows, op);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* mode 0: Coefficients.significance into dst; mode 1: dst = src * (wgt * significance)
+ * (Coefficients.denoise with dst == src), watroo/wavelets.py:129-149 */
+extern "C" int wt64_significance(wt_plan64 *p, int src, int dst, double tau, double wgt, int soft, int noise_plane, int mode)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_significance: null plan");
+    double *c = nullptr, *d = nullptr, *nz = nullptr;
+    WT_TRY(plan64_base(p, src, &c));
+    WT_TRY(plan64_base(p, dst, &d));
+    if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
+    hipLaunchKernelGGL(wt64_signif_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)c, (const double *)nz, d, p->g.W, p->g.P, p->g.nrows,
+                       tau, wgt, soft, mode);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt64_plane_sum(wt_plan64 *p, int first, int count, int dst)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_plane_sum: null plan");
+    if (count < 1 || count > 32 || first < 0 || first + count - 1 > p->max_level) WT_FAIL("wt64_plane_sum: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
+    Sum64Args a{};
+    a.n = count;
+    for (int i = 0; i < count; ++i) {
+        double *b = nullptr;
+        WT_TRY(plan64_base(p, first + i, &b));
+        a.p[i] = b;
+    }
+    double *d = nullptr;
+    WT_TRY(plan64_base(p, dst, &d));
+    hipLaunchKernelGGL(wt64_plane_sum_kernel, grid64(p), dim3(256), 0, p->ctx->stream, a, d, p->g.W, p->g.P, p->g.nrows);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt64_anscombe(wt_plan64 *p, int src, int dst, double alpha, double g, double sigma, int inverse)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_anscombe: null plan");
+    if (alpha == 0.0) WT_FAIL("wt64_anscombe: alpha must be non-zero");
+    double *s = nullptr, *d = nullptr;
+    WT_TRY(plan64_base(p, src, &s));
+    WT_TRY(plan64_base(p, dst, &d));
+    hipLaunchKernelGGL(wt64_anscombe_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)s, d, p->g.W, p->g.P, p->g.nrows, alpha, g, sigma, inverse);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* np.median(np.abs(plane)) in float64 (watroo/wavelets.py:127): exact */
+extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !median) WT_FAIL("wt64_abs_median: null pointer");
+    wt_ctx *c = p->ctx;
+    c->prehist_plan = nullptr;                                   // the bins are shared with the float32 select
+    double *b = nullptr;
+    WT_TRY(plan64_base(p, plane, &b));
+    const int64_t N = (int64_t)p->g.nrows * p->g.W;
+    const int64_t klo = (N - 1) / 2;
+    Select64State *st = (Select64State *)(c->d_hist + WT_HIST_BINS + 16);
+    Select64State *hst = (Select64State *)c->h_pinned;
+    hst->k = (unsigned long long)klo; hst->cum_le = 0; hst->prefix = 0; hst->failed = 0; hst->pad = 0;
+    WT_HIP(hipMemcpyAsync(st, hst, sizeof(Select64State), hipMemcpyHostToDevice, c->stream));
+    WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+    const int shifts[6] = {52, 41, 30, 19, 8, 0};
+    const int bits[6] = {11, 11, 11, 11, 11, 8};
+    unsigned long long mask = 0;
+    for (int i = 0; i < 6; ++i) {
+        const uint32_t bin_mask = (1u << bits[i]) - 1u;
+        hipLaunchKernelGGL(wt64_hist_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W,
+                           mask, (const Select64State *)st, shifts[i], bin_mask, c->d_hist);
+        hipLaunchKernelGGL(wt64_select_step_kernel, dim3(1), dim3(256), 0, c->stream, c->d_hist, st, (int)bin_mask + 1, shifts[i], i == 5);
+        mask |= (unsigned long long)bin_mask << shifts[i];
+    }
+    WT_HIP(hipGetLastError());
+    WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(Select64State), hipMemcpyDeviceToHost, c->stream));
+    WT_HIP(hipStreamSynchronize(c->stream));
+    const Select64State res = *(const Select64State *)((const char *)c->h_pinned + 64);
+    if (res.failed) WT_FAIL("wt64_abs_median: rank %lld not found (NaN input?)", (long long)klo);
+    const unsigned long long ulo = res.prefix;
+    unsigned long long uhi = ulo;
+    if ((N & 1) == 0 && (int64_t)res.cum_le < klo + 2) {
+        unsigned long long *r = (unsigned long long *)(c->d_hist + WT_HIST_BINS + 32);
+        WT_HIP(hipMemsetAsync(r, 0xff, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(wt64_min_greater_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, ulo, r);
+        WT_HIP(hipGetLastError());
+        WT_HIP(hipMemcpyAsync(c->h_pinned, r, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        WT_HIP(hipStreamSynchronize(c->stream));
+        uhi = *(const unsigned long long *)c->h_pinned;
+        if (uhi == ~0ull) WT_FAIL("wt64_abs_median: upper median not found");
+    }
+    double lo, hi;
+    memcpy(&lo, &ulo, 8);
+    memcpy(&hi, &uhi, 8);
+    *median = (N & 1) ? lo : (lo + hi) / 2.0;
+    return 0;
+}

@@ -76,8 +76,10 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     ``weights[s]`` sigma, sum the planes (ref:83-102).  Optional Anscombe pre/post transform.
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
     """
-    if np.ndim(data) in (1, 3):                 # signals and cubes: the generic call sequence
-        arr = np.asarray(data, np.float32)
+    f64 = _result_dtype(data) == np.float64 and bilateral is None     # float64 engine (ref:319-320)
+    if np.ndim(data) in (1, 3) or (f64 and np.ndim(data) == 2):
+        # signals, cubes and float64 images: the generic call sequence
+        arr = np.asarray(data, np.float64 if f64 else np.float32)
         if anscombe:
             arr = generalized_anscombe(arr)
         coefficients = AtrousTransform(scaling_function, bilateral=bilateral)(arr, len(weights))
@@ -168,7 +170,7 @@ def wow(data,
     if type(data) is np.ndarray:                                          # ref:148-151
         transform = AtrousTransform(scaling_function, bilateral=sigma_bilateral,
                                     bilateral_scaling=bilateral_scaling)
-        coefficients = transform(data, n_scales)
+        coefficients = transform(data, n_scales, _f64=False)     # whitening: float32 engine
         coefficients.noise = noise
     else:
         coefficients = data
@@ -186,6 +188,7 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
     """The device-resident part of wow (ref:157-217): per-scale loop, plane sum, gamma blend.
     Leaves the whitened planes on the plan and the image in PLANE_OUT; returns the plan.
     (bench.py --config cfg5 times exactly this behind the transform, without the PCIe legs.)"""
+    coefficients._use_f32_engine()
     plan = coefficients._device()
     coefficients._sum_valid = False
     npix = float(plan.H) * float(plan.W)

@@ -4,13 +4,15 @@ Same public names, argument meaning and error behaviour as the reference module
 (/root/reference/watroo/wavelets.py, cited as ``ref:LINE``), but the arithmetic runs in
 ``libwatroo_hip.so`` on the GPU and coefficient planes stay resident in HBM.
 
-Scope: float32 COMPUTE.  dtype policy: the
-reference keeps float64 inputs in float64 and promotes int / big-endian inputs to float64
-(ref:297,319-320; the README examples are float64).  Here such inputs are converted to float32
-on upload, every kernel runs in float32, and the containers and results handed back carry the
-dtype the reference would return (float64 for float64 / promoted inputs, float32 for float32) -
-same types for downstream code, float32 precision (about 1e-7 relative; the parity tests state
-it).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
+dtype policy: the reference keeps float64 inputs in float64 and promotes
+int / big-endian inputs to float64 (ref:297,319-320; the README examples are float64).  Here the
+tuned engine is float32 and serves float32 inputs; float64 / promoted inputs run on the float64
+engine (``_lib.Plan64``: double planes, double arithmetic, generic kernels) for the standard
+transform without bilateral filtering, the ``Coefficients`` operators, ``denoise``, ``enhance``,
+``convolution``, ``sdev_loc`` and ``generalized_anscombe``.  The remaining operators (bilateral
+filtering, ``recursive=True``, ``wow``, ``richardson_lucy``, ``atrous_convolution``) compute such
+inputs in float32 and hand back float64 containers (float32 precision, about 1e-7 relative; the
+parity tests state it).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
 as (Z*Y) x X images (per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no
 CPU fallback.
 """
@@ -19,8 +21,8 @@ import copy
 import numpy as np
 
 from . import _lib
-from ._lib import (PLANE_INPUT, PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, FLAG_FUSED, Plan,
-                   default_context, acquire_plan, release_plan)
+from ._lib import (PLANE_INPUT, PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, FLAG_FUSED, Plan, Plan64,
+                   default_context, acquire_plan, acquire_plan64, release_plan)
 
 __all__ = ['AtrousTransform', 'B3spline', 'Triangle', 'Coefficients', 'generalized_anscombe',
            'convolution']
@@ -162,6 +164,30 @@ def _family_of(scaling_function, ndim=2):
     return tuple(float(t) for t in (taps[::-1] if ndim == 1 else taps))
 
 
+def _taps_f64(scaling_function, ndim):
+    """1-D taps of a scaling function for the float64 engine, in the engine's correlation order
+    (reversed for 1-D signals, whose smoothing is scipy's convolution, ref:65-69)."""
+    taps = np.asarray(scaling_function.coefficients_1d, dtype=np.float64).ravel()
+    if taps.size % 2 == 0 or taps.size > 15:
+        raise NotImplementedError("scaling functions need an odd number of taps (at most 15) "
+                                  "in the HIP engine")
+    return tuple(float(t) for t in (taps[::-1] if ndim == 1 else taps))
+
+
+def _plane_shape(shape):
+    """(rows, cols) of the 2-D image an array of this shape is stored as: 1 x N, H x W, (Z*Y) x X"""
+    if len(shape) == 1:
+        return 1, shape[0]
+    if len(shape) == 3:
+        return shape[0] * shape[1], shape[2]
+    return tuple(shape)
+
+
+def _is_f64(arr):
+    """the reference would compute this input in float64 (ref:297,319-320)"""
+    return _result_dtype(arr) == np.float64
+
+
 def _is_1d(arr):
     return np.ndim(arr) == 1
 
@@ -207,8 +233,13 @@ def generalized_anscombe(signal, alpha=1, g=0, sigma=0, inverse=False):
         raise ValueError("Unsupported number of dimensions")
     shape = arr.shape
     # pointwise: any dimensionality runs as a (rows, last axis) image
-    img = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, shape[-1] if arr.ndim else 1)
-    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _lib.B3SPLINE, 0)
+    f64 = _is_f64(arr)
+    img = np.ascontiguousarray(arr, dtype=np.float64 if f64 else np.float32).reshape(
+        -1, shape[-1] if arr.ndim else 1)
+    if f64:
+        plan = acquire_plan64(default_context(), img.shape[0], img.shape[1], (1.0,), 0)
+    else:
+        plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _lib.B3SPLINE, 0)
     try:
         plan.upload(PLANE_INPUT, img)
         plan.anscombe(PLANE_INPUT, PLANE_OUT, alpha, g, sigma, inverse)
@@ -225,6 +256,25 @@ def convolution(arr, scaling_function, s=0, output=None):
     1 x N image under the engine's mirror border rule."""
     one_d = _is_1d(arr)
     three_d = np.ndim(arr) == 3
+    if _is_f64(arr) and np.ndim(arr) in (1, 2, 3):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        plan = acquire_plan64(default_context(), *_plane_shape(a.shape),
+                              _taps_f64(scaling_function, a.ndim), 0)
+        try:
+            if one_d:
+                plan.set_border(2)
+            plan.upload(PLANE_INPUT, a.reshape(plan.shape))
+            if three_d:
+                plan.smooth3d(PLANE_INPUT, PLANE_OUT, s, a.shape[0])
+            else:
+                plan.smooth(PLANE_INPUT, PLANE_OUT, s)
+            res = plan.download(PLANE_OUT).reshape(a.shape)
+        finally:
+            release_plan(plan)
+        if output is None:
+            return res
+        output[...] = res
+        return output
     if three_d:
         cube = np.ascontiguousarray(arr, dtype=np.float32)
         img = cube.reshape(cube.shape[0] * cube.shape[1], cube.shape[2])
@@ -252,6 +302,15 @@ def convolution(arr, scaling_function, s=0, output=None):
 
 def sdev_loc(image, scaling_function, s=0, variance=False):
     """Local standard deviation (or variance) at scale ``s`` (ref:24-32)."""
+    if _is_f64(image) and np.ndim(image) == 2:
+        a = np.ascontiguousarray(image, dtype=np.float64)
+        plan = acquire_plan64(default_context(), a.shape[0], a.shape[1], _taps_f64(scaling_function, 2), 0)
+        try:
+            plan.upload(PLANE_INPUT, a)
+            plan.local_variance(PLANE_INPUT, PLANE_OUT, s, 1.0, 1.0, take_sqrt=not variance)
+            return plan.download(PLANE_OUT)
+        finally:
+            release_plan(plan)
     img = _to_f32_image(image, "image")
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                         _family_of(scaling_function), 0)
@@ -336,7 +395,8 @@ class Coefficients:
         self._sum_valid = False     # PLANE_OUT holds np.sum(planes, axis=0) of the CURRENT planes
         # logical shape of one plane: (N,), (H, W) or (Z, Y, X); the engine stores it as a 2-D
         # image: 1 x N, H x W or (Z*Y) x X
-        if isinstance(data, Plan):
+        self._force_f32 = False     # wow / bilateral operators exist in the float32 engine only
+        if isinstance(data, (Plan, Plan64)):
             self._plan = data
             self._nplanes = data.max_level + 1
             if _shape is not None:
@@ -354,9 +414,12 @@ class Coefficients:
             self._host = np.ascontiguousarray(data, dtype=_dtype)
             self._nplanes = self._host.shape[0]
             self._shape = tuple(self._host.shape[1:])
-        # dtype of the host mirror and of every array handed back (the planes on the device and all
-        # arithmetic are float32): what the reference would return for the transform's input
+        # dtype of the host mirror and of every array handed back: what the reference would return
+        # for the transform's input.  float64 objects compute on the float64 engine (Plan64) unless
+        # an operator that only the float32 engine has was applied (_use_f32_engine)
         self._dtype = np.dtype(np.float32 if _dtype is None else _dtype)
+        if isinstance(data, Plan64):
+            self._dtype = np.dtype(np.float64)
         self._ndim = len(self._shape)
 
     def __del__(self):
@@ -422,8 +485,12 @@ class Coefficients:
         run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
             H, W = self._plane_hw()
-            self._plan = acquire_plan(default_context(), H, W,
-                                      _family_of(self.scaling_function), self._nplanes - 1)
+            if self._dtype == np.float64 and not self._force_f32:
+                self._plan = acquire_plan64(default_context(), H, W,
+                                            _taps_f64(self.scaling_function, self._ndim), self._nplanes - 1)
+            else:
+                self._plan = acquire_plan(default_context(), H, W,
+                                          _family_of(self.scaling_function), self._nplanes - 1)
         if self._host is not None:
             for s in range(self._nplanes):
                 self._plan.upload(s, self._as_plane(self._host[s]))
@@ -432,11 +499,23 @@ class Coefficients:
 
     def _refresh_host(self, planes):
         if self._host is not None:
+            plan_dtype = np.float64 if isinstance(self._plan, Plan64) else np.float32
             for s in planes:
-                if self._host.dtype == np.float32:
+                if self._host.dtype == plan_dtype:
                     self._plan.download(s, self._as_plane(self._host[s]))
                 else:                        # float64 mirror of float32 planes
                     self._as_plane(self._host[s])[...] = self._plan.download(s)
+
+    def _use_f32_engine(self):
+        """Move a float64-engine object to the float32 engine (operators that exist there only:
+        wow's whitening, bilateral filtering): the planes travel through the host mirror, the
+        containers stay float64."""
+        self._force_f32 = True
+        if isinstance(self._plan, Plan64):
+            self.data                                  # materialise the mirror
+            release_plan(self._plan)
+            self._plan = None
+            self._sum_valid = False
 
     # -- reference interface -----------------------------------------------------------
     def __len__(self):
@@ -483,7 +562,8 @@ class Coefficients:
         plan = self._plan
         if self._noise_uploaded is not self.noise:
             plan.upload(_NOISE_PLANE, np.broadcast_to(
-                self._as_plane(np.asarray(self.noise, np.float32)), plan.shape))
+                self._as_plane(np.asarray(self.noise, np.float64 if isinstance(plan, Plan64) else np.float32)),
+                plan.shape))
             self._noise_uploaded = self.noise
         tau = float(sigma * self.sigma_e[scale])
         if tau < 0 and not soft:
@@ -649,7 +729,7 @@ class AtrousTransform:
         self.bilateral = bilateral
         self.bilateral_scaling = bilateral_scaling
 
-    def __call__(self, arr, level, recursive=False, *, with_sum=False):
+    def __call__(self, arr, level, recursive=False, *, with_sum=False, _f64=True):
         """``level`` scales -> ``Coefficients`` with ``level + 1`` planes (ref:307-328).
 
         ``with_sum=True`` (keyword-only, not in the reference) asks the transform to carry the
@@ -657,7 +737,13 @@ class AtrousTransform:
         planes are written as usual but not re-read).  The sum is kept on the device next to the
         planes and handed out by ``np.sum(coefficients, axis=0)`` / ``coefficients.sum(axis=0)``
         as long as no plane has been modified since; it is bit-identical to summing afterwards.
-        Without the keyword nothing extra is computed."""
+        Without the keyword nothing extra is computed.
+
+        float64 / int inputs (computed in float64 by the reference, ref:297,319-320) run on the
+        float64 engine when the transform is the standard one without bilateral filtering."""
+        if _f64 and self.bilateral is None and not recursive and _is_f64(arr) \
+                and np.ndim(arr) in (1, 2, 3):
+            return self._call_f64(arr, level)
         if _is_1d(arr):
             return self._call_1d(arr, level, recursive)
         if np.ndim(arr) == 3:
@@ -677,6 +763,25 @@ class AtrousTransform:
         coefficients = Coefficients(plan, scaling_function, self.bilateral, _dtype=_result_dtype(arr))
         coefficients._sum_valid = summed
         return coefficients
+
+    def _call_f64(self, arr, level):
+        """Standard algorithm in float64 (ref:408-444 on float64 / promoted input, ref:319-320):
+        double planes on a Plan64, one generic pass per scale; signals as 1 x N images under the
+        'mirror' border of the 1-D branch (ref:65-69), cubes as (Z*Y) x X images (ref:46-63)."""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        nd = a.ndim
+        scaling_function = self.scaling_function_class(nd)
+        plan = acquire_plan64(default_context(), *_plane_shape(a.shape), _taps_f64(scaling_function, nd), level)
+        plan.upload(PLANE_INPUT, a.reshape(plan.shape))
+        if nd == 1:
+            plan.set_border(2)
+        if nd == 3:
+            plan.decompose3d(PLANE_INPUT, level, a.shape[0])
+        else:
+            plan.decompose(PLANE_INPUT, level)
+        plan.set_border(0)
+        return Coefficients(plan, scaling_function, None, _shape=a.shape if nd == 3 else None,
+                            _dtype=np.float64)
 
     # the reference's two algorithm entry points return the stacked planes as an ndarray
     # (ref:330-406, 408-444); kept for code that calls them directly
