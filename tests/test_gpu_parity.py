@@ -132,10 +132,10 @@ def test_dtype_policy(W, O):
     g = load_golden("g7_misc")
     ai = g["img_int32"]
     c = W.AtrousTransform()(ai, 2)
-    # the engine computes in fp32 (dtype policy) and hands back the dtype the reference
-    # would: ints are promoted to float64 (ref:297,319-320)
+    # ints are promoted to float64 (ref:297,319-320) and computed on the float64 engine
+    # (dtype policy)
     assert c.data.dtype == np.float64 and g["coef_int32_L2"].dtype == np.float64
-    close(c.data, g["coef_int32_L2"], 1e-5 * np.abs(ai).max())
+    close(c.data, g["coef_int32_L2"], 1e-12 * np.abs(ai).max())
     a64 = rnd((40, 52), 3).astype(np.float64)
     a32 = a64.astype(np.float32)
     for a, dt in ((a64, np.float64), (a32, np.float32)):
@@ -149,7 +149,10 @@ def test_dtype_policy(W, O):
         assert W.convolution(a, W.B3spline(2), s=1).dtype == dt
         assert W.generalized_anscombe(np.abs(a)).dtype == dt
     c64 = W.AtrousTransform(W.Triangle)(a64, 3)
-    close(c64.data, O.atrous_standard(a64, 3, "triangle"), 1e-5 * np.abs(a64).max())   # f64 oracle, f32 compute
+    close(c64.data, O.atrous_standard(a64, 3, "triangle"), 1e-13 * np.abs(a64).max())   # f64 oracle, f64 engine
+    cb = W.AtrousTransform(W.Triangle, bilateral=1)(a64, 2)    # float32-only operator: f64 containers, f32 precision
+    assert cb.data.dtype == np.float64
+    close(cb.data, O.atrous_standard(a64, 2, "triangle", 1), 1e-4 * np.abs(a64).max())
     c64.data[1] *= 0.5                                  # in-place edit of the float64 mirror is honoured
     close(np.sum(c64, axis=0), c64.data.sum(axis=0), 1e-5 * np.abs(a64).max())
     ones = np.ones((128, 128))                         # reference tests/test_wavelets.py:8-13
