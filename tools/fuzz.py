@@ -172,6 +172,25 @@ def main():
             if bad.sum() > (0 if soft else max(2, a.size // 20000)):
                 fails += 1
                 print(f"FAIL {tag}: denoise(sigma={sig}, soft={soft}) {int(bad.sum())} pixels beyond tolerance")
+        # float64 engine: float64 input is computed in float64 (ref wavelets.py:319-320)
+        if case % 2 == 0 and H * Wd <= 600000:
+            cls = W.B3spline if fam == "b3spline" else W.Triangle
+            lev = min(level, 6)
+            a64 = (a.astype(np.float64) * 37.0 + 1e4) if case % 4 else a.astype(np.float64)
+            c64 = W.AtrousTransform(cls)(a64, lev)
+            r64 = O.atrous_standard(a64, lev, fam)
+            e = float(np.abs(c64.data - r64).max())
+            n64 = c64.get_noise()
+            n_own = np.median(np.abs(c64.data[0])) / 0.6745 / cls(2).sigma_e()[0]
+            if c64.data.dtype != np.float64 or not e <= 1e-12 * max(1.0, float(np.abs(a64).max())) or n64 != n_own:
+                fails += 1
+                print(f"FAIL {tag}: float64 transform max err {e:.3e}, noise {n64!r} vs {n_own!r}")
+            sig64 = [5.0, 3.0][:min(2, lev)]
+            d64 = W.denoise(a64, sig64, cls)
+            e = float(np.abs(d64 - O.denoise(a64.copy(), sig64, fam)).max())
+            if not e <= 1e-11 * max(1.0, float(np.abs(a64).max())):
+                fails += 1
+                print(f"FAIL {tag}: float64 denoise max err {e:.3e}")
         if case % 5 == 0 and H * Wd < 400000 and level <= 6:
             r = W.AtrousTransform(W.B3spline if fam == "b3spline" else W.Triangle)(a, level, recursive=True)
             e = float(np.abs(r.data - O.atrous_recursive(a, level, fam)).max())

@@ -359,7 +359,10 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
     const Geo g = p->g;
     const dim3 grid = grid64(p), block(256);
     const int Z = depth > 0 ? depth : 1, Y = g.H / Z;
-    const bool cols = Y > 1, deep = Z > 1;
+    // a 1 x N image under the 'mirror' border is a 1-D signal (watroo/wavelets.py:65-69: row filter
+    // only); any other one-row image or one-slice cube still sees every axis' taps (they reflect
+    // onto the same sample and contribute sum(k) - which is 1 only for normalised taps)
+    const bool cols = !(Y == 1 && depth == 0 && g.border == 2), deep = depth > 0;
     double *r_out = (cols || deep) ? t1 : out;
     hipLaunchKernelGGL(wt64_rows_kernel, grid, block, 0, p->ctx->stream, in, r_out, g, d, t, square);
     if (!cols && !deep) {
