@@ -76,6 +76,73 @@ __global__ __launch_bounds__(256) void wt64_axis_kernel(const double *in, double
     }
 }
 
+// One scale of an image in ONE kernel: a thread owns a column x and one chunk of one polyphase row
+// chain y = q, q + d, q + 2d, ... and marches down it.  Every step it filters the next row of the
+// chain along x (K taps through L1 / L2), pushes the result into a K-deep register window and
+// emits the vertical filter of the window: every input row is row-filtered once per chain instead
+// of K times, nothing goes through a scratch plane (24 B per sample of HBM traffic instead of two
+// passes of 5 loads + 1 store).  Same arithmetic and order as wt64_rows_kernel + wt64_axis_kernel
+// (rows first, then columns, FMA chains in tap order): identical results.
+__global__ __launch_bounds__(256) void wt64_chain_kernel(const double *in, double *out_c, double *out_w, Geo g, int d, Taps64 t,
+                                                         int S, int chunks)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int n = t.n, hw = n / 2;
+    for (int item = blockIdx.y; item < d * chunks; item += gridDim.y) {
+        const int q = item % d, c = item / d;
+        if (q >= g.H) continue;
+        const int n_q = (g.H - q + d - 1) / d;           // chain length
+        const int r0 = c * S, r1 = min(r0 + S, n_q);
+        if (r0 >= r1) continue;
+        int xi[WT64_MAX_TAPS];
+#pragma unroll
+        for (int j = 0; j < WT64_MAX_TAPS; ++j) xi[j] = j < n ? wt_refl_b(x + (j - hw) * d, g.W, d, g.border) : 0;
+        double win[WT64_MAX_TAPS];
+#pragma unroll
+        for (int j = 0; j < WT64_MAX_TAPS; ++j) win[j] = 0.0;
+        // the taps of the NEXT row are loaded before this row is consumed (one row in flight)
+        double nx[WT64_MAX_TAPS];
+        {
+            const double *row = in + (int64_t)wt_refl_b(q + d * (r0 - hw), g.H, d, g.border) * g.P;
+#pragma unroll
+            for (int j = 0; j < WT64_MAX_TAPS; ++j) nx[j] = j < n ? row[xi[j]] : 0.0;
+        }
+        for (int tt = r0 - hw; tt < r1 + hw; ++tt) {
+            double cu[WT64_MAX_TAPS];
+#pragma unroll
+            for (int j = 0; j < WT64_MAX_TAPS; ++j) cu[j] = nx[j];
+            {
+                const double *row = in + (int64_t)wt_refl_b(q + d * min(tt + 1, r1 + hw - 1), g.H, d, g.border) * g.P;
+#pragma unroll
+                for (int j = 0; j < WT64_MAX_TAPS; ++j)
+                    if (j < n) nx[j] = row[xi[j]];
+            }
+            double h = 0.0;
+#pragma unroll
+            for (int j = 0; j < WT64_MAX_TAPS; ++j)
+                if (j < n) h = j == 0 ? t.k[0] * cu[0] : fma(t.k[j], cu[j], h);
+            // window: win[0] oldest ... win[n-1] newest
+#pragma unroll
+            for (int j = 0; j < WT64_MAX_TAPS - 1; ++j)
+                if (j < n - 1) win[j] = win[j + 1];
+#pragma unroll
+            for (int j = 0; j < WT64_MAX_TAPS; ++j)
+                if (j == n - 1) win[j] = h;
+            const int r = tt - hw;                       // chain element whose window is complete
+            if (r >= r0) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < WT64_MAX_TAPS; ++j)
+                    if (j < n) v = j == 0 ? t.k[0] * win[0] : fma(t.k[j], win[j], v);
+                const int64_t o = (int64_t)(q + d * r) * g.P + x;
+                if (out_w) out_w[o] = in[o] - v;
+                out_c[o] = v;
+            }
+        }
+    }
+}
+
 // pointwise: 0 add, 1 sub, 2 mul, 3 div
 __global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const double *b, double *dst, int W, int P, int nrows, int op)
 {
@@ -363,6 +430,19 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
     // only); any other one-row image or one-slice cube still sees every axis' taps (they reflect
     // onto the same sample and contribute sum(k) - which is 1 only for normalised taps)
     const bool cols = !(Y == 1 && depth == 0 && g.border == 2), deep = depth > 0;
+    if (cols && !deep && !square) {
+        // images: one kernel per scale (register window down every polyphase row chain)
+        const int n_max = (g.H + d - 1) / d;             // longest chain
+        // enough work items to fill the chip, chunks of at least 32 chain steps (2 * hw warm-up rows each)
+        const int xblocks = (g.W + 255) / 256;
+        int chunks = std::max(1, std::min((n_max + 31) / 32, (4 * p->ctx->num_cus + xblocks * d - 1) / (xblocks * d)));
+        const int S = (n_max + chunks - 1) / chunks;
+        chunks = (n_max + S - 1) / S;
+        const dim3 cgrid(xblocks, (unsigned)std::min<int64_t>((int64_t)d * chunks, 65535));
+        hipLaunchKernelGGL(wt64_chain_kernel, cgrid, block, 0, p->ctx->stream, in, out, out_w, g, d, t, S, chunks);
+        WT_HIP(hipGetLastError());
+        return 0;
+    }
     double *r_out = (cols || deep) ? t1 : out;
     hipLaunchKernelGGL(wt64_rows_kernel, grid, block, 0, p->ctx->stream, in, r_out, g, d, t, square);
     if (!cols && !deep) {
