@@ -291,8 +291,8 @@ int wt_anscombe(wt_plan *plan, int src, int dst, float alpha, float g, float sig
 /* ---- float64 engine ------------------------------------------------------------------------
  * The reference computes float64 inputs in float64 and promotes int / big-endian inputs to
  * float64 (watroo/wavelets.py:297,319-320).  A wt_plan64 holds double planes (same plane ids as a
- * wt_plan: 0..max_level, WT_PLANE_INPUT, WT_PLANE_OUT, 8 scratch planes; scratch 5-7 are used
- * internally) and runs the standard decomposition without bilateral filtering and the
+ * wt_plan: 0..max_level, WT_PLANE_INPUT, WT_PLANE_OUT, 8 scratch planes; wt64_decompose uses
+ * scratch 0 and 1) and runs the standard decomposition without bilateral filtering and the
  * Coefficients operators in double arithmetic on generic kernels with the given 1-D taps
  * (cv2.filter2D's correlation order).  Single GPU, whole images.  `depth`: 0 = an H x W image (a
  * 1 x N image is a signal: no column pass; its 'mirror' border is border mode 2), Z > 0 = a
@@ -322,6 +322,14 @@ int wt64_significance(wt_plan64 *plan, int src, int dst, double tau, double wgt,
 int wt64_plane_sum(wt_plan64 *plan, int first, int count, int dst);
 /* dst = a OP b: 0 add, 1 sub, 2 mul, 3 div */
 int wt64_binary(wt_plan64 *plan, int op, int a, int b, int dst);
+/* the operators of utils.wow without bilateral filtering (watroo/utils.py:157-217) in float64:
+ * per-scale update (as wt_wow_update), gamma blend, fill, {sum, sumsq, min, max} */
+int wt64_wow_update(wt_plan64 *plan, int plane, int power_plane, double tau, int soft,
+                    int noise_plane, double factor, int gamma_plane);
+int wt64_gamma_blend(wt_plan64 *plan, int recon, int gamma_plane, double gmin, double gmax,
+                     double inv_gamma, double h);
+int wt64_fill_plane(wt_plan64 *plan, int plane, double value);
+int wt64_reduce(wt_plan64 *plan, int plane, double out[4]);
 /* generalized_anscombe (watroo/wavelets.py:14-21) */
 int wt64_anscombe(wt_plan64 *plan, int src, int dst, double alpha, double g, double sigma,
                   int inverse);

@@ -466,6 +466,22 @@ def g20_float64():
     out["skew5_coef2_L2"] = AtrousTransform(Skew5)(a, 2).data
     out["skew5_coef1_L2"] = AtrousTransform(Skew5)(sig, 2).data
     out["skew5_den2"] = denoise(a.copy(), [4, 2], Skew5)
+    # wow without bilateral filtering in float64 (utils.py:105-219): image (own n_scales), keyword
+    # combinations, a signal and a cube
+    b = a - 1e5                                          # structure at unit scale on a small offset
+    out["wow_img"] = b
+    cases = {"default": dict(), "den": dict(denoise_coefficients=[5, 2], n_scales=3),
+             "gamma": dict(denoise_coefficients=[4, 2], n_scales=3, h=0.5, gamma=2.5),
+             "pv": dict(preserve_variance=True, weights=[0.5, 2], n_scales=3),
+             "tri_hard": dict(scaling_function=Triangle, denoise_coefficients=[3, 1], soft_threshold=False, n_scales=4)}
+    for name, kw in cases.items():
+        r, cc = wow(b.copy(), **kw)
+        assert r.dtype == np.float64 and cc.data.dtype == np.float64
+        out[f"wow_{name}"], out[f"wow_{name}_coef"] = r, cc.data
+    r, cc = wow(sig.copy() - 1e4, denoise_coefficients=[4, 2], n_scales=3)
+    out["wow_sig"], out["wow_sig_coef"] = r, cc.data
+    r, cc = wow(cube.copy(), denoise_coefficients=[4], n_scales=2)
+    out["wow_cube"], out["wow_cube_coef"] = r, cc.data
     for k, v in out.items():
         if k not in ("ints", "u16", "sig_hard_s0", "noise"):
             assert np.asarray(v).dtype == np.float64, (k, np.asarray(v).dtype)

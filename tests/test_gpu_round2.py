@@ -539,13 +539,38 @@ def test_float64_engine_vs_golden(WA):
     close(WA.AtrousTransform(Skew5)(a, 2).data, g["skew5_coef2_L2"], tol)
     close(WA.AtrousTransform(Skew5)(sig, 2).data, g["skew5_coef1_L2"], 1e-12 * float(np.abs(sig).max()))
     close(WA.denoise(a.copy(), [4, 2], Skew5), g["skew5_den2"], 10 * tol)
-    # operators of the float32 engine on a float64 object: float64 containers, float32 precision
-    cw = WA.AtrousTransform(WA.B3spline)(a - 1e5, 3)
-    r, c2 = WA.wow(cw)
-    assert c2 is cw and r.dtype == np.float64 and cw.data.dtype == np.float64
-    assert isinstance(cw._plan, L.Plan)
-    r_ref, _ = WA.wow((a - 1e5).astype(np.float32), n_scales=3)
-    close(r, r_ref, 1e-4 * float(np.abs(r_ref).max()))
+    # wow without bilateral filtering: float64 engine too (whitening divides by the local power:
+    # 1e-10 relative)
+    b = g["wow_img"]
+    cases = {"default": dict(), "den": dict(denoise_coefficients=[5, 2], n_scales=3),
+             "gamma": dict(denoise_coefficients=[4, 2], n_scales=3, h=0.5, gamma=2.5),
+             "pv": dict(preserve_variance=True, weights=[0.5, 2], n_scales=3),
+             "tri_hard": dict(scaling_function=WA.Triangle, denoise_coefficients=[3, 1], soft_threshold=False, n_scales=4)}
+    for name, kw in cases.items():
+        r, cc = WA.wow(b.copy(), **kw)
+        assert r.dtype == np.float64 and cc.data.dtype == np.float64 and isinstance(cc._plan, L.Plan64)
+        ref_r, ref_c = g[f"wow_{name}"], g[f"wow_{name}_coef"]
+        if name == "tri_hard":                            # hard threshold: ties within rounding of tau
+            assert (np.abs(cc.data - ref_c) > 1e-10 * np.abs(ref_c).max()).sum() <= 2
+        else:
+            close(cc.data, ref_c, 1e-10 * float(np.abs(ref_c).max()))
+            close(r, ref_r, 1e-10 * float(np.abs(ref_r).max()))
+    r, cc = WA.wow(sig.copy() - 1e4, denoise_coefficients=[4, 2], n_scales=3)
+    close(r, g["wow_sig"], 1e-10 * float(np.abs(g["wow_sig"]).max()))
+    close(cc.data, g["wow_sig_coef"], 1e-10 * float(np.abs(g["wow_sig_coef"]).max()))
+    r, cc = WA.wow(cube.copy(), denoise_coefficients=[4], n_scales=2)
+    close(r, g["wow_cube"], 1e-10 * float(np.abs(g["wow_cube"]).max()))
+    close(cc.data, g["wow_cube_coef"], 1e-10 * float(np.abs(g["wow_cube_coef"]).max()))
+    # wow on an existing float64 Coefficients object mutates and returns it (ref:128-131,152-153)
+    cw = WA.AtrousTransform(WA.B3spline)(b, 3)
+    r, c2 = WA.wow(cw, denoise_coefficients=[5, 2])
+    assert c2 is cw and isinstance(cw._plan, L.Plan64)
+    close(r, g["wow_den"], 1e-10 * float(np.abs(g["wow_den"]).max()))
+    # operators of the float32 engine on float64 data: float64 containers, float32 precision
+    rb, cb = WA.wow(b.copy(), bilateral=1, n_scales=3)
+    assert rb.dtype == np.float64 and cb.data.dtype == np.float64 and isinstance(cb._plan, L.Plan)
+    r_ref, _ = WA.wow(b.astype(np.float32), bilateral=1, n_scales=3)
+    close(rb, r_ref, 1e-4 * float(np.abs(r_ref).max()))
     # median on an even and an odd number of samples, ties and zeros, in float64
     for shape in ((64, 64), (63, 65), (1, 7)):
         z = np.random.default_rng(3).standard_normal(shape)

@@ -131,6 +131,12 @@ SIGNATURES = {
     "wt64_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                                  _c.c_int]),
+    "wt64_wow_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
+                                   _c.c_double, _c.c_int]),
+    "wt64_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
+                                    _c.c_double, _c.c_double]),
+    "wt64_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_double]),
+    "wt64_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
 }
 
 _lib = None
@@ -680,11 +686,19 @@ class Plan64:
         check(load().wt64_significance(self._h, plane, plane, tau, weight, int(soft), noise_plane, 1))
 
     def wow_update(self, plane, power_plane, tau, soft, noise_plane, factor, gamma_plane):
-        """Only the form Coefficients.denoise needs: plane *= factor * significance."""
-        if power_plane != PLANE_NONE or gamma_plane != PLANE_NONE:
-            raise NotImplementedError("float64 plans implement the plain threshold update only")
-        check(load().wt64_significance(self._h, plane, plane, tau, float(factor), int(soft),
-                                       noise_plane, 1))
+        check(load().wt64_wow_update(self._h, plane, power_plane, float(tau), int(soft),
+                                     noise_plane, float(factor), gamma_plane))
+
+    def gamma_blend(self, recon, gamma_plane, gmin, gmax, inv_gamma, h):
+        check(load().wt64_gamma_blend(self._h, recon, gamma_plane, gmin, gmax, inv_gamma, h))
+
+    def fill(self, plane, value):
+        check(load().wt64_fill_plane(self._h, plane, value))
+
+    def reduce(self, plane):
+        out = (_c.c_double * 4)()
+        check(load().wt64_reduce(self._h, plane, out))
+        return tuple(out)
 
     def denoise_sum(self, n, taus, wgts, soft, noise_plane=PLANE_NONE, write_back=True, dst=PLANE_OUT):
         """Coefficients.denoise over the first len(taus) planes, then the plane sum (two steps

@@ -22,6 +22,7 @@ struct wt_plan64 {
     std::vector<double *> coef;
     double *input = nullptr, *out = nullptr;
     double *scratch[WT64_NUM_SCRATCH] = {nullptr};
+    double *tmp[3] = {nullptr, nullptr, nullptr};   // private temporaries of the filters (no plane id)
     std::vector<void *> allocs;
 };
 
@@ -172,6 +173,83 @@ __global__ __launch_bounds__(256) void wt64_signif_kernel(const double *c, const
             sg = soft ? erf(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
         }
         dst[o] = mode ? v * (wgt * sg) : sg;
+    }
+}
+
+// wow per-scale update (watroo/utils.py:193-203): c <- c * significance; gamma += c;
+// c <- c * factor / sqrt(clip(power, 1e-15)).  power / noise / gamma may be null.
+__global__ __launch_bounds__(256) void wt64_wow_kernel(double *c, const double *power, const double *noise, double *gamma, int W, int P,
+                                                       int nrows, double tau, int soft, double factor)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        double t = c[o];
+        if (tau > 0.0) {
+            const double tt = noise ? tau * noise[o] : tau;
+            t = t * (soft ? erf(fabs(t / tt)) : (fabs(t) > tt ? 1.0 : 0.0));
+        }
+        if (gamma) gamma[o] = gamma[o] + t;
+        double q = factor;
+        if (power) {
+            const double lp = power[o] <= 0.0 ? 1e-15 : power[o];
+            q = factor / sqrt(lp);
+        }
+        c[o] = t * q;
+    }
+}
+
+// gamma blend (watroo/utils.py:212-217)
+__global__ __launch_bounds__(256) void wt64_gamma_kernel(double *recon, const double *gamma, int W, int P, int nrows, double gmin,
+                                                         double range, double inv_gamma, double h)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        double t = (gamma[o] - gmin) / range;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        t = pow(t, inv_gamma);
+        recon[o] = (1.0 - h) * recon[o] + h * t;
+    }
+}
+
+__global__ __launch_bounds__(256) void wt64_fill_kernel(double *dst, int W, int P, int nrows, double value)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) dst[(int64_t)y * P + x] = value;
+}
+
+// {sum, sumsq, min, max}: per-block partials over whole rows, folded by wt_reduce_final_kernel
+__global__ __launch_bounds__(256) void wt64_reduce_kernel(const double *p, int nrows, int P, int W, double *partials)
+{
+    double s = 0.0, s2 = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const double *row = p + (int64_t)r * P;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const double t = row[x];
+            s += t;
+            s2 = fma(t, t, s2);
+            mn = fmin(mn, t);
+            mx = fmax(mx, t);
+        }
+    }
+    __shared__ double red[4][4];
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        s2 += __shfl_down(s2, off);
+        mn = fmin(mn, __shfl_down(mn, off));
+        mx = fmax(mx, __shfl_down(mx, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = s; red[wave][1] = s2; red[wave][2] = mn; red[wave][3] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { s += red[w][0]; s2 += red[w][1]; mn = fmin(mn, red[w][2]); mx = fmax(mx, red[w][3]); }
+        double *o = partials + (int64_t)blockIdx.x * 4;
+        o[0] = s; o[1] = s2; o[2] = mn; o[3] = mx;
     }
 }
 
@@ -331,6 +409,19 @@ static int plan64_base(wt_plan64 *p, int id, double **base)
     return 0;
 }
 
+static int plan64_tmp(wt_plan64 *p, int i, double **base)
+{
+    if (!p->tmp[i]) {
+        void *q = nullptr;
+        WT_HIP(hipSetDevice(p->ctx->device));
+        WT_HIP(hipMalloc(&q, (size_t)p->g.nrows * p->g.P * sizeof(double)));
+        p->allocs.push_back(q);
+        p->tmp[i] = (double *)q;
+    }
+    *base = p->tmp[i];
+    return 0;
+}
+
 static inline wt_ctx *ctx_of(wt_plan64 *p) { return p ? p->ctx : nullptr; }
 static inline dim3 grid64(const wt_plan64 *p) { return dim3((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)); }
 static Taps64 taps64(const wt_plan64 *p)
@@ -409,17 +500,12 @@ extern "C" int wt64_download(wt_plan64 *p, int plane, double *host, int64_t host
     return 0;
 }
 
-// conv_s of a plane: rows -> scratch 7, axis 1 (-> scratch 6 when an axis-0 pass follows), axis 0.
+// conv_s of a plane: rows -> a private temporary, axis 1 (-> a second one when an axis-0 pass follows), axis 0.
 // depth = 0: an image (or a 1 x N signal: no column pass); depth = Z > 0: a (Z, Y, X) cube.
 static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, int s, int square, int depth)
 {
     if (s < 0 || s > 24) WT_FAIL("float64 plan: scale %d out of range", s);
     if (depth < 0 || (depth > 0 && p->g.H % depth)) WT_FAIL("float64 plan: height %d is not a multiple of depth %d", p->g.H, depth);
-    double *t1 = nullptr, *t2 = nullptr;
-    WT_TRY(plan64_base(p, WT_PLANE_SCRATCH(7), &t1));
-    WT_TRY(plan64_base(p, WT_PLANE_SCRATCH(6), &t2));
-    if (in == t1 || in == t2 || out == t1 || out == t2 || out_w == t1 || out_w == t2)
-        WT_FAIL("float64 plan: scratch planes 6 and 7 are used internally by the filters");
     if (out == in || out_w == in) WT_FAIL("float64 plan: in-place filtering");
     const Taps64 t = taps64(p);
     const int d = 1 << s;
@@ -443,6 +529,9 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
         WT_HIP(hipGetLastError());
         return 0;
     }
+    double *t1 = nullptr, *t2 = nullptr;                 // private temporaries, allocated on first use
+    if (cols || deep) WT_TRY(plan64_tmp(p, 0, &t1));
+    if (cols && deep) WT_TRY(plan64_tmp(p, 1, &t2));
     double *r_out = (cols || deep) ? t1 : out;
     hipLaunchKernelGGL(wt64_rows_kernel, grid, block, 0, p->ctx->stream, in, r_out, g, d, t, square);
     if (!cols && !deep) {
@@ -510,8 +599,7 @@ extern "C" int wt64_local_variance(wt_plan64 *p, int src, int dst, int s, double
     double *in = nullptr, *o = nullptr, *mean = nullptr;
     WT_TRY(plan64_base(p, src, &in));
     WT_TRY(plan64_base(p, dst, &o));
-    WT_TRY(plan64_base(p, WT_PLANE_SCRATCH(5), &mean));
-    if (in == mean || o == mean) WT_FAIL("wt64_local_variance: scratch plane 5 is used internally");
+    WT_TRY(plan64_tmp(p, 2, &mean));
     WT_TRY(smooth64(p, in, mean, nullptr, s, 0, 0));
     WT_TRY(smooth64(p, in, o, nullptr, s, 1, 0));
     hipLaunchKernelGGL(wt64_var_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)mean, (const double *)o, o, p->g.W, p->g.P, p->g.nrows,
@@ -629,5 +717,69 @@ extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
     memcpy(&lo, &ulo, 8);
     memcpy(&hi, &uhi, 8);
     *median = (N & 1) ? lo : (lo + hi) / 2.0;
+    return 0;
+}
+
+/* one scale of the wow loop (watroo/utils.py:193-203): plane <- plane * significance(tau); gamma_plane
+ * += plane (or WT_PLANE_NONE); plane <- plane * factor / sqrt(clip(power_plane, 1e-15)) (or
+ * WT_PLANE_NONE: plane * factor) */
+extern "C" int wt64_wow_update(wt_plan64 *p, int plane, int power_plane, double tau, int soft, int noise_plane, double factor,
+                               int gamma_plane)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_wow_update: null plan");
+    double *c = nullptr, *pw = nullptr, *nz = nullptr, *gm = nullptr;
+    WT_TRY(plan64_base(p, plane, &c));
+    if (power_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, power_plane, &pw));
+    if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
+    if (gamma_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, gamma_plane, &gm));
+    if (pw == c || gm == c || nz == c) WT_FAIL("wt64_wow_update: the plane aliases one of its operands");
+    hipLaunchKernelGGL(wt64_wow_kernel, grid64(p), dim3(256), 0, p->ctx->stream, c, (const double *)pw, (const double *)nz, gm, p->g.W, p->g.P,
+                       p->g.nrows, tau, soft, factor);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* gamma blend (watroo/utils.py:212-217): recon <- (1-h) recon + h clip((gamma-gmin)/(gmax-gmin))^inv_gamma */
+extern "C" int wt64_gamma_blend(wt_plan64 *p, int recon, int gamma_plane, double gmin, double gmax, double inv_gamma, double h)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_gamma_blend: null plan");
+    double *r = nullptr, *g = nullptr;
+    WT_TRY(plan64_base(p, recon, &r));
+    WT_TRY(plan64_base(p, gamma_plane, &g));
+    hipLaunchKernelGGL(wt64_gamma_kernel, grid64(p), dim3(256), 0, p->ctx->stream, r, (const double *)g, p->g.W, p->g.P, p->g.nrows, gmin,
+                       gmax - gmin, inv_gamma, h);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt64_fill_plane(wt_plan64 *p, int plane, double value)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_fill_plane: null plan");
+    double *b = nullptr;
+    WT_TRY(plan64_base(p, plane, &b));
+    hipLaunchKernelGGL(wt64_fill_kernel, grid64(p), dim3(256), 0, p->ctx->stream, b, p->g.W, p->g.P, p->g.nrows, value);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* {sum, sum of squares, min, max} of a plane in float64 (c.std(), min / max of watroo/utils.py:176-214) */
+extern "C" int wt64_reduce(wt_plan64 *p, int plane, double out[4])
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !out) WT_FAIL("wt64_reduce: null pointer");
+    wt_ctx *c = p->ctx;
+    double *b = nullptr;
+    WT_TRY(plan64_base(p, plane, &b));
+    const int blocks = std::min(p->g.nrows, c->partial_blocks);
+    double *dout = c->d_partials + (size_t)c->partial_blocks * 4;
+    hipLaunchKernelGGL(wt64_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, c->d_partials);
+    hipLaunchKernelGGL(wt_reduce_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->d_partials, blocks, dout);
+    WT_HIP(hipGetLastError());
+    WT_HIP(hipMemcpyAsync(c->h_pinned, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    WT_HIP(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_pinned, 4 * sizeof(double));
     return 0;
 }

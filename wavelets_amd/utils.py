@@ -170,7 +170,7 @@ def wow(data,
     if type(data) is np.ndarray:                                          # ref:148-151
         transform = AtrousTransform(scaling_function, bilateral=sigma_bilateral,
                                     bilateral_scaling=bilateral_scaling)
-        coefficients = transform(data, n_scales, _f64=False)     # whitening: float32 engine
+        coefficients = transform(data, n_scales)      # float64 engine for float64 data, no bilateral
         coefficients.noise = noise
     else:
         coefficients = data
@@ -188,7 +188,8 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
     """The device-resident part of wow (ref:157-217): per-scale loop, plane sum, gamma blend.
     Leaves the whitened planes on the plan and the image in PLANE_OUT; returns the plan.
     (bench.py --config cfg5 times exactly this behind the transform, without the PCIe legs.)"""
-    coefficients._use_f32_engine()
+    if coefficients.bilateral is not None:
+        coefficients._use_f32_engine()       # (planes of a bilateral transform: float32 engine anyway)
     plan = coefficients._device()
     coefficients._sum_valid = False
     npix = float(plan.H) * float(plan.W)
@@ -231,13 +232,14 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
 def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
                 preserve_variance, whitening, h, soft_threshold, gplane):
     """The per-scale loop of wow (ref:174-203)."""
+    ft = np.float64 if isinstance(plan, _lib.Plan64) else np.float32      # the data's compute type
     for s, (_, w, d) in enumerate(zip(range(nplanes), recomposition_weights, sdc)):  # ref:174
         need_moments = preserve_variance or (s == n_scales and whitening and h < 1)
         if need_moments:
             tot, tot2, _, _ = plan.reduce(s)
             mean = tot / npix
-            std = np.float32(np.sqrt(max(tot2 / npix - mean * mean, 0.0)))
-            rms = np.float32(np.sqrt(tot2 / npix))
+            std = ft(np.sqrt(max(tot2 / npix - mean * mean, 0.0)))
+            rms = ft(np.sqrt(tot2 / npix))
         if preserve_variance:                                             # ref:178-184
             power_norm = std if s == n_scales else rms
         else:
@@ -249,12 +251,12 @@ def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sd
                     local_power = 1e-15
             else:
                 local_power = 1
-            factor = np.float32(w * power_norm / local_power)             # ref:203
+            factor = ft(w * power_norm / local_power)                     # ref:203
             plan.wow_update(s, PLANE_NONE, 0.0, soft_threshold, PLANE_NONE, factor, gplane)
         else:
             t = coefficients._tau(d, s, soft_threshold)                   # ref:199
             tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
-            factor = np.float32(w * power_norm)
+            factor = ft(w * power_norm)
             if whitening and h < 1 and coefficients._ndim == 3:           # ref:193-196 on a cube
                 # local power = 3-D conv_s(c^2): per-slice 2-D filter + axis-0 filter
                 plan.binary("mul", s, s, _SQ_PLANE)

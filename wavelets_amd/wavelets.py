@@ -9,8 +9,8 @@ int / big-endian inputs to float64 (ref:297,319-320; the README examples are flo
 tuned engine is float32 and serves float32 inputs; float64 / promoted inputs run on the float64
 engine (``_lib.Plan64``: double planes, double arithmetic, generic kernels) for the standard
 transform without bilateral filtering, the ``Coefficients`` operators, ``denoise``, ``enhance``,
-``convolution``, ``sdev_loc`` and ``generalized_anscombe``.  The remaining operators (bilateral
-filtering, ``recursive=True``, ``wow``, ``richardson_lucy``, ``atrous_convolution``) compute such
+``wow``, ``convolution``, ``sdev_loc`` and ``generalized_anscombe``.  The remaining operators (bilateral
+filtering, ``recursive=True``, ``richardson_lucy``, ``atrous_convolution``) compute such
 inputs in float32 and hand back float64 containers (float32 precision, about 1e-7 relative; the
 parity tests state it).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
 as (Z*Y) x X images (per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no
