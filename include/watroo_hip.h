@@ -292,9 +292,9 @@ int wt_anscombe(wt_plan *plan, int src, int dst, float alpha, float g, float sig
  * The reference computes float64 inputs in float64 and promotes int / big-endian inputs to
  * float64 (watroo/wavelets.py:297,319-320).  A wt_plan64 holds double planes (same plane ids as a
  * wt_plan: 0..max_level, WT_PLANE_INPUT, WT_PLANE_OUT, 8 scratch planes; wt64_decompose uses
- * scratch 0 and 1) and runs the standard decomposition without bilateral filtering and the
- * Coefficients operators in double arithmetic on generic kernels with the given 1-D taps
- * (cv2.filter2D's correlation order).  Single GPU, whole images.  `depth`: 0 = an H x W image (a
+ * scratch 0 and 1) and runs the decomposition (standard and, through border modes 1 / 3, recursive;
+ * plain or bilateral), the Coefficients operators and wow's per-scale loop in double arithmetic
+ * on generic kernels with the given 1-D taps (cv2.filter2D's correlation order).  Single GPU, whole images.  `depth`: 0 = an H x W image (a
  * 1 x N image is a signal: no column pass; its 'mirror' border is border mode 2), Z > 0 = a
  * (Z, Y, X) cube stored as a (Z*Y) x X image (watroo/wavelets.py:46-63). */
 typedef struct wt_plan64 wt_plan64;
@@ -308,9 +308,16 @@ int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
 int wt64_decompose(wt_plan64 *plan, int src, int level, int depth);
 /* convolution(arr, scaling_function, s) (watroo/wavelets.py:35-69); square_input: of src*src */
 int wt64_smooth(wt_plan64 *plan, int src, int dst, int s, int square_input, int depth);
-/* sdev_loc (watroo/wavelets.py:24-32) times f1 then f2; images */
+/* sdev_loc (watroo/wavelets.py:24-32) times f1 then f2 */
 int wt64_local_variance(wt_plan64 *plan, int src, int dst, int s, double f1, double f2,
-                        int take_sqrt);
+                        int take_sqrt, int depth);
+/* atrous_convolution(image, kernel, bilateral_variance, s) (watroo/wavelets.py:74-105);
+ * taps_reversed as flag bit3 of wt_bilateral_conv */
+int wt64_bilateral_conv(wt_plan64 *plan, int src, int var, int dst, int s, int depth,
+                        int taps_reversed);
+/* device copy of a window between planes of two plans (crop of atrous_recursive, :405-406) */
+int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, int dst_plane, int64_t sy,
+                     int64_t sx, int64_t dy, int64_t dx, int64_t rows, int64_t cols);
 /* np.median(np.abs(plane)) (watroo/wavelets.py:127): exact 63-bit radix select */
 int wt64_abs_median(wt_plan64 *plan, int plane, double *median);
 /* mode 0: dst = Coefficients.significance (watroo/wavelets.py:129-143); mode 1: dst = src * (wgt *

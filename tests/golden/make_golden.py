@@ -482,6 +482,23 @@ def g20_float64():
     out["wow_sig"], out["wow_sig_coef"] = r, cc.data
     r, cc = wow(cube.copy(), denoise_coefficients=[4], n_scales=2)
     out["wow_cube"], out["wow_cube_coef"] = r, cc.data
+    # bilateral filtering and the recursive algorithm in float64 (small arrays: K^2 / K^3 taps)
+    sb_img = b[:30, :38].copy()
+    sb_sig = (sig[:120] - 1e4) + 2 * np.sin(np.arange(120) / 9.)
+    sb_cube = cube[:6, :10, :12] + np.linspace(0, 3, 12)[None, None, :]
+    out.update(bil_img=sb_img, bil_sig=sb_sig, bil_cube=sb_cube)
+    for fam, cls in FAM.items():
+        out[f"{fam}_bil2_L3"] = AtrousTransform(cls, bilateral=1)(sb_img, 3).data
+        out[f"{fam}_bil2_list_L2"] = AtrousTransform(cls, bilateral=[2.0, .7], bilateral_scaling=True)(sb_img, 2).data
+        out[f"{fam}_bil1_L3"] = AtrousTransform(cls, bilateral=1)(sb_sig, 3).data
+        out[f"{fam}_bil3_L2"] = AtrousTransform(cls, bilateral=1)(sb_cube, 2).data
+        out[f"{fam}_rec2_L3"] = AtrousTransform(cls)(sb_img, 3, recursive=True).data
+        out[f"{fam}_rec2_bil_L2"] = AtrousTransform(cls, bilateral=1)(sb_img, 2, recursive=True).data
+        out[f"{fam}_rec1_L3"] = AtrousTransform(cls)(sb_sig, 3, recursive=True).data
+        out[f"{fam}_rec3_L2"] = AtrousTransform(cls)(sb_cube, 2, recursive=True).data
+    r, cc = wow(sb_img.copy(), bilateral=1, denoise_coefficients=[5, 2], n_scales=3)
+    out["wow_bil"], out["wow_bil_coef"] = r, cc.data
+    out["den_bil"] = denoise(sb_img.copy(), [4, 2], bilateral=1)
     for k, v in out.items():
         if k not in ("ints", "u16", "sig_hard_s0", "noise"):
             assert np.asarray(v).dtype == np.float64, (k, np.asarray(v).dtype)

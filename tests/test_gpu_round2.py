@@ -566,11 +566,31 @@ def test_float64_engine_vs_golden(WA):
     r, c2 = WA.wow(cw, denoise_coefficients=[5, 2])
     assert c2 is cw and isinstance(cw._plan, L.Plan64)
     close(r, g["wow_den"], 1e-10 * float(np.abs(g["wow_den"]).max()))
-    # operators of the float32 engine on float64 data: float64 containers, float32 precision
-    rb, cb = WA.wow(b.copy(), bilateral=1, n_scales=3)
-    assert rb.dtype == np.float64 and cb.data.dtype == np.float64 and isinstance(cb._plan, L.Plan)
-    r_ref, _ = WA.wow(b.astype(np.float32), bilateral=1, n_scales=3)
-    close(rb, r_ref, 1e-4 * float(np.abs(r_ref).max()))
+    # bilateral filtering and the recursive algorithm in float64
+    bi, bs, bc = g["bil_img"], g["bil_sig"], g["bil_cube"]
+    for fam, cls in (("b3spline", WA.B3spline), ("triangle", WA.Triangle)):
+        T1 = WA.AtrousTransform(cls, bilateral=1)
+        c = T1(bi, 3)
+        assert isinstance(c._plan, L.Plan64)
+        close(c.data, g[f"{fam}_bil2_L3"], 1e-11 * float(np.abs(bi).max()))
+        close(WA.AtrousTransform(cls, bilateral=[2.0, .7], bilateral_scaling=True)(bi, 2).data,
+              g[f"{fam}_bil2_list_L2"], 1e-11 * float(np.abs(bi).max()))
+        close(T1(bs, 3).data, g[f"{fam}_bil1_L3"], 1e-11 * float(np.abs(bs).max()))
+        close(T1(bc, 2).data, g[f"{fam}_bil3_L2"], 1e-11 * float(np.abs(bc).max()))
+        T0 = WA.AtrousTransform(cls)
+        close(T0(bi, 3, recursive=True).data, g[f"{fam}_rec2_L3"], 1e-12 * float(np.abs(bi).max()))
+        close(T1(bi, 2, recursive=True).data, g[f"{fam}_rec2_bil_L2"], 1e-11 * float(np.abs(bi).max()))
+        close(T0(bs, 3, recursive=True).data, g[f"{fam}_rec1_L3"], 1e-12 * float(np.abs(bs).max()))
+        close(T0(bc, 2, recursive=True).data, g[f"{fam}_rec3_L2"], 1e-12 * float(np.abs(bc).max()))
+    rb, cb = WA.wow(bi.copy(), bilateral=1, denoise_coefficients=[5, 2], n_scales=3)
+    assert rb.dtype == np.float64 and isinstance(cb._plan, L.Plan64)
+    close(cb.data, g["wow_bil_coef"], 1e-9 * float(np.abs(g["wow_bil_coef"]).max()))
+    close(rb, g["wow_bil"], 1e-9 * float(np.abs(g["wow_bil"]).max()))
+    close(WA.denoise(bi.copy(), [4, 2], bilateral=1), g["den_bil"], 1e-10 * float(np.abs(bi).max()))
+    # the two operators that stay in the float32 engine: float64 out, float32 precision
+    k2 = WA.B3spline(2).kernel
+    ac = WA.atrous_convolution(bi, k2, None, s=1)
+    close(ac, WA.convolution(bi, WA.B3spline(2), s=1), 1e-5 * float(np.abs(bi).max()))
     # median on an even and an odd number of samples, ties and zeros, in float64
     for shape in ((64, 64), (63, 65), (1, 7)):
         z = np.random.default_rng(3).standard_normal(shape)

@@ -123,7 +123,11 @@ SIGNATURES = {
     "wt64_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
-                                       _c.c_double, _c.c_int]),
+                                       _c.c_double, _c.c_int, _c.c_int]),
+    "wt64_bilateral_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                       _c.c_int]),
+    "wt64_copy_window": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64, _i64, _i64, _i64,
+                                    _i64]),
     "wt64_abs_median": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt64_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int,
                                      _c.c_int, _c.c_int]),
@@ -672,7 +676,24 @@ class Plan64:
         check(load().wt64_smooth(self._h, src, dst, s, 0, depth))
 
     def local_variance(self, src, dst, s, f1=1.0, f2=1.0, take_sqrt=False, flags=0):
-        check(load().wt64_local_variance(self._h, src, dst, s, f1, f2, int(take_sqrt)))
+        check(load().wt64_local_variance(self._h, src, dst, s, f1, f2, int(take_sqrt), 0))
+
+    def local_variance3d(self, src, dst, s, depth, f1=1.0, f2=1.0):
+        check(load().wt64_local_variance(self._h, src, dst, s, f1, f2, 0, depth))
+
+    def bilateral_conv(self, src, var, dst, s, flags=0):
+        check(load().wt64_bilateral_conv(self._h, src, var, dst, s, 0,
+                                         int(bool(flags & FLAG_TAPS_REVERSED))))
+
+    def bilateral3d_conv(self, src, var, dst, s, depth):
+        check(load().wt64_bilateral_conv(self._h, src, var, dst, s, depth, 0))
+
+    def copy_window_from(self, src_plan, src_plane, dst_plane, sy, sx, dy, dx, rows, cols):
+        check(load().wt64_copy_window(src_plan._h, src_plane, self._h, dst_plane, sy, sx, dy, dx,
+                                      rows, cols))
+
+    def crop_from(self, src_plan, src_plane, dst_plane, y0, x0):
+        self.copy_window_from(src_plan, src_plane, dst_plane, y0, x0, 0, 0, self.H, self.W)
 
     def abs_median(self, plane):
         m = _c.c_double(0)

@@ -144,6 +144,50 @@ __global__ __launch_bounds__(256) void wt64_chain_kernel(const double *in, doubl
     }
 }
 
+// atrous_convolution(image, kernel, bilateral_variance, s) in float64 (watroo/wavelets.py:74-105):
+// K^2 taps on an image (Z == 0) or K^3 on a (Z, Y, X) cube, range-weighted.  The reference's tap loop
+// is a true convolution (kernel index i pairs with the sample at offset (hw - i) * d, :87-91) while
+// the plan stores the taps in correlation order; rev = the plan's taps are stored reversed (1-D
+// signals).  Taps in the reference's order.  One sample per thread.
+__global__ __launch_bounds__(256) void wt64_bilateral_kernel(const double *in, const double *var, double *out, Geo g, int Y, int Z, int d,
+                                                             Taps64 t, int rev)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int n = t.n, hw = n / 2;
+    const bool cube = Z > 0;
+    const int nrows = cube ? Z * Y : g.nrows;
+    const int H = cube ? Y : g.H;
+    const double kc = t.k[hw];
+    for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+        const int z = cube ? row / Y : 0;
+        const int y = cube ? row - z * Y : row;
+        const int64_t o = (int64_t)row * g.P + x;
+        const double I = in[o];
+        const double m = -0.5 / var[o];
+        double den = cube ? kc * kc * kc : kc * kc;
+        double num = den * I;
+        for (int iz = 0; iz < (cube ? n : 1); ++iz) {
+            const int zz = cube ? wt_refl_b(z + (hw - iz) * d, Z, d, g.border) : 0;
+            const double kz = cube ? t.k[rev ? n - 1 - iz : iz] : 1.0;
+            for (int iy = 0; iy < n; ++iy) {
+                const int yy = wt_refl_b(y + (hw - iy) * d, H, d, g.border);
+                const double kzy = kz * t.k[rev ? n - 1 - iy : iy];
+                const double *r = in + (cube ? ((int64_t)zz * Y + yy) : (int64_t)yy) * g.P;
+                for (int ix = 0; ix < n; ++ix) {
+                    if (ix == hw && iy == hw && (!cube || iz == hw)) continue;
+                    const double It = r[wt_refl_b(x + (hw - ix) * d, g.W, d, g.border)];
+                    const double dl = I - It;
+                    const double w = kzy * t.k[rev ? n - 1 - ix : ix] * exp(dl * dl * m);
+                    num = fma(w, It, num);
+                    den += w;
+                }
+            }
+        }
+        out[o] = num / den;
+    }
+}
+
 // pointwise: 0 add, 1 sub, 2 mul, 3 div
 __global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const double *b, double *dst, int W, int P, int nrows, int op)
 {
@@ -468,12 +512,12 @@ extern "C" int wt64_plan_destroy(wt_plan64 *p)
     return 0;
 }
 
-/* 0 = symmetric, 2 = 'mirror' (1-D signals: a 1 x N image), as wt_plan_set_border */
+/* border modes 0..3 as wt_plan_set_border (2 / 3: the 'mirror' border of 1-D signals, 1 x N images) */
 extern "C" int wt64_plan_set_border(wt_plan64 *p, int border)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_plan_set_border: null plan");
-    if (border != 0 && border != 2) WT_FAIL("wt64_plan_set_border: border %d unsupported (0 symmetric, 2 mirror)", border);
+    if (border < 0 || border > 3) WT_FAIL("wt64_plan_set_border: border %d unsupported (0..3, as wt_plan_set_border)", border);
     p->g.border = border;
     return 0;
 }
@@ -515,7 +559,7 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
     // a 1 x N image under the 'mirror' border is a 1-D signal (watroo/wavelets.py:65-69: row filter
     // only); any other one-row image or one-slice cube still sees every axis' taps (they reflect
     // onto the same sample and contribute sum(k) - which is 1 only for normalised taps)
-    const bool cols = !(Y == 1 && depth == 0 && g.border == 2), deep = depth > 0;
+    const bool cols = !(Y == 1 && depth == 0 && (g.border == 2 || g.border == 3)), deep = depth > 0;
     if (cols && !deep && !square) {
         // images: one kernel per scale (register window down every polyphase row chain)
         const int n_max = (g.H + d - 1) / d;             // longest chain
@@ -590,8 +634,8 @@ extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
     return 0;
 }
 
-/* sdev_loc(image, sf, s, variance) (watroo/wavelets.py:24-32), times f1 then f2; images only */
-extern "C" int wt64_local_variance(wt_plan64 *p, int src, int dst, int s, double f1, double f2, int take_sqrt)
+/* sdev_loc(image, sf, s, variance) (watroo/wavelets.py:24-32), times f1 then f2 */
+extern "C" int wt64_local_variance(wt_plan64 *p, int src, int dst, int s, double f1, double f2, int take_sqrt, int depth)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_local_variance: null plan");
@@ -600,8 +644,8 @@ extern "C" int wt64_local_variance(wt_plan64 *p, int src, int dst, int s, double
     WT_TRY(plan64_base(p, src, &in));
     WT_TRY(plan64_base(p, dst, &o));
     WT_TRY(plan64_tmp(p, 2, &mean));
-    WT_TRY(smooth64(p, in, mean, nullptr, s, 0, 0));
-    WT_TRY(smooth64(p, in, o, nullptr, s, 1, 0));
+    WT_TRY(smooth64(p, in, mean, nullptr, s, 0, depth));
+    WT_TRY(smooth64(p, in, o, nullptr, s, 1, depth));
     hipLaunchKernelGGL(wt64_var_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)mean, (const double *)o, o, p->g.W, p->g.P, p->g.nrows,
                        f1, f2, take_sqrt);
     WT_HIP(hipGetLastError());
@@ -781,5 +825,44 @@ extern "C" int wt64_reduce(wt_plan64 *p, int plane, double out[4])
     WT_HIP(hipMemcpyAsync(c->h_pinned, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     WT_HIP(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_pinned, 4 * sizeof(double));
+    return 0;
+}
+
+/* atrous_convolution(image, kernel, bilateral_variance, s) (watroo/wavelets.py:74-105) in float64;
+ * depth as for wt64_smooth; taps_reversed: the plan's taps are stored reversed (1-D signals) */
+extern "C" int wt64_bilateral_conv(wt_plan64 *p, int src, int var, int dst, int s, int depth, int taps_reversed)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_bilateral_conv: null plan");
+    if (s < 0 || s > 24) WT_FAIL("wt64_bilateral_conv: scale %d out of range", s);
+    if (depth < 0 || (depth > 0 && p->g.H % depth)) WT_FAIL("wt64_bilateral_conv: height %d is not a multiple of depth %d", p->g.H, depth);
+    if (p->g.border != 0 && p->g.border != 1) WT_FAIL("wt64_bilateral_conv: symmetric border (whole array or polyphase) only");
+    if (src == dst || var == dst) WT_FAIL("wt64_bilateral_conv: dst must differ from src and var");
+    double *in = nullptr, *v = nullptr, *o = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    WT_TRY(plan64_base(p, var, &v));
+    WT_TRY(plan64_base(p, dst, &o));
+    hipLaunchKernelGGL(wt64_bilateral_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, (const double *)v, o, p->g,
+                       depth > 0 ? p->g.H / depth : p->g.H, depth, 1 << s, taps64(p), taps_reversed);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* dst[dst_plane][dy:dy+rows, dx:dx+cols] = src[src_plane][sy:sy+rows, sx:sx+cols] on the device (the
+ * crop of atrous_recursive, watroo/wavelets.py:405-406) */
+extern "C" int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, int dst_plane, int64_t sy, int64_t sx, int64_t dy,
+                                int64_t dx, int64_t rows, int64_t cols)
+{
+    WtGuard guard_(ctx_of(src), ctx_of(dst));
+    if (!src || !dst) WT_FAIL("wt64_copy_window: null plan");
+    if (src->ctx != dst->ctx) WT_FAIL("wt64_copy_window: plans of different contexts");
+    if (rows < 1 || cols < 1 || sy < 0 || sx < 0 || dy < 0 || dx < 0 || sy + rows > src->g.nrows || sx + cols > src->g.W ||
+        dy + rows > dst->g.nrows || dx + cols > dst->g.W)
+        WT_FAIL("wt64_copy_window: window outside a plane");
+    double *a = nullptr, *b = nullptr;
+    WT_TRY(plan64_base(src, src_plane, &a));
+    WT_TRY(plan64_base(dst, dst_plane, &b));
+    WT_HIP(hipMemcpy2DAsync(b + dy * dst->g.P + dx, (size_t)dst->g.P * 8, a + sy * src->g.P + sx, (size_t)src->g.P * 8, (size_t)cols * 8, (size_t)rows,
+                            hipMemcpyDeviceToDevice, src->ctx->stream));
     return 0;
 }

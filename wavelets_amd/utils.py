@@ -76,7 +76,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     ``weights[s]`` sigma, sum the planes (ref:83-102).  Optional Anscombe pre/post transform.
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
     """
-    f64 = _result_dtype(data) == np.float64 and bilateral is None     # float64 engine (ref:319-320)
+    f64 = _result_dtype(data) == np.float64                           # float64 engine (ref:319-320)
     if np.ndim(data) in (1, 3) or (f64 and np.ndim(data) == 2):
         # signals, cubes and float64 images: the generic call sequence
         arr = np.asarray(data, np.float64 if f64 else np.float32)
@@ -188,8 +188,6 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
     """The device-resident part of wow (ref:157-217): per-scale loop, plane sum, gamma blend.
     Leaves the whitened planes on the plan and the image in PLANE_OUT; returns the plan.
     (bench.py --config cfg5 times exactly this behind the transform, without the PCIe legs.)"""
-    if coefficients.bilateral is not None:
-        coefficients._use_f32_engine()       # (planes of a bilateral transform: float32 engine anyway)
     plan = coefficients._device()
     coefficients._sum_valid = False
     npix = float(plan.H) * float(plan.W)

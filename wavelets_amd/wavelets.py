@@ -7,12 +7,11 @@ Same public names, argument meaning and error behaviour as the reference module
 dtype policy: the reference keeps float64 inputs in float64 and promotes
 int / big-endian inputs to float64 (ref:297,319-320; the README examples are float64).  Here the
 tuned engine is float32 and serves float32 inputs; float64 / promoted inputs run on the float64
-engine (``_lib.Plan64``: double planes, double arithmetic, generic kernels) for the standard
-transform without bilateral filtering, the ``Coefficients`` operators, ``denoise``, ``enhance``,
-``wow``, ``convolution``, ``sdev_loc`` and ``generalized_anscombe``.  The remaining operators (bilateral
-filtering, ``recursive=True``, ``richardson_lucy``, ``atrous_convolution``) compute such
-inputs in float32 and hand back float64 containers (float32 precision, about 1e-7 relative; the
-parity tests state it).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
+engine (``_lib.Plan64``: double planes, double arithmetic, generic kernels): the transform
+(standard and recursive, with or without bilateral filtering; signals, images, cubes), the
+``Coefficients`` operators, ``denoise``, ``enhance``, ``wow``, ``convolution``, ``sdev_loc`` and
+``generalized_anscombe``.  ``richardson_lucy`` and ``atrous_convolution`` compute such inputs in
+float32 and hand back float64 (float32 precision, about 1e-7 relative).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
 as (Z*Y) x X images (per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no
 CPU fallback.
 """
@@ -395,7 +394,6 @@ class Coefficients:
         self._sum_valid = False     # PLANE_OUT holds np.sum(planes, axis=0) of the CURRENT planes
         # logical shape of one plane: (N,), (H, W) or (Z, Y, X); the engine stores it as a 2-D
         # image: 1 x N, H x W or (Z*Y) x X
-        self._force_f32 = False     # wow / bilateral operators exist in the float32 engine only
         if isinstance(data, (Plan, Plan64)):
             self._plan = data
             self._nplanes = data.max_level + 1
@@ -415,8 +413,7 @@ class Coefficients:
             self._nplanes = self._host.shape[0]
             self._shape = tuple(self._host.shape[1:])
         # dtype of the host mirror and of every array handed back: what the reference would return
-        # for the transform's input.  float64 objects compute on the float64 engine (Plan64) unless
-        # an operator that only the float32 engine has was applied (_use_f32_engine)
+        # for the transform's input.  float64 objects compute on the float64 engine (Plan64)
         self._dtype = np.dtype(np.float32 if _dtype is None else _dtype)
         if isinstance(data, Plan64):
             self._dtype = np.dtype(np.float64)
@@ -485,7 +482,7 @@ class Coefficients:
         run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
             H, W = self._plane_hw()
-            if self._dtype == np.float64 and not self._force_f32:
+            if self._dtype == np.float64:
                 self._plan = acquire_plan64(default_context(), H, W,
                                             _taps_f64(self.scaling_function, self._ndim), self._nplanes - 1)
             else:
@@ -505,17 +502,6 @@ class Coefficients:
                     self._plan.download(s, self._as_plane(self._host[s]))
                 else:                        # float64 mirror of float32 planes
                     self._as_plane(self._host[s])[...] = self._plan.download(s)
-
-    def _use_f32_engine(self):
-        """Move a float64-engine object to the float32 engine (operators that exist there only:
-        wow's whitening, bilateral filtering): the planes travel through the host mirror, the
-        containers stay float64."""
-        self._force_f32 = True
-        if isinstance(self._plan, Plan64):
-            self.data                                  # materialise the mirror
-            release_plan(self._plan)
-            self._plan = None
-            self._sum_valid = False
 
     # -- reference interface -----------------------------------------------------------
     def __len__(self):
@@ -740,9 +726,11 @@ class AtrousTransform:
         Without the keyword nothing extra is computed.
 
         float64 / int inputs (computed in float64 by the reference, ref:297,319-320) run on the
-        float64 engine when the transform is the standard one without bilateral filtering."""
-        if _f64 and self.bilateral is None and not recursive and _is_f64(arr) \
-                and np.ndim(arr) in (1, 2, 3):
+        float64 engine."""
+        if _f64 and _is_f64(arr) and np.ndim(arr) in (1, 2, 3):
+            if recursive:
+                return self._recursive(np.asarray(arr), level, self.scaling_function_class(np.ndim(arr)),
+                                       np.float64)
             return self._call_f64(arr, level)
         if _is_1d(arr):
             return self._call_1d(arr, level, recursive)
@@ -767,21 +755,43 @@ class AtrousTransform:
     def _call_f64(self, arr, level):
         """Standard algorithm in float64 (ref:408-444 on float64 / promoted input, ref:319-320):
         double planes on a Plan64, one generic pass per scale; signals as 1 x N images under the
-        'mirror' border of the 1-D branch (ref:65-69), cubes as (Z*Y) x X images (ref:46-63)."""
+        'mirror' border of the 1-D branch (ref:65-69), cubes as (Z*Y) x X images (ref:46-63);
+        with bilateral filtering the per-scale sequence of ref:433-442."""
         a = np.ascontiguousarray(arr, dtype=np.float64)
         nd = a.ndim
         scaling_function = self.scaling_function_class(nd)
         plan = acquire_plan64(default_context(), *_plane_shape(a.shape), _taps_f64(scaling_function, nd), level)
         plan.upload(PLANE_INPUT, a.reshape(plan.shape))
-        if nd == 1:
-            plan.set_border(2)
-        if nd == 3:
-            plan.decompose3d(PLANE_INPUT, level, a.shape[0])
+        if self.bilateral is None:
+            if nd == 1:
+                plan.set_border(2)
+            if nd == 3:
+                plan.decompose3d(PLANE_INPUT, level, a.shape[0])
+            else:
+                plan.decompose(PLANE_INPUT, level)
+            plan.set_border(0)
         else:
-            plan.decompose(PLANE_INPUT, level)
-        plan.set_border(0)
-        return Coefficients(plan, scaling_function, None, _shape=a.shape if nd == 3 else None,
-                            _dtype=np.float64)
+            sb = self._sigma_bilateral(level)
+            cur = PLANE_INPUT
+            for s in range(level):
+                nxt = level if s == level - 1 else PLANE_SCRATCH(s & 1)
+                f1 = float(sb[s]) ** 2
+                f2 = float(s + 1) if self.bilateral_scaling else 1.0
+                if nd == 3:
+                    plan.local_variance3d(cur, _TMP_PLANE, s, a.shape[0], f1, f2)
+                    plan.bilateral3d_conv(cur, _TMP_PLANE, nxt, s, a.shape[0])
+                else:
+                    plan.set_border(2 if nd == 1 else 0)           # variance: convolution()'s border
+                    plan.local_variance(cur, _TMP_PLANE, s, f1, f2)
+                    plan.set_border(0)                             # ref:77: symmetric pad
+                    plan.bilateral_conv(cur, _TMP_PLANE, nxt, s,
+                                        _lib.FLAG_TAPS_REVERSED if nd == 1 else 0)
+                plan.binary("sub", cur, nxt, s)                    # ref:442
+                cur = nxt
+            if level == 0:
+                plan.decompose(PLANE_INPUT, 0)
+        return Coefficients(plan, scaling_function, self.bilateral,
+                            _shape=a.shape if nd == 3 else None, _dtype=np.float64)
 
     # the reference's two algorithm entry points return the stacked planes as an ndarray
     # (ref:330-406, 408-444); kept for code that calls them directly
@@ -875,16 +885,18 @@ class AtrousTransform:
         'mirror' border of the 1-D convolution) and the planes are cropped on the device."""
         if level < 1:
             raise ValueError("recursive=True needs level >= 1")
-        arr = np.asarray(arr, dtype=np.float32)
+        f64 = np.dtype(dtype) == np.float64 and _is_f64(arr)          # float64 engine (ref:319-320)
+        arr = np.asarray(arr, dtype=np.float64 if f64 else np.float32)
         nd = arr.ndim
         ctx = default_context()
-        fam = _family_of(scaling_function, nd)
+        fam = _taps_f64(scaling_function, nd) if f64 else _family_of(scaling_function, nd)
+        acquire = acquire_plan64 if f64 else acquire_plan
         pad = (len(scaling_function.coefficients_1d) // 2) * 2 ** (level - 1)
         padded = np.pad(arr, pad, mode='symmetric')
         shape2 = {1: lambda a: (1, a.shape[0]), 2: lambda a: a.shape,
                   3: lambda a: (a.shape[0] * a.shape[1], a.shape[2])}[nd]
-        big = acquire_plan(ctx, *shape2(padded), fam, level)
-        plan = acquire_plan(ctx, *shape2(arr), fam, level)
+        big = acquire(ctx, *shape2(padded), fam, level)
+        plan = acquire(ctx, *shape2(arr), fam, level)
         sym, conv_border = 1, (3 if nd == 1 else 1)   # symmetric / convolution() border, per sub-array
         try:
             big.upload(PLANE_INPUT, padded.reshape(shape2(padded)))
