@@ -291,7 +291,7 @@ int wt_anscombe(wt_plan *plan, int src, int dst, float alpha, float g, float sig
 /* ---- float64 engine ------------------------------------------------------------------------
  * The reference computes float64 inputs in float64 and promotes int / big-endian inputs to
  * float64 (watroo/wavelets.py:297,319-320).  A wt_plan64 holds double planes (same plane ids as a
- * wt_plan: 0..max_level, WT_PLANE_INPUT, WT_PLANE_OUT, 8 scratch planes; wt64_decompose uses
+ * wt_plan: 0..max_level, WT_PLANE_INPUT, WT_PLANE_OUT, 32 scratch planes; wt64_decompose uses
  * scratch 0 and 1) and runs the decomposition (standard and, through border modes 1 / 3, recursive;
  * plain or bilateral), the Coefficients operators and wow's per-scale loop in double arithmetic
  * on generic kernels with the given 1-D taps (cv2.filter2D's correlation order).  Single GPU, whole images.  `depth`: 0 = an H x W image (a
@@ -327,7 +327,7 @@ int wt64_significance(wt_plan64 *plan, int src, int dst, double tau, double wgt,
                       int noise_plane, int mode);
 /* np.sum(planes[first..first+count), axis=0) in plane order (watroo/utils.py:98) */
 int wt64_plane_sum(wt_plan64 *plan, int first, int count, int dst);
-/* dst = a OP b: 0 add, 1 sub, 2 mul, 3 div */
+/* dst = a OP b: 0 add, 1 sub, 2 mul, 3 div, 4 (a+b)/b */
 int wt64_binary(wt_plan64 *plan, int op, int a, int b, int dst);
 /* the operators of utils.wow without bilateral filtering (watroo/utils.py:157-217) in float64:
  * per-scale update (as wt_wow_update), gamma blend, fill, {sum, sumsq, min, max} */
@@ -337,6 +337,12 @@ int wt64_gamma_blend(wt_plan64 *plan, int recon, int gamma_plane, double gmin, d
                      double inv_gamma, double h);
 int wt64_fill_plane(wt_plan64 *plan, int plane, double value);
 int wt64_reduce(wt_plan64 *plan, int plane, double out[4]);
+/* Richardson-Lucy support in float64 (watroo/utils.py:222-290), as wt_filter2d_ex / wt_mrs_update;
+ * `kernel` is a host pointer to kh*kw doubles */
+int wt64_filter2d(wt_plan64 *plan, int src, int dst, const double *kernel, int kh, int kw, int ay,
+                  int ax, int border);
+int wt64_mrs_update(wt_plan64 *plan, int plane, int mrs_plane, double tau, int soft,
+                    int noise_plane, int persistent, double inv_pow);
 /* generalized_anscombe (watroo/wavelets.py:14-21) */
 int wt64_anscombe(wt_plan64 *plan, int src, int dst, double alpha, double g, double sigma,
                   int inverse);

@@ -499,6 +499,25 @@ def g20_float64():
     r, cc = wow(sb_img.copy(), bilateral=1, denoise_coefficients=[5, 2], n_scales=3)
     out["wow_bil"], out["wow_bil_coef"] = r, cc.data
     out["den_bil"] = denoise(sb_img.copy(), [4, 2], bilateral=1)
+    # richardson_lucy and the stand-alone atrous_convolution on float64 data
+    from watroo.wavelets import atrous_convolution
+    yy, xx = np.mgrid[:48, :40]
+    truth = 5 + 40 * np.exp(-((yy - 20) ** 2 + (xx - 15) ** 2) / 18.) + 25 * np.exp(-((yy - 33) ** 2 + (xx - 28) ** 2) / 8.)
+    gk = np.exp(-(np.arange(-2, 3) ** 2) / 2.0)
+    psf = np.outer(gk, gk * np.array([1, 1, 1, .8, .6]))
+    psf = psf / psf.sum()
+    rl_data = ndimage.correlate(truth, psf[::-1, ::-1], mode="reflect") + rng.standard_normal(truth.shape) * .5
+    out["rl_data"], out["rl_psf"] = rl_data, psf
+    assert rl_data.dtype == np.float64
+    for name, kw in {"soft": dict(iterations=3), "hard": dict(iterations=3, threshold_type='hard'),
+                     "nonpers": dict(iterations=2, persistent_mrs=False, denoise_coefficients=(4, 2)),
+                     "fft": dict(iterations=3, fft=True)}.items():
+        out[f"rl_{name}"] = richardson_lucy(rl_data.copy(), psf, **kw)
+    k2 = B3spline(2).kernel
+    vmap = 0.5 + np.abs(rng.standard_normal(sb_img.shape))
+    out["ac_var"] = vmap
+    out["ac_plain_s1"] = atrous_convolution(sb_img, k2, None, s=1)
+    out["ac_var_s1"] = atrous_convolution(sb_img, k2, vmap, s=1)
     for k, v in out.items():
         if k not in ("ints", "u16", "sig_hard_s0", "noise"):
             assert np.asarray(v).dtype == np.float64, (k, np.asarray(v).dtype)

@@ -587,10 +587,24 @@ def test_float64_engine_vs_golden(WA):
     close(cb.data, g["wow_bil_coef"], 1e-9 * float(np.abs(g["wow_bil_coef"]).max()))
     close(rb, g["wow_bil"], 1e-9 * float(np.abs(g["wow_bil"]).max()))
     close(WA.denoise(bi.copy(), [4, 2], bilateral=1), g["den_bil"], 1e-10 * float(np.abs(bi).max()))
-    # the two operators that stay in the float32 engine: float64 out, float32 precision
+    # stand-alone atrous_convolution and richardson_lucy on float64 data
     k2 = WA.B3spline(2).kernel
-    ac = WA.atrous_convolution(bi, k2, None, s=1)
-    close(ac, WA.convolution(bi, WA.B3spline(2), s=1), 1e-5 * float(np.abs(bi).max()))
+    close(WA.atrous_convolution(bi, k2, None, s=1), g["ac_plain_s1"], 1e-12 * float(np.abs(bi).max()))
+    close(WA.atrous_convolution(bi, k2, g["ac_var"], s=1), g["ac_var_s1"], 1e-11 * float(np.abs(bi).max()))
+    from wavelets_amd.utils import richardson_lucy
+    rd, psf = g["rl_data"], g["rl_psf"]
+    for name, kw in {"soft": dict(iterations=3), "hard": dict(iterations=3, threshold_type='hard'),
+                     "nonpers": dict(iterations=2, persistent_mrs=False, denoise_coefficients=(4, 2)),
+                     "fft": dict(iterations=3, fft=True)}.items():
+        got = richardson_lucy(rd.copy(), psf, **kw)
+        assert got.dtype == np.float64
+        if name == "hard":                               # support flips for coefficients at tau
+            assert (np.abs(got - g[f"rl_{name}"]) > 1e-9 * float(np.abs(rd).max())).sum() <= 4
+        else:
+            close(got, g[f"rl_{name}"], 1e-10 * float(np.abs(rd).max()))
+    # uniform_init: the reference keeps the estimate in float32 (utils.py:233): float32 engine
+    u = richardson_lucy(rd.copy(), psf, iterations=2, uniform_init=True)
+    assert u.dtype == np.float32
     # median on an even and an odd number of samples, ties and zeros, in float64
     for shape in ((64, 64), (63, 65), (1, 7)):
         z = np.random.default_rng(3).standard_normal(shape)

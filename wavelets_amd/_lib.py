@@ -141,6 +141,10 @@ SIGNATURES = {
                                     _c.c_double, _c.c_double]),
     "wt64_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_double]),
     "wt64_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
+    "wt64_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_int,
+                                 _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_mrs_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
+                                   _c.c_int, _c.c_double]),
 }
 
 _lib = None
@@ -733,8 +737,23 @@ class Plan64:
         check(load().wt64_plane_sum(self._h, first, count, dst))
 
     def binary(self, op, a, b, dst):
-        code = {"add": 0, "sub": 1, "mul": 2, "div": 3}[op]
+        code = {"add": 0, "sub": 1, "mul": 2, "div": 3, "add_div": 4}[op]
         check(load().wt64_binary(self._h, code, a, b, dst))
+
+    def copy(self, src, dst):
+        self.copy_window_from(self, src, dst, 0, 0, 0, 0, self.H, self.W)
+
+    def filter2d(self, src, dst, kernel, flags=0, anchor=None, periodic=False):
+        k = np.ascontiguousarray(kernel, dtype=np.float64)
+        if k.ndim != 2:
+            raise ValueError("filter2d kernel must be 2-D")
+        ay, ax = (k.shape[0] // 2, k.shape[1] // 2) if anchor is None else anchor
+        check(load().wt64_filter2d(self._h, src, dst, k.ctypes.data_as(_dp), k.shape[0], k.shape[1],
+                                   ay, ax, 3 if periodic else 0))
+
+    def mrs_update(self, plane, mrs_plane, tau, soft, noise_plane, persistent, inv_pow):
+        check(load().wt64_mrs_update(self._h, plane, mrs_plane, float(tau), int(soft), noise_plane,
+                                     int(persistent), float(inv_pow)))
 
     def anscombe(self, src, dst, alpha=1, g=0, sigma=0, inverse=False):
         check(load().wt64_anscombe(self._h, src, dst, alpha, g, sigma, int(inverse)))

@@ -10,7 +10,7 @@
 // Included at the end of wt_api.hip (one translation unit).
 #pragma once
 
-#define WT64_NUM_SCRATCH 8
+#define WT64_NUM_SCRATCH 32
 #define WT64_MAX_TAPS 15
 
 struct wt_plan64 {
@@ -23,6 +23,8 @@ struct wt_plan64 {
     double *input = nullptr, *out = nullptr;
     double *scratch[WT64_NUM_SCRATCH] = {nullptr};
     double *tmp[3] = {nullptr, nullptr, nullptr};   // private temporaries of the filters (no plane id)
+    double *psf = nullptr;                          // PSF taps of wt64_filter2d
+    size_t psf_cap = 0;
     std::vector<void *> allocs;
 };
 
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void wt64_bilateral_kernel(const double *in, c
     }
 }
 
-// pointwise: 0 add, 1 sub, 2 mul, 3 div
+// pointwise: 0 add, 1 sub, 2 mul, 3 div, 4 (a + b) / b (watroo/utils.py:280-281)
 __global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const double *b, double *dst, int W, int P, int nrows, int op)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const
     for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
         const int64_t o = (int64_t)y * P + x;
         const double u = a[o], v = b[o];
-        dst[o] = op == 0 ? u + v : op == 1 ? u - v : op == 2 ? u * v : u / v;
+        dst[o] = op == 0 ? u + v : op == 1 ? u - v : op == 2 ? u * v : op == 3 ? u / v : (u + v) / v;
     }
 }
 
@@ -294,6 +296,56 @@ __global__ __launch_bounds__(256) void wt64_reduce_kernel(const double *p, int n
         for (int w = 1; w < 4; ++w) { s += red[w][0]; s2 += red[w][1]; mn = fmin(mn, red[w][2]); mx = fmax(mx, red[w][3]); }
         double *o = partials + (int64_t)blockIdx.x * 4;
         o[0] = s; o[1] = s2; o[2] = mn; o[3] = mx;
+    }
+}
+
+// cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with an arbitrary small kernel
+// (watroo/utils.py:257,286), or - wrap - the periodic correlation that the reference's rFFT products
+// are (:245-254, 284); (ay, ax) = anchor.  One sample per thread, taps from a device buffer.
+__global__ __launch_bounds__(256) void wt64_filter2d_kernel(const double *in, double *out, Geo g, const double *psf, int kh, int kw, int ay,
+                                                            int ax, int wrap)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    for (int y = blockIdx.y; y < g.nrows; y += gridDim.y) {
+        double acc = 0.0;
+        for (int i = 0; i < kh; ++i) {
+            int yy = y + i - ay;
+            if (wrap) { yy %= g.H; if (yy < 0) yy += g.H; } else yy = wt_refl(yy, g.H);
+            const double *row = in + (int64_t)yy * g.P;
+            for (int j = 0; j < kw; ++j) {
+                int xx = x + j - ax;
+                if (wrap) { xx %= g.W; if (xx < 0) xx += g.W; } else xx = wt_refl(xx, g.W);
+                acc = fma(psf[i * kw + j], row[xx], acc);
+            }
+        }
+        out[(int64_t)y * g.P + x] = acc;
+    }
+}
+
+// multiresolution-support update of a residual plane (watroo/utils.py:263-276), as wt_mrs_kernel
+__global__ __launch_bounds__(256) void wt64_mrs_kernel(double *c, double *mrs, const double *noise, int W, int P, int nrows, double tau,
+                                                       int soft, int persistent, double inv_pow)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        const int64_t o = (int64_t)y * P + x;
+        const double v = c[o];
+        double sg = 1.0;
+        if (tau > 0.0) {
+            const double tt = noise ? tau * noise[o] : tau;
+            sg = soft ? erf(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
+        }
+        double m = mrs[o];
+        if (soft) {
+            m = persistent ? m * sg : sg;
+            c[o] = v * pow(m, inv_pow);
+        } else {
+            m = persistent ? fmax(m, sg) : sg;
+            c[o] = v * m;
+        }
+        mrs[o] = m;
     }
 }
 
@@ -656,7 +708,7 @@ extern "C" int wt64_binary(wt_plan64 *p, int op, int a, int b, int dst)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_binary: null plan");
-    if (op < 0 || op > 3) WT_FAIL("wt64_binary: unknown op %d", op);
+    if (op < 0 || op > 4) WT_FAIL("wt64_binary: unknown op %d", op);
     double *pa = nullptr, *pb = nullptr, *pd = nullptr;
     WT_TRY(plan64_base(p, a, &pa));
     WT_TRY(plan64_base(p, b, &pb));
@@ -864,5 +916,50 @@ extern "C" int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, i
     WT_TRY(plan64_base(dst, dst_plane, &b));
     WT_HIP(hipMemcpy2DAsync(b + dy * dst->g.P + dx, (size_t)dst->g.P * 8, a + sy * src->g.P + sx, (size_t)src->g.P * 8, (size_t)cols * 8, (size_t)rows,
                             hipMemcpyDeviceToDevice, src->ctx->stream));
+    return 0;
+}
+
+/* cv2.filter2D with a small kernel (host pointer, kh * kw doubles), explicit anchor, symmetric
+ * (border 0) or periodic (border 3, WT_BORDER_PERIODIC) border: as wt_filter2d_ex, in float64 */
+extern "C" int wt64_filter2d(wt_plan64 *p, int src, int dst, const double *kernel, int kh, int kw, int ay, int ax, int border)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !kernel) WT_FAIL("wt64_filter2d: null pointer");
+    if (kh < 1 || kw < 1 || (int64_t)kh * kw > (1 << 20)) WT_FAIL("wt64_filter2d: kernel %d x %d unsupported", kh, kw);
+    if (ay < 0 || ay >= kh || ax < 0 || ax >= kw) WT_FAIL("wt64_filter2d: anchor (%d, %d) outside the %d x %d kernel", ay, ax, kh, kw);
+    if (border != WT_BORDER_SYMMETRIC && border != WT_BORDER_PERIODIC) WT_FAIL("wt64_filter2d: border %d unsupported", border);
+    if (src == dst) WT_FAIL("wt64_filter2d: src and dst must differ");
+    double *in = nullptr, *o = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    WT_TRY(plan64_base(p, dst, &o));
+    const size_t n = (size_t)kh * kw;
+    if (p->psf_cap < n) {
+        void *q = nullptr;
+        WT_HIP(hipMalloc(&q, n * sizeof(double)));
+        p->allocs.push_back(q);
+        p->psf = (double *)q;
+        p->psf_cap = n;
+    }
+    WT_HIP(hipMemcpyAsync(p->psf, kernel, n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));        // the host buffer may be pageable and short-lived
+    hipLaunchKernelGGL(wt64_filter2d_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, o, p->g, (const double *)p->psf, kh, kw,
+                       ay, ax, border == WT_BORDER_PERIODIC);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* multiresolution-support update (watroo/utils.py:263-276), as wt_mrs_update */
+extern "C" int wt64_mrs_update(wt_plan64 *p, int plane, int mrs_plane, double tau, int soft, int noise_plane, int persistent, double inv_pow)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_mrs_update: null plan");
+    double *c = nullptr, *m = nullptr, *nz = nullptr;
+    WT_TRY(plan64_base(p, plane, &c));
+    WT_TRY(plan64_base(p, mrs_plane, &m));
+    if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
+    if (c == m) WT_FAIL("wt64_mrs_update: plane and support plane must differ");
+    hipLaunchKernelGGL(wt64_mrs_kernel, grid64(p), dim3(256), 0, p->ctx->stream, c, m, (const double *)nz, p->g.W, p->g.P, p->g.nrows, tau, soft,
+                       persistent, inv_pow);
+    WT_HIP(hipGetLastError());
     return 0;
 }

@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of,
-                       _result_dtype, _to_f32_image,
+                       _result_dtype, _taps_f64, _to_f32_image,
                        generalized_anscombe,
                        PLANE_INPUT)
 
@@ -276,10 +276,10 @@ def _periodic_operand(kernel, ay, ax):
     anchor lies inside - wt_filter2d_ex wants 0 <= ay < kh."""
     kh = kernel.shape[0]
     if ay < 0:
-        kernel = np.concatenate([np.zeros((-ay, kernel.shape[1]), np.float32), kernel])
+        kernel = np.concatenate([np.zeros((-ay, kernel.shape[1]), kernel.dtype), kernel])
         ay = 0
     elif ay >= kh:
-        kernel = np.concatenate([kernel, np.zeros((ay - kh + 1, kernel.shape[1]), np.float32)])
+        kernel = np.concatenate([kernel, np.zeros((ay - kh + 1, kernel.shape[1]), kernel.dtype)])
     return np.ascontiguousarray(kernel), dict(anchor=(ay, ax), periodic=True)
 
 
@@ -293,14 +293,21 @@ def richardson_lucy(data, psf,
     the final estimate.  ``fft=True`` selects the reference's circular (periodic-border)
     products (ref:245-254, 284); they are evaluated as direct periodic correlations of the PSF
     (equal to the rFFT products up to rounding) so the loop stays on the device."""
-    img = _to_f32_image(data, "data")
-    psf = np.ascontiguousarray(psf, dtype=np.float32)
+    # float64 / promoted data: the float64 engine (ref wavelets.py:319-320) - except with
+    # uniform_init, where the reference itself keeps the estimate in float32 (ref:233)
+    f64 = _result_dtype(data) == np.float64 and not uniform_init and np.ndim(data) == 2
+    ft = np.float64 if f64 else np.float32
+    img = np.ascontiguousarray(data, dtype=np.float64) if f64 else _to_f32_image(data, "data")
+    psf = np.ascontiguousarray(psf, dtype=ft)
     if psf.ndim != 2:
         raise ValueError("psf must be 2-D")
     level = len(denoise_coefficients)
     soft = threshold_type == 'soft'
     sf = B3spline(2)                                                     # ref:229 default transform
-    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
+    if f64:
+        plan = _lib.acquire_plan64(default_context(), img.shape[0], img.shape[1], _taps_f64(sf, 2), level)
+    else:
+        plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
     DATA, PSI, PHI, RES, CONV = (PLANE_SCRATCH(i) for i in (6, 7, 8, 9, 10))
     if level > _lib.NUM_SCRATCH - 16:            # one support plane per scale (scratch 16 ..)
         raise ValueError(f"richardson_lucy: at most {_lib.NUM_SCRATCH - 16} denoise coefficients")

@@ -10,8 +10,8 @@ tuned engine is float32 and serves float32 inputs; float64 / promoted inputs run
 engine (``_lib.Plan64``: double planes, double arithmetic, generic kernels): the transform
 (standard and recursive, with or without bilateral filtering; signals, images, cubes), the
 ``Coefficients`` operators, ``denoise``, ``enhance``, ``wow``, ``convolution``, ``sdev_loc`` and
-``generalized_anscombe``.  ``richardson_lucy`` and ``atrous_convolution`` compute such inputs in
-float32 and hand back float64 (float32 precision, about 1e-7 relative).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
+``generalized_anscombe``, ``atrous_convolution``, ``richardson_lucy`` (with ``uniform_init`` the
+reference itself keeps the estimate in float32, ref utils.py:233, and so does the float32 engine).  1-D signals run as 1 x N images with the 1-D branch's 'mirror' border and (Z, Y, X) cubes
 as (Z*Y) x X images (per-slice 2-D filter + axis-0 filter, ref:46-64).  There is deliberately no
 CPU fallback.
 """
@@ -329,7 +329,8 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
     be 'symmetric'."""
     if mode != "symmetric":
         raise NotImplementedError("the HIP engine implements mode='symmetric' only")
-    img = _to_f32_image(image, "image")
+    f64 = _is_f64(image) and np.ndim(image) == 2          # float64 engine (ref:319-320)
+    img = np.ascontiguousarray(image, dtype=np.float64) if f64 else _to_f32_image(image, "image")
     kernel = np.asarray(kernel)
     fam = None
     for cls in (Triangle, B3spline):
@@ -354,13 +355,18 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
                                       "of 1-D taps with itself")
         fam = tuple(float(t) for t in taps[::-1])
         flags = _lib.FLAG_TAPS_REVERSED
-    plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
+    if f64:
+        if not isinstance(fam, tuple):                   # built-in family: its (symmetric) taps
+            fam = _taps_f64(Triangle if fam == _lib.TRIANGLE else B3spline, 2)
+        plan = acquire_plan64(default_context(), img.shape[0], img.shape[1], fam, 0)
+    else:
+        plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
     try:
         plan.upload(PLANE_INPUT, img)
         if bilateral_variance is None:
             plan.smooth(PLANE_INPUT, PLANE_OUT, s)
         else:
-            var = np.broadcast_to(np.asarray(bilateral_variance, np.float32), img.shape)
+            var = np.broadcast_to(np.asarray(bilateral_variance, img.dtype), img.shape)
             plan.upload(_TMP_PLANE, var)
             plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s, flags)
         res = plan.download(PLANE_OUT)
