@@ -384,7 +384,8 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
 class Coefficients:
     """``level+1`` coefficient planes: 0..level-1 detail, ``level`` the final smooth.
 
-    Planes live in HBM.  ``.data`` materialises a float32 ndarray mirror on first access;
+    Planes live in HBM (float32 planes of a Plan, or float64 planes of a Plan64 for float64 /
+    promoted inputs).  ``.data`` materialises an ndarray mirror of that dtype on first access;
     from then on the mirror is treated as user-owned (the reference's idiom is in-place
     edits such as ``coefficients.data[s] *= ...``): every device operation first re-uploads
     it and afterwards refreshes it in place, so references held by the caller stay valid.
