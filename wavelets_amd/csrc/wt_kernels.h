@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wt_internal.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -265,21 +267,26 @@ __device__ __forceinline__ void wt_hrow_filter(const float4 *raw, int d, float4 
         }
         cen = C;
         float o[4], o2[4];
+        // d is 1 or 2 at run time and wave-uniform: one scalar branch, two bodies with static
+        // indices (selecting per tap with `d == 1 ? e[..] : e[..]` doubled the VALU count of the
+        // d < 4 kernels: a v_cndmask per operand)
+        auto taps = [&](auto dtag) {
+            constexpr int DD = decltype(dtag)::value;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // d is 1 or 2 at run time; index arithmetic stays in registers after unrolling
-            float a = wt_tap<K>(0) * (d == 1 ? e[4 + k - hw] : e[4 + k - 2 * hw]);
-            float a2 = wt_tap<K>(0) * (d == 1 ? e2[4 + k - hw] : e2[4 + k - 2 * hw]);
+            for (int k = 0; k < 4; ++k) {
+                float a = wt_tap<K>(0) * e[4 + k - DD * hw];
+                float a2 = wt_tap<K>(0) * e2[4 + k - DD * hw];
 #pragma unroll
-            for (int j = 1; j < K; ++j) {
-                const float v = d == 1 ? e[4 + k + (j - hw)] : e[4 + k + 2 * (j - hw)];
-                const float v2 = d == 1 ? e2[4 + k + (j - hw)] : e2[4 + k + 2 * (j - hw)];
-                a = fmaf(wt_tap<K>(j), v, a);
-                a2 = fmaf(wt_tap<K>(j), v2, a2);
+                for (int j = 1; j < K; ++j) {
+                    a = fmaf(wt_tap<K>(j), e[4 + k + DD * (j - hw)], a);
+                    a2 = fmaf(wt_tap<K>(j), e2[4 + k + DD * (j - hw)], a2);
+                }
+                o[k] = a;
+                o2[k] = a2;
             }
-            o[k] = a;
-            o2[k] = a2;
-        }
+        };
+        if (d == 1) taps(std::integral_constant<int, 1>{});
+        else taps(std::integral_constant<int, 2>{});
         h = make_float4(o[0], o[1], o[2], o[3]);
         if (MODE == MODE_VAR) h2 = make_float4(o2[0], o2[1], o2[2], o2[3]);
     }
