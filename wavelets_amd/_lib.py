@@ -378,9 +378,9 @@ class _HostPool:
 _host_pool = _HostPool()
 
 
-def host_empty(shape, ctx=None):
-    """float32 ndarray for a result coming back from the device (see _HostPool)."""
-    return _host_pool.empty(ctx if ctx is not None else default_context(), shape)
+def host_empty(shape, ctx=None, dtype=np.float32):
+    """ndarray (float32 unless told otherwise) for a result coming back from the device (see _HostPool)."""
+    return _host_pool.empty(ctx if ctx is not None else default_context(), shape, dtype)
 
 
 def _as_f32(a):
@@ -656,7 +656,7 @@ class Plan64:
 
     def download(self, plane, out=None):
         if out is None:
-            out = np.empty(self.shape, np.float64)
+            out = host_empty(self.shape, self.ctx, np.float64)
         assert out.dtype == np.float64 and out.shape == self.shape and out.strides[1] == 8
         check(load().wt64_download(self._h, plane, out.ctypes.data_as(_dp), out.strides[0] // 8))
         return out

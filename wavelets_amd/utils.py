@@ -48,7 +48,7 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     img = np.asarray(args[0])
     channels = [0, 1, 2] if img.ndim == 3 else [Ellipsis]                 # ref:47-50
     if out is None:
-        out = _lib.host_empty(img.shape) if _result_dtype(img) == np.float32 else np.empty(img.shape, np.float64)
+        out = _lib.host_empty(img.shape, dtype=_result_dtype(img))
     weights = prepare_params(weights, img.ndim)
     denoise = prepare_params(denoise, img.ndim)
     atrous = AtrousTransform(**kwargs)

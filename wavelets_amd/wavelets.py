@@ -468,10 +468,7 @@ class Coefficients:
     @property
     def data(self):
         if self._host is None:
-            if self._dtype == np.float32:
-                host = _lib.host_empty((self._nplanes,) + self._img_shape(), self._plan.ctx)
-            else:
-                host = np.empty((self._nplanes,) + self._img_shape(), self._dtype)
+            host = _lib.host_empty((self._nplanes,) + self._img_shape(), self._plan.ctx, self._dtype)
             self._host = host
             self._refresh_host(range(self._nplanes))
         return self._host
