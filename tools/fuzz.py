@@ -38,6 +38,8 @@ def main():
     fails = 0
     for case in range(n_cases):
         kind = case % 4
+        if case % 10 == 0:
+            print(f"... case {case} of {n_cases}, {fails} failures so far", flush=True)
         H = int(rng.integers(1, 1600)) if kind else int(rng.integers(1, 64))
         Wd = int(rng.integers(1, 3000)) if kind != 1 else int(rng.integers(1, 64))
         level = int(rng.integers(1, 10))
