@@ -67,6 +67,26 @@ int main(int argc, char **argv)
     printf("noise estimate %.5f; energy in %.4e -> denoised %.4e\n", noise, e_in, e_out);
     if (!(noise > 0.0) || !(e_out < e_in)) return 1;
     CHECK(wt_plan_destroy(plan));
+    /* the float64 engine: the same image with an offset float32 cannot hold, in double precision */
+    {
+        double *img64 = malloc(sizeof(double) * H * W), *rec64 = malloc(sizeof(double) * H * W);
+        for (long i = 0; i < H * W; ++i) img64[i] = (double)img[i] + 1.0e7;
+        const double b3[5] = {1.0 / 16, 4.0 / 16, 6.0 / 16, 4.0 / 16, 1.0 / 16};
+        wt_plan64 *p64 = NULL;
+        CHECK(wt64_plan_create(ctx, H, W, level, b3, 5, &p64));
+        CHECK(wt64_upload(p64, WT_PLANE_INPUT, img64, W));
+        CHECK(wt64_decompose(p64, WT_PLANE_INPUT, level, 0));
+        CHECK(wt64_plane_sum(p64, 0, level + 1, WT_PLANE_OUT));
+        CHECK(wt64_download(p64, WT_PLANE_OUT, rec64, W));
+        double worst64 = 0.0, med64 = 0.0;
+        for (long i = 0; i < H * W; ++i) worst64 = fmax(worst64, fabs(rec64[i] - img64[i]));
+        CHECK(wt64_abs_median(p64, 0, &med64));
+        printf("float64: sum of planes - input: max %.3e at offset 1e7; median |w_0| %.6f (float32 engine %.6f)\n",
+               worst64, med64, (double)med);
+        if (worst64 > 1e-8 || fabs(med64 - (double)med) > 1e-5 * fabs((double)med)) return 1;
+        CHECK(wt64_plan_destroy(p64));
+        free(img64); free(rec64);
+    }
     CHECK(wt_ctx_destroy(ctx));
     free(img); free(rec); free(rec2);
     printf("abi_demo: OK\n");
