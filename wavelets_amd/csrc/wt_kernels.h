@@ -1567,6 +1567,9 @@ __global__ __launch_bounds__(256) void wt_select_step_kernel(uint32_t *hist, WtS
     for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;     // ready for the next pass
 }
 
+#ifndef WT_HIST_UNROLL
+#define WT_HIST_UNROLL 4      // 16-byte loads in flight per thread
+#endif
 __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows, int P4, int W,
                                                       uint32_t prefix_mask, const WtSelectState *st,
                                                       int shift, uint32_t bin_mask,
@@ -1581,12 +1584,12 @@ __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows,
     const int X4 = (W + 3) >> 2;
     for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
         const float *row = p + (int64_t)r * P4 * 4;
-        for (int x4 = threadIdx.x; x4 < X4; x4 += 1024) {
-            float4 v[4];
+        for (int x4 = threadIdx.x; x4 < X4; x4 += 256 * WT_HIST_UNROLL) {
+            float4 v[WT_HIST_UNROLL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = wt_ldnt4(row + 4 * min(x4 + 256 * u, X4 - 1));
+            for (int u = 0; u < WT_HIST_UNROLL; ++u) v[u] = wt_ldnt4(row + 4 * min(x4 + 256 * u, X4 - 1));
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < WT_HIST_UNROLL; ++u) {
                 const int xx = x4 + 256 * u;
                 const int nv = xx < X4 ? min(4, W - xx * 4) : 0;
                 const uint32_t b[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y),
