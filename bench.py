@@ -45,7 +45,7 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes_per_pixel(kernel, level=LEVEL, interleaved=False):
+def algorithmic_bytes_per_pixel(kernel, level=LEVEL, interleaved=False, n_fold=3):
     """Compulsory HBM bytes per pixel attributed to one launch of `kernel`.
 
     SURVEY 8(d): decompose = 4*(L+2) (read the input, write L+1 planes), sum = 4*(L+2) (read
@@ -65,7 +65,8 @@ def algorithmic_bytes_per_pixel(kernel, level=LEVEL, interleaved=False):
     if kernel.startswith("wt_plane_sum"):
         return 4.0 * (level + 2)                 # read level+1 planes, write one
     if kernel.startswith("wt_denoise_sum"):
-        return (4.0 * 3 if interleaved else 4.0 * (level + 2)) + 8.0 * 3   # + RMW of the three thresholded planes
+        # interleaved: the sum's share is 4 per plane the kernel folds (the planes of the first pass)
+        return (4.0 * n_fold if interleaved else 4.0 * (level + 2)) + 8.0 * 3   # + RMW of the three thresholded planes
     if kernel.startswith("wt_hist"):
         # the launches of a select share the one compulsory read (two when the first level rides
         # on the transform's first pass, three otherwise)
@@ -84,7 +85,7 @@ def algorithmic_bytes_per_pixel(kernel, level=LEVEL, interleaved=False):
         tag = kernel[kernel.index("<") + 1:-1]                    # e.g. d8x3
         d, ns = int(tag[1:tag.index("x")]), int(tag.split("x")[1])
         first = d == 1
-        last = {1: 0, 8: 3, 64: 6}[d] + ns == level
+        last = {1: 0, 8: 3, 16: 4, 64: 6}[d] + ns == level
         b = 4.0 * ns + (4.0 if first else 0.0) + (4.0 if last else 0.0)
         if kernel.startswith("wt_fused_acc") or kernel.startswith("wt_fused_sum"):
             b += 4.0 * ns + (8.0 if last else 0.0)
@@ -374,12 +375,13 @@ def main():
     roofline = None
     kernels = {}
     my_pix = float(nrows) * W
+    sched = _lib.schedule(fam, level, not args.unfused)
     def algo_bytes(name, calls):
         """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
         fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
         its bytes are per STEP; every other kernel's are per launch."""
         bpp = algorithmic_bytes_per_pixel(name, level, interleaved=any(
-            k.startswith("wt_fused_hist") for k in prof))
+            k.startswith("wt_fused_hist") for k in prof), n_fold=sched[0][1] if sched else 3)
         if bpp is None:
             return None
         return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)

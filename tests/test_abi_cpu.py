@@ -44,7 +44,10 @@ def test_schedule_host_logic():
     sch = _lib.schedule(_lib.B3SPLINE, 11, True)
     assert sum(n for _, n, _ in sch) == 11 and [s for s, _, _ in sch][:3] == [0, 3, 6]
     # scales 6-7 fuse too (D = 64, two scales): Triangle L = 8 is three fused passes
-    assert _lib.schedule(_lib.TRIANGLE, 8, True) == [(0, 3, 7), (3, 3, 56), (6, 2, 192)]
+    # ... and since round 2 the 3-tap family fuses FOUR scales per pass from 8 scales on
+    assert _lib.schedule(_lib.TRIANGLE, 8, True) == [(0, 4, 15), (4, 4, 240)]
+    assert _lib.schedule(_lib.TRIANGLE, 7, True) == [(0, 3, 7), (3, 3, 56), (6, 1, 64)]
+    assert _lib.schedule(_lib.TRIANGLE, 10, True)[:3] == [(0, 4, 15), (4, 4, 240), (8, 1, 256)]
     assert sch[2] == (6, 2, 2 * (256 - 64)) and sch[3][:2] == (8, 1)
     total = sum(h for _, _, h in _lib.schedule(_lib.B3SPLINE, 6, False))
     assert total == 2 * 63 == sum(h for _, _, h in _lib.schedule(_lib.B3SPLINE, 6, True))

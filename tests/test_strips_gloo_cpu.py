@@ -91,6 +91,7 @@ def _worker(rank, world, port, H, W, family, level, fused, result_dir):
     (3, 100, 37, "b3spline", 3, True),     # ragged partition 34/33/33, one fused pass
     (2, 128, 24, "triangle", 5, True),     # (0,3,7), (3,2,24)
     (3, 99, 20, "b3spline", 4, False),     # per-scale exchange, halos 2,4,8,16
+    (2, 520, 16, "triangle", 8, True),     # four-scale passes of the 3-tap family: (0,4,15), (4,4,240)
 ])
 def test_strips_match_unsharded_bitwise(tmp_path, world, H, W, family, level, fused):
     # stdlib multiprocessing (spawn): the pytest process itself never imports torch, so a GPU

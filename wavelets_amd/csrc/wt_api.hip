@@ -358,6 +358,8 @@ extern "C" int wt_profile_entry(wt_ctx *c, int i, char *name64, int64_t *calls, 
 // plan
 // =============================================================================================
 static inline int family_taps(int family) { return family == WT_B3SPLINE ? 5 : 3; }
+// A/B switch (wt_set_option "tri4"): four-scale passes of the 3-tap family for level >= 8
+static int g_opt_tri4 = getenv("WT_NO_TRI4") ? 0 : 1;
 
 extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int *n_passes)
 {
@@ -366,9 +368,14 @@ extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, i
     if (level < 0 || level > 30) WT_FAIL("wt_schedule: level %d out of range", level);
     const int hw = family_taps(family) / 2;
     int n = 0, s = 0;
+    // 3-tap family, 8 or more scales: two passes of FOUR scales, (0,4) and (4,4) (wt_fused.h); else
+    // passes of up to three scales from scales 0 and 3 and of two from scale 6
+    const bool four = fused && family == WT_TRIANGLE && level >= 8 && g_opt_tri4;
     while (s < level) {
         int ns = 1;
-        if (fused && s <= 3) ns = std::min(WT_FUSED_MAX_SCALES, level - s);
+        if (four && (s == 0 || s == 4)) ns = 4;
+        else if (four) ns = 1;
+        else if (fused && s <= 3) ns = std::min(3, level - s);
         else if (fused && s == 6) ns = std::min(2, level - s);   // D = 64: two scales (x halo hw*3*64)
         if (n >= cap) WT_FAIL("wt_schedule: capacity %d too small", cap);
         triples[3 * n + 0] = s;
@@ -1053,6 +1060,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
+    if (!strcmp(name, "tri4")) { g_opt_tri4 = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }
 
@@ -1331,7 +1339,7 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
         return launch_chain<MODE_DECOMP>(p, in, oc, ow, s0, 1.f, 1.f, 0, "wt_chain_kernel<decomp>");
     }
     if (p->g.border) WT_FAIL("wt_decompose_pass: fused passes implement the symmetric border only (use flags without bit0)");
-    if (!wt_fused_has_pass(s0, ns)) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
+    if (!wt_fused_has_pass(s0, ns, p->family)) WT_FAIL("wt_decompose_pass: no fused kernel for first scale %d x %d scales", s0, ns);
     float *ow[WT_FUSED_MAX_SCALES] = {nullptr};
     for (int k = 0; k < ns; ++k) WT_TRY(plane_base(p, s0 + k, &ow[k]));
     float *ps = nullptr;
@@ -1362,7 +1370,7 @@ extern "C" int wt_decompose_pass_sum(wt_plan *p, int cur, int nxt, int s0, int n
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_decompose_pass_sum: null plan");
-    if (!wt_fused_has_pass(s0, ns)) WT_FAIL("wt_decompose_pass_sum: no fused kernel for first scale %d x %d scales", s0, ns);
+    if (!wt_fused_has_pass(s0, ns, p->family)) WT_FAIL("wt_decompose_pass_sum: no fused kernel for first scale %d x %d scales", s0, ns);
     if (sum_plane == cur || sum_plane == nxt || (sum_plane >= s0 && sum_plane < s0 + ns))
         WT_FAIL("wt_decompose_pass_sum: the sum plane aliases a plane of the pass");
     return decompose_pass_impl(p, cur, nxt, s0, ns, flags, last ? 2 : 1, first != 0, sum_plane);
@@ -1446,7 +1454,7 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
     bool fusable = (flags & 1) && level > 0 && !p->g.border && !p->ntaps && wt_fused_supported(p);
     if (fusable) {
         WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
-        for (int i = 0; i < np; ++i) fusable = fusable && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1]);
+        for (int i = 0; i < np; ++i) fusable = fusable && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1], p->family);
     }
     if (!fusable) {      // a schedule with single-scale passes: the two-step form
         WT_TRY(wt_decompose(p, src, level, flags));
@@ -1467,7 +1475,7 @@ extern "C" int wt_plan_fused_ok(wt_plan *p, int level, int *ok)
     int np = 0;
     WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
     for (int i = 0; i < np; ++i)
-        if (!wt_fused_has_pass(tr[3 * i], tr[3 * i + 1])) return 0;
+        if (!wt_fused_has_pass(tr[3 * i], tr[3 * i + 1], p->family)) return 0;
     *ok = 1;
     return 0;
 }

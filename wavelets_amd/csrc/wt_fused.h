@@ -41,13 +41,13 @@
 #include "wt_internal.h"
 #include "wt_kernels.h"
 
-#define WT_FUSED_MAX_SCALES 3
+#define WT_FUSED_MAX_SCALES 4      // four only for the 3-tap family (register window 2 * 15 float4)
 #define WT_FUSED_MAX_FIRST_SCALE 3
 
 struct FusedArgs {
     const float *in;                       // c_{s0}, local row 0
     float *out_c;                          // c_{s0+NS}
-    float *out_w[WT_FUSED_MAX_SCALES];     // w_{s0+a}
+    float *out_w[3];                       // w_{s0+a}, a < 3 (the fourth plane of a four-scale pass: out_w3, last field)
     Geo g;
     int Vx;       // valid (stored) pixels per x-strip, multiple of 32
     int S;        // chain steps stored per chunk
@@ -67,6 +67,7 @@ struct FusedArgs {
     int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
+    float *out_w3;  // w_{s0+3} of a four-scale pass (3-tap family); LAST on purpose: the older fields keep their offsets
 };
 
 template <int K, int SHIFT_PX, int NLANES>
@@ -255,7 +256,11 @@ template <int K, int NS, int D, int NW, int PDREQ, int ACC, bool FAST>
 #ifndef WT_FUSED_WPS4
 #define WT_FUSED_WPS4 2   // waves per SIMD requested for the 4-wave workgroup variant
 #endif
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 3) ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : 2)) void wt_fused_kernel(FusedArgs a)
+// workgroups of 4 waves per CU (= waves per SIMD): 3 for the plain 3-tap passes of up to three scales,
+// 1 for the four-scale accumulate variants (98 KB of LDS), else 2
+#define WT_FUSED_WG4_PER_CU(K, NS, ACC) \
+    ((K) == 3 && (NS) < 4 && ((ACC) == 0 || (ACC) == 3) ? WT_FUSED_WPS4_K3 : ((NS) == 4 && ((ACC) == 1 || (ACC) == 2) ? 1 : WT_FUSED_WPS4))
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC) : 2)) void wt_fused_kernel(FusedArgs a)
 {
     // ACC: 0 = plain pass; 1 / 2 = the pass carries the plane sum (2: last pass, adds the smooth
     // plane); 3 = plain pass that also histograms |w_{s0}| (first level of wt_abs_median's select:
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
     constexpr bool SUM = ACC == 1 || ACC == 2;
     constexpr bool HIST = ACC == 3;
     static_assert(!HIST || D == 1, "the histogram variant exists for the first pass only");
+    static_assert(NS <= 3 || K == 3, "four scales per pass: 3-tap family only");
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
     constexpr int LAT_IN = hw * ((1 << NS) - 1);         // rows of input beyond a stored row
@@ -277,14 +283,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
 
     __shared__ float4 vbuf[2][NS][NL];
     // output row of scale a at step t: t - a - hw*(2^(a+1)-1)
-    constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw;
-    constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : LAG2);
+    constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw, LAG3 = 3 + 15 * hw;
+    constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : (NS == 3 ? LAG2 : LAG3));
     // ACC: the running sum of a row waits in per-lane LDS rings until the next scale's detail
     // row of the SAME image row comes out of the cascade (G1, then G2 steps later); only lanes
     // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
-    constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0;
+    constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0, G3 = NS > 3 ? LAG3 - LAG2 : 0;
     constexpr int NV = NL - HX / 2;
-    __shared__ float4 ring[SUM ? (G1 + G2) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
+    __shared__ float4 ring[SUM ? (G1 + G2 + G3) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
 
     __shared__ uint32_t lh[HIST ? WT_HIST_BINS : 1];
     if constexpr (HIST) {                                // (before the early exits: all waves pass the barrier)
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
     const int X0 = blockIdx.x * a.Vx;                    // first valid pixel of this x-strip
-    constexpr bool WA = WT_FUSED_WA && D == 1;           // wave-autonomous horizontal taps (experiment)
+    constexpr bool WA = WT_FUSED_WA && D == 1 && NS <= 3;   // wave-autonomous horizontal taps (experiment)
     const int wa_ln = gl & 63, wa_vw = a.Vx / NW;        // lane in the wave; stored pixels per wave
     const int x = WA ? X0 + (gl >> 6) * wa_vw - 16 + 4 * wa_ln
                      : X0 - HX + 4 * gl;                 // this lane's first pixel (may be < 0)
@@ -369,10 +375,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         return (uint64_t)base + (uint64_t)((int64_t)(q + (int64_t)D * ro) * (int64_t)row_bytes);
     };
 
-    constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0;
+    constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0, A3 = NS > 3 ? 3 : 0;
     VWin<K, 0> w0;
     VWin<K, A1> w1;
     VWin<K, A2> w2;
+    VWin<K, A3> w3;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < KM; ++j) {
@@ -381,6 +388,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         for (int r = 0; r < (1 << A1); ++r) w1.w[r][j] = zero;
 #pragma unroll
         for (int r = 0; r < (1 << A2); ++r) w2.w[r][j] = zero;
+        if constexpr (NS > 3) {
+#pragma unroll
+            for (int r = 0; r < (1 << A3); ++r) w3.w[r][j] = zero;
+        }
     }
 
     const int t0 = r0 - LAT_IN;                          // first input chain index
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
     float4 pf[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
-    float4 c1 = zero, c2 = zero;                         // rows handed from scale a to a+1
+    float4 c1 = zero, c2 = zero, c3 = zero;              // rows handed from scale a to a+1
     // Stores: every plane has ONE descriptor for the whole march - base = row r0 of the chain (the
     // chunk's first stored row), length = the chunk's byte span.  At step k a plane stores row
     // k - (LAT_IN + LAG) of the chunk, i.e. the lane offset is x*4 + (k - LAT_IN - LAG) * step_bytes:
@@ -405,10 +416,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
     };
     // byte offset of a plane's row at step 0 (negative, as unsigned): -(LAT_IN + LAG) * step_bytes
     auto lag_off = [&](int lag) -> unsigned { return 0u - (unsigned)(LAT_IN + lag) * step_bytes; };
-    const unsigned o0 = lag_off(LAG0), o1 = lag_off(LAG1), o2 = lag_off(LAG2), oc = lag_off(LAGC);
+    const unsigned o0 = lag_off(LAG0), o1 = lag_off(LAG1), o2 = lag_off(LAG2), o3 = NS > 3 ? lag_off(LAG3) : 0u, oc = lag_off(LAGC);
     const __amdgpu_buffer_rsrc_t rw0 = plane_rsrc(a.out_w[0], LAG0);
     const __amdgpu_buffer_rsrc_t rw1 = plane_rsrc(a.out_w[A1], LAG1);
     const __amdgpu_buffer_rsrc_t rw2 = plane_rsrc(a.out_w[A2], LAG2);
+    // (only a four-scale pass builds the fourth descriptor: plane_rsrc pins four SGPRs)
+    const __amdgpu_buffer_rsrc_t rw3 = NS > 3 ? plane_rsrc(a.out_w3, LAG3) : rw2;
     const __amdgpu_buffer_rsrc_t rc = plane_rsrc(a.out_c, LAGC);
     // ---- ACC state.  The first pass of a sum (D = 1, s0 = 0) has no incoming partial sum, every
     // later pass has one: decided at compile time (the host checks first == (s0 == 0)).
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
     // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
     // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
     const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
-    int i1 = 0, i2 = 0;                                  // ring positions (wave-uniform)
+    int i1 = 0, i2 = 0, i3 = 0;                          // ring positions (wave-uniform)
 
     // One chain step.
     auto step = [&](const int kb, const int kk, auto stores_tag) {
@@ -449,7 +462,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         // step k stores row t0 + k - LAG of a plane: inside the chunk iff k - (LAT_IN + LAG) < span
         const unsigned vk = voff + koff + ((dbg & 1) ? WT_FUSED_PARKED : 0u);
         auto at = [&](int lag) -> unsigned {             // lane offset of this step's row of a plane
-            return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : oc);
+            if constexpr (NS > 3) return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : o3);
+            else return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : oc);
         };
         float4 cur = pf[kk % PD];
         pf[kk % PD] = load_row(t + PD);
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
             wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), cur);
             if constexpr (NS > 1) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), cur);
             if constexpr (NS > 2) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), cur);
+            if constexpr (NS > 3) wt_bstore4v<WT_FUSED_W_AUX>(rw3, at(LAG3), cur);
             wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), cur);
             if constexpr (SUM) {
                 float4 pv = cur;
@@ -490,12 +505,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         // them before the barrier so the LDS latency hides behind the vertical filters.  Lanes
         // without stored pixels share the spare slot NV of each ring row (their sums are never
         // stored), which keeps the ring traffic free of exec-mask branches.
-        float4 old1 = zero, old2 = zero;
+        float4 old1 = zero, old2 = zero, old3 = zero;
         if constexpr (SUM && NS > 1) {
             old1 = ring[i1 * (NV + 1) + li];
             if constexpr (NS > 2) old2 = ring[(G1 + i2) * (NV + 1) + li];
+            if constexpr (NS > 3) old3 = ring[(G1 + G2 + i3) * (NV + 1) + li];
         }
-        float4 cen0, cen1, cen2, v0, v1, v2;
+        float4 cen0, cen1, cen2, cen3, v0, v1, v2, v3;
         v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
         if constexpr (!WA) buf[0][gl] = v0;
         if constexpr (NS > 1) {
@@ -505,6 +521,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
         if constexpr (NS > 2) {
             v2 = wt_fused_vstage<K, A2>(w2, kk, c2, cen2);
             if constexpr (!WA) buf[A2][gl] = v2;
+        }
+        if constexpr (NS > 3) {
+            v3 = wt_fused_vstage<K, A3>(w3, kk, c3, cen3);
+            buf[A3][gl] = v3;
         }
         if constexpr (!WA) __syncthreads();
         float4 n0;
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
             }
         }
         if constexpr (ST_ON && (NS == 1)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
-        float4 d1 = zero, d2 = zero, n1 = zero, n2 = zero;
+        float4 d1 = zero, d2 = zero, d3 = zero, n1 = zero, n2 = zero, n3 = zero;
         if constexpr (NS > 1) {
             if constexpr (WA) n1 = wt_hfilter_dpp<K, ((D << A1) <= 4 ? (D << A1) : 4)>(v1);
             else n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
@@ -536,7 +556,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
                 else n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
                 d2 = f4_sub(cen2, n2);
                 if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
-                if constexpr (ST_ON) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
+                if constexpr (ST_ON && (NS == 3)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
+                if constexpr (NS > 3) {
+                    n3 = wt_hfilter_lds<K, (D << A3), NL>(buf[A3], gl, v3);
+                    d3 = f4_sub(cen3, n3);
+                    if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw3, at(LAG3), d3);
+                    if constexpr (ST_ON) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n3);
+                    c3 = n2;
+                }
             }
             c2 = n1;
         }
@@ -551,11 +578,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? (K == 3 && (ACC == 0 || ACC == 
                 if constexpr (NS > 2) s2 = f4_add(old2, d2);              // row t - LAG2
                 ring[i1 * (NV + 1) + li] = s;
                 if constexpr (NS > 2) ring[(G1 + i2) * (NV + 1) + li] = s1;
-                s = s2;
+                if constexpr (NS > 3) {
+                    ring[(G1 + G2 + i3) * (NV + 1) + li] = s2;
+                    s = f4_add(old3, d3);                                 // row t - LAG3
+                } else {
+                    s = s2;
+                }
                 i1 = (i1 + 1 == G1) ? 0 : i1 + 1;
                 if constexpr (NS > 2) i2 = (i2 + 1 == G2) ? 0 : i2 + 1;
+                if constexpr (NS > 3) i3 = (i3 + 1 == G3) ? 0 : i3 + 1;
             }
-            if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : n2));
+            if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : (NS == 3 ? n2 : n3)));
             // the finished reconstruction is a write-once stream; an intermediate sum is re-read
             // by the next pass
             if constexpr (ST_ON) wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
@@ -672,7 +705,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // that minimises (dispatch rounds) x (rows per workgroup): usually ONE round with every
     // slot filled; when the x-strips x phases alone under-fill the chip (tall narrow-ish strips:
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
-    const int wg_per_cu = NW == 4 ? (K == 3 && (ACC == 0 || ACC == 3) ? WT_FUSED_WPS4_K3 : WT_FUSED_WPS4) : std::max(1, 8 / NW);
+    const int wg_per_cu = NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC) : std::max(1, 8 / NW);
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
     const int64_t nbase = (int64_t)nx * phases * nranges;
     int chunks = 1, S = n_max;
@@ -742,11 +775,23 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
 template <int K, int ACC>
 static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns, const FusedRows &rows)
 {
-    static const char *names[4][5] = {
-        {"wt_fused<d1x3>", "wt_fused<d1x2>", "wt_fused<d8x3>", "wt_fused<d8x2>", "wt_fused<d64x2>"},
-        {"wt_fused_acc<d1x3>", "wt_fused_acc<d1x2>", "wt_fused_acc<d8x3>", "wt_fused_acc<d8x2>", "wt_fused_acc<d64x2>"},
-        {"wt_fused_sum<d1x3>", "wt_fused_sum<d1x2>", "wt_fused_sum<d8x3>", "wt_fused_sum<d8x2>", "wt_fused_sum<d64x2>"},
-        {"wt_fused_hist<d1x3>", "wt_fused_hist<d1x2>", "", "", ""}};
+    static const char *names[4][7] = {
+        {"wt_fused<d1x3>", "wt_fused<d1x2>", "wt_fused<d8x3>", "wt_fused<d8x2>", "wt_fused<d64x2>", "wt_fused<d1x4>", "wt_fused<d16x4>"},
+        {"wt_fused_acc<d1x3>", "wt_fused_acc<d1x2>", "wt_fused_acc<d8x3>", "wt_fused_acc<d8x2>", "wt_fused_acc<d64x2>", "wt_fused_acc<d1x4>",
+         "wt_fused_acc<d16x4>"},
+        {"wt_fused_sum<d1x3>", "wt_fused_sum<d1x2>", "wt_fused_sum<d8x3>", "wt_fused_sum<d8x2>", "wt_fused_sum<d64x2>", "wt_fused_sum<d1x4>",
+         "wt_fused_sum<d16x4>"},
+        {"wt_fused_hist<d1x3>", "wt_fused_hist<d1x2>", "", "", "", "wt_fused_hist<d1x4>", ""}};
+    // 3-tap family: FOUR scales per pass (register window 2 * 15 float4): L = 8 is two passes,
+    // (0,4) at D = 1 and (4,4) at D = 16 (x halo 240 px: 8-wave workgroups; the accumulate variants
+    // take 7 waves, their delay rings of 3 + 5 + 9 rows would not fit the LDS with 8)
+    if constexpr (K == 3) {
+        if (s0 == 0 && ns == 4) return wt_fused_launch_t<K, 4, 1, 4, 4, ACC>(p, a, names[ACC][5], rows);
+        if constexpr (ACC != 3) {
+            if (s0 == 4 && ns == 4)
+                return wt_fused_launch_t<K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, names[ACC][6], rows);   // (accumulate: 2 rows ahead, 256 VGPRs)
+        }
+    }
     if (s0 == 0 && ns == 3) return wt_fused_launch_t<K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0], rows);
     if (s0 == 0 && ns == 2) return wt_fused_launch_t<K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1], rows);
     if constexpr (ACC != 3) {
@@ -758,8 +803,9 @@ static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns,
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
-static inline bool wt_fused_has_pass(int s0, int ns)
+static inline bool wt_fused_has_pass(int s0, int ns, int family = WT_B3SPLINE)
 {
+    if (family == WT_TRIANGLE && ns == 4 && (s0 == 0 || s0 == 4)) return true;
     return (s0 == 0 && (ns == 2 || ns == 3)) || (s0 == 3 && (ns == 2 || ns == 3)) || (s0 == 6 && ns == 2);
 }
 
@@ -771,7 +817,8 @@ static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **ou
     FusedArgs a{};
     a.in = in;
     a.out_c = out_c;
-    for (int i = 0; i < ns; ++i) a.out_w[i] = out_w[i];
+    for (int i = 0; i < ns && i < 3; ++i) a.out_w[i] = out_w[i];
+    a.out_w3 = ns > 3 ? out_w[3] : nullptr;
     a.g = p->g;
     a.p_in = p_in;
     a.p_out = p_out;
