@@ -614,3 +614,41 @@ def test_float64_engine_vs_golden(WA):
         p64.upload(0, z)
         assert p64.abs_median(0) == np.median(np.abs(z))
         p64.close()
+
+
+@pytest.mark.parametrize("H,W,level", [(700, 1100, 8), (333, 1001, 8), (1024, 4096, 9), (600, 260, 10), (2048, 2048, 8)])
+def test_four_scale_passes_of_the_3tap_family_vs_the_three_scale_schedule(L, H, W, level):
+    """From 8 scales on the 3-tap family fuses four scales per pass ((0,4) at D = 1, (4,4) at D = 16).
+    Per pixel the arithmetic is the same vertical-then-horizontal FMA chain whatever the grouping:
+    away from the borders planes and carried sum equal the three-scale schedule ((0,3), (3,3), (6,2))
+    BIT FOR BIT.  Inside the reflection halo a fused pass continues the cascade through mirrored
+    rows / columns instead of re-reading a stored plane, which reverses the order of the FMA chain
+    there: last-bit differences from scale 3 on, as between any fused pass and separate passes.
+    Fast and generic addressing, decompose and decompose_sum, first-pass histogram."""
+    a = rnd((H, W), H + W)
+    amax = float(np.abs(a).max())
+    out = {}
+    for tri4 in (1, 0):
+        L.set_option("tri4", tri4)
+        sched = L.schedule(L.TRIANGLE, level, True)
+        assert (sched[0][:2] == (0, 4)) == bool(tri4)
+        plan = L.Plan(L.default_context(), H, W, L.TRIANGLE, level)
+        plan.upload(L.PLANE_INPUT, a)
+        plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, L.FLAG_FUSED)
+        planes = [plan.download(s) for s in range(level + 1)] + [plan.download(L.PLANE_OUT)]
+        plan.decompose(L.PLANE_INPUT, level, L.FLAG_FUSED | L.FLAG_MEDIAN_HIST)
+        med = plan.abs_median(0)
+        planes2 = [plan.download(s) for s in range(level + 1)]
+        out[tri4] = (planes, med, planes2)
+        plan.close()
+    L.set_option("tri4", 1)
+    m = 256                                               # reach of the reflection up to scale 7
+    for i, (x, y) in enumerate(zip(out[1][0], out[0][0])):
+        close(x, y, 1e-6 * amax)
+        if i < 3:
+            np.testing.assert_array_equal(x, y)           # scales 0-2: the same first stages
+        elif i < 8 and H > 2 * m + 8 and W > 2 * m + 8:
+            np.testing.assert_array_equal(x[m:-m, m:-m], y[m:-m, m:-m])
+    assert out[1][1] == out[0][1] == np.median(np.abs(out[0][2][0]))
+    for x, y in zip(out[1][0][:-1], out[1][2]):          # decompose_sum's planes == decompose's, bit for bit
+        np.testing.assert_array_equal(x, y)
