@@ -318,7 +318,7 @@ def test_with_sum_keyword_carries_the_synthesis_through_the_passes(WA):
 
 
 @pytest.mark.parametrize("fam,level,sigma,weights", [
-    ("triangle", 8, [5, 3, 2], None),                       # BASELINE config 3: passes (0,3) | (3,3) (6,2)
+    ("triangle", 8, [5, 3, 2], None),                       # BASELINE config 3: passes (0,4) | (4,4)
     ("b3spline", 6, [5, 3], [.5, 2]),                       # thresholded planes inside the first pass
     ("b3spline", 6, [5, 3, 2, 1], None),                    # reaches into the second pass: both first
     ("b3spline", 8, [0, 0, 0, 0, 3], None),                 # leading zeros

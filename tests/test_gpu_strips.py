@@ -229,7 +229,7 @@ def test_real_rccl_ranks_share_the_gpu(nranks, shape):
     ("b3spline", 6, 700, 1100, 1, 3),      # both neighbours: two edge ranges + interior
     ("b3spline", 6, 512, 300, 0, 2),       # bottom neighbour only
     ("b3spline", 5, 333, 257, 2, 3),       # top neighbour only, d1x3 + d8x2
-    ("triangle", 8, 1000, 192, 1, 3),      # three passes: D = 1, 8, 64 sub-ranges
+    ("triangle", 8, 1000, 192, 1, 3),      # two four-scale passes: D = 1, 16 sub-ranges
 ])
 def test_split_launches_equal_whole_pass_bitwise(L, fam_name, level, nrows, W, rank, nranks):
     """The overlapped multi-GPU schedule launches a pass as edge rows + interior rows (row
