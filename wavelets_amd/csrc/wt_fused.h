@@ -1,4 +1,5 @@
-// Fused multi-scale a-trous passes: NS consecutive scales per HBM round trip.
+// Fused multi-scale a-trous passes: NS consecutive scales per HBM round trip (NS = 2, 3; 4 for the
+// 3-tap family, whose window for four scales is as large as the 5-tap family's for three).
 //
 //   pass(s0, NS):  read c_{s0} once  ->  write w_{s0} .. w_{s0+NS-1} and c_{s0+NS}
 //                  (watroo/wavelets.py:429-442 for NS consecutive iterations of the loop)
