@@ -47,6 +47,9 @@ def test_schedule_host_logic():
     # ... and since round 2 the 3-tap family fuses FOUR scales per pass from 8 scales on
     assert _lib.schedule(_lib.TRIANGLE, 8, True) == [(0, 4, 15), (4, 4, 240)]
     assert _lib.schedule(_lib.TRIANGLE, 7, True) == [(0, 3, 7), (3, 3, 56), (6, 1, 64)]
+    assert _lib.schedule(_lib.TRIANGLE, 4, True) == [(0, 4, 15)]
+    assert _lib.schedule(_lib.TRIANGLE, 5, True) == [(0, 3, 7), (3, 2, 24)]
+    assert _lib.schedule(_lib.TRIANGLE, 6, True) == [(0, 3, 7), (3, 3, 56)]
     assert _lib.schedule(_lib.TRIANGLE, 10, True)[:3] == [(0, 4, 15), (4, 4, 240), (8, 1, 256)]
     assert sch[2] == (6, 2, 2 * (256 - 64)) and sch[3][:2] == (8, 1)
     total = sum(h for _, _, h in _lib.schedule(_lib.B3SPLINE, 6, False))

@@ -368,12 +368,15 @@ extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, i
     if (level < 0 || level > 30) WT_FAIL("wt_schedule: level %d out of range", level);
     const int hw = family_taps(family) / 2;
     int n = 0, s = 0;
-    // 3-tap family, 8 or more scales: two passes of FOUR scales, (0,4) and (4,4) (wt_fused.h); else
-    // passes of up to three scales from scales 0 and 3 and of two from scale 6
-    const bool four = fused && family == WT_TRIANGLE && level >= 8 && g_opt_tri4;
+    // 3-tap family: passes of FOUR scales (wt_fused.h) - (0,4) and (4,4) from 8 scales on, (0,4)
+    // alone for exactly 4 scales (one pass instead of two; at 5 to 7 scales the three-scale passes
+    // stay: every pass of the schedule is then a fused one, which is what lets wt_decompose_sum
+    // and the interleaved denoise carry the sum); else passes of up to three scales from scales 0
+    // and 3 and of two from scale 6
+    const bool four = fused && family == WT_TRIANGLE && (level >= 8 || level == 4) && g_opt_tri4;
     while (s < level) {
         int ns = 1;
-        if (four && (s == 0 || s == 4)) ns = 4;
+        if (four && (s == 0 || (s == 4 && level >= 8))) ns = 4;
         else if (four) ns = 1;
         else if (fused && s <= 3) ns = std::min(3, level - s);
         else if (fused && s == 6) ns = std::min(2, level - s);   // D = 64: two scales (x halo hw*3*64)
