@@ -185,7 +185,8 @@ int wt_decompose_pass(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags
  * SAME passes: all level+1 planes are written as usual and the plane-order sum rides along
  * (each pass reads the running sum and writes it back), so the planes are not re-read:
  * 4*(L+2) + 8*passes - 4 B/pixel of traffic instead of 8*(L+2).  Bit-identical to the two-call
- * form.  Schedules that contain single-scale passes run as the two calls. */
+ * form.  Schedules with single-scale passes other than the one that ends 4 or 7 scales (9 scales
+ * and more, user-defined taps, non-symmetric borders) run as the two calls. */
 int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
 /* *ok = 1 when wt_decompose_sum(plan, ., level, ., bit0) runs as accumulate passes (else it is the
  * two-call form).  The host uses it to interleave Coefficients.denoise with the passes:

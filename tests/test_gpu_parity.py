@@ -835,7 +835,8 @@ def test_host_pool_recycles_pinned_result_blocks(W):
 @pytest.mark.parametrize("fam", FAMS)
 def test_decompose_sum_is_bitwise_the_two_call_form(fam):
     """wt_decompose_sum (sum carried through the fused passes) == wt_decompose + wt_plane_sum,
-    planes and reconstruction, for every level (levels 4 and 7 take the two-call fallback)."""
+    planes and reconstruction, for every level (levels 4 and 7 end in a single-scale fused pass, 8
+    is three passes for B3 and two four-scale passes for the 3-tap family)."""
     from wavelets_amd import _lib as L
     ctx = L.default_context()
     f = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam]

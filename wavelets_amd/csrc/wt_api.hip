@@ -1334,7 +1334,10 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
     float *in = nullptr, *oc = nullptr;
     WT_TRY(plane_base(p, cur, &in));
     WT_TRY(plane_base(p, nxt, &oc));
-    if (ns == 1) {
+    // a single scale: the per-scale kernels - except the scale that ends a 4- or 7-scale fused
+    // schedule, which has a fused kernel of its own (same bits with and without the carried sum)
+    if (ns == 1 && !((flags & 1) && !p->g.border && !p->ntaps && wt_fused_supported(p) && wt_fused_has_pass(s0, 1, p->family))) {
+        if (acc) WT_FAIL("wt_decompose_pass_sum: no accumulate kernel for the single scale %d", s0);
         if (rows.n) WT_FAIL("wt_decompose_pass: row ranges need a fused pass");
         WT_TRY(check_scale(p, s0, "wt_decompose_pass"));
         float *ow = nullptr;

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
     constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0, G3 = NS > 3 ? LAG3 - LAG2 : 0;
     constexpr int NV = NL - HX / 2;
-    __shared__ float4 ring[SUM ? (G1 + G2 + G3) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
+    __shared__ float4 ring[SUM && NS > 1 ? (G1 + G2 + G3) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
 
     __shared__ uint32_t lh[HIST ? WT_HIST_BINS : 1];
     if constexpr (HIST) {                                // (before the early exits: all waves pass the barrier)
@@ -706,7 +706,8 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     // that minimises (dispatch rounds) x (rows per workgroup): usually ONE round with every
     // slot filled; when the x-strips x phases alone under-fill the chip (tall narrow-ish strips:
     // 160 workgroups for 256 CUs at 32768 columns) a few shorter chunks in two rounds win.
-    const int wg_per_cu = NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC) : std::max(1, 8 / NW);
+    // (the single-scale passes are light - 92 VGPRs, 16 KB of LDS - two 8-wave workgroups per CU)
+    const int wg_per_cu = NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC) : (NS == 1 ? 2 : std::max(1, 8 / NW));
     static const int rounds_env = getenv("WT_FUSED_ROUNDS") ? std::max(1, atoi(getenv("WT_FUSED_ROUNDS"))) : 0;
     const int64_t nbase = (int64_t)nx * phases * nranges;
     int chunks = 1, S = n_max;
@@ -801,12 +802,23 @@ static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns,
         // D = 64 (scales 6-7): taps are 16 / 32 lanes apart
         if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4], rows);
     }
+    // Single-scale passes that END a schedule ((3,1) of 4 scales, (6,1) of 7): with them every pass
+    // of such a schedule can carry the plane sum (wt_decompose_sum, the interleaved denoise).  The
+    // plain variant exists so that wt_decompose writes the same bits as wt_decompose_sum (the fused
+    // passes filter rows first, the per-scale kernels columns first: last-bit differences).
+    if constexpr (ACC != 3) {
+        static const char *names1[3][2] = {{"wt_fused<d8x1>", "wt_fused<d64x1>"}, {"wt_fused_acc<d8x1>", "wt_fused_acc<d64x1>"},
+                                           {"wt_fused_sum<d8x1>", "wt_fused_sum<d64x1>"}};
+        if (s0 == 3 && ns == 1) return wt_fused_launch_t<K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, names1[ACC][0], rows);
+        if (s0 == 6 && ns == 1) return wt_fused_launch_t<K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, names1[ACC][1], rows);
+    }
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
 static inline bool wt_fused_has_pass(int s0, int ns, int family = WT_B3SPLINE)
 {
     if (family == WT_TRIANGLE && ns == 4 && (s0 == 0 || s0 == 4)) return true;
+    if (ns == 1 && (s0 == 3 || s0 == 6)) return true;    // the single scale that ends a 4- or 7-scale schedule
     return (s0 == 0 && (ns == 2 || ns == 3)) || (s0 == 3 && (ns == 2 || ns == 3)) || (s0 == 6 && ns == 2);
 }
 
