@@ -18,6 +18,21 @@
     cfg5  8192^2 wow(bilateral=1, denoise_coefficients=[5,2])  (B3spline, 11 scales)
 
 One step = one pass of the hot path over the image.  Rank 0 prints ONE JSON line.
+
+The default invocation (N = 1, --config headline) additionally times cfg2, cfg3 and cfg5 after the
+headline and appends them to the same line as `"configs": {"cfg2": {...}, "cfg3": {...}, "cfg5":
+{...}}` (value, ms_per_step, SURVEY 8(d) bytes per pixel and fraction, PMC-based achieved-HBM
+fraction, dominant kernel), so that every BASELINE.json configuration is timed by whoever runs the
+benchmark; --no-configs skips them.
+
+Two HBM fractions are reported, and they are different things:
+  `frac` / `frac_of_hbm_peak`   SURVEY 8(d) ALGORITHMIC bytes (a property of the problem statement)
+                                / time / 8 TB/s - a throughput-equivalent;
+  `hbm_achieved`                bytes that really crossed the HBM interface (rocprofv3 PMC passes,
+                                2 x FETCH_SIZE + WRITE_SIZE, stored per kernel in
+                                profiles/traffic.json - NOT re-measured in this run) / time / 8 TB/s.
+The fused passes carry the plane sum along and therefore move FEWER bytes than the algorithmic
+figure: hbm_achieved < frac.
 """
 import argparse
 import json
@@ -114,9 +129,13 @@ def make_strip(nrows, W, seed):
     return out
 
 
-def cpu_baseline(config, side, family, level):
+def cpu_baseline(config, side, family, level, budget=15.0):
     """The C/OpenMP oracle (a port of the reference algorithm, oracle/atrous_ref.c) timed on
-    this host on a bounded sample of the same workload."""
+    this host on a bounded sample of the same workload (`budget` seconds of CPU work per run).
+    cfg5: the sample image is smaller than 8192^2, and wow() derives its scale count from the
+    image size (ref utils.py:122) - the sample therefore runs FEWER scales than the GPU's 11; the
+    baseline is normalised per scale (value = Mpix/s at the GPU's scale count, assuming equal cost
+    per scale; the sample's own n_scales is stated)."""
     import numpy as np
     from oracle import cref
     cref.build()
@@ -141,22 +160,32 @@ def cpu_baseline(config, side, family, level):
     run(probe)
     per_pix = (time.perf_counter() - t) / probe.size
     s = side
-    while s > probe_side and per_pix * s * s > 15.0:
+    while s > probe_side and per_pix * s * s > budget:
         s //= 2
     img = np.random.default_rng(0).standard_normal((s, s), dtype=np.float32)
     reps, t_tot = 0, 0.0
-    while reps < 5 and t_tot < 10.0:
+    while reps < 5 and t_tot < budget * 0.67:
         t = time.perf_counter()
         run(img)
         t_tot += time.perf_counter() - t
         reps += 1
-    what = {"cfg3": f"decompose + MAD + denoise([5,3,2]) + sum, {family} L={level}",
-            "cfg5": "wow(bilateral=1, denoise_coefficients=[5,2]) at this size's own n_scales"}.get(
+    rate = img.size * reps / t_tot / 1e6
+    extra = {}
+    what = {"cfg3": f"decompose + MAD + denoise([5,3,2]) + sum, {family} L={level}"}.get(
         config, f"decompose+sum, {family} L={level}")
-    return {"value": round(img.size * reps / t_tot / 1e6, 3), "unit": "Mpix/s",
-            "cores": threads, "kind": "port",
-            "sample": f"{reps} x {what} of {s}x{s} f32 "
-                      f"(oracle/atrous_ref.c, gcc -O3 -fopenmp, {threads} threads)"}
+    if config == "cfg5":
+        ns_sample = int(np.round(np.log2(s) - np.log2(5)))           # ref utils.py:122
+        what = (f"wow(bilateral=1, denoise_coefficients=[5,2]) at the sample's own n_scales = "
+                f"{ns_sample}, rate scaled by {ns_sample}/{level} to the GPU run's {level} scales")
+        extra = {"n_scales_sample": ns_sample, "n_scales_gpu": level,
+                 "value_at_sample_scales": round(rate, 3)}
+        rate *= ns_sample / float(level)
+    out = {"value": round(rate, 3), "unit": "Mpix/s",
+           "cores": threads, "kind": "port",
+           "sample": f"{reps} x {what} of {s}x{s} f32 "
+                     f"(oracle/atrous_ref.c, gcc -O3 -fopenmp, {threads} threads)"}
+    out.update(extra)
+    return out
 
 
 def self_launch(args, argv):
@@ -195,6 +224,8 @@ def main():
                     help="do not run __graft_entry__.build() (profiled runs: no child process "
                          "under the profiler's preload)")
     ap.add_argument("--brief", action="store_true", help="one short line (tuning sweeps)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline only: do not append cfg2 / cfg3 / cfg5 to the line")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the launcher plumbing (gloo rendezvous, RCCL communicator) even "
                          "with one rank (plumbing check on a 1-GPU box)")
@@ -265,232 +296,299 @@ def main():
         if args.force_dist:
             assert ctx.comm_selftest(1 << 20), "RCCL self-test failed"
 
-    config = args.config
-    side, family, level, what = CONFIGS[config]
-    if config == "headline" and world > 1:
-        side = 32768
-    side = args.size or side
-    H = W = side
-    if args.rows:
-        H = args.rows
-    if config == "cfg5":                          # wow's own scale count (utils.py:122)
-        level = int(np.round(np.log2(min(H, W)) - np.log2(5)))
-    nrows = H // world
-    row0 = rank * nrows
-    if rank == world - 1:
-        nrows = H - row0
-    fam = {"b3spline": _lib.B3SPLINE, "triangle": _lib.TRIANGLE}[family]
-    plan = _lib.Plan(ctx, H, W, fam, level, row0=row0, nrows=nrows, rank=rank, nranks=world)
-    if config == "cfg5":
-        # the cfg5 image of tools/bench_configs.py: noise on a smooth structure (pure noise has
-        # no edges for the bilateral weights to act on)
-        img0 = make_strip(nrows, W, seed=0) + 3 * np.sin(np.arange(W, dtype=np.float32) / 50.)[None, :]
-        plan.upload(PLANE_INPUT, img0.astype(np.float32))
-        del img0
-    else:
-        plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
-    flags = 0 if args.unfused else _lib.FLAG_FUSED
-    two_call = args.two_call or args.unfused
+    traffic_db = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        traffic_db = json.load(open(tpath))
 
-    if config in ("headline", "cfg2"):
-        def step():
-            if two_call:
-                plan.decompose(PLANE_INPUT, level, flags)
-                plan.plane_sum(0, level + 1, PLANE_OUT)
-            else:   # same outputs (planes + reconstruction, bit-identical), sum carried along
-                plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
-    elif config == "cfg3":
-        import wavelets_amd as WA
-        coefficients = WA.Coefficients(plan, WA.Triangle(2))
+    def run_workload(config, steps, warmup, full):
+        """Time `steps` steps of BASELINE configuration `config`; returns the JSON object (rank 0)
+        or None.  full: PCIe-inclusive rate and CPU baseline too (the line's own configuration)."""
+        side, family, level, what = CONFIGS[config]
+        if config == "headline" and world > 1:
+            side = 32768
+        side = args.size or side
+        H = W = side
+        if args.rows:
+            H = args.rows
+        if config == "cfg5":                          # wow's own scale count (utils.py:122)
+            level = int(np.round(np.log2(min(H, W)) - np.log2(5)))
+        nrows = H // world
+        row0 = rank * nrows
+        if rank == world - 1:
+            nrows = H - row0
+        fam = {"b3spline": _lib.B3SPLINE, "triangle": _lib.TRIANGLE}[family]
+        plan = _lib.Plan(ctx, H, W, fam, level, row0=row0, nrows=nrows, rank=rank, nranks=world)
+        if config == "cfg5":
+            # the cfg5 image of tools/bench_configs.py: noise on a smooth structure (pure noise has
+            # no edges for the bilateral weights to act on)
+            img0 = make_strip(nrows, W, seed=0) + 3 * np.sin(np.arange(W, dtype=np.float32) / 50.)[None, :]
+            plan.upload(PLANE_INPUT, img0.astype(np.float32))
+            del img0
+        else:
+            plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
+        flags = 0 if args.unfused else _lib.FLAG_FUSED
+        two_call = args.two_call or args.unfused
+        coefficients = None
 
-        from wavelets_amd.wavelets import _decompose_denoise_sum
-        transform = WA.AtrousTransform(WA.Triangle)
+        if config in ("headline", "cfg2"):
+            def step():
+                if two_call:
+                    plan.decompose(PLANE_INPUT, level, flags)
+                    plan.plane_sum(0, level + 1, PLANE_OUT)
+                else:   # same outputs (planes + reconstruction, bit-identical), sum carried along
+                    plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+        elif config == "cfg3":
+            import wavelets_amd as WA
+            coefficients = WA.Coefficients(plan, WA.Triangle(2))
 
-        def step():         # transform, Coefficients.denoise([5,3,2]), np.sum(coefficients, axis=0)
-            coefficients.noise = None                      # lazy MAD estimate, every step
-            if two_call:
-                plan.decompose(PLANE_INPUT, level, flags)
-                coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
-            else:           # the same three results with the threshold step between the passes
-                _decompose_denoise_sum(transform, plan, level, coefficients, [5, 3, 2],
-                                       soft_threshold=True, write_back=True)
-    else:
-        import wavelets_amd as WA
-        from wavelets_amd import utils as WU
-        transform = WA.AtrousTransform(WA.B3spline, bilateral=[1] * (level + 1))
-        coefficients = WA.Coefficients(plan, WA.B3spline(2), [1] * (level + 1))
+            from wavelets_amd.wavelets import _decompose_denoise_sum
+            transform = WA.AtrousTransform(WA.Triangle)
 
-        def step():         # utils.wow without its PCIe legs (ref utils.py:148-217)
-            transform._run(plan, level)
-            coefficients.noise = None
-            WU._wow_device(coefficients, level, [], True, [5, 2], True, False, 3.2, None, None, 0)
+            def step():         # transform, Coefficients.denoise([5,3,2]), np.sum(coefficients, axis=0)
+                coefficients.noise = None                      # lazy MAD estimate, every step
+                if two_call:
+                    plan.decompose(PLANE_INPUT, level, flags)
+                    coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
+                else:           # the same three results with the threshold step between the passes
+                    _decompose_denoise_sum(transform, plan, level, coefficients, [5, 3, 2],
+                                           soft_threshold=True, write_back=True)
+        else:
+            import wavelets_amd as WA
+            from wavelets_amd import utils as WU
+            transform = WA.AtrousTransform(WA.B3spline, bilateral=[1] * (level + 1))
+            coefficients = WA.Coefficients(plan, WA.B3spline(2), [1] * (level + 1))
 
-    def fence():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-        ctx.sync()
+            def step():         # utils.wow without its PCIe legs (ref utils.py:148-217)
+                transform._run(plan, level)
+                coefficients.noise = None
+                WU._wow_device(coefficients, level, [], True, [5, 2], True, False, 3.2, None, None, 0)
 
-    # Untimed spin-up: the GPU idles at 94 MHz and its clocks ramp over the first milliseconds of
-    # work; W = 3 warm-up steps are only 2.5 ms.  Run the same step for a quarter of a second so
-    # that the timed region starts at steady clocks (measured: K = 5 reads 4 % low otherwise).
-    if dist is None:
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < args.spinup:
-            for _ in range(20 if config in ("headline", "cfg2") else 2):
+        def fence():
+            ctx.sync()
+            if dist is not None:
+                dist.barrier()
+            ctx.sync()
+
+        # Untimed spin-up: the GPU idles at 94 MHz and its clocks ramp over the first milliseconds of
+        # work; W = 3 warm-up steps are only 2.5 ms.  Run the same step for a quarter of a second so
+        # that the timed region starts at steady clocks (measured: K = 5 reads 4 % low otherwise).
+        if dist is None:
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < args.spinup:
+                for _ in range(20 if config in ("headline", "cfg2") else 2):
+                    step()
+                ctx.sync()
+        elif args.spinup > 0:
+            # every rank must issue the same number of halo exchanges: a fixed count, not a clock
+            for _ in range(60):
                 step()
             ctx.sync()
-    elif args.spinup > 0:
-        # every rank must issue the same number of halo exchanges: a fixed count, not a clock
-        for _ in range(60):
+        for _ in range(warmup):
             step()
-        ctx.sync()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    dev_ms = ctx.timer_stop()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        fence()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(steps):
+            step()
+        dev_ms = ctx.timer_stop()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = H * W * args.steps / elapsed / 1e6
+        ms_per_step = elapsed / steps * 1e3
+        value = H * W * steps / elapsed / 1e6
 
-    # ---- live per-kernel timing (HIP events on the launch stream) for the roofline figure
-    ctx.profile(True)
-    ctx.profile_reset()
-    nprof = max(3, min(args.steps, 10))
-    for _ in range(nprof):
-        step()
-    prof = ctx.profile_entries()
-    ctx.profile(False)
-    roofline = None
-    kernels = {}
-    my_pix = float(nrows) * W
-    sched = _lib.schedule(fam, level, not args.unfused)
-    def algo_bytes(name, calls):
-        """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
-        fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
-        its bytes are per STEP; every other kernel's are per launch."""
-        bpp = algorithmic_bytes_per_pixel(name, level, interleaved=any(
-            k.startswith("wt_fused_hist") for k in prof), n_fold=sched[0][1] if sched else 3)
-        if bpp is None:
-            return None
-        return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)
+        # ---- live per-kernel timing (HIP events on the launch stream) for the roofline figure
+        ctx.profile(True)
+        ctx.profile_reset()
+        nprof = max(3, min(steps, 10))
+        for _ in range(nprof):
+            step()
+        prof = ctx.profile_entries()
+        ctx.profile(False)
+        roofline = None
+        kernels = {}
+        my_pix = float(nrows) * W
+        sched = _lib.schedule(fam, level, not args.unfused)
 
-    for name, (calls, ms) in prof.items():
-        ab = algo_bytes(name, calls)
-        kernels[name] = {"calls_per_step": calls // nprof,
-                         "avg_ms": round(ms / calls, 4),
-                         "algorithmic_GBs": None if ab is None else round(ab / (ms * 1e-3) / 1e9, 1)}
-    # Dominant kernel = the SOURCE kernel with the largest total time.  The fused passes are
-    # instantiations of one kernel (wt_fused_kernel<..., D=1> and <..., D=8>; rocprof lists them
-    # as two rows), so the roofline entry describes them together: per launch algorithmic bytes /
-    # average launch duration over the instantiations.
-    groups = {}
-    for n, (c, ms) in prof.items():
-        ab = algo_bytes(n, c)
-        if ab is None:
-            continue
-        key = "wt_fused_kernel" if n.startswith("wt_fused") else n.split("<")[0]
-        f = groups.setdefault(key, {"ms": 0.0, "calls": 0, "bytes": 0.0, "members": []})
-        f["ms"] += ms
-        f["calls"] += c
-        f["bytes"] += ab
-        f["members"].append(n)
-    if groups:
-        dom = max(groups, key=lambda k: groups[k]["ms"])
-        f = groups[dom]
-        achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            vals = [tj.get(f"{m}@{side}") for m in f["members"]]
-            if vals and all(v is not None for v in vals):
-                traffic = round(sum(vals) / len(vals))             # HBM bytes per launch
-        roofline = {"bound": "hbm", "kernel": dom, "instantiations": sorted(f["members"]),
-                    "launches_per_step": f["calls"] // nprof,
-                    "avg_launch_ms": round(f["ms"] / f["calls"], 4),
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
-        if dom.startswith("wt_bilateral"):
-            # SURVEY 8(d): the bilateral operator is VALU / transcendental bound - K*K-1 taps of
-            # (sub, mul, fma into the exponent, v_exp, two fmas) + variance + normalisation per
-            # pixel and scale: ~10 flop per tap + 40.  HBM stays the `bound` the schema knows;
-            # the vector-ALU fraction is reported beside it.
-            taps = 24 if family == "b3spline" else 8
-            flops = (10.0 * taps + 40.0) * my_pix * f["calls"]
-            roofline["valu"] = {"algorithmic_flop_per_pixel_scale": 10.0 * taps + 40.0,
-                                "achieved_TFLOPs": round(flops / (f["ms"] * 1e-3) / 1e12, 1),
-                                "peak_TFLOPs": VALU_PEAK_TFLOPS,
-                                "frac": round(flops / (f["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+        def algo_bytes(name, calls):
+            """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
+            fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
+            its bytes are per STEP; every other kernel's are per launch."""
+            bpp = algorithmic_bytes_per_pixel(name, level, interleaved=any(
+                k.startswith("wt_fused_hist") for k in prof), n_fold=sched[0][1] if sched else 3)
+            if bpp is None:
+                return None
+            return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)
 
-    if rank == 0:
-        bpp_whole = whole_path_bytes_per_pixel(config, level)
-        whole_job_GBs = bpp_whole * H * W * args.steps / elapsed / 1e9
-        metric = {"headline": f"Mpix/s decompose+sum, {H}x{W} f32 B3spline 6 scales; %HBM roofline"
-                              if (world > 1 or side != 8192) else
-                              "Mpix/s decompose+sum, 8192^2 f32 B3spline 6 scales; %HBM roofline",
-                  "cfg2": "Mpix/s decompose+sum, 4096^2 f32 B3spline 6 scales; %HBM roofline",
-                  "cfg3": "Mpix/s decompose+denoise([5,3,2])+sum, 8192^2 f32 Triangle 8 scales; %HBM roofline",
-                  "cfg5": "Mpix/s wow(bilateral=1, denoise_coefficients=[5,2]), 8192^2 f32"}[config]
-        out = {
-            "metric": metric,
-            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{H}x{W} float32 np.random.default_rng(seed).standard_normal, "
-                                   f"{family} L={level}, " + what.format(n=level + 1)
-                                   + "; device-resident"
-                                   + ("" if world == 1 else f"; {world} row strips, RCCL halo "
-                                      "exchange per pass"),
-                       "name": config, "image": [H, W], "levels": level, "family": family,
-                       "fused": not args.unfused, "sum_in_passes": not two_call,
-                       "schedule": _lib.schedule(fam, level, not args.unfused),
-                       "parallelism": f"strips{world}"},
-            "rccl_ranks": rccl_ranks,
-            "device_ms_per_step": round(dev_ms / args.steps, 4),
-            "whole_path": {"algorithmic_GBs": round(whole_job_GBs, 1),
-                           "frac_of_hbm_peak": round(whole_job_GBs / (HBM_PEAK_GBS * world), 4),
-                           "bytes_per_pixel": bpp_whole},
-            "roofline": roofline,
-            "kernels": kernels,
-        }
-        if world == 1 and config in ("headline", "cfg2"):
-            # PCIe-inclusive rate (host numpy in, reconstruction out as a numpy array) - never
-            # `value`.  First call: the result's page-locked block is allocated; later calls
-            # reuse it from the host pool (wavelets_amd/_lib.py _HostPool), which is the steady
-            # state of a frame loop.
-            img = make_strip(nrows, W, seed=0)
-            rates = []
-            for _ in range(3):
-                t = time.perf_counter()
-                plan.upload(PLANE_INPUT, img)
-                step()
-                recon = plan.download(PLANE_OUT)
-                rates.append(H * W / (time.perf_counter() - t) / 1e6)
-                del recon
-            out["pcie_inclusive_first_call_mpix_s"] = round(rates[0], 1)
-            out["pcie_inclusive_mpix_s"] = round(max(rates[1:]), 1)
-        if world == 1 and not args.no_cpu and not args.brief:
-            out["cpu_baseline"] = cpu_baseline(config, side, family, level)
-        if args.brief:
-            emit(f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
-                f"{k}={v['avg_ms']}" for k, v in kernels.items()))
-        else:
-            emit(json.dumps(out))
-    if config in ("cfg3", "cfg5"):
-        coefficients._plan = None                 # the plan is ours, not the pool's
+        def pmc_bytes(name):
+            """HBM bytes per launch of `name` at this image size from profiles/traffic.json (the
+            rocprofv3 --pmc passes of an earlier run of the same command; None: not recorded)."""
+            if world > 1 or H != W:
+                return None
+            return traffic_db.get(f"{name}@{config}", traffic_db.get(f"{name}@{side}") if config == "headline" else None)
+
+        step_traffic, traffic_complete = 0.0, True
+        for name, (calls, ms) in prof.items():
+            ab = algo_bytes(name, calls)
+            tb = pmc_bytes(name)
+            kernels[name] = {"calls_per_step": calls // nprof,
+                             "avg_ms": round(ms / calls, 4),
+                             "algorithmic_GBs": None if ab is None else round(ab / (ms * 1e-3) / 1e9, 1)}
+            if tb is not None:
+                kernels[name]["hbm_GBs"] = round(tb * calls / (ms * 1e-3) / 1e9, 1)
+                step_traffic += tb * calls / nprof
+            elif ms / nprof > 0.002 and not name.startswith("rccl"):   # (select steps etc. move nothing)
+                traffic_complete = False
+        # Dominant kernel = the SOURCE kernel with the largest total time.  The fused passes are
+        # instantiations of one kernel (wt_fused_kernel<..., D=1> and <..., D=8>; rocprof lists them
+        # as two rows), so the roofline entry describes them together: per launch algorithmic bytes /
+        # average launch duration over the instantiations.
+        groups = {}
+        for n, (c, ms) in prof.items():
+            ab = algo_bytes(n, c)
+            if ab is None:
+                continue
+            key = "wt_fused_kernel" if n.startswith("wt_fused") else n.split("<")[0]
+            f = groups.setdefault(key, {"ms": 0.0, "calls": 0, "bytes": 0.0, "members": [], "pmc": 0.0,
+                                        "pmc_ok": True})
+            f["ms"] += ms
+            f["calls"] += c
+            f["bytes"] += ab
+            f["members"].append(n)
+            tb = pmc_bytes(n)
+            if tb is None:
+                f["pmc_ok"] = False
+            else:
+                f["pmc"] += tb * c
+        if groups:
+            dom = max(groups, key=lambda k: groups[k]["ms"])
+            f = groups[dom]
+            achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+            have_pmc = f["pmc_ok"] and f["pmc"] > 0
+            roofline = {"bound": "hbm", "kernel": dom, "instantiations": sorted(f["members"]),
+                        "launches_per_step": f["calls"] // nprof,
+                        "avg_launch_ms": round(f["ms"] / f["calls"], 4),
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "achieved_is": "SURVEY 8(d) algorithmic bytes / measured launch time "
+                                       "(throughput-equivalent, not bytes on the HBM interface)",
+                        "traffic": round(f["pmc"] / f["calls"]) if have_pmc else None,
+                        "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                          "WRITE_SIZE passes of an earlier run of this command; "
+                                          "not re-measured here)" if have_pmc else None,
+                        "hbm_achieved_GBs": round(f["pmc"] / (f["ms"] * 1e-3) / 1e9, 1) if have_pmc else None,
+                        "hbm_achieved": round(f["pmc"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                        if have_pmc else None}
+            if dom.startswith("wt_bilateral"):
+                # SURVEY 8(d): the bilateral operator is VALU / transcendental bound - K*K-1 taps of
+                # (sub, mul, fma into the exponent, v_exp, two fmas) + variance + normalisation per
+                # pixel and scale: ~10 flop per tap + 40.  HBM stays the `bound` the schema knows;
+                # the vector-ALU fraction is reported beside it.
+                taps = 24 if family == "b3spline" else 8
+                flops = (10.0 * taps + 40.0) * my_pix * f["calls"]
+                roofline["valu"] = {"algorithmic_flop_per_pixel_scale": 10.0 * taps + 40.0,
+                                    "achieved_TFLOPs": round(flops / (f["ms"] * 1e-3) / 1e12, 1),
+                                    "peak_TFLOPs": VALU_PEAK_TFLOPS,
+                                    "frac": round(flops / (f["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+
+        out = None
+        if rank == 0:
+            bpp_whole = whole_path_bytes_per_pixel(config, level)
+            whole_job_GBs = bpp_whole * H * W * steps / elapsed / 1e9
+            metric = {"headline": f"Mpix/s decompose+sum, {H}x{W} f32 B3spline 6 scales; %HBM roofline"
+                                  if (world > 1 or side != 8192) else
+                                  "Mpix/s decompose+sum, 8192^2 f32 B3spline 6 scales; %HBM roofline",
+                      "cfg2": "Mpix/s decompose+sum, 4096^2 f32 B3spline 6 scales; %HBM roofline",
+                      "cfg3": "Mpix/s decompose+denoise([5,3,2])+sum, 8192^2 f32 Triangle 8 scales; %HBM roofline",
+                      "cfg5": "Mpix/s wow(bilateral=1, denoise_coefficients=[5,2]), 8192^2 f32"}[config]
+            whole = {"algorithmic_GBs": round(whole_job_GBs, 1),
+                     "frac_of_hbm_peak": round(whole_job_GBs / (HBM_PEAK_GBS * world), 4),
+                     "bytes_per_pixel": bpp_whole}
+            if traffic_complete and step_traffic > 0:
+                whole["hbm_bytes_per_pixel"] = round(step_traffic / my_pix, 2)
+                whole["hbm_achieved_GBs"] = round(step_traffic / (ms_per_step * 1e-3) / 1e9, 1)
+                whole["hbm_achieved"] = round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                whole["hbm_traffic_source"] = "profiles/traffic.json (PMC passes, not re-measured here)"
+            out = {
+                "metric": metric,
+                "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{H}x{W} float32 np.random.default_rng(seed).standard_normal, "
+                                       f"{family} L={level}, " + what.format(n=level + 1)
+                                       + "; device-resident"
+                                       + ("" if world == 1 else f"; {world} row strips, RCCL halo "
+                                          "exchange per pass"),
+                           "name": config, "image": [H, W], "levels": level, "family": family,
+                           "fused": not args.unfused, "sum_in_passes": not two_call,
+                           "schedule": _lib.schedule(fam, level, not args.unfused),
+                           "parallelism": f"strips{world}"},
+                "rccl_ranks": rccl_ranks,
+                "device_ms_per_step": round(dev_ms / steps, 4),
+                "whole_path": whole,
+                "roofline": roofline,
+                "kernels": kernels,
+            }
+            if full and world == 1 and config in ("headline", "cfg2"):
+                # PCIe-inclusive rate (host numpy in, reconstruction out as a numpy array) - never
+                # `value`.  First call: the result's page-locked block is allocated; later calls
+                # reuse it from the host pool (wavelets_amd/_lib.py _HostPool), which is the steady
+                # state of a frame loop.
+                img = make_strip(nrows, W, seed=0)
+                rates = []
+                for _ in range(3):
+                    t = time.perf_counter()
+                    plan.upload(PLANE_INPUT, img)
+                    step()
+                    recon = plan.download(PLANE_OUT)
+                    rates.append(H * W / (time.perf_counter() - t) / 1e6)
+                    del recon
+                out["pcie_inclusive_first_call_mpix_s"] = round(rates[0], 1)
+                out["pcie_inclusive_mpix_s"] = round(max(rates[1:]), 1)
+            if world == 1 and not args.no_cpu and not args.brief:
+                out["cpu_baseline"] = cpu_baseline(config, side, family, level,
+                                                   budget=15.0 if full else 5.0)
+            out["_brief"] = f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
+                f"{k}={v['avg_ms']}" for k, v in kernels.items())
+        if coefficients is not None:
+            coefficients._plan = None                 # the plan is ours, not the pool's
+        plan.close()
+        return out
+
+    out = run_workload(args.config, args.steps, args.warmup, full=True)
+    if (out is not None and args.config == "headline" and world == 1 and not args.no_configs
+            and not args.size and not args.rows and not args.unfused and not args.two_call
+            and not args.brief):
+        # every other single-GPU BASELINE.json configuration, timed in the same run
+        extra = {}
+        for cfg in ("cfg2", "cfg3", "cfg5"):
+            o = run_workload(cfg, max(5, min(args.steps, 20)) if cfg != "cfg5" else 5,
+                             args.warmup, full=False)
+            r = o["roofline"] or {}
+            extra[cfg] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"],
+                          "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                          "workload": o["config"]["workload"], "schedule": o["config"]["schedule"],
+                          "bytes_per_pixel": o["whole_path"]["bytes_per_pixel"],
+                          "frac_of_hbm_peak": o["whole_path"]["frac_of_hbm_peak"],
+                          "hbm_achieved": o["whole_path"].get("hbm_achieved"),
+                          "hbm_bytes_per_pixel": o["whole_path"].get("hbm_bytes_per_pixel"),
+                          "dominant_kernel": r.get("kernel"),
+                          "dominant_kernel_frac": r.get("frac"),
+                          "dominant_kernel_hbm_achieved": r.get("hbm_achieved"),
+                          "dominant_kernel_valu_frac": (r.get("valu") or {}).get("frac"),
+                          "kernels": o["kernels"],
+                          "cpu_baseline": o.get("cpu_baseline")}
+        out["configs"] = extra
+    if out is not None:
+        brief = out.pop("_brief")
+        emit(brief if args.brief else json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

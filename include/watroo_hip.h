@@ -59,6 +59,9 @@ int wt_device_count(int *count);
  *   "overlap_reserve" (16): compute units the interior launch leaves to the RCCL kernels.
  * "fused_fast" (1): fused passes use the single-bounce / aligned-group addressing where the image
  *   allows (W % 4 == 0, halo <= image); 0 forces the generic (multi-bounce, gather) addressing.
+ * "scatter" (4; env WT_SCATTER): planes >= 8 MiB of single-GPU plans created from now on are
+ *   mapped over shuffled 2-MiB physical chunks created in groups worth this many planes
+ *   (DESIGN.md section 2); 0 = one hipMalloc per plane (see wt_plane_ptr).
  * "split_dry" (0): measurement aid - launch the passes of a strip plan split into edge and
  *   interior rows as "overlap" does, without exchanging (FLAG_NO_EXCHANGE runs). */
 int wt_set_option(const char *name, int value);
@@ -67,6 +70,9 @@ int wt_set_option(const char *name, int value);
 int wt_ctx_create(int device, wt_ctx **out);
 int wt_ctx_destroy(wt_ctx *ctx);
 int wt_ctx_sync(wt_ctx *ctx);
+/* hipMemGetInfo of the context's device: out[0] = free bytes, out[1] = total bytes (leak checks
+ * around plan create / destroy cycles; sizing of strips for 288 GB of HBM). */
+int wt_device_memory(wt_ctx *ctx, int64_t out[2]);
 /* hipEvent stopwatch on the context's stream (the stream every kernel is launched on). */
 int wt_timer_start(wt_ctx *ctx);
 int wt_timer_stop(wt_ctx *ctx, float *elapsed_ms);
@@ -101,6 +107,16 @@ int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_
 int wt_plan_destroy(wt_plan *plan);
 /* geometry query: out[0..7] = H, W, pitch, row0, nrows, halo, max_level, family */
 int wt_plan_info(wt_plan *plan, int64_t out[8]);
+/* Device memory held by the plan right now: out[0] = all bytes (hipMalloc'ed planes, the bounce
+ * plane of host transfers, mapped chunks, idle chunks), out[1] = bytes of planes mapped over
+ * scattered 2-MiB chunks, out[2] = bytes of idle chunks (created in groups, not yet mapped:
+ * wt_plan_trim gives them back), out[3] = 1 when this context has stopped scattering planes
+ * because the virtual-memory API failed on it (wt_last_error then holds the failing call; the
+ * fused passes run ~20 % slower on physically contiguous planes). */
+int wt_plan_memory(wt_plan *plan, int64_t out[4]);
+/* Release the plan's idle physical chunks (a plan keeps up to three planes' worth after its last
+ * plane was allocated).  The Python plan pool calls this when a plan is handed back. */
+int wt_plan_trim(wt_plan *plan);
 /* Decomposition schedule (host logic, needs no GPU): for `level` scales of `family`, writes
  * up to `cap` passes as triples {first_scale, n_scales, halo_rows_of_input}.  The same
  * schedule drives the kernels and the halo exchange; tests use it for the gloo CPU model. */
@@ -139,7 +155,14 @@ int wt_paste_plane(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int
  * (atrous_recursive on 3-D data, watroo/wavelets.py:394-406). */
 int wt_copy_window(wt_plan *src, int src_plane, wt_plan *dst, int dst_plane, int64_t sy,
                    int64_t sx, int64_t dy, int64_t dx, int64_t rows, int64_t cols);
-/* device pointer of a plane's local row 0 (for zero-copy interop / virtual-strip tests) */
+/* Device pointer of a plane's local row 0 (zero-copy interop / virtual-strip tests).
+ * RESTRICTION: on a single-GPU plan a plane of 8 MiB or more is one contiguous VIRTUAL range
+ * mapped over many 2-MiB physical allocations (hipMemMap).  Kernels read and write it like any
+ * pointer; hipMemcpy / hipMemcpy2D, IPC handles and RCCL transports may refuse a range that
+ * spans several mappings (the library's own transfers bounce through a hipMalloc'ed plane for
+ * that reason).  Consumers that need plain hipMalloc memory create their plans after
+ * wt_set_option("scatter", 0) (or with WT_SCATTER=0 in the environment); strip plans
+ * (nranks > 1) are always plain hipMalloc. */
 int wt_plane_ptr(wt_plan *plan, int plane, void **dev_ptr);
 
 /* ---- host <-> device ---------------------------------------------------------------- */

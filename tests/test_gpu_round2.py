@@ -54,9 +54,10 @@ def test_bench_step_8192_vs_c_oracle(L, C, fam, level):
     plan.upload(L.PLANE_INPUT, a)
     plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT, L.FLAG_FUSED)
     ref = C.decompose(a, level, fam)
+    from conftest import measured
     for s in range(level + 1):
-        close(plan.download(s), ref[s], 1e-5 * amax)
-    close(plan.download(L.PLANE_OUT), C.plane_sum(ref), 2e-5 * amax)
+        measured(f"bench step {fam} plane {s}", plan.download(s), ref[s], 1e-5 * amax)
+    measured(f"bench step {fam} carried sum", plan.download(L.PLANE_OUT), C.plane_sum(ref), 2e-5 * amax)
     plan.close()
 
 

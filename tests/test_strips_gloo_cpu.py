@@ -1,4 +1,4 @@
-"""CPU model of the multi-GPU path: world_size 2 and 3 over gloo.
+"""CPU model of the multi-GPU path: world_size 2, 3 and 8 over gloo.
 
 What is under test is the HOST LOGIC that the GPU path shares - the row partition
 (wavelets_amd.parallel.partition_rows), the pass schedule and its halo sizes
@@ -92,6 +92,7 @@ def _worker(rank, world, port, H, W, family, level, fused, result_dir):
     (2, 128, 24, "triangle", 5, True),     # (0,3,7), (3,2,24)
     (3, 99, 20, "b3spline", 4, False),     # per-scale exchange, halos 2,4,8,16
     (2, 520, 16, "triangle", 8, True),     # four-scale passes of the 3-tap family: (0,4,15), (4,4,240)
+    (8, 1024, 12, "b3spline", 6, True),    # BASELINE config 4's world: 8 strips of 128 rows, halos 14 / 112
 ])
 def test_strips_match_unsharded_bitwise(tmp_path, world, H, W, family, level, fused):
     # stdlib multiprocessing (spawn): the pytest process itself never imports torch, so a GPU

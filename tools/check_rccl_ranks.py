@@ -158,6 +158,16 @@ def main():
             same(f"denoise_sum plane {s}", st.plane(s), c.data[s][r0:r0 + n])
         st.plan.close()
 
+    # a self-test between a transform whose first pass histogrammed |w_0| and the median that would
+    # start from those bins: the self-test zeroes words of the same buffer, so the marker must go
+    # (constant image: every |w_0| is exactly 0 and lives in the bins the self-test wipes)
+    st = StripTransform(ctx, H, W, 3, B3spline)
+    st.upload(np.zeros((st.nrows, W), np.float32))
+    st.plan.decompose(L.PLANE_INPUT, 3, L.FLAG_FUSED | L.FLAG_MEDIAN_HIST)
+    assert ctx.comm_selftest(4096)
+    same("median after a self-test (constant image)", np.float64(st.get_noise()), np.float64(0.0))
+    st.plan.close()
+
     ctx.sync()
     bad = [n for n, ok in checks if not ok]
     flag = torch.tensor([len(bad)], dtype=torch.int64)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc passes of tools/profile_round.sh.
 
-    python tools/pmc_summary.py gpurun_out/final profiles/r01_e [side]
+    python tools/pmc_summary.py gpurun_out/final profiles/r01_e [side] [config] [fetch_dir write_dir]
 
 Reads <dir>/pmc_fetch and <dir>/pmc_write (one counter per pass, as MI355X_MICROARCH.md
 prescribes), writes <prefix>_pmc_summary.csv (KiB per dispatch, averaged) and updates
@@ -16,6 +16,8 @@ import sys
 
 src, prefix = sys.argv[1], sys.argv[2]
 side = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+config = sys.argv[4] if len(sys.argv) > 4 else None      # cfg2 / cfg3 / cfg5: keys "<kernel>@<config>"
+subdirs = (sys.argv[5], sys.argv[6]) if len(sys.argv) > 6 else ("pmc_fetch", "pmc_write")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,12 +26,19 @@ def scope_name(kernel):
     m = re.match(r"void wt_fused_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel)
     if m:
         _, ns, d, _, _, acc = map(int, m.groups())
-        return f"{('wt_fused', 'wt_fused_acc', 'wt_fused_sum')[acc]}<d{d}x{ns}>"
+        return f"{('wt_fused', 'wt_fused_acc', 'wt_fused_sum', 'wt_fused_hist')[acc]}<d{d}x{ns}>"
+    m = re.match(r"void (wt_row_kernel|wt_lattice_kernel|wt_chain_kernel)<(\d+), (\d+)", kernel)
+    if m:       # the single-scale operators are named by their mode (wt_api.hip row_name / lattice_name)
+        mode = int(m.group(3))
+        names = {"wt_row_kernel": ("smooth", "smooth_sq", "decomp", "variance", "wow"),
+                 "wt_lattice_kernel": ("smooth", "smooth_sq", "decomp", "var", "wow"),
+                 "wt_chain_kernel": ("smooth", "smooth_sq", "decomp", "variance", "wow")}[m.group(1)]
+        return f"{m.group(1)}<{names[min(mode, 4)]}>"
     return re.sub(r"^void ", "", kernel).split("(")[0].split("<")[0]
 
 
 rows, traffic = [], {}
-for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+for counter, sub in (("FETCH_SIZE", subdirs[0]), ("WRITE_SIZE", subdirs[1])):
     acc = {}
     for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
@@ -40,18 +49,18 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     for k, (n, tot) in sorted(acc.items()):
         rows.append((counter, k, n, tot / n))
         if k.startswith("void wt_") or k.startswith("wt_"):
-            key = f"{scope_name(k)}@{side}"
+            key = f"{scope_name(k)}@{config or side}"
             traffic[key] = traffic.get(key, 0.0) + (2 if counter == "FETCH_SIZE" else 1) * tot / n * 1024
 
 with open(prefix + "_pmc_summary.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
-            f"--steps 5 --warmup 1 --no-cpu --brief; {side}x{side} f32 B3 L=6\n"
+            f"--steps 5 --warmup 1 --no-cpu --brief{' --config ' + config if config else ''}; {side}x{side} f32\n"
             "# KiB per dispatch, averaged. gfx950 correction (MI355X_MICROARCH.md, HBM): hbm_read = 2*FETCH_SIZE*1024\n"
             "counter,kernel,dispatches,avg_value_KiB\n")
     for c, k, n, v in rows:
         f.write(f'{c},"{k}",{n},{v:.1f}\n')
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 old = json.load(open(tpath)) if os.path.exists(tpath) else {}
-old.update({k: round(v) for k, v in traffic.items() if "wt_fused" in k or "plane_sum" in k})
+old.update({k: round(v) for k, v in traffic.items()})
 json.dump(old, open(tpath, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: round(v) for k, v in traffic.items()}, indent=1))

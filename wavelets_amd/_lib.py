@@ -44,6 +44,7 @@ SIGNATURES = {
     "wt_ctx_create": (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
     "wt_ctx_destroy": (_c.c_int, [_vp]),
     "wt_ctx_sync": (_c.c_int, [_vp]),
+    "wt_device_memory": (_c.c_int, [_vp, _c.POINTER(_i64)]),
     "wt_timer_start": (_c.c_int, [_vp]),
     "wt_timer_stop": (_c.c_int, [_vp, _c.POINTER(_c.c_float)]),
     "wt_profile_enable": (_c.c_int, [_vp, _c.c_int]),
@@ -60,6 +61,8 @@ SIGNATURES = {
                                         _c.c_int, _c.c_int, _c.POINTER(_vp)]),
     "wt_plan_destroy": (_c.c_int, [_vp]),
     "wt_plan_info": (_c.c_int, [_vp, _c.POINTER(_i64)]),
+    "wt_plan_memory": (_c.c_int, [_vp, _c.POINTER(_i64)]),
+    "wt_plan_trim": (_c.c_int, [_vp]),
     "wt_schedule": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.c_int,
                                _c.POINTER(_c.c_int)]),
     "wt_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
@@ -213,6 +216,12 @@ class Context:
 
     def sync(self):
         check(load().wt_ctx_sync(self._h))
+
+    def device_memory(self):
+        """(free, total) bytes of the device (hipMemGetInfo)."""
+        out = (_i64 * 2)()
+        check(load().wt_device_memory(self._h, out))
+        return int(out[0]), int(out[1])
 
     def timer_start(self):
         check(load().wt_timer_start(self._h))
@@ -425,14 +434,24 @@ class Plan:
 
     def close(self):
         if self._h:
-            load().wt_plan_destroy(self._h)
-            self._h = _vp()
+            h, self._h = self._h, _vp()
+            check(load().wt_plan_destroy(h))     # a failed release (leaked HBM) is not silent
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    def memory(self):
+        """(bytes held, bytes in scattered planes, idle chunk bytes, scatter disabled on this
+        context) - wt_plan_memory."""
+        out = (_i64 * 4)()
+        check(load().wt_plan_memory(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+
+    def trim(self):
+        check(load().wt_plan_trim(self._h))
 
     @property
     def shape(self):
@@ -602,7 +621,11 @@ _pool = []            # [(key, plan)] most recently released last
 
 
 def _plan_bytes(plan):
-    return (plan.nrows + 2 * plan.halo) * plan.pitch * (8 if isinstance(plan, Plan64) else 4) * (plan.max_level + 1 + 2 + 4)
+    """Device bytes a pooled plan holds: the library's own count for float32 plans (planes, the
+    bounce plane of host transfers, idle chunks), an estimate for float64 plans."""
+    if isinstance(plan, Plan) and plan._h:
+        return plan.memory()[0]
+    return (plan.nrows + 2 * plan.halo) * plan.pitch * 8 * (plan.max_level + 1 + 2 + 4)
 
 
 _pool_lock = threading.RLock()      # plan pool and default contexts are shared by host threads
@@ -790,6 +813,8 @@ def release_plan(plan):
         return
     evicted = []
     fam = ("f64",) + plan.family if isinstance(plan, Plan64) else plan.family
+    if isinstance(plan, Plan):
+        plan.trim()               # idle physical chunks (up to three planes' worth) go back now
     with _pool_lock:
         _pool.append(((id(plan.ctx), plan.H, plan.W, fam, plan.max_level), plan))
         total = sum(_plan_bytes(p) for _, p in _pool)

@@ -287,6 +287,18 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
     return 0;
 }
 
+extern "C" int wt_device_memory(wt_ctx *c, int64_t out[2])
+{
+    WtGuard guard_(ctx_of(c));
+    if (!c || !out) WT_FAIL("wt_device_memory: null pointer");
+    WT_HIP(hipSetDevice(c->device));
+    size_t fr = 0, tot = 0;
+    WT_HIP(hipMemGetInfo(&fr, &tot));
+    out[0] = (int64_t)fr;
+    out[1] = (int64_t)tot;
+    return 0;
+}
+
 extern "C" int wt_ctx_sync(wt_ctx *c)
 {
     WtGuard guard_(ctx_of(c));
@@ -360,6 +372,9 @@ extern "C" int wt_profile_entry(wt_ctx *c, int i, char *name64, int64_t *calls, 
 static inline int family_taps(int family) { return family == WT_B3SPLINE ? 5 : 3; }
 // A/B switch (wt_set_option "tri4"): four-scale passes of the 3-tap family for level >= 8
 static int g_opt_tri4 = getenv("WT_NO_TRI4") ? 0 : 1;
+// planes over shuffled physical chunks (plan_alloc): chunks are created in groups worth this many
+// planes; 0 = plain hipMalloc per plane (contiguous planes: interop through wt_plane_ptr)
+static int g_opt_scatter = getenv("WT_SCATTER") ? atoi(getenv("WT_SCATTER")) : 4;
 
 extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int *n_passes)
 {
@@ -392,16 +407,27 @@ extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, i
 }
 
 // One plane of `need` bytes as a contiguous virtual range over shuffled physical chunks (see
-// plan_alloc).  Returns non-zero without leaving a mapping behind if any step fails.
-static int vmm_plane_alloc(wt_plan *p, size_t need, int scatter, void **out)
+// plan_alloc).  Returns non-zero without leaving a mapping or a fresh handle behind if any step
+// fails; `why` then names the failing call.
+static int vmm_plane_alloc(wt_plan *p, size_t need, int scatter, void **out, std::string &why, hipError_t &err)
 {
+    auto fail = [&](const char *call, hipError_t e) {
+        err = e;
+        char buf[160];
+        snprintf(buf, sizeof buf, "%s: HIP error %d (%s)", call, (int)e, hipGetErrorString(e));
+        why = buf;
+        (void)hipGetLastError();
+        return 1;
+    };
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = p->ctx->device;
+    hipError_t e;
     if (!p->vmm_gran) {
         size_t g = 0;
-        if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) return 1;
+        e = hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended);
+        if (e != hipSuccess || g == 0) return fail("hipMemGetAllocationGranularity", e);
         // chunk size: 2 MiB (WT_SCATTER_CHUNK_KB for experiments: chunks below 2 MiB cost TLB reach -
         // 512 KiB: +30 %, 128 KiB: +85 % step time; 8-64 MiB: no different from 2 MiB)
         static const size_t chunk_kb = getenv("WT_SCATTER_CHUNK_KB") ? (size_t)atoll(getenv("WT_SCATTER_CHUNK_KB")) : 2048;
@@ -413,40 +439,86 @@ static int vmm_plane_alloc(wt_plan *p, size_t need, int scatter, void **out)
     const size_t nchunks = (need + g - 1) / g;
     const size_t size = nchunks * g;
     if (p->vmm_pool.size() < nchunks) {        // refill: chunks for `scatter` planes, shuffled
-        const size_t add = nchunks * (size_t)scatter;
+        const size_t add = nchunks * (size_t)scatter - p->vmm_pool.size();
         std::vector<hipMemGenericAllocationHandle_t> fresh;
         fresh.reserve(add);
+        e = hipSuccess;
         for (size_t i = 0; i < add; ++i) {
             hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, g, &prop, 0) != hipSuccess) break;     // out of memory: use what we got
+            e = hipMemCreate(&h, g, &prop, 0);
+            // out of memory part-way: what we got is enough if it covers THIS plane
+            if (e != hipSuccess) break;
             fresh.push_back(h);
-            p->vmm_handles.push_back(h);
         }
-        uint64_t st = 0x9e3779b97f4a7c15ull;
+        if (p->vmm_pool.size() + fresh.size() < nchunks) {
+            // give the fresh chunks back before the caller falls back to hipMalloc for this plane:
+            // the fallback must not fail for want of the memory a failed refill is sitting on
+            for (auto h : fresh) (void)hipMemRelease(h);
+            return fail("hipMemCreate", e);
+        }
+        uint64_t st = p->vmm_seed;
         for (size_t i = fresh.size(); i > 1; --i) {                     // Fisher-Yates, xorshift stream
             st ^= st << 13; st ^= st >> 7; st ^= st << 17;
             std::swap(fresh[i - 1], fresh[st % i]);
         }
+        p->vmm_seed = st;
         p->vmm_pool.insert(p->vmm_pool.end(), fresh.begin(), fresh.end());
-        if (p->vmm_pool.size() < nchunks) return 1;
     }
     void *va = nullptr;
-    if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) return 1;
+    e = hipMemAddressReserve(&va, size, 0, nullptr, 0);
+    if (e != hipSuccess) return fail("hipMemAddressReserve", e);
+    wt_plan::VmmPlane vp{va, size, {}};
+    vp.chunks.reserve(nchunks);
     size_t mapped = 0;
-    for (; mapped < nchunks; ++mapped)
-        if (hipMemMap((char *)va + mapped * g, g, 0, p->vmm_pool[p->vmm_pool.size() - 1 - mapped], 0) != hipSuccess) break;
+    for (; mapped < nchunks; ++mapped) {
+        e = hipMemMap((char *)va + mapped * g, g, 0, p->vmm_pool[p->vmm_pool.size() - 1 - mapped], 0);
+        if (e != hipSuccess) break;
+    }
     hipMemAccessDesc acc{};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (mapped < nchunks || hipMemSetAccess(va, size, &acc, 1) != hipSuccess) {
-        if (mapped) (void)hipMemUnmap(va, mapped * g);
+    hipError_t e2 = mapped < nchunks ? e : hipMemSetAccess(va, size, &acc, 1);
+    if (e2 != hipSuccess) {
+        // unmap chunk by chunk, at the granularity of the hipMemMap calls (one range per handle)
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char *)va + i * g, g);
         (void)hipMemAddressFree(va, size);
-        return 1;
+        return fail(mapped < nchunks ? "hipMemMap" : "hipMemSetAccess", e2);
     }
+    for (size_t i = 0; i < nchunks; ++i) vp.chunks.push_back(p->vmm_pool[p->vmm_pool.size() - 1 - i]);
     p->vmm_pool.resize(p->vmm_pool.size() - nchunks);
-    p->vmm_planes.push_back({va, size});
+    p->vmm_planes.push_back(std::move(vp));
     *out = va;
     return 0;
+}
+
+// Tear down everything vmm_plane_alloc built.  Every mapping is undone with the granularity it was
+// made with (HIP documents hipMemUnmap for whole mappings, not for a range that spans several), and
+// every return code is looked at: a rejected unmap / release would leave the physical chunks
+// referenced, i.e. leak HBM silently.  Returns the number of failed calls (first one in `why`).
+static int vmm_release_all(wt_plan *p, std::string &why)
+{
+    int bad = 0;
+    auto chk = [&](const char *call, hipError_t e) {
+        if (e == hipSuccess) return;
+        if (!bad++) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "%s: HIP error %d (%s)", call, (int)e, hipGetErrorString(e));
+            why = buf;
+        }
+        (void)hipGetLastError();
+    };
+    const size_t g = p->vmm_gran;
+    for (auto &v : p->vmm_planes) {
+        for (size_t i = 0; i < v.chunks.size(); ++i) {
+            chk("hipMemUnmap", hipMemUnmap((char *)v.va + i * g, g));
+            chk("hipMemRelease", hipMemRelease(v.chunks[i]));
+        }
+        chk("hipMemAddressFree", hipMemAddressFree(v.va, v.size));
+    }
+    p->vmm_planes.clear();
+    for (auto h : p->vmm_pool) chk("hipMemRelease", hipMemRelease(h));
+    p->vmm_pool.clear();
+    return bad;
 }
 
 static int plan_alloc(wt_plan *p, float **slot)
@@ -466,6 +538,7 @@ static int plan_alloc(wt_plan *p, float **slot)
         if (!p->arena) {
             WT_HIP(hipMalloc(&p->arena, stride * (size_t)arena_planes));
             p->raw_allocs.push_back(p->arena);
+            p->raw_bytes += stride * (size_t)arena_planes;
             p->arena_left = arena_planes;
             p->arena_stride = stride;
         }
@@ -485,22 +558,33 @@ static int plan_alloc(wt_plan *p, float **slot)
     // `scatter` planes and dealt to the planes in a shuffled order (fixed seed); each plane stays one
     // contiguous VIRTUAL range (hipMemAddressReserve / hipMemMap).  Small planes (< 8 MiB) stay on
     // hipMalloc: nothing to gain, and a map call per chunk to lose.
-    static const int scatter = getenv("WT_SCATTER") ? atoi(getenv("WT_SCATTER")) : 4;
-    static bool vmm_ok = true;           // cleared when the virtual-memory API is not usable here
+    const int scatter = g_opt_scatter;   // wt_set_option("scatter", n); WT_SCATTER sets the initial value
     // Strip plans keep plain hipMalloc unless WT_SCATTER_STRIPS=1: RCCL reads and writes the planes
     // of a strip, and its xGMI transport has never run on mapped memory here (the socket transport
     // of the one-GPU rank test has, green) - the one multi-GPU measurement must not hinge on it.
     static const int scatter_strips = getenv("WT_SCATTER_STRIPS") ? atoi(getenv("WT_SCATTER_STRIPS")) : 0;
-    if (!raw && scatter > 0 && vmm_ok && need >= ((size_t)8 << 20) && (p->nranks == 1 || scatter_strips)) {
-        if (vmm_plane_alloc(p, need, scatter, &raw)) {
-            (void)hipGetLastError();     // e.g. hipErrorNotSupported: plain hipMalloc from now on
-            vmm_ok = false;
+    if (!raw && scatter > 0 && !p->ctx->vmm_disabled && need >= ((size_t)8 << 20) && (p->nranks == 1 || scatter_strips)) {
+        std::string why;
+        hipError_t err = hipSuccess;
+        if (vmm_plane_alloc(p, need, scatter, &raw, why, err)) {
+            // Out of memory is transient (this plane takes the hipMalloc path, which reports it if
+            // it persists).  Anything else, e.g. hipErrorNotSupported: plain hipMalloc on THIS
+            // context from now on.  Not silent: wt_plan_memory reports the state and keeps the
+            // reason (WT_VERBOSE prints it) - the headline step is ~20 % slower with the planes
+            // physically back to back.
+            if (err != hipErrorOutOfMemory) {
+                p->ctx->vmm_disabled = true;
+                p->ctx->vmm_reason = why;
+            }
+            if (getenv("WT_VERBOSE")) fprintf(stderr, "watroo_hip: plane not scattered on device %d (%s)%s\n", p->ctx->device, why.c_str(),
+                                              err != hipErrorOutOfMemory ? "; scattering disabled for this context" : "");
             raw = nullptr;
         }
     }
     if (!raw) {
         WT_HIP(hipMalloc(&raw, need));
         p->raw_allocs.push_back(raw);
+        p->raw_bytes += need;
     }
     *slot = (float *)raw + p->skew_floats * (size_t)(p->n_allocs % 16);
     p->n_allocs++;
@@ -594,13 +678,45 @@ extern "C" int wt_plan_destroy(wt_plan *p)
     if (p->ctx->prehist_plan == p) p->ctx->prehist_plan = nullptr;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    for (void *q : p->raw_allocs) (void)hipFree(q);
-    for (auto &v : p->vmm_planes) {
-        (void)hipMemUnmap(v.va, v.size);
-        (void)hipMemAddressFree(v.va, v.size);
+    int bad = 0;
+    std::string why;
+    for (void *q : p->raw_allocs) {
+        hipError_t e = hipFree(q);
+        if (e != hipSuccess && !bad++) why = std::string("hipFree: ") + hipGetErrorString(e);
     }
-    for (auto h : p->vmm_handles) (void)hipMemRelease(h);
+    bad += vmm_release_all(p, why);
     delete p;
+    if (bad) WT_FAIL("wt_plan_destroy: %d release call(s) failed, device memory may still be held (%s)", bad, why.c_str());
+    return 0;
+}
+
+extern "C" int wt_plan_memory(wt_plan *p, int64_t out[4])
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !out) WT_FAIL("wt_plan_memory: null pointer");
+    size_t mapped = 0;
+    for (auto &v : p->vmm_planes) mapped += v.size;
+    const size_t idle = p->vmm_pool.size() * p->vmm_gran;
+    out[0] = (int64_t)(p->raw_bytes + mapped + idle);
+    out[1] = (int64_t)mapped;
+    out[2] = (int64_t)idle;
+    out[3] = p->ctx->vmm_disabled ? 1 : 0;
+    if (p->ctx->vmm_disabled) wt_set_error("scattered planes disabled on this context: %s", p->ctx->vmm_reason.c_str());
+    return 0;
+}
+
+extern "C" int wt_plan_trim(wt_plan *p)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_plan_trim: null plan");
+    int bad = 0;
+    hipError_t first = hipSuccess;
+    for (auto h : p->vmm_pool) {
+        hipError_t e = hipMemRelease(h);
+        if (e != hipSuccess && !bad++) first = e;
+    }
+    p->vmm_pool.clear();
+    if (bad) WT_FAIL("wt_plan_trim: hipMemRelease failed %d time(s) (%s)", bad, hipGetErrorString(first));
     return 0;
 }
 
@@ -638,6 +754,7 @@ static int vmm_stage(wt_plan *p, float **stage)
         void *raw = nullptr;
         WT_HIP(hipMalloc(&raw, p->plane_floats * sizeof(float)));
         p->raw_allocs.push_back(raw);
+        p->raw_bytes += p->plane_floats * sizeof(float);
         p->vmm_stage = (float *)raw;
     }
     *stage = p->vmm_stage + (size_t)p->g.halo * p->g.P;
@@ -982,7 +1099,9 @@ extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
     WT_NCCL(g_rccl.Send(a, nfloats, NCCL_FLOAT32, to, c->comm, c->stream));
     WT_NCCL(g_rccl.Recv(b, nfloats, NCCL_FLOAT32, from, c->comm, c->stream));
     WT_NCCL(g_rccl.GroupEnd());
-    // all-reduce of a tiny vector
+    // all-reduce of a tiny vector (d_hist is also where a fused first pass leaves the first level of
+    // the median select: that marker does not survive this)
+    c->prehist_plan = nullptr;
     WT_HIP(hipMemsetAsync(c->d_hist, 0, 16, c->stream));
     WT_NCCL(g_rccl.AllReduce(c->d_hist, c->d_hist, 4, NCCL_UINT32, NCCL_SUM, c->comm, c->stream));
     WT_HIP(hipMemcpyAsync(r.data(), b, nfloats * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1064,6 +1183,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
     if (!strcmp(name, "tri4")) { g_opt_tri4 = value != 0; return 0; }
+    if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }
 

@@ -101,6 +101,10 @@ struct wt_ctx {
     struct wt_plan *prehist_plan = nullptr;
     int prehist_plane = 0;
     bool prehist_ran = false;     // set by the launch of the histogram variant (per entry point)
+    // scattered planes (plan_alloc): cleared PER CONTEXT when the virtual-memory API fails on this
+    // device (plain hipMalloc from then on); the reason is kept for wt_plan_memory / wt_last_error
+    bool vmm_disabled = false;
+    std::string vmm_reason;
 };
 
 #define WT_MAX_CUSTOM_TAPS 15
@@ -126,11 +130,16 @@ struct wt_plan {
     size_t arena_stride = 0;
     // scattered planes (hipMem* virtual memory management): every plane is a contiguous VIRTUAL range
     // mapped onto physical chunks taken from a shuffled pool (see plan_alloc)
-    struct VmmPlane { void *va; size_t size; };
+    struct VmmPlane {                       // one hipMemMap of vmm_gran bytes per chunk
+        void *va;
+        size_t size;
+        std::vector<hipMemGenericAllocationHandle_t> chunks;
+    };
     std::vector<VmmPlane> vmm_planes;
-    std::vector<hipMemGenericAllocationHandle_t> vmm_pool;   // created, not yet mapped
-    std::vector<hipMemGenericAllocationHandle_t> vmm_handles; // everything to release
+    std::vector<hipMemGenericAllocationHandle_t> vmm_pool;   // created, not yet mapped (idle HBM: wt_plan_trim)
     size_t vmm_gran = 0;
+    uint64_t vmm_seed = 0x9e3779b97f4a7c15ull;   // shuffle stream (advances: every refill deals differently)
+    size_t raw_bytes = 0;                   // bytes behind raw_allocs (hipMalloc'ed planes, stage, arena)
     float *vmm_stage = nullptr;             // hipMalloc'ed bounce plane: hipMemcpy2D does not cross mapped chunks
     // user-defined scaling function (wt_plan_set_taps): odd number of 1-D taps, 0 = built-in family
     int ntaps = 0;
