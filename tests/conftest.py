@@ -36,3 +36,24 @@ def measured(what, got, ref, bound):
         pass
     assert d <= bound, f"{what}: max abs diff {d:.3e} > {bound:.3e}"
     return d
+
+
+# Full-size parity bounds (round 3): 4 x the error MEASURED on MI355X against the C oracle for
+# N(0,1) float32 images (gpurun_out/parity_errors.log of the run that set them; max|input| = 5.98):
+# plane s of the transform, either family, fused passes vs the oracle's dense K x K form:
+#   measured 7.2e-7, 4.8e-7, 2.4e-7, 1.0e-7, 5.2e-8, 3.0e-8, 1.5e-8, 6.5e-9, 3.7e-9
+#   (= 1 ulp of the largest coefficients: the planes shrink by ~2x per scale)
+# reconstruction (sum of planes) 9.5e-7, denoised reconstruction of cfg3 1.43e-6.
+# The bounds scale with max|input| like the rounding errors they budget for.  (Until round 3 these
+# tests asserted 1e-5 * max|input| = 6e-5: 100 x what the engine delivers.)
+_PLANE_BOUND = (2.9e-6, 1.9e-6, 9.6e-7, 4.2e-7, 2.1e-7, 1.2e-7, 6.0e-8, 2.7e-8, 1.5e-8)
+_REF_AMAX = 5.98
+
+
+def plane_bound(s, amax):
+    """bound for plane s of a full-size transform of an image with max|input| = amax"""
+    return _PLANE_BOUND[min(s, len(_PLANE_BOUND) - 1)] * float(amax) / _REF_AMAX
+
+
+def recon_bound(amax, denoised=False):
+    return (5.8e-6 if denoised else 3.9e-6) * float(amax) / _REF_AMAX
