@@ -328,8 +328,18 @@ int wt64_plan_destroy(wt_plan64 *plan);
 int wt64_plan_set_border(wt_plan64 *plan, int border);
 int wt64_upload(wt_plan64 *plan, int plane, const double *host, int64_t host_pitch);
 int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
-/* AtrousTransform.atrous_standard (watroo/wavelets.py:408-444) */
+/* AtrousTransform.atrous_standard (watroo/wavelets.py:408-444).  Images (depth 0) under the
+ * symmetric border with the taps of a built-in family run the FUSED multi-scale passes of the
+ * float32 engine instantiated for double (two pixels per lane; wavelets_amd/csrc/wt_fused.h)
+ * when the size admits them (W even and at least the widest pass's x halo, H at least the
+ * pass's row reach); everything else runs one generic kernel per scale.
+ * wt_set_option("fused64", 0) forces the generic kernels (A/B; results agree to rounding: the
+ * fused passes filter columns first, the generic kernels rows first). */
 int wt64_decompose(wt_plan64 *plan, int src, int level, int depth);
+/* wt_decompose_sum in float64: planes 0..level and np.sum(planes, axis=0) (plane order) -> dst,
+ * the sum carried through the fused passes where they apply (*fused = 1), else transform +
+ * wt64_plane_sum (*fused = 0; fused may be NULL). */
+int wt64_decompose_sum(wt_plan64 *plan, int src, int level, int dst, int *fused);
 /* convolution(arr, scaling_function, s) (watroo/wavelets.py:35-69); square_input: of src*src */
 int wt64_smooth(wt_plan64 *plan, int src, int dst, int s, int square_input, int depth);
 /* sdev_loc (watroo/wavelets.py:24-32) times f1 then f2 */

@@ -184,3 +184,98 @@ def test_bench_default_line_carries_every_config():
     assert rf["kernel"] == "wt_fused_kernel" and 0 < rf["frac"] < 1.2
     if rf["traffic"] is not None:
         assert "traffic.json" in rf["traffic_source"] and 0 < rf["hbm_achieved"] < rf["frac"] * 1.05
+
+
+# --------------------------------------------------------------------------- float64 fused passes
+F64_SHAPES = [
+    # (H, W, family, level)
+    (64, 96, "b3spline", 3),          # one pass d1x3
+    (130, 260, "b3spline", 6),        # d1x3 + d8x3 (W >= 112, H >= 8 * 15)
+    (700, 1100, "b3spline", 6),       # several x strips, ragged last strip
+    (301, 514, "b3spline", 5),        # d1x3 + d8x2, odd height
+    (640, 512, "b3spline", 4),        # d1x3 + d8x1
+    (520, 400, "b3spline", 7),        # + d64x1
+    (600, 640, "b3spline", 8),        # + d64x2
+    (300, 200, "triangle", 5),
+    (1030, 520, "triangle", 8),       # four-scale passes d1x4 + d16x4
+    (90, 128, "triangle", 4),         # single four-scale pass
+    (64, 50, "b3spline", 2),          # d1x2
+]
+
+
+@pytest.mark.parametrize("H,W,fam,level", F64_SHAPES)
+def test_float64_fused_passes_vs_generic_and_oracle(L, H, W, fam, level):
+    """wt64_decompose / wt64_decompose_sum on the fused double passes (wt_fused_kernel<double>)
+    against (a) the generic one-kernel-per-scale float64 engine (option fused64 = 0) and (b) the
+    numpy oracle in float64: 1e-13 * max|input| (double rounding; the fused passes filter columns
+    first, the generic kernels rows first).  The carried sum is bit-identical to wt64_plane_sum
+    over the planes the same passes wrote (plane order, numpy's association)."""
+    from oracle import atrous_numpy as O
+    import wavelets_amd as WA
+    cls = {"b3spline": WA.B3spline, "triangle": WA.Triangle}[fam]
+    a = np.random.default_rng(H * 7 + W).standard_normal((H, W)) * 3 + 1e4
+    amax = float(np.abs(a).max())
+    taps = tuple(float(t) for t in cls.coefficients_1d)
+    plan = L.Plan64(L.default_context(), H, W, taps, level)
+    plan.upload(L.PLANE_INPUT, a)
+    fused = plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT)
+    assert fused, "this shape should take the fused float64 passes"
+    planes = [plan.download(s).copy() for s in range(level + 1)]
+    carried = plan.download(L.PLANE_OUT).copy()
+    plan.plane_sum(0, level + 1, L.PLANE_SCRATCH(5))
+    np.testing.assert_array_equal(carried, plan.download(L.PLANE_SCRATCH(5)))
+    plan.decompose(L.PLANE_INPUT, level)                       # plain fused passes: same bits
+    for s in range(level + 1):
+        np.testing.assert_array_equal(plan.download(s), planes[s])
+    try:
+        L.set_option("fused64", 0)
+        assert not plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT)
+        generic = [plan.download(s).copy() for s in range(level + 1)]
+    finally:
+        L.set_option("fused64", 1)
+    ref = O.atrous_standard(a, level, fam)
+    assert ref.dtype == np.float64
+    for s in range(level + 1):
+        assert float(np.abs(planes[s] - generic[s]).max()) <= 1e-13 * amax, f"plane {s} fused vs generic"
+        assert float(np.abs(planes[s] - ref[s]).max()) <= 1e-13 * amax, f"plane {s} fused vs oracle"
+    assert float(np.abs(carried - a).max()) <= 1e-12 * amax    # perfect reconstruction
+    plan.close()
+
+
+def test_float64_shapes_that_keep_the_generic_kernels(L):
+    """Odd widths, images narrower than a pass's halo, user-defined taps and non-default borders are
+    served by the generic float64 kernels: wt64_decompose_sum says so and the planes match the oracle."""
+    from oracle import atrous_numpy as O
+    import wavelets_amd as WA
+    taps = tuple(float(t) for t in WA.B3spline.coefficients_1d)
+    for H, W, level in ((64, 95, 3), (40, 10, 3), (100, 64, 6)):
+        a = np.random.default_rng(H + W).standard_normal((H, W)) + 50.0
+        plan = L.Plan64(L.default_context(), H, W, taps, level)
+        plan.upload(L.PLANE_INPUT, a)
+        assert not plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT)
+        ref = O.atrous_standard(a, level, "b3spline")
+        for s in range(level + 1):
+            assert float(np.abs(plan.download(s) - ref[s]).max()) <= 1e-13 * float(np.abs(a).max())
+        np.testing.assert_allclose(plan.download(L.PLANE_OUT), a, rtol=0, atol=1e-12 * float(np.abs(a).max()))
+        plan.close()
+    plan = L.Plan64(L.default_context(), 128, 128, (0.2, 0.6, 0.2), 3)      # not a built-in family
+    plan.upload(L.PLANE_INPUT, np.ones((128, 128)))
+    assert not plan.decompose_sum(L.PLANE_INPUT, 3, L.PLANE_OUT)
+    plan.close()
+
+
+def test_float64_with_sum_and_public_api_at_size(L):
+    """AtrousTransform(with_sum=True) / denoise on a float64 image large enough for every fused pass
+    (1024 x 2048, L = 6) vs the float64 oracle at 1e-13 relative."""
+    from oracle import atrous_numpy as O
+    import wavelets_amd as WA
+    b = np.random.default_rng(1).standard_normal((1024, 2048)) * 50 + 3e4
+    bmax = float(np.abs(b).max())
+    c = WA.AtrousTransform(WA.B3spline)(b, 6, with_sum=True)
+    assert isinstance(c._plan, L.Plan64) and c._sum_valid
+    ref = O.atrous_standard(b, 6, "b3spline")
+    assert float(np.abs(c.data - ref).max()) <= 1e-13 * bmax
+    assert float(np.abs(np.sum(c, axis=0) - b).max()) <= 1e-12 * bmax
+    den = WA.denoise(b, [5, 3, 2])
+    assert den.dtype == np.float64
+    assert float(np.abs(den - O.denoise(b.copy(), [5, 3, 2], "b3spline")).max()) <= 1e-12 * bmax

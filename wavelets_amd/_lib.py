@@ -124,6 +124,7 @@ SIGNATURES = {
     "wt64_upload": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double), _i64]),
     "wt64_download": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double), _i64]),
     "wt64_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_decompose_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
     "wt64_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_local_variance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
                                        _c.c_double, _c.c_int, _c.c_int]),
@@ -688,10 +689,16 @@ class Plan64:
         check(load().wt64_plan_set_border(self._h, int(border)))
 
     def fused_ok(self, level):
-        return False
+        return False              # (the float32-only interleavings of the Python layer stay off)
 
     def decompose(self, src, level, flags=0):
         check(load().wt64_decompose(self._h, src, level, 0))
+
+    def decompose_sum(self, src, level, dst=PLANE_OUT, flags=0):
+        """Transform + np.sum(planes, axis=0) -> dst; True when the sum rode in the fused passes."""
+        fused = _c.c_int(0)
+        check(load().wt64_decompose_sum(self._h, src, level, dst, _c.byref(fused)))
+        return bool(fused.value)
 
     def decompose3d(self, src, level, depth):
         check(load().wt64_decompose(self._h, src, level, depth))

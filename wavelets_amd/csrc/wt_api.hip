@@ -1172,6 +1172,8 @@ static int g_opt_overlap_reserve = getenv("WT_OVERLAP_RESERVE") ? atoi(getenv("W
 // exchange (FLAG_NO_EXCHANGE runs on one GPU: what do the edge / interior launches cost?)
 static int g_opt_split_dry = 0;
 
+static void wt_set_fused64(int on);     // wt_f64.h (included at the end of this file)
+
 extern "C" int wt_set_option(const char *name, int value)
 {
     if (!name) WT_FAIL("wt_set_option: null name");
@@ -1183,6 +1185,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
     if (!strcmp(name, "tri4")) { g_opt_tri4 = value != 0; return 0; }
+    if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }

@@ -656,6 +656,103 @@ extern "C" int wt64_smooth(wt_plan64 *p, int src, int dst, int s, int square_inp
     return smooth64(p, in, o, nullptr, s, square_input, depth);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused multi-scale passes in float64 (round 3): wt_fused_kernel instantiated for double - a lane
+// owns two pixels (double2 = the same 16 bytes per access and the same register window as the
+// float4 passes), same polyphase march, LDS row exchange, delay rings and fixed-descriptor stores.
+// Served: images under the symmetric border whose taps are one of the built-in families and whose
+// size admits the fast addressing (W even, W >= the widest pass's x halo, H >= D * (rows of input
+// beyond a stored row + 1)); everything else keeps the generic per-scale kernels above.
+// ---------------------------------------------------------------------------------------------
+static int g_opt_fused64 = getenv("WT_NO_FUSED64") ? 0 : 1;      // wt_set_option("fused64", 0/1)
+static void wt_set_fused64(int on) { g_opt_fused64 = on; }
+
+static int fused64_family(const wt_plan64 *p)
+{
+    static const double b3[5] = {1. / 16, 1. / 4, 3. / 8, 1. / 4, 1. / 16}, tri[3] = {1. / 4, 1. / 2, 1. / 4};
+    if (p->ntaps == 5 && !memcmp(p->taps, b3, sizeof b3)) return WT_B3SPLINE;
+    if (p->ntaps == 3 && !memcmp(p->taps, tri, sizeof tri)) return WT_TRIANGLE;
+    return -1;
+}
+
+// every pass of the fused schedule for `level` scales exists and takes the fast addressing
+static bool fused64_ok(const wt_plan64 *p, int level, int depth, int32_t *tr, int *np)
+{
+    const int fam = fused64_family(p);
+    if (!g_opt_fused64 || fam < 0 || depth != 0 || p->g.border != 0 || level < 1 || (p->g.W & 1)) return false;
+    if (!wt_fused_supported_bytes((int64_t)p->g.P * 8)) return false;
+    if (wt_schedule(fam, level, 1, tr, 32, np)) return false;
+    const int hw = p->ntaps / 2;
+    for (int i = 0; i < *np; ++i) {
+        const int s0 = tr[3 * i], ns = tr[3 * i + 1], D = 1 << s0;
+        if (!wt_fused_has_pass(s0, ns, fam)) return false;
+        const int lat = hw * ((1 << ns) - 1);
+        const int HX = (lat * D + 15) / 16 * 16;
+        if (p->g.W < HX || p->g.H < D * (lat + 1)) return false;
+    }
+    return true;
+}
+
+template <int K, int ACC>
+static int fused64_dispatch(wt_plan64 *p, const FusedArgsT<double> &a, int s0, int ns)
+{
+    typedef double T;
+    static const char *pre[3] = {"wt64_fused", "wt64_fused_acc", "wt64_fused_sum"};
+    static char names[3][16][32];
+    auto nm = [&](int slot, const char *tag) -> const char * {
+        if (!names[ACC][slot][0]) snprintf(names[ACC][slot], sizeof names[ACC][slot], "%s<%s>", pre[ACC], tag);
+        return names[ACC][slot];
+    };
+    const FusedRows rows;
+    // Workgroup shapes as the float passes: 4 waves at D = 1 (512 pixels per row step), 8 waves for
+    // the dilated passes (1024 pixels, x halo 112 / 48 / 192 px per side).
+    if constexpr (K == 3) {
+        if (s0 == 0 && ns == 4) return wt_fused_launch_t<T, K, 4, 1, 4, 4, ACC>(p, a, nm(7, "d1x4"), rows);
+        if (s0 == 4 && ns == 4) return wt_fused_launch_t<T, K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, nm(8, "d16x4"), rows);
+    }
+    if (s0 == 0 && ns == 3) return wt_fused_launch_t<T, K, 3, 1, 4, 4, ACC>(p, a, nm(0, "d1x3"), rows);
+    if (s0 == 0 && ns == 2) return wt_fused_launch_t<T, K, 2, 1, 4, 4, ACC>(p, a, nm(1, "d1x2"), rows);
+    if (s0 == 3 && ns == 3) return wt_fused_launch_t<T, K, 3, 8, 8, 4, ACC>(p, a, nm(2, "d8x3"), rows);
+    if (s0 == 3 && ns == 2) return wt_fused_launch_t<T, K, 2, 8, 8, 4, ACC>(p, a, nm(3, "d8x2"), rows);
+    if (s0 == 6 && ns == 2) return wt_fused_launch_t<T, K, 2, 64, 8, 4, ACC>(p, a, nm(4, "d64x2"), rows);
+    if (s0 == 3 && ns == 1) return wt_fused_launch_t<T, K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(5, "d8x1"), rows);
+    if (s0 == 6 && ns == 1) return wt_fused_launch_t<T, K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(6, "d64x1"), rows);
+    WT_FAIL("float64 fused pass (first scale %d, %d scales) is not built", s0, ns);
+}
+
+// the fused schedule: planes 0..level, optionally the plane sum carried through the passes into dst
+static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int np, bool with_sum, int dst)
+{
+    const bool b3 = fused64_family(p) == WT_B3SPLINE;
+    int cur = src;
+    for (int i = 0; i < np; ++i) {
+        const int s0 = tr[3 * i], ns = tr[3 * i + 1];
+        const bool last = s0 + ns == level;
+        const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+        FusedArgsT<double> a{};
+        double *in = nullptr;
+        WT_TRY(plan64_base(p, cur, &in));
+        a.in = in;
+        WT_TRY(plan64_base(p, nxt, &a.out_c));
+        for (int k = 0; k < ns && k < 3; ++k) WT_TRY(plan64_base(p, s0 + k, &a.out_w[k]));
+        if (ns > 3) WT_TRY(plan64_base(p, s0 + 3, &a.out_w3));
+        a.g = p->g;
+        int acc = 0;
+        if (with_sum) {
+            acc = last ? 2 : 1;
+            WT_TRY(plan64_base(p, dst, &a.p_out));
+            a.p_in = i == 0 ? nullptr : a.p_out;
+        }
+        int rc;
+        if (acc == 2) rc = b3 ? fused64_dispatch<5, 2>(p, a, s0, ns) : fused64_dispatch<3, 2>(p, a, s0, ns);
+        else if (acc == 1) rc = b3 ? fused64_dispatch<5, 1>(p, a, s0, ns) : fused64_dispatch<3, 1>(p, a, s0, ns);
+        else rc = b3 ? fused64_dispatch<5, 0>(p, a, s0, ns) : fused64_dispatch<3, 0>(p, a, s0, ns);
+        WT_TRY(rc);
+        cur = nxt;
+    }
+    return 0;
+}
+
 /* AtrousTransform.atrous_standard in float64 (watroo/wavelets.py:408-444): planes 0..level-1 detail,
  * plane level smooth, from plane src (left intact).  depth as above. */
 extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
@@ -673,6 +770,11 @@ extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
         WT_HIP(hipMemcpyAsync(o, in, (size_t)p->g.nrows * p->g.P * 8, hipMemcpyDeviceToDevice, p->ctx->stream));
         return 0;
     }
+    {
+        int32_t tr[3 * 32];
+        int np = 0;
+        if (fused64_ok(p, level, depth, tr, &np)) return fused64_run(p, src, level, tr, np, false, WT_PLANE_NONE);
+    }
     int cur = src;
     for (int s = 0; s < level; ++s) {
         const int nxt = (s == level - 1) ? level : WT_PLANE_SCRATCH(s & 1);
@@ -684,6 +786,29 @@ extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
         cur = nxt;
     }
     return 0;
+}
+
+extern "C" int wt64_plane_sum(wt_plan64 *p, int first, int count, int dst);
+
+/* wt_decompose_sum in float64: the transform and np.sum(planes, axis=0) -> dst; the sum rides in the
+ * fused passes where the schedule is fused (plane order, the association of numpy's sum over axis
+ * 0), else the two-step form.  *fused_out (may be null) tells which. */
+extern "C" int wt64_decompose_sum(wt_plan64 *p, int src, int level, int dst, int *fused_out)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_decompose_sum: null plan");
+    if (level < 0 || level > p->max_level) WT_FAIL("wt64_decompose_sum: level %d exceeds plan max_level %d", level, p->max_level);
+    if ((src >= 0 && src <= level) || (dst >= 0 && dst <= level) || dst == src)
+        WT_FAIL("wt64_decompose_sum: src / dst plane is one of the output planes (or the same plane)");
+    if (src == WT_PLANE_SCRATCH(0) || src == WT_PLANE_SCRATCH(1) || dst == WT_PLANE_SCRATCH(0) || dst == WT_PLANE_SCRATCH(1))
+        WT_FAIL("wt64_decompose_sum: scratch planes 0/1 are used internally");
+    int32_t tr[3 * 32];
+    int np = 0;
+    const bool fused = fused64_ok(p, level, 0, tr, &np);
+    if (fused_out) *fused_out = fused ? 1 : 0;
+    if (fused) return fused64_run(p, src, level, tr, np, true, dst);
+    WT_TRY(wt64_decompose(p, src, level, 0));
+    return wt64_plane_sum(p, 0, level + 1, dst);
 }
 
 /* sdev_loc(image, sf, s, variance) (watroo/wavelets.py:24-32), times f1 then f2 */

@@ -45,10 +45,41 @@
 #define WT_FUSED_MAX_SCALES 4      // four only for the 3-tap family (register window 2 * 15 float4)
 #define WT_FUSED_MAX_FIRST_SCALE 3
 
-struct FusedArgs {
-    const float *in;                       // c_{s0}, local row 0
-    float *out_c;                          // c_{s0+NS}
-    float *out_w[3];                       // w_{s0+a}, a < 3 (the fourth plane of a four-scale pass: out_w3, last field)
+// Element type of a pass (round 3): float - a lane owns 4 adjacent pixels - or double - 2 pixels.
+// Either way a lane moves 16 bytes per access and the register window costs the same VGPRs, so the
+// float64 passes are the float32 design at twice the bytes per pixel (the reference computes
+// float64 / integer inputs in float64, watroo/wavelets.py:297,319-320).
+template <typename T> struct WtVec;
+template <> struct WtVec<float> {
+    typedef float4 V;
+    static constexpr int PX = 4;
+};
+template <> struct WtVec<double> {
+    typedef double2 V;
+    static constexpr int PX = 2;
+};
+__device__ __forceinline__ double2 f4_scale(double k, double2 a) { return make_double2(k * a.x, k * a.y); }
+__device__ __forceinline__ double2 f4_fma(double k, double2 a, double2 c) { return make_double2(fma(k, a.x, c.x), fma(k, a.y, c.y)); }
+__device__ __forceinline__ double2 f4_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 f4_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// the taps are dyadic rationals: exact in either precision
+template <int K, typename T>
+__device__ __forceinline__ constexpr T wt_tap_s(int i) { return (T)wt_tap<K>(i); }
+template <typename V> __device__ __forceinline__ V wt_vzero();
+template <> __device__ __forceinline__ float4 wt_vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ double2 wt_vzero<double2>() { return make_double2(0.0, 0.0); }
+// the group read backwards (reflection of an aligned group that lies outside the image)
+__device__ __forceinline__ float4 wt_vrev(float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
+__device__ __forceinline__ double2 wt_vrev(double2 v) { return make_double2(v.y, v.x); }
+// scheduling fence on the components of a row (see the FAST path of the kernel)
+__device__ __forceinline__ void wt_vfence(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void wt_vfence(double2 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+
+template <typename T>
+struct FusedArgsT {
+    const T *in;                           // c_{s0}, local row 0
+    T *out_c;                              // c_{s0+NS}
+    T *out_w[3];                           // w_{s0+a}, a < 3 (the fourth plane of a four-scale pass: out_w3, last field)
     Geo g;
     int Vx;       // valid (stored) pixels per x-strip, multiple of 32
     int S;        // chain steps stored per chunk
@@ -56,8 +87,8 @@ struct FusedArgs {
     // accumulate variants (ACC != 0): the plane sum np.sum(planes, axis=0) carried through the
     // passes in plane order - p_in = w_0 + ... + w_{s0-1} (nullptr for the first pass),
     // p_out = p_in + w_{s0} + ... + w_{s0+NS-1} (+ c_{s0+NS} in the last pass); may alias p_in
-    const float *p_in;
-    float *p_out;
+    const T *p_in;
+    T *p_out;
     // rows stored by this launch: up to two ranges [rlo, rhi) of strip-local rows (blockIdx.z);
     // a whole pass is the single range [0, nrows).  Splitting a pass into its edge rows and its
     // interior lets the halo exchange of the NEXT pass overlap with the interior (multi-GPU).
@@ -68,30 +99,48 @@ struct FusedArgs {
     int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
-    float *out_w3;  // w_{s0+3} of a four-scale pass (3-tap family); LAST on purpose: the older fields keep their offsets
+    T *out_w3;      // w_{s0+3} of a four-scale pass (3-tap family); LAST on purpose: the older fields keep their offsets
 };
+typedef FusedArgsT<float> FusedArgs;
 
-template <int K, int SHIFT_PX, int NLANES>
-__device__ __forceinline__ float4 wt_hfilter_lds(const float4 *vrow, int gl, float4 own)
+template <typename T, int K, int SHIFT_PX, int NLANES>
+__device__ __forceinline__ typename WtVec<T>::V wt_hfilter_lds(const typename WtVec<T>::V *vrow, int gl, typename WtVec<T>::V own)
 {
     // horizontal K-tap filter with taps SHIFT_PX pixels apart; vrow = the WG's LDS row of
-    // vertically filtered values (float4 per lane), gl = this lane's index in the row.
+    // vertically filtered values (one 16-byte group per lane), gl = this lane's index in the row.
+    typedef typename WtVec<T>::V V;
+    constexpr int PX = WtVec<T>::PX;
     constexpr int hw = K / 2;
-    if constexpr (SHIFT_PX % 4 == 0) {
-        constexpr int LO = SHIFT_PX / 4;
-        float4 acc;
+    if constexpr (SHIFT_PX % PX == 0) {
+        constexpr int LO = SHIFT_PX / PX;
+        V acc;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            float4 v;
+            V v;
             if (j == hw) v = own;
             else {
                 int idx = gl + (j - hw) * LO;
                 idx = idx < 0 ? 0 : (idx > NLANES - 1 ? NLANES - 1 : idx);
                 v = vrow[idx];
             }
-            acc = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, acc);
+            acc = (j == 0) ? f4_scale(wt_tap_s<K, T>(0), v) : f4_fma(wt_tap_s<K, T>(j), v, acc);
         }
         return acc;
+    } else if constexpr (PX == 2) {
+        // double: the only sub-group shift is 1 pixel (D = 1, first scale): both neighbours' pairs
+        static_assert(SHIFT_PX == 1, "float64: sub-group shift is 1 px");
+        const V L = vrow[gl > 0 ? gl - 1 : 0];
+        const V R = vrow[gl < NLANES - 1 ? gl + 1 : NLANES - 1];
+        const T e[6] = {L.x, L.y, own.x, own.y, R.x, R.y};
+        T o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            T acc = wt_tap_s<K, T>(0) * e[2 + k - hw];
+#pragma unroll
+            for (int j = 1; j < K; ++j) acc = fma(wt_tap_s<K, T>(j), e[2 + k + (j - hw)], acc);
+            o[k] = acc;
+        }
+        return make_double2(o[0], o[1]);
     } else {
         static_assert(SHIFT_PX == 1 || SHIFT_PX == 2, "sub-float4 shifts are 1 or 2 px");
         const float4 L = vrow[gl > 0 ? gl - 1 : 0];
@@ -174,9 +223,9 @@ __device__ __forceinline__ float4 wt_hfilter_dpp(float4 own)
 }
 
 // vertical window of scale A: 2^A interleaved sub-chains, K-1 stored rows each
-template <int K, int A>
+template <typename V, int K, int A>
 struct VWin {
-    float4 w[1 << A][K - 1];
+    V w[1 << A][K - 1];
 };
 
 typedef unsigned int wt_v4u __attribute__((ext_vector_type(4)));
@@ -199,6 +248,23 @@ __device__ __forceinline__ void wt_bstore4v(__amdgpu_buffer_rsrc_t r, unsigned v
 {
     wt_v4f t = {v.x, v.y, v.z, v.w};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
+}
+typedef double wt_v2d __attribute__((ext_vector_type(2)));
+template <int AUX>
+__device__ __forceinline__ void wt_bstore4v(__amdgpu_buffer_rsrc_t r, unsigned voff, double2 v)
+{
+    wt_v2d t = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_v4u, t), r, voff, 0, AUX);
+}
+__device__ __forceinline__ float4 wt_from_v4u(wt_v4u t, float4)
+{
+    const wt_v4f f = __builtin_bit_cast(wt_v4f, t);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ double2 wt_from_v4u(wt_v4u t, double2)
+{
+    const wt_v2d f = __builtin_bit_cast(wt_v2d, t);
+    return make_double2(f.x, f.y);
 }
 
 // Ablation switches (FusedArgs::debug, env WT_FUSED_DEBUG) are compiled in only with
@@ -228,19 +294,20 @@ __device__ __forceinline__ void wt_bstore4v(__amdgpu_buffer_rsrc_t r, unsigned v
 // Vertical half of one scale of one step: push `cur` (a row of c_{s0+A}) into the window and
 // return the vertically filtered row (centred hw*2^A steps back); `cen` = matching row of
 // c_{s0+A} (for the detail plane).
-template <int K, int A>
-__device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk, const float4 cur,
-                                                  float4 &cen)
+template <typename T, int K, int A>
+__device__ __forceinline__ typename WtVec<T>::V wt_fused_vstage(VWin<typename WtVec<T>::V, K, A> &win, const int kk,
+                                                                const typename WtVec<T>::V cur, typename WtVec<T>::V &cen)
 {
+    typedef typename WtVec<T>::V V;
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
     const int rho = kk % (1 << A);
     const int p = (kk >> A) % KM;
-    float4 *w = win.w[rho];
-    float4 v = f4_scale(wt_tap<K>(0), w[p]);
+    V *w = win.w[rho];
+    V v = f4_scale(wt_tap_s<K, T>(0), w[p]);
 #pragma unroll
-    for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap<K>(j), w[(p + j) % KM], v);
-    v = f4_fma(wt_tap<K>(KM), cur, v);
+    for (int j = 1; j < KM; ++j) v = f4_fma(wt_tap_s<K, T>(j), w[(p + j) % KM], v);
+    v = f4_fma(wt_tap_s<K, T>(KM), cur, v);
     cen = w[(p + hw) % KM];
     w[p] = cur;
     return v;
@@ -250,7 +317,7 @@ __device__ __forceinline__ float4 wt_fused_vstage(VWin<K, A> &win, const int kk,
 // a-1 produced in step j-1, so the NS vertical filters, the NS LDS row writes, ONE barrier and
 // the NS horizontal filters of a step are mutually independent (one s_barrier per row instead
 // of NS, 4*NS LDS reads in flight together).  LDS rows are double-buffered by step parity.
-template <int K, int NS, int D, int NW, int PDREQ, int ACC, bool FAST>
+template <typename T, int K, int NS, int D, int NW, int PDREQ, int ACC, bool FAST>
 #ifndef WT_FUSED_WPS4_K3
 #define WT_FUSED_WPS4_K3 3   // 3-tap family: 148 VGPRs, three 4-wave workgroups per CU (0.345 -> 0.32 ms)
 #endif
@@ -261,14 +328,18 @@ template <int K, int NS, int D, int NW, int PDREQ, int ACC, bool FAST>
 // 1 for the four-scale accumulate variants (98 KB of LDS), else 2
 #define WT_FUSED_WG4_PER_CU(K, NS, ACC) \
     ((K) == 3 && (NS) < 4 && ((ACC) == 0 || (ACC) == 3) ? WT_FUSED_WPS4_K3 : ((NS) == 4 && ((ACC) == 1 || (ACC) == 2) ? 1 : WT_FUSED_WPS4))
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC) : 2)) void wt_fused_kernel(FusedArgs a)
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC) : 2)) void wt_fused_kernel(FusedArgsT<T> a)
 {
+    typedef typename WtVec<T>::V V;                      // a lane's 16 bytes: float4 or double2
+    constexpr int PX = WtVec<T>::PX;                     // pixels per lane
+    constexpr int ALIGN_PX = 128 / (int)sizeof(T);       // pixels per 128-byte line
     // ACC: 0 = plain pass; 1 / 2 = the pass carries the plane sum (2: last pass, adds the smooth
     // plane); 3 = plain pass that also histograms |w_{s0}| (first level of wt_abs_median's select:
     // Coefficients.get_noise reads plane 0 once less)
     constexpr bool SUM = ACC == 1 || ACC == 2;
     constexpr bool HIST = ACC == 3;
     static_assert(!HIST || D == 1, "the histogram variant exists for the first pass only");
+    static_assert(!HIST || PX == 4, "the histogram variant is float32 (the float64 select has 63-bit keys)");
     static_assert(NS <= 3 || K == 3, "four scales per pass: 3-tap family only");
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
@@ -276,13 +347,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     constexpr int LAT = LAT_IN + (NS - 1);               // + pipeline skew between the scales
     // x halo rounded up to 32 pixels (128 B): with strip starts that are multiples of 32 pixels
     // every wave's 1-KiB row access is cache-line aligned (8 lines, not 9 with two half lines)
-    constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
+    constexpr int HX = (hw * ((1 << NS) - 1) * D + ALIGN_PX - 1) / ALIGN_PX * ALIGN_PX;
     constexpr int U = KM << (NS - 1);                    // register-rotation period
     constexpr int PD = (U % PDREQ == 0) ? PDREQ : 4;     // rows prefetched ahead
-    constexpr int NL = NW * 64;                          // lanes (float4 columns) per WG
+    constexpr int NL = NW * 64;                          // lanes (16-byte columns) per WG
     static_assert(U % PD == 0 && U % 2 == 0, "prefetch depth / LDS parity must divide the unroll period");
 
-    __shared__ float4 vbuf[2][NS][NL];
+    __shared__ V vbuf[2][NS][NL];
     // output row of scale a at step t: t - a - hw*(2^(a+1)-1)
     constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw, LAG3 = 3 + 15 * hw;
     constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : (NS == 3 ? LAG2 : LAG3));
@@ -290,8 +361,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // row of the SAME image row comes out of the cascade (G1, then G2 steps later); only lanes
     // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
     constexpr int G1 = NS > 1 ? LAG1 - LAG0 : 0, G2 = NS > 2 ? LAG2 - LAG1 : 0, G3 = NS > 3 ? LAG3 - LAG2 : 0;
-    constexpr int NV = NL - HX / 2;
-    __shared__ float4 ring[SUM && NS > 1 ? (G1 + G2 + G3) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
+    constexpr int NV = NL - 2 * HX / PX;
+    __shared__ V ring[SUM && NS > 1 ? (G1 + G2 + G3) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
 
     __shared__ uint32_t lh[HIST ? WT_HIST_BINS : 1];
     if constexpr (HIST) {                                // (before the early exits: all waves pass the barrier)
@@ -302,10 +373,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
     const int X0 = blockIdx.x * a.Vx;                    // first valid pixel of this x-strip
-    constexpr bool WA = WT_FUSED_WA && D == 1 && NS <= 3;   // wave-autonomous horizontal taps (experiment)
+    constexpr bool WA = WT_FUSED_WA && D == 1 && NS <= 3 && PX == 4;   // wave-autonomous horizontal taps (experiment)
     const int wa_ln = gl & 63, wa_vw = a.Vx / NW;        // lane in the wave; stored pixels per wave
     const int x = WA ? X0 + (gl >> 6) * wa_vw - 16 + 4 * wa_ln
-                     : X0 - HX + 4 * gl;                 // this lane's first pixel (may be < 0)
+                     : X0 - HX + PX * gl;                // this lane's first pixel (may be < 0)
     const int item = blockIdx.y;
     const int q = item % D;                              // chain phase
     const int chunk = item / D;
@@ -322,8 +393,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // padding (allocated, never read as image data)
     const bool lane_store = WA ? (wa_ln >= 4 && 4 * (wa_ln - 4) < wa_vw && x < g.W)
                                : (x >= X0) && (x < X0 + a.Vx) && (x < g.W);
-    const unsigned voff = lane_store ? (unsigned)x * 4u : WT_FUSED_PARKED;
-    const int row_bytes = g.P * 4;
+    const unsigned voff = lane_store ? (unsigned)x * (unsigned)sizeof(T) : WT_FUSED_PARKED;
+    const int row_bytes = g.P * (int)sizeof(T);
     // Every lane issues ONE aligned in-bounds dwordx4 per row.
     // FAST (host: W % 4 == 0, W >= HX, H >= D * (LAT_IN + 1) - every image the benchmarks name):
     //   the reflection of an aligned 4-pixel group that lies outside the image is an aligned group
@@ -334,33 +405,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // generic: lanes whose 4 pixels are not all inside the image (reflected halo at the image
     //   border, ragged right edge) patch the value with a reflected gather under a wave-uniform
     //   branch (border waves only); rows reflect any number of times.
-    const bool lane_interior = (x >= 0) && (x + 3 < g.W);
+    const bool lane_interior = (x >= 0) && (x + PX - 1 < g.W);
     const bool wave_has_edge = !__all(lane_interior);
     const bool lane_rev = FAST && !lane_interior;
-    const int xg = x < 0 ? -4 - x : (x >= g.W ? 2 * g.W - 4 - x : x);   // FAST: the group this lane loads
-    const int xc = FAST ? min(max(xg, 0), g.W - 4) : min(max(x, 0), g.P - 4);
-    const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + 2, g.W),
-              xi3 = wt_refl(x + 3, g.W);
+    const int xg = x < 0 ? -PX - x : (x >= g.W ? 2 * g.W - PX - x : x);   // FAST: the group this lane loads
+    const int xc = FAST ? min(max(xg, 0), g.W - PX) : min(max(x, 0), g.P - PX);
+    const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + (PX > 2 ? 2 : 0), g.W),
+              xi3 = wt_refl(x + (PX > 2 ? 3 : 0), g.W);
     const int gy0 = g.row0 + q;                          // global row of chain element 0
 
     const int dbg = WT_FUSED_DBG(a);
     const int t_last = r1 - 1 + LAT_IN;                  // last input row any stored output needs
-    const unsigned xoff = (unsigned)xc * 4u;             // byte offset of this lane's aligned load
+    const unsigned xoff = (unsigned)xc * (unsigned)sizeof(T);   // byte offset of this lane's aligned load
     const int H2m1 = 2 * g.H - 1;
-    auto load_row = [&](int t) -> float4 {
+    auto load_row = [&](int t) -> V {
         // steps past t_last only flush the pipeline / unroll padding: keep the address in range.
         // Uniform row pointer + 32-bit lane offset: one global_load_dwordx4 with an SGPR base.
         if constexpr (FAST) {
             const int gy = gy0 + D * ((dbg & 2) ? r0 : min(t, t_last));
             const int up = max(gy, ~gy);                 // -1 - gy above the image
             const int ry = min(up, H2m1 - up);           // 2H - 1 - gy below it
-            const float *row = a.in + (int64_t)(ry - g.row0) * g.P;
-            return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(row) + xoff);
+            const T *row = a.in + (int64_t)(ry - g.row0) * g.P;
+            return *reinterpret_cast<const V *>(reinterpret_cast<const char *>(row) + xoff);
         } else {
-            const float *row = wt_row(a.in, g, gy0 + D * ((dbg & 2) ? r0 : min(t, t_last)));
-            float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(row) + xoff);
+            const T *row = a.in + (int64_t)(wt_refl(gy0 + D * ((dbg & 2) ? r0 : min(t, t_last)), g.H) - g.row0) * g.P;   // (= wt_row)
+            V v = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(row) + xoff);
             if (wave_has_edge) {
-                if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
+                if constexpr (PX == 4) {
+                    if (!lane_interior) v = make_float4(row[xi0], row[xi1], row[xi2], row[xi3]);
+                } else {
+                    if (!lane_interior) v = make_double2(row[xi0], row[xi1]);
+                }
             }
             return v;
         }
@@ -372,16 +447,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // offset instead of branching, so control flow stays uniform.
     const unsigned span = (unsigned)(r1 - r0);
     const unsigned step_bytes = (unsigned)D * (unsigned)row_bytes;
-    auto row_addr0 = [&](float *base, int ro) -> uint64_t {
+    auto row_addr0 = [&](T *base, int ro) -> uint64_t {
         return (uint64_t)base + (uint64_t)((int64_t)(q + (int64_t)D * ro) * (int64_t)row_bytes);
     };
 
     constexpr int A1 = NS > 1 ? 1 : 0, A2 = NS > 2 ? 2 : 0, A3 = NS > 3 ? 3 : 0;
-    VWin<K, 0> w0;
-    VWin<K, A1> w1;
-    VWin<K, A2> w2;
-    VWin<K, A3> w3;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    VWin<V, K, 0> w0;
+    VWin<V, K, A1> w1;
+    VWin<V, K, A2> w2;
+    VWin<V, K, A3> w3;
+    const V zero = wt_vzero<V>();
 #pragma unroll
     for (int j = 0; j < KM; ++j) {
         w0.w[0][j] = zero;
@@ -397,10 +472,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
 
     const int t0 = r0 - LAT_IN;                          // first input chain index
     const int nsteps = ((r1 - r0) + LAT + LAT_IN + U - 1) / U * U;
-    float4 pf[PD];
+    V pf[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) pf[i] = load_row(t0 + i);
-    float4 c1 = zero, c2 = zero, c3 = zero;              // rows handed from scale a to a+1
+    V c1 = zero, c2 = zero, c3 = zero;                   // rows handed from scale a to a+1
     // Stores: every plane has ONE descriptor for the whole march - base = row r0 of the chain (the
     // chunk's first stored row), length = the chunk's byte span.  At step k a plane stores row
     // k - (LAT_IN + LAG) of the chunk, i.e. the lane offset is x*4 + (k - LAT_IN - LAG) * step_bytes:
@@ -408,7 +483,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // range check IS the row predicate, no scalar work per store.  Halo lanes park at 2^31 (the host
     // keeps a chunk's span incl. warm-up below 2^31, so a parked lane never wraps into range).
     const unsigned chunk_len = (span - 1u) * step_bytes + (unsigned)row_bytes;
-    auto plane_rsrc = [&](float *base, int) -> __amdgpu_buffer_rsrc_t {
+    auto plane_rsrc = [&](T *base, int) -> __amdgpu_buffer_rsrc_t {
         // Length and flag words pass through an empty asm so that every descriptor owns its four
         // SGPRs: shared words would be copied into place before every store (2 s_mov each).
         unsigned len = chunk_len, flags = 0x00020000;
@@ -432,14 +507,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // incoming partial sum: the same fixed-descriptor addressing as the stores (row r0 of the chain,
     // the chunk's byte span) - a row before or after the chunk reads as 0 without touching memory
     // (its sum is never stored), so there is no clamp and no scalar address arithmetic per step
-    const __amdgpu_buffer_rsrc_t rpin = plane_rsrc(PIN ? const_cast<float *>(a.p_in) : a.out_c, 0);
+    const __amdgpu_buffer_rsrc_t rpin = plane_rsrc(PIN ? const_cast<T *>(a.p_in) : a.out_c, 0);
     // (halo lanes are parked like their stores: they read nothing)
-    auto load_acc = [&](int k_ahead) -> float4 {         // p_in row of chain element t0 + k - LAG0, k = current step + k_ahead
+    auto load_acc = [&](int k_ahead) -> V {              // p_in row of chain element t0 + k - LAG0, k = current step + k_ahead
         const wt_v4u t = __builtin_amdgcn_raw_buffer_load_b128(rpin, voff + koff + o0 + (unsigned)k_ahead * step_bytes, 0, 0);
-        const wt_v4f f = __builtin_bit_cast(wt_v4f, t);
-        return make_float4(f.x, f.y, f.z, f.w);
+        return wt_from_v4u(t, V());
     };
-    float4 pa[PIN ? PD : 1];
+    V pa[PIN ? PD : 1];
     if constexpr (PIN) {
 #pragma unroll
         for (int i = 0; i < PD; ++i) pa[i] = load_acc(i);   // koff = 0 here
@@ -452,7 +526,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
     // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
     // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
-    const int li = lane_store ? (x - X0) >> 2 : NV;      // slot in the ring rows; NV = the spare slot
+    const int li = lane_store ? (x - X0) / PX : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0, i3 = 0;                          // ring positions (wave-uniform)
 
     // One chain step.
@@ -466,18 +540,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             if constexpr (NS > 3) return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : o3);
             else return vk + (lag == LAG0 ? o0 : lag == LAG1 ? o1 : lag == LAG2 ? o2 : oc);
         };
-        float4 cur = pf[kk % PD];
+        V cur = pf[kk % PD];
         pf[kk % PD] = load_row(t + PD);
         if constexpr (FAST) {
             // The fence pins the reversal to THIS step: without it the (w, z) swap is scheduled
             // right behind the load it reads (same basic block), and the wave waits for every row
             // in the step that issued it - no prefetch left.
-            asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w));
+            wt_vfence(cur);
             if (wave_has_edge) {
-                if (lane_rev) cur = make_float4(cur.w, cur.z, cur.y, cur.x);
+                if (lane_rev) cur = wt_vrev(cur);
             }
         }
-        float4 (*buf)[NL] = vbuf[kk & 1];
+        V (*buf)[NL] = vbuf[kk & 1];
 #ifdef WT_FUSED_ABLATION
         if (dbg & 4) {   // ablation: same loads / stores / addresses, no filtering at all
             wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), cur);
@@ -486,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             if constexpr (NS > 3) wt_bstore4v<WT_FUSED_W_AUX>(rw3, at(LAG3), cur);
             wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), cur);
             if constexpr (SUM) {
-                float4 pv = cur;
+                V pv = cur;
                 if constexpr (PIN) {
                     pv = pa[kk % PD];
                     pa[kk % PD] = load_acc(PD);
@@ -497,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             return;
         }
 #endif
-        float4 pin_cur = zero;
+        V pin_cur = zero;
         if constexpr (PIN) {
             pin_cur = pa[kk % PD];
             pa[kk % PD] = load_acc(PD);
@@ -506,34 +580,34 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
         // them before the barrier so the LDS latency hides behind the vertical filters.  Lanes
         // without stored pixels share the spare slot NV of each ring row (their sums are never
         // stored), which keeps the ring traffic free of exec-mask branches.
-        float4 old1 = zero, old2 = zero, old3 = zero;
+        V old1 = zero, old2 = zero, old3 = zero;
         if constexpr (SUM && NS > 1) {
             old1 = ring[i1 * (NV + 1) + li];
             if constexpr (NS > 2) old2 = ring[(G1 + i2) * (NV + 1) + li];
             if constexpr (NS > 3) old3 = ring[(G1 + G2 + i3) * (NV + 1) + li];
         }
-        float4 cen0, cen1, cen2, cen3, v0, v1, v2, v3;
-        v0 = wt_fused_vstage<K, 0>(w0, kk, cur, cen0);
+        V cen0, cen1, cen2, cen3, v0, v1, v2, v3;
+        v0 = wt_fused_vstage<T, K, 0>(w0, kk, cur, cen0);
         if constexpr (!WA) buf[0][gl] = v0;
         if constexpr (NS > 1) {
-            v1 = wt_fused_vstage<K, A1>(w1, kk, c1, cen1);
+            v1 = wt_fused_vstage<T, K, A1>(w1, kk, c1, cen1);
             if constexpr (!WA) buf[A1][gl] = v1;
         }
         if constexpr (NS > 2) {
-            v2 = wt_fused_vstage<K, A2>(w2, kk, c2, cen2);
+            v2 = wt_fused_vstage<T, K, A2>(w2, kk, c2, cen2);
             if constexpr (!WA) buf[A2][gl] = v2;
         }
         if constexpr (NS > 3) {
-            v3 = wt_fused_vstage<K, A3>(w3, kk, c3, cen3);
+            v3 = wt_fused_vstage<T, K, A3>(w3, kk, c3, cen3);
             buf[A3][gl] = v3;
         }
         if constexpr (!WA) __syncthreads();
-        float4 n0;
+        V n0;
         if constexpr (WA) n0 = wt_hfilter_dpp<K, (D <= 4 ? D : 4)>(v0);
-        else n0 = wt_hfilter_lds<K, D, NL>(buf[0], gl, v0);
-        const float4 d0 = f4_sub(cen0, n0);
+        else n0 = wt_hfilter_lds<T, K, D, NL>(buf[0], gl, v0);
+        const V d0 = f4_sub(cen0, n0);
         if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
-        if constexpr (HIST) {
+        if constexpr (HIST && PX == 4) {
             // the same predicate as the store of this row: chunk row k - (LAT_IN + LAG0) in [0, span)
             // (wave-uniform) and a lane that owns stored pixels
             if ((unsigned)(k - (LAT_IN + LAG0)) < span && lane_store) {
@@ -545,21 +619,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             }
         }
         if constexpr (ST_ON && (NS == 1)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
-        float4 d1 = zero, d2 = zero, d3 = zero, n1 = zero, n2 = zero, n3 = zero;
+        V d1 = zero, d2 = zero, d3 = zero, n1 = zero, n2 = zero, n3 = zero;
         if constexpr (NS > 1) {
             if constexpr (WA) n1 = wt_hfilter_dpp<K, ((D << A1) <= 4 ? (D << A1) : 4)>(v1);
-            else n1 = wt_hfilter_lds<K, (D << A1), NL>(buf[A1], gl, v1);
+            else n1 = wt_hfilter_lds<T, K, (D << A1), NL>(buf[A1], gl, v1);
             d1 = f4_sub(cen1, n1);
             if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
             if constexpr (ST_ON && (NS == 2)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
             if constexpr (NS > 2) {
                 if constexpr (WA) n2 = wt_hfilter_dpp<K, ((D << A2) <= 4 ? (D << A2) : 4)>(v2);
-                else n2 = wt_hfilter_lds<K, (D << A2), NL>(buf[A2], gl, v2);
+                else n2 = wt_hfilter_lds<T, K, (D << A2), NL>(buf[A2], gl, v2);
                 d2 = f4_sub(cen2, n2);
                 if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
                 if constexpr (ST_ON && (NS == 3)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
                 if constexpr (NS > 3) {
-                    n3 = wt_hfilter_lds<K, (D << A3), NL>(buf[A3], gl, v3);
+                    n3 = wt_hfilter_lds<T, K, (D << A3), NL>(buf[A3], gl, v3);
                     d3 = f4_sub(cen3, n3);
                     if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw3, at(LAG3), d3);
                     if constexpr (ST_ON) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n3);
@@ -572,10 +646,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             // plane-order sum of image row rho: ((p_in + w_s0) + w_s0+1) + w_s0+2 (+ c): the
             // partial sum of a row is parked in the ring until the next scale's detail row of the
             // same image row appears (G1, then G2 steps later)
-            float4 s = PIN ? f4_add(pin_cur, d0) : d0;                  // row t - LAG0
+            V s = PIN ? f4_add(pin_cur, d0) : d0;                       // row t - LAG0
             if constexpr (NS > 1) {
-                float4 s1 = f4_add(old1, d1);                             // row t - LAG1
-                float4 s2 = s1;
+                V s1 = f4_add(old1, d1);                                  // row t - LAG1
+                V s2 = s1;
                 if constexpr (NS > 2) s2 = f4_add(old2, d2);              // row t - LAG2
                 ring[i1 * (NV + 1) + li] = s;
                 if constexpr (NS > 2) ring[(G1 + i2) * (NV + 1) + li] = s1;
@@ -661,6 +735,7 @@ done:;
 // descriptors): the shortest chunk of the widest-dilation pass (D = 64: ~48 steps of 64 rows)
 // must stay below 2 GiB, i.e. rows up to ~174 000 pixels.  Wider images take the per-scale kernels.
 static inline bool wt_fused_supported(const wt_plan *p) { return (int64_t)p->g.P * 4 * 64 * 48 < ((int64_t)1 << 31); }
+static inline bool wt_fused_supported_bytes(int64_t pitch_bytes) { return pitch_bytes * 64 * 48 < ((int64_t)1 << 31); }
 
 // Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = compute units the chunk
 // search leaves free (for the RCCL kernels of an exchange running beside the launch).
@@ -673,23 +748,26 @@ struct FusedRows {
     int reserve = 0;
 };
 
-template <int K, int NS, int D, int NW, int PD, int ACC>
-static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name, const FusedRows &rows)
+// S = element type (float: wt_plan, double: wt_plan64 - both carry `ctx` and the geometry `g`)
+template <typename T, int K, int NS, int D, int NW, int PD, int ACC, typename PLAN>
+static int wt_fused_launch_t(PLAN *p, const FusedArgsT<T> &base, const char *name, const FusedRows &rows)
 {
+    constexpr int PX = WtVec<T>::PX;
+    constexpr int ALIGN_PX = 128 / (int)sizeof(T);           // strips start on 128-byte lines
 
     constexpr int hw = K / 2;
     constexpr int LAT = hw * ((1 << NS) - 1) + (NS - 1);
-    constexpr int HX = (hw * ((1 << NS) - 1) * D + 31) / 32 * 32;
+    constexpr int HX = (hw * ((1 << NS) - 1) * D + ALIGN_PX - 1) / ALIGN_PX * ALIGN_PX;
     constexpr int NL = NW * 64;
-    constexpr int VXMAX = (WT_FUSED_WA && D == 1) ? NW * 56 * 4     // 56 storing lanes per wave
-                                                  : NL * 4 - 2 * HX; // widest valid strip per WG
+    constexpr int VXMAX = (WT_FUSED_WA && D == 1 && PX == 4) ? NW * 56 * 4     // 56 storing lanes per wave
+                                                             : NL * PX - 2 * HX; // widest valid strip per WG
     constexpr int UMAX = (K - 1) << (NS - 1);
-    static_assert(VXMAX >= 64, "workgroup too narrow for this halo");
+    static_assert(VXMAX >= 2 * ALIGN_PX, "workgroup too narrow for this halo");
     const Geo &g = p->g;
-    FusedArgs a = base;
-    const int W4 = (g.W + 3) / 4 * 4;
-    const int nx = (W4 + VXMAX / 32 * 32 - 1) / (VXMAX / 32 * 32);
-    a.Vx = std::min(VXMAX / 32 * 32, ((W4 + nx - 1) / nx + 31) / 32 * 32);   // balanced, 128-B aligned
+    FusedArgsT<T> a = base;
+    const int W4 = (g.W + PX - 1) / PX * PX;
+    const int nx = (W4 + VXMAX / ALIGN_PX * ALIGN_PX - 1) / (VXMAX / ALIGN_PX * ALIGN_PX);
+    a.Vx = std::min(VXMAX / ALIGN_PX * ALIGN_PX, ((W4 + nx - 1) / nx + ALIGN_PX - 1) / ALIGN_PX * ALIGN_PX);   // balanced, 128-B aligned
     if ((int64_t)a.Vx * nx < W4) WT_FAIL("fused pass: strip sizing failed");
     const int phases = std::min(D, g.nrows);
     int nranges = rows.n ? rows.n : 1, span_rows = 0;
@@ -719,7 +797,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
             const int cc = (n_max + Sc - 1) / Sc;                    // chunks actually needed
             const int64_t rounds = (nbase * cc + slots - 1) / slots;
             // the kernel addresses the rows of a chunk with 31-bit byte offsets
-            if ((int64_t)(Sc + 2 * LAT + 2 * UMAX + 1) * D * g.P * 4 >= ((int64_t)1 << 31)) continue;
+            if ((int64_t)(Sc + 2 * LAT + 2 * UMAX + 1) * D * g.P * (int64_t)sizeof(T) >= ((int64_t)1 << 31)) continue;
             // more than one round: keep the warm-up <= ~50 % of a chunk.  A grid that fits in one
             // round anyway (small images: the chip is not full) is latency-bound by the steps of
             // ONE workgroup, so shorter chunks win even if most of their steps are warm-up.
@@ -763,9 +841,9 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
     dim3 grid(nx, (unsigned)gy, nranges), block(NL);
     ProfScope ps(p->ctx, name);
     // fast addressing: aligned groups reflect onto aligned groups and no index reflects twice
-    const bool fast = g_opt_fused_fast && g.W % 4 == 0 && g.W >= HX && g.H >= D * (hw * ((1 << NS) - 1) + 1);
-    if (fast) hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
-    else hipLaunchKernelGGL((wt_fused_kernel<K, NS, D, NW, PD, ACC, false>), grid, block, 0, p->ctx->stream, a);
+    const bool fast = g_opt_fused_fast && g.W % PX == 0 && g.W >= HX && g.H >= D * (hw * ((1 << NS) - 1) + 1);
+    if (fast) hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
+    else hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }
@@ -777,6 +855,7 @@ static int wt_fused_launch_t(wt_plan *p, const FusedArgs &base, const char *name
 template <int K, int ACC>
 static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns, const FusedRows &rows)
 {
+    typedef float T;
     static const char *names[4][7] = {
         {"wt_fused<d1x3>", "wt_fused<d1x2>", "wt_fused<d8x3>", "wt_fused<d8x2>", "wt_fused<d64x2>", "wt_fused<d1x4>", "wt_fused<d16x4>"},
         {"wt_fused_acc<d1x3>", "wt_fused_acc<d1x2>", "wt_fused_acc<d8x3>", "wt_fused_acc<d8x2>", "wt_fused_acc<d64x2>", "wt_fused_acc<d1x4>",
@@ -788,19 +867,19 @@ static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns,
     // (0,4) at D = 1 and (4,4) at D = 16 (x halo 240 px: 8-wave workgroups; the accumulate variants
     // take 7 waves, their delay rings of 3 + 5 + 9 rows would not fit the LDS with 8)
     if constexpr (K == 3) {
-        if (s0 == 0 && ns == 4) return wt_fused_launch_t<K, 4, 1, 4, 4, ACC>(p, a, names[ACC][5], rows);
+        if (s0 == 0 && ns == 4) return wt_fused_launch_t<T, K, 4, 1, 4, 4, ACC>(p, a, names[ACC][5], rows);
         if constexpr (ACC != 3) {
             if (s0 == 4 && ns == 4)
-                return wt_fused_launch_t<K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, names[ACC][6], rows);   // (accumulate: 2 rows ahead, 256 VGPRs)
+                return wt_fused_launch_t<T, K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, names[ACC][6], rows);   // (accumulate: 2 rows ahead, 256 VGPRs)
         }
     }
-    if (s0 == 0 && ns == 3) return wt_fused_launch_t<K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0], rows);
-    if (s0 == 0 && ns == 2) return wt_fused_launch_t<K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1], rows);
+    if (s0 == 0 && ns == 3) return wt_fused_launch_t<T, K, 3, 1, 4, 4, ACC>(p, a, names[ACC][0], rows);
+    if (s0 == 0 && ns == 2) return wt_fused_launch_t<T, K, 2, 1, 4, 4, ACC>(p, a, names[ACC][1], rows);
     if constexpr (ACC != 3) {
-        if (s0 == 3 && ns == 3) return wt_fused_launch_t<K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2], rows);
-        if (s0 == 3 && ns == 2) return wt_fused_launch_t<K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3], rows);
+        if (s0 == 3 && ns == 3) return wt_fused_launch_t<T, K, 3, 8, 8, 4, ACC>(p, a, names[ACC][2], rows);
+        if (s0 == 3 && ns == 2) return wt_fused_launch_t<T, K, 2, 8, 8, 4, ACC>(p, a, names[ACC][3], rows);
         // D = 64 (scales 6-7): taps are 16 / 32 lanes apart
-        if (s0 == 6 && ns == 2) return wt_fused_launch_t<K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4], rows);
+        if (s0 == 6 && ns == 2) return wt_fused_launch_t<T, K, 2, 64, 8, 4, ACC>(p, a, names[ACC][4], rows);
     }
     // Single-scale passes that END a schedule ((3,1) of 4 scales, (6,1) of 7): with them every pass
     // of such a schedule can carry the plane sum (wt_decompose_sum, the interleaved denoise).  The
@@ -809,8 +888,8 @@ static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns,
     if constexpr (ACC != 3) {
         static const char *names1[3][2] = {{"wt_fused<d8x1>", "wt_fused<d64x1>"}, {"wt_fused_acc<d8x1>", "wt_fused_acc<d64x1>"},
                                            {"wt_fused_sum<d8x1>", "wt_fused_sum<d64x1>"}};
-        if (s0 == 3 && ns == 1) return wt_fused_launch_t<K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, names1[ACC][0], rows);
-        if (s0 == 6 && ns == 1) return wt_fused_launch_t<K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, names1[ACC][1], rows);
+        if (s0 == 3 && ns == 1) return wt_fused_launch_t<T, K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, names1[ACC][0], rows);
+        if (s0 == 6 && ns == 1) return wt_fused_launch_t<T, K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, names1[ACC][1], rows);
     }
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }

@@ -735,7 +735,7 @@ class AtrousTransform:
             if recursive:
                 return self._recursive(np.asarray(arr), level, self.scaling_function_class(np.ndim(arr)),
                                        np.float64)
-            return self._call_f64(arr, level)
+            return self._call_f64(arr, level, with_sum)
         if _is_1d(arr):
             return self._call_1d(arr, level, recursive)
         if np.ndim(arr) == 3:
@@ -756,11 +756,13 @@ class AtrousTransform:
         coefficients._sum_valid = summed
         return coefficients
 
-    def _call_f64(self, arr, level):
+    def _call_f64(self, arr, level, with_sum=False):
         """Standard algorithm in float64 (ref:408-444 on float64 / promoted input, ref:319-320):
-        double planes on a Plan64, one generic pass per scale; signals as 1 x N images under the
-        'mirror' border of the 1-D branch (ref:65-69), cubes as (Z*Y) x X images (ref:46-63);
-        with bilateral filtering the per-scale sequence of ref:433-442."""
+        double planes on a Plan64.  Images with a built-in family run the fused multi-scale passes
+        instantiated for double (wt64_decompose decides; with_sum carries the plane sum through
+        them); otherwise one generic pass per scale: signals as 1 x N images under the 'mirror'
+        border of the 1-D branch (ref:65-69), cubes as (Z*Y) x X images (ref:46-63); with
+        bilateral filtering the per-scale sequence of ref:433-442."""
         a = np.ascontiguousarray(arr, dtype=np.float64)
         nd = a.ndim
         scaling_function = self.scaling_function_class(nd)
@@ -769,11 +771,18 @@ class AtrousTransform:
         if self.bilateral is None:
             if nd == 1:
                 plan.set_border(2)
+            summed = False
             if nd == 3:
                 plan.decompose3d(PLANE_INPUT, level, a.shape[0])
+            elif nd == 2 and with_sum and level > 0:
+                summed = plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT) or True   # (two-step form: the sum is there too)
             else:
                 plan.decompose(PLANE_INPUT, level)
             plan.set_border(0)
+            c = Coefficients(plan, scaling_function, self.bilateral,
+                             _shape=a.shape if nd == 3 else None, _dtype=np.float64)
+            c._sum_valid = summed
+            return c
         else:
             sb = self._sigma_bilateral(level)
             cur = PLANE_INPUT
