@@ -543,15 +543,25 @@ def main():
                 # state of a frame loop.
                 img = make_strip(nrows, W, seed=0)
                 rates = []
-                for _ in range(3):
+                for _ in range(4):
                     t = time.perf_counter()
-                    plan.upload(PLANE_INPUT, img)
-                    step()
-                    recon = plan.download(PLANE_OUT)
+                    if two_call:
+                        plan.upload(PLANE_INPUT, img)
+                        step()
+                        recon = plan.download(PLANE_OUT)
+                    else:       # the same three legs, pipelined over blocks of rows (wt_decompose_sum_host)
+                        recon = plan.decompose_sum_host(img, level, PLANE_OUT)
                     rates.append(H * W / (time.perf_counter() - t) / 1e6)
                     del recon
                 out["pcie_inclusive_first_call_mpix_s"] = round(rates[0], 1)
                 out["pcie_inclusive_mpix_s"] = round(max(rates[1:]), 1)
+                # for comparison: upload, passes, download one after the other
+                t = time.perf_counter()
+                plan.upload(PLANE_INPUT, img)
+                step()
+                recon = plan.download(PLANE_OUT)
+                out["pcie_inclusive_serial_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
+                del recon
             if world == 1 and not args.no_cpu and not args.brief:
                 out["cpu_baseline"] = cpu_baseline(config, side, family, level,
                                                    budget=15.0 if full else 5.0)

@@ -211,6 +211,18 @@ int wt_decompose_pass(wt_plan *plan, int cur, int nxt, int s0, int ns, int flags
  * form.  Schedules with single-scale passes other than the one that ends 4 or 7 scales (9 scales
  * and more, user-defined taps, non-symmetric borders) run as the two calls. */
 int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
+/* Host-to-host form of wt_decompose_sum: host_in (H x W floats, row stride in_stride) -> planes
+ * 0..level and the reconstruction in plane dst on the device AND in host_out.  Equivalent to
+ * wt_upload(WT_PLANE_INPUT) + wt_decompose_sum + wt_download(dst), with identical bits, but the
+ * three legs are PIPELINED over blocks of rows (block_rows, 0 = H/8): the passes run on a block as
+ * soon as its rows and the pass's halo rows have arrived, finished rows of the reconstruction go
+ * down while later blocks are still coming up (PCIe is full duplex): about one transfer leg
+ * instead of two (8192^2: 10.2 -> ~6 ms).  Single-GPU plans with a fully fused schedule;
+ * anything else (and wt_set_option("host_pipeline", 0)) runs the three legs in turn.  The host
+ * buffers are page-locked for the duration of the call when they are not already.
+ * Reference flow: watroo/utils.py:83-102 (numpy in, numpy out). */
+int wt_decompose_sum_host(wt_plan *plan, const float *host_in, int64_t in_stride, int level,
+                          int dst, float *host_out, int64_t out_stride, int block_rows);
 /* *ok = 1 when wt_decompose_sum(plan, ., level, ., bit0) runs as accumulate passes (else it is the
  * two-call form).  The host uses it to interleave Coefficients.denoise with the passes:
  * wt_decompose_pass for the passes that produce the thresholded planes, wt_abs_median,

@@ -279,3 +279,78 @@ def test_float64_with_sum_and_public_api_at_size(L):
     den = WA.denoise(b, [5, 3, 2])
     assert den.dtype == np.float64
     assert float(np.abs(den - O.denoise(b.copy(), [5, 3, 2], "b3spline")).max()) <= 1e-12 * bmax
+
+
+# --------------------------------------------------------------------------- pipelined PCIe legs
+@pytest.mark.parametrize("H,W,fam,level,block", [
+    (2048, 2048, "b3spline", 6, 0),          # default: 8 blocks of 256 rows
+    (1100, 4100, "b3spline", 6, 128),        # ragged last block, generic addressing off the fast path? (W % 4 == 0)
+    (2050, 2052, "b3spline", 5, 512),        # (0,3) + (3,2)
+    (4096, 1024, "triangle", 8, 512),        # four-scale passes, halo 240 rows
+    (3000, 1500, "b3spline", 4, 704),        # (0,3) + (3,1)
+])
+def test_pipelined_host_call_is_bitwise_the_serial_sequence(L, H, W, fam, level, block):
+    """wt_decompose_sum_host (upload, passes and download pipelined over blocks of rows, passes on
+    row sub-ranges) == wt_upload + wt_decompose_sum + wt_download, bit for bit: reconstruction on
+    the host, and every plane, the input plane and the reconstruction plane on the device."""
+    f = {"b3spline": L.B3SPLINE, "triangle": L.TRIANGLE}[fam]
+    img = rnd((H, W), H + W)
+    plan = L.Plan(L.default_context(), H, W, f, level)
+    for s in list(range(level + 1)) + [L.PLANE_OUT, L.PLANE_INPUT]:
+        plan.fill(s, np.nan)
+    got = plan.decompose_sum_host(img, level, L.PLANE_OUT, block_rows=block).copy()
+    dev = [plan.download(s).view(np.uint32).copy() for s in list(range(level + 1)) + [L.PLANE_OUT, L.PLANE_INPUT]]
+    for s in list(range(level + 1)) + [L.PLANE_OUT, L.PLANE_INPUT]:
+        plan.fill(s, np.nan)
+    try:
+        L.set_option("host_pipeline", 0)
+        ref = plan.decompose_sum_host(img, level, L.PLANE_OUT).copy()
+    finally:
+        L.set_option("host_pipeline", 1)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    for a, s in zip(dev, list(range(level + 1)) + [L.PLANE_OUT, L.PLANE_INPUT]):
+        np.testing.assert_array_equal(a, plan.download(s).view(np.uint32), err_msg=f"plane {s}")
+    np.testing.assert_array_equal(dev[-1], img.view(np.uint32))
+    # strided host buffers (views of wider arrays)
+    wide_in = np.zeros((H, W + 12), np.float32)
+    wide_in[:, 4:W + 4] = img
+    wide_out = np.full((H, W + 8), -7.0, np.float32)
+    plan.decompose_sum_host(wide_in[:, 4:W + 4], level, L.PLANE_OUT, out=wide_out[:, 8:], block_rows=block)
+    np.testing.assert_array_equal(wide_out[:, 8:].view(np.uint32), ref.view(np.uint32))
+    assert (wide_out[:, :8] == -7.0).all()
+    plan.close()
+
+
+def test_with_sum_transform_of_a_host_image_hands_out_the_pipelined_synthesis(L):
+    import wavelets_amd as WA
+    img = rnd((2304, 2048), 5)
+    c = WA.AtrousTransform(WA.B3spline)(img, 6, with_sum=True)
+    assert c._sum_valid and c._host_sum is not None
+    rec = np.sum(c, axis=0)
+    assert c._host_sum is None                                  # handed out once
+    c2 = WA.AtrousTransform(WA.B3spline)(img, 6)
+    np.testing.assert_array_equal(rec, np.sum(c2, axis=0))      # bit-identical to summing afterwards
+    np.testing.assert_array_equal(np.sum(c, axis=0), rec)       # second call: from the device plane
+    c.denoise([3, 2])
+    assert not c._sum_valid and c._host_sum is None
+    np.testing.assert_array_equal(np.sum(c, axis=0), c.data.sum(axis=0))
+
+
+# --------------------------------------------------------------------------- select histogram
+@pytest.mark.parametrize("shape", [(1024, 4096), (333, 1001), (2048, 8192), (5, 100000)])
+def test_exact_median_with_the_replicated_first_level_histogram(L, shape):
+    """wt_abs_median on planes whose magnitudes crowd into a few bins (Gaussian detail planes), with
+    ties (integers) and on a constant plane: exact np.median(|x|) through the four-copy first-level
+    histogram and the double-buffered read loop, for row lengths below / above one work item."""
+    ctx = L.default_context()
+    plan = L.Plan(ctx, shape[0], shape[1], L.B3SPLINE, 1)
+    for kind in ("gauss", "ints", "const"):
+        if kind == "gauss":
+            a = rnd(shape, 3) * 0.3
+        elif kind == "ints":
+            a = np.random.default_rng(4).integers(-5, 6, shape).astype(np.float32)
+        else:
+            a = np.full(shape, -2.5, np.float32)
+        plan.upload(0, a)
+        assert plan.abs_median(0) == np.median(np.abs(a)), kind
+    plan.close()

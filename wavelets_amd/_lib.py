@@ -83,6 +83,7 @@ SIGNATURES = {
     "wt_decompose_pass": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose_pass_sum": (_c.c_int, [_vp] + [_c.c_int] * 8),
+    "wt_decompose_sum_host": (_c.c_int, [_vp, _fp, _i64, _c.c_int, _c.c_int, _fp, _i64, _c.c_int]),
     "wt_plan_fused_ok": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_int)]),
     "wt_atrous_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -511,6 +512,20 @@ class Plan:
     def decompose_sum(self, src, level, dst=PLANE_OUT, flags=FLAG_FUSED):
         """decompose + plane sum in the same passes (bit-identical to the two calls)."""
         check(load().wt_decompose_sum(self._h, src, level, dst, flags))
+
+    def decompose_sum_host(self, host, level, dst=PLANE_OUT, out=None, block_rows=0):
+        """upload + decompose_sum + download(dst) with the PCIe legs pipelined behind the passes
+        (wt_decompose_sum_host): returns the reconstruction as an ndarray; the device state is
+        that of the three calls."""
+        host = _as_f32(host)
+        if host.shape != self.shape:
+            raise ValueError(f"image shape {host.shape} != plan strip shape {self.shape}")
+        if out is None:
+            out = host_empty(self.shape, self.ctx)
+        assert out.dtype == np.float32 and out.shape == self.shape and out.strides[1] == 4
+        check(load().wt_decompose_sum_host(self._h, host.ctypes.data_as(_fp), host.shape[1], level, dst,
+                                           out.ctypes.data_as(_fp), out.strides[0] // 4, block_rows))
+        return out
 
     def decompose_pass_sum(self, cur, nxt, s0, ns, flags, sum_plane, first, last):
         check(load().wt_decompose_pass_sum(self._h, cur, nxt, s0, ns, flags, sum_plane,

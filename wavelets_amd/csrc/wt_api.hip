@@ -271,6 +271,10 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
         (void)hipEventDestroy(c->ev_to_comm);
         (void)hipEventDestroy(c->ev_from_comm);
     }
+    if (c->xfer_in) {
+        (void)hipStreamDestroy(c->xfer_in);
+        (void)hipStreamDestroy(c->xfer_out);
+    }
     for (auto &p : c->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -1173,6 +1177,8 @@ static int g_opt_overlap_reserve = getenv("WT_OVERLAP_RESERVE") ? atoi(getenv("W
 static int g_opt_split_dry = 0;
 
 static void wt_set_fused64(int on);     // wt_f64.h (included at the end of this file)
+// wt_decompose_sum_host: pipeline the PCIe legs with the passes (0: upload, passes, download in turn)
+static int g_opt_host_pipeline = getenv("WT_NO_HOST_PIPELINE") ? 0 : 1;
 
 extern "C" int wt_set_option(const char *name, int value)
 {
@@ -1185,6 +1191,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
     if (!strcmp(name, "tri4")) { g_opt_tri4 = value != 0; return 0; }
+    if (!strcmp(name, "host_pipeline")) { g_opt_host_pipeline = value != 0; return 0; }
     if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
@@ -1594,6 +1601,132 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
 
 // Would wt_decompose_sum(plan, ., level, ., FLAG_FUSED) run as accumulate passes (every pass of the
 // schedule has a fused kernel, symmetric border, built-in taps, rows short enough)?  Host logic.
+// Host-to-host form of wt_decompose_sum, pipelined over PCIe (round 3).
+//   serial:     upload 4.7 ms | passes 0.7 ms | download 4.7 ms      (8192^2, 57 GB/s per direction)
+//   pipelined:  the image goes up in blocks of rows on a transfer stream; as soon as the rows a pass
+//               needs (its own rows + the pass's halo) are there the pass runs on them (row
+//               sub-ranges of the fused kernels: same per-pixel arithmetic, identical bits); the
+//               rows of the reconstruction that the last pass has finished go down on a second
+//               transfer stream while later blocks are still coming up - PCIe is full duplex, so
+//               the call costs about one leg plus one block of latency instead of two legs.
+// Device state afterwards is that of the serial sequence: PLANE_INPUT holds the image, planes
+// 0..level the coefficients, `dst` the reconstruction.  Planes mapped over scattered chunks cannot
+// be the target of a 2-D memcpy: blocks bounce through the plan's contiguous stage plane (a copy
+// kernel per block, hidden behind the transfers); the stage rows of a block are reused for the
+// reconstruction rows once the block has been copied on (stream order).
+extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t in_stride, int level, int dst, float *host_out,
+                                     int64_t out_stride, int block_rows)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !host_in || !host_out) WT_FAIL("wt_decompose_sum_host: null pointer");
+    if (in_stride < p->g.W || out_stride < p->g.W) WT_FAIL("wt_decompose_sum_host: host stride below the width %d", p->g.W);
+    if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose_sum_host: level %d exceeds plan max_level %d", level, p->max_level);
+    if ((dst >= 0 && dst <= level) || dst == WT_PLANE_INPUT || dst == WT_PLANE_SCRATCH(0) || dst == WT_PLANE_SCRATCH(1))
+        WT_FAIL("wt_decompose_sum_host: dst plane %d is an input / output / internal plane of the transform", dst);
+    wt_ctx *c = p->ctx;
+    const int H = p->g.nrows, P = p->g.P, W = p->g.W;
+    int32_t tr[3 * 32];
+    int np = 0;
+    bool pipe = g_opt_host_pipeline && p->nranks == 1 && level > 0 && !p->g.border && !p->ntaps && wt_fused_supported(p);
+    if (pipe) {
+        WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
+        for (int i = 0; i < np; ++i) pipe = pipe && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1], p->family);
+    }
+    if (block_rows <= 0) block_rows = std::max(256, (H + 7) / 8);    // eight blocks: one block of latency = 1/8 of a leg
+    block_rows = (block_rows + 63) / 64 * 64;
+    if (pipe && (H < 2 * block_rows || (int64_t)H * W < (1 << 22))) pipe = false;      // small images: nothing to overlap
+    if (!pipe) {
+        WT_TRY(wt_upload(p, WT_PLANE_INPUT, host_in, in_stride));
+        WT_TRY(wt_decompose_sum(p, WT_PLANE_INPUT, level, dst, 1));
+        return wt_download(p, dst, host_out, out_stride);
+    }
+    WT_HIP(hipSetDevice(c->device));
+    if (!c->xfer_in) {
+        WT_HIP(hipStreamCreateWithFlags(&c->xfer_in, hipStreamNonBlocking));
+        WT_HIP(hipStreamCreateWithFlags(&c->xfer_out, hipStreamNonBlocking));
+    }
+    float *in_b = nullptr, *out_b = nullptr, *stage = nullptr;
+    WT_TRY(plane_base(p, WT_PLANE_INPUT, &in_b));
+    WT_TRY(plane_base(p, dst, &out_b));
+    for (int s = 0; s <= level; ++s) {                       // (allocate before the first launch; drops the median marker)
+        float *t = nullptr;
+        WT_TRY(plane_base(p, s, &t));
+    }
+    const bool vin = is_vmm(p, in_b), vout = is_vmm(p, out_b);
+    if (vin || vout) WT_TRY(vmm_stage(p, &stage));
+    float *up_b = vin ? stage : in_b, *down_b = vout ? stage : out_b;
+    const size_t in_span = ((size_t)(H - 1) * (size_t)in_stride + (size_t)W) * 4, out_span = ((size_t)(H - 1) * (size_t)out_stride + (size_t)W) * 4;
+    const bool pin_in = try_pin(host_in, in_span), pin_out = try_pin(host_out, out_span);
+    std::vector<hipEvent_t> evs;
+    auto new_event = [&](hipEvent_t *e) -> hipError_t {
+        hipError_t rc = hipEventCreateWithFlags(e, hipEventDisableTiming);
+        if (rc == hipSuccess) evs.push_back(*e);
+        return rc;
+    };
+    std::vector<int> done(np, 0);
+    int out_done = 0, rc = 0;
+    hipError_t e = hipSuccess;
+    auto run = [&]() -> int {
+        // the transfer streams start behind whatever the compute stream was doing to these planes
+        hipEvent_t e0;
+        WT_HIP(new_event(&e0));
+        WT_HIP(hipEventRecord(e0, c->stream));
+        WT_HIP(hipStreamWaitEvent(c->xfer_in, e0, 0));
+        WT_HIP(hipStreamWaitEvent(c->xfer_out, e0, 0));
+        for (int y0 = 0; y0 < H; y0 += block_rows) {
+            const int y1 = std::min(H, y0 + block_rows);
+            WT_HIP(hipMemcpy2DAsync(up_b + (size_t)y0 * P, (size_t)P * 4, host_in + (size_t)y0 * in_stride, (size_t)in_stride * 4, (size_t)W * 4,
+                                    (size_t)(y1 - y0), hipMemcpyHostToDevice, c->xfer_in));
+            hipEvent_t eu;
+            WT_HIP(new_event(&eu));
+            WT_HIP(hipEventRecord(eu, c->xfer_in));
+            WT_HIP(hipStreamWaitEvent(c->stream, eu, 0));
+            if (vin) WT_TRY(copy2d(p, p, in_b + (size_t)y0 * P, (size_t)P, stage + (size_t)y0 * P, (size_t)P, (size_t)P, (size_t)(y1 - y0), c->stream));
+            int avail = y1, cur = WT_PLANE_INPUT;
+            for (int i = 0; i < np; ++i) {
+                const int s0 = tr[3 * i], ns = tr[3 * i + 1], halo = tr[3 * i + 2];
+                const bool last = s0 + ns == level;
+                const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+                const int ready = avail == H ? H : std::max(done[i], avail - halo);
+                if (ready > done[i]) {
+                    FusedRows rows;
+                    rows.n = 1;
+                    rows.lo[0] = done[i];
+                    rows.hi[0] = ready;
+                    WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, 1 | 2, last ? 2 : 1, i == 0, dst, rows));
+                    done[i] = ready;
+                }
+                avail = done[i];
+                cur = nxt;
+            }
+            const int fin = done[np - 1];
+            if (fin > out_done) {
+                if (vout) WT_TRY(copy2d(p, p, stage + (size_t)out_done * P, (size_t)P, out_b + (size_t)out_done * P, (size_t)P, (size_t)P,
+                                        (size_t)(fin - out_done), c->stream));
+                hipEvent_t ec;
+                WT_HIP(new_event(&ec));
+                WT_HIP(hipEventRecord(ec, c->stream));
+                WT_HIP(hipStreamWaitEvent(c->xfer_out, ec, 0));
+                WT_HIP(hipMemcpy2DAsync(host_out + (size_t)out_done * out_stride, (size_t)out_stride * 4, down_b + (size_t)out_done * P, (size_t)P * 4,
+                                        (size_t)W * 4, (size_t)(fin - out_done), hipMemcpyDeviceToHost, c->xfer_out));
+                out_done = fin;
+            }
+        }
+        return 0;
+    };
+    rc = run();
+    // drain everything whatever happened (host buffers are unpinned below, events destroyed)
+    hipError_t e1 = hipStreamSynchronize(c->xfer_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->xfer_out);
+    e = e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3);
+    for (auto ev : evs) (void)hipEventDestroy(ev);
+    if (pin_in) (void)hipHostUnregister(const_cast<float *>(host_in));
+    if (pin_out) (void)hipHostUnregister(host_out);
+    if (rc) return rc;
+    WT_HIP(e);
+    if (out_done != H) WT_FAIL("wt_decompose_sum_host: internal error, %d of %d rows delivered", out_done, H);
+    return 0;
+}
+
 extern "C" int wt_plan_fused_ok(wt_plan *p, int level, int *ok)
 {
     WtGuard guard_(ctx_of(p));
@@ -2096,8 +2229,16 @@ static int select_pass(wt_plan *p, const float *b, WtSelectState *st, uint32_t p
     wt_ctx *c = p->ctx;
     if (!have_hist) {
         ProfScope ps(c, "wt_hist_kernel");
-        hipLaunchKernelGGL(wt_hist_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, b, p->g.nrows, p->g.P / 4, p->g.W,
-                           prefix_mask, (const WtSelectState *)st, shift, bin_mask, c->d_hist);
+        // first level (no prefix yet): every element is binned - four interleaved LDS copies;
+        // 4 blocks per CU (32 KB of LDS each) against 8 for the later levels
+        const int X4 = (p->g.W + 3) / 4, nchunk = (X4 + 256 * WT_HIST_UNROLL - 1) / (256 * WT_HIST_UNROLL);
+        const int64_t nitems = (int64_t)p->g.nrows * nchunk;
+        if (prefix_mask == 0u)
+            hipLaunchKernelGGL(wt_hist_kernel<4>, dim3((unsigned)std::min<int64_t>(nitems, 4 * c->num_cus)), dim3(256), 0, c->stream, b,
+                               p->g.nrows, p->g.P / 4, p->g.W, prefix_mask, (const WtSelectState *)st, shift, bin_mask, c->d_hist);
+        else
+            hipLaunchKernelGGL(wt_hist_kernel<1>, dim3((unsigned)std::min<int64_t>(nitems, 8 * c->num_cus)), dim3(256), 0, c->stream, b,
+                               p->g.nrows, p->g.P / 4, p->g.W, prefix_mask, (const WtSelectState *)st, shift, bin_mask, c->d_hist);
     }
     WT_HIP(hipGetLastError());
     if (p->nranks > 1) {

@@ -88,6 +88,8 @@ struct wt_ctx {
     // order it against `stream` (created with the communicator)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_to_comm = nullptr, ev_from_comm = nullptr;
+    // transfer streams of the pipelined host-to-host call (wt_decompose_sum_host), created on first use
+    hipStream_t xfer_in = nullptr, xfer_out = nullptr;
     // small device/host scratch for selects & reductions
     uint32_t *d_hist = nullptr;   // 2048 bins + extras
     double *d_partials = nullptr; // reduction partials

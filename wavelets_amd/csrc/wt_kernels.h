@@ -1568,44 +1568,75 @@ __global__ __launch_bounds__(256) void wt_select_step_kernel(uint32_t *hist, WtS
 }
 
 #ifndef WT_HIST_UNROLL
-#define WT_HIST_UNROLL 4      // 16-byte loads in flight per thread
+#define WT_HIST_UNROLL 4      // 16-byte loads per thread and item; two items in flight (double-buffered)
 #endif
+// One level of the radix select: histogram of (|x| >> shift) & bin_mask over the elements whose bits
+// under prefix_mask equal the selection prefix.
+//  * REP interleaved copies of the LDS histogram (lh[bin * REP + (lane & (REP - 1))]).  The first
+//    level bins EVERY element, and the magnitudes of a detail plane crowd into a few dozen bins (a
+//    handful of exponents x 8 mantissa sub-bins): with one copy, same-address LDS atomics of a wave
+//    serialise (round 2 counters: 47 % of the LDS cycles were bank conflicts).  Four copies put
+//    neighbouring lanes on different addresses AND different banks (hot neighbouring bins times
+//    four copies cover all 32 banks).  Later levels bin a few per cent of the elements: one copy.
+//  * work items are (row, chunk of 256 * UNROLL float4) pairs; the loads of the NEXT item are
+//    issued before the atomics of the current one (8 loads of 16 B in flight per thread instead of
+//    4 with a full drain per iteration: the read stream was latency-bound at 4.7 TB/s).
+template <int REP>
 __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows, int P4, int W,
                                                       uint32_t prefix_mask, const WtSelectState *st,
                                                       int shift, uint32_t bin_mask,
                                                       uint32_t *hist)
 {
     const uint32_t prefix_val = st->prefix & prefix_mask;      // wave-uniform scalar load
-    __shared__ uint32_t lh[WT_HIST_BINS];
-    for (int i = threadIdx.x; i < WT_HIST_BINS; i += blockDim.x) lh[i] = 0;
+    __shared__ uint32_t lh[WT_HIST_BINS * REP];
+    for (int i = threadIdx.x; i < WT_HIST_BINS * REP; i += 256) lh[i] = 0;
     __syncthreads();
-    // whole rows per block, 2-D indices (no 64-bit modulo per element); 4 independent 16-byte
-    // loads per thread in flight before the LDS atomics of the first one are issued
+    constexpr int U = WT_HIST_UNROLL;
     const int X4 = (W + 3) >> 2;
-    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int nchunk = (X4 + 256 * U - 1) / (256 * U);
+    const int64_t nitems = (int64_t)nrows * nchunk;
+    const int rep = threadIdx.x & (REP - 1);
+    auto load = [&](int64_t item, float4 (&v)[U]) {
+        const int r = (int)(item / nchunk), c = (int)(item - (int64_t)r * nchunk);
         const float *row = p + (int64_t)r * P4 * 4;
-        for (int x4 = threadIdx.x; x4 < X4; x4 += 256 * WT_HIST_UNROLL) {
-            float4 v[WT_HIST_UNROLL];
 #pragma unroll
-            for (int u = 0; u < WT_HIST_UNROLL; ++u) v[u] = wt_ldnt4(row + 4 * min(x4 + 256 * u, X4 - 1));
+        for (int u = 0; u < U; ++u) v[u] = wt_ldnt4(row + 4 * min(c * 256 * U + 256 * u + (int)threadIdx.x, X4 - 1));
+    };
+    auto bin = [&](int64_t item, const float4 (&v)[U]) {
+        const int c = (int)(item % nchunk);
 #pragma unroll
-            for (int u = 0; u < WT_HIST_UNROLL; ++u) {
-                const int xx = x4 + 256 * u;
-                const int nv = xx < X4 ? min(4, W - xx * 4) : 0;
-                const uint32_t b[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y),
-                                       __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
+        for (int u = 0; u < U; ++u) {
+            const int xx = c * 256 * U + 256 * u + (int)threadIdx.x;
+            const int nv = xx < X4 ? min(4, W - xx * 4) : 0;
+            const uint32_t b[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y),
+                                   __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t w = b[k] & 0x7fffffffu;
-                    if (k < nv && (w & prefix_mask) == prefix_val)
-                        atomicAdd(&lh[(w >> shift) & bin_mask], 1u);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w = b[k] & 0x7fffffffu;
+                if (k < nv && (w & prefix_mask) == prefix_val)
+                    atomicAdd(&lh[((w >> shift) & bin_mask) * REP + rep], 1u);
             }
         }
+    };
+    float4 va[U], vb[U];
+    int64_t item = blockIdx.x;
+    if (item < nitems) load(item, va);
+    while (item < nitems) {                                  // two items per trip: no register copies
+        const int64_t i1 = item + gridDim.x, i2 = i1 + gridDim.x;
+        if (i1 < nitems) load(i1, vb);
+        bin(item, va);
+        if (i1 >= nitems) break;
+        if (i2 < nitems) load(i2, va);
+        bin(i1, vb);
+        item = i2;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < WT_HIST_BINS; i += blockDim.x)
-        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256) {
+        uint32_t n = 0;
+#pragma unroll
+        for (int k = 0; k < REP; ++k) n += lh[i * REP + k];
+        if (n) atomicAdd(&hist[i], n);
+    }
 }
 
 // smallest |x| bit pattern strictly greater than `than` (for the upper median when N is even);

@@ -398,7 +398,8 @@ class Coefficients:
         self._plan = None
         self._host = None
         self._noise_uploaded = None
-        self._sum_valid = False     # PLANE_OUT holds np.sum(planes, axis=0) of the CURRENT planes
+        self._sum_ok = False        # PLANE_OUT holds np.sum(planes, axis=0) of the CURRENT planes (_sum_valid)
+        self._host_sum = None       # ... and this host array too (with_sum=True transforms of host images)
         # logical shape of one plane: (N,), (H, W) or (Z, Y, X); the engine stores it as a 2-D
         # image: 1 x N, H x W or (Z*Y) x X
         if isinstance(data, (Plan, Plan64)):
@@ -506,6 +507,16 @@ class Coefficients:
                     self._plan.download(s, self._as_plane(self._host[s]))
                 else:                        # float64 mirror of float32 planes
                     self._as_plane(self._host[s])[...] = self._plan.download(s)
+
+    @property
+    def _sum_valid(self):
+        return self._sum_ok
+
+    @_sum_valid.setter
+    def _sum_valid(self, value):
+        # whatever (re)defines the content of PLANE_OUT invalidates the host copy of the synthesis
+        self._sum_ok = bool(value)
+        self._host_sum = None
 
     # -- reference interface -----------------------------------------------------------
     def __len__(self):
@@ -637,7 +648,11 @@ class Coefficients:
             if not self._sum_valid:           # with_sum=True transforms carried it along already
                 plan.plane_sum(0, self._nplanes, PLANE_OUT)
                 self._sum_valid = self._host is None
-            res = self._from_plane(plan.download(PLANE_OUT)).astype(self._dtype, copy=False)
+            if self._sum_valid and self._host_sum is not None:
+                host, self._host_sum = self._host_sum, None      # came down with the transform
+            else:
+                host = plan.download(PLANE_OUT)
+            res = self._from_plane(host).astype(self._dtype, copy=False)
             if out is None:
                 return res
             out[...] = res
@@ -746,14 +761,18 @@ class AtrousTransform:
             return self._recursive(img, level, scaling_function, _result_dtype(arr))
         plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                             _family_of(scaling_function), level)
-        plan.upload(PLANE_INPUT, img)
         summed = bool(with_sum) and self.bilateral is None and not plan.custom
+        host_sum = None
         if summed:
-            plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, FLAG_FUSED)     # ref:432,442 + utils.py:98
+            # ref:432,442 + utils.py:98; the upload, the passes and the download of the synthesis are
+            # pipelined over blocks of rows (wt_decompose_sum_host: about one PCIe leg instead of two)
+            host_sum = plan.decompose_sum_host(img, level, PLANE_OUT)
         else:
+            plan.upload(PLANE_INPUT, img)
             self._run(plan, level)
         coefficients = Coefficients(plan, scaling_function, self.bilateral, _dtype=_result_dtype(arr))
         coefficients._sum_valid = summed
+        coefficients._host_sum = host_sum        # handed out once by np.sum(coefficients, axis=0)
         return coefficients
 
     def _call_f64(self, arr, level, with_sum=False):
