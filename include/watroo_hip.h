@@ -214,7 +214,7 @@ int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
 /* Host-to-host form of wt_decompose_sum: host_in (H x W floats, row stride in_stride) -> planes
  * 0..level and the reconstruction in plane dst on the device AND in host_out.  Equivalent to
  * wt_upload(WT_PLANE_INPUT) + wt_decompose_sum + wt_download(dst), with identical bits, but the
- * three legs are PIPELINED over blocks of rows (block_rows, 0 = H/8): the passes run on a block as
+ * three legs are PIPELINED over blocks of rows (block_rows, 0 = H/16): the passes run on a block as
  * soon as its rows and the pass's halo rows have arrived, finished rows of the reconstruction go
  * down while later blocks are still coming up (PCIe is full duplex): about one transfer leg
  * instead of two (8192^2: 10.2 -> ~6 ms).  Single-GPU plans with a fully fused schedule;

@@ -1632,7 +1632,7 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
         WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
         for (int i = 0; i < np; ++i) pipe = pipe && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1], p->family);
     }
-    if (block_rows <= 0) block_rows = std::max(256, (H + 7) / 8);    // eight blocks: one block of latency = 1/8 of a leg
+    if (block_rows <= 0) block_rows = std::max(256, (H + 15) / 16);  // sixteen blocks: measured best at 8192^2 (tail = one block of each leg)
     block_rows = (block_rows + 63) / 64 * 64;
     if (pipe && (H < 2 * block_rows || (int64_t)H * W < (1 << 22))) pipe = false;      // small images: nothing to overlap
     if (!pipe) {
@@ -1675,8 +1675,12 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
         WT_HIP(hipStreamWaitEvent(c->xfer_out, e0, 0));
         for (int y0 = 0; y0 < H; y0 += block_rows) {
             const int y1 = std::min(H, y0 + block_rows);
-            WT_HIP(hipMemcpy2DAsync(up_b + (size_t)y0 * P, (size_t)P * 4, host_in + (size_t)y0 * in_stride, (size_t)in_stride * 4, (size_t)W * 4,
-                                    (size_t)(y1 - y0), hipMemcpyHostToDevice, c->xfer_in));
+            // (rows that are contiguous on both sides go as ONE linear copy: the DMA engines' fast path)
+            if (in_stride == W && P == W)
+                WT_HIP(hipMemcpyAsync(up_b + (size_t)y0 * P, host_in + (size_t)y0 * in_stride, (size_t)(y1 - y0) * W * 4, hipMemcpyHostToDevice, c->xfer_in));
+            else
+                WT_HIP(hipMemcpy2DAsync(up_b + (size_t)y0 * P, (size_t)P * 4, host_in + (size_t)y0 * in_stride, (size_t)in_stride * 4, (size_t)W * 4,
+                                        (size_t)(y1 - y0), hipMemcpyHostToDevice, c->xfer_in));
             hipEvent_t eu;
             WT_HIP(new_event(&eu));
             WT_HIP(hipEventRecord(eu, c->xfer_in));
@@ -1707,8 +1711,12 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
                 WT_HIP(new_event(&ec));
                 WT_HIP(hipEventRecord(ec, c->stream));
                 WT_HIP(hipStreamWaitEvent(c->xfer_out, ec, 0));
-                WT_HIP(hipMemcpy2DAsync(host_out + (size_t)out_done * out_stride, (size_t)out_stride * 4, down_b + (size_t)out_done * P, (size_t)P * 4,
-                                        (size_t)W * 4, (size_t)(fin - out_done), hipMemcpyDeviceToHost, c->xfer_out));
+                if (out_stride == W && P == W)
+                    WT_HIP(hipMemcpyAsync(host_out + (size_t)out_done * out_stride, down_b + (size_t)out_done * P, (size_t)(fin - out_done) * W * 4,
+                                          hipMemcpyDeviceToHost, c->xfer_out));
+                else
+                    WT_HIP(hipMemcpy2DAsync(host_out + (size_t)out_done * out_stride, (size_t)out_stride * 4, down_b + (size_t)out_done * P, (size_t)P * 4,
+                                            (size_t)W * 4, (size_t)(fin - out_done), hipMemcpyDeviceToHost, c->xfer_out));
                 out_done = fin;
             }
         }

@@ -357,6 +357,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // output row of scale a at step t: t - a - hw*(2^(a+1)-1)
     constexpr int LAG0 = hw, LAG1 = 1 + 3 * hw, LAG2 = 2 + 7 * hw, LAG3 = 3 + 15 * hw;
     constexpr int LAGC = NS == 1 ? LAG0 : (NS == 2 ? LAG1 : (NS == 3 ? LAG2 : LAG3));
+    // peeled prologue steps (see `step` below): the cascade's fill time rounded up to whole unrolled
+    // bodies, at most two of them (code size); none for the single-scale passes
+    // Built where the extra code does not cost registers the kernel does not have: the float D = 1
+    // passes of up to three scales (B3 d1x3: 220 -> 240 VGPRs, no scratch).  The D = 8 three-scale
+    // passes sit at 256 VGPRs already and the four-scale / double variants spill with it (measured
+    // with -save-temps: 16 - 220 spilled registers), so they keep the plain march.
+#ifdef WT_FUSED_NO_PROLOGUE
+    constexpr int PRO = 0;
+#else
+    constexpr bool PRO_FITS = D == 1 && NS >= 2 && NS <= 3 && sizeof(T) == 4;
+    constexpr int PRO = !PRO_FITS ? 0 : (((LAT_IN + LAGC + U - 1) / U) < 2 ? ((LAT_IN + LAGC + U - 1) / U) : 2) * U;
+#endif
     // ACC: the running sum of a row waits in per-lane LDS rings until the next scale's detail
     // row of the SAME image row comes out of the cascade (G1, then G2 steps later); only lanes
     // that own stored pixels take part (NV of them), nothing crosses lanes: no barrier.
@@ -515,25 +527,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     };
     V pa[PIN ? PD : 1];
     if constexpr (PIN) {
+        // (with a prologue the first p_in row that matters is loaded by its step LAT_IN + LAG0 - PD)
 #pragma unroll
-        for (int i = 0; i < PD; ++i) pa[i] = load_acc(i);   // koff = 0 here
+        for (int i = 0; i < PD; ++i) pa[i] = PRO > 0 ? zero : load_acc(i);   // koff = 0 here
     }
-    // The compiler sizes every `s_waitcnt vmcnt(N)` of the loop from the FEWEST vector-memory
-    // operations that can lie between a prefetch and its use on any path into that point - and on
-    // the path from here the PD prefetches would be back to back, while in the steady state a
-    // step's stores sit between them.  Without the padding below the first PD steps of every trip
-    // through the unrolled body wait with vmcnt(2..15), i.e. for the STORES of the previous steps
-    // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
-    // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
-    // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
     const int li = lane_store ? (x - X0) / PX : NV;      // slot in the ring rows; NV = the spare slot
     int i1 = 0, i2 = 0, i3 = 0;                          // ring positions (wave-uniform)
 
     // One chain step.
-    auto step = [&](const int kb, const int kk, auto stores_tag) {
-        constexpr bool ST_ON = decltype(stores_tag)::value;   // false: the peeled first U steps, where no plane stores yet
+    // PROLOGUE (round 3).  The cascade fills over the first LAT_IN + LAG_last steps of a chunk: scale
+    // a's horizontal filter produces a row that some stored row depends on only from step H_a on,
+    // its vertical window needs real input only from step V_a on, and plane a stores from step
+    // ST_a on:
+    //     R_a  = hw * (2^NS - 2^(a+1))      rows of c_{a+1} beyond the chunk that later scales reach
+    //     H_a  = LAG_a + LAT_IN - R_a       B3, NS = 3:  4, 13, 30
+    //     V_a  = H_a - 2 * hw * 2^a                      0,  5, 14
+    //     ST_a = LAT_IN + LAG_a                          16, 21, 30
+    // The steady-state step does all of it at every step (3 * 30 scale-steps where 47 + 43 are
+    // needed), which nobody notices while the pass waits for memory, but a grid of short chunks
+    // (4096^2: 40 stored rows per chunk behind 30 warm-up steps) is bound by instruction issue.
+    // The first PRO steps therefore run as peeled copies of the step in which everything that is
+    // not needed yet is compiled out (k is a constant there): no vertical / horizontal filter, no
+    // LDS row, no parked store, no ring traffic, no p_in load before its time.  The last PD peeled
+    // steps keep the full store pattern, so that the loop is entered with the steady state's
+    // vector-memory queue (what the parked stores of the vmcnt padding provided before).
+    // Bit-identical: every value a stored row depends on is computed by the same instructions.
+    auto step = [&](const int kb, const int kk, auto pro_tag) {
+        constexpr bool PROL = decltype(pro_tag)::value;       // a peeled prologue step (kb + kk is a constant)
         const int k = kb + kk;
         const int t = t0 + k;
+        constexpr int R0 = hw * ((1 << NS) - 2), R1 = hw * ((1 << NS) - 4), R2 = hw * ((1 << NS) - 8);
+        constexpr int H0 = LAG0 + LAT_IN - R0, H1 = LAG1 + LAT_IN - R1, H2 = LAG2 + LAT_IN - R2, H3 = LAG3 + LAT_IN;
+        constexpr int V1 = H1 - 4 * hw, V2 = H2 - 8 * hw, V3 = H3 - 16 * hw;
+        constexpr int ST0 = LAT_IN + LAG0, ST1 = LAT_IN + LAG1, ST2 = LAT_IN + LAG2, ST3 = LAT_IN + LAG3;
+        const bool full = !PROL || k >= PRO - PD;             // steady-state store pattern
+        const bool eh0 = !PROL || k >= H0, eh1 = !PROL || k >= H1, eh2 = !PROL || k >= H2, eh3 = !PROL || k >= H3;
+        const bool ev1 = !PROL || k >= V1, ev2 = !PROL || k >= V2, ev3 = !PROL || k >= V3;
+        const bool es0 = full || k >= ST0, es1 = full || k >= ST1, es2 = full || k >= ST2, es3 = full || k >= ST3;
+        const bool esc = full || k >= LAT_IN + LAGC;          // smooth plane / carried sum
         // step k stores row t0 + k - LAG of a plane: inside the chunk iff k - (LAT_IN + LAG) < span
         const unsigned vk = voff + koff + ((dbg & 1) ? WT_FUSED_PARKED : 0u);
         auto at = [&](int lag) -> unsigned {             // lane offset of this step's row of a plane
@@ -574,7 +605,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
         V pin_cur = zero;
         if constexpr (PIN) {
             pin_cur = pa[kk % PD];
-            pa[kk % PD] = load_acc(PD);
+            if (!PROL || k + PD >= ST0) pa[kk % PD] = load_acc(PD);   // (rows before the chunk read as 0 anyway)
         }
         // ACC: the ring slots that come due in this step were written G1 / G2 steps ago - read
         // them before the barrier so the LDS latency hides behind the vertical filters.  Lanes
@@ -582,35 +613,52 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
         // stored), which keeps the ring traffic free of exec-mask branches.
         V old1 = zero, old2 = zero, old3 = zero;
         if constexpr (SUM && NS > 1) {
-            old1 = ring[i1 * (NV + 1) + li];
-            if constexpr (NS > 2) old2 = ring[(G1 + i2) * (NV + 1) + li];
-            if constexpr (NS > 3) old3 = ring[(G1 + G2 + i3) * (NV + 1) + li];
+            if (es1) old1 = ring[i1 * (NV + 1) + li];
+            if constexpr (NS > 2) {
+                if (es2) old2 = ring[(G1 + i2) * (NV + 1) + li];
+            }
+            if constexpr (NS > 3) {
+                if (es3) old3 = ring[(G1 + G2 + i3) * (NV + 1) + li];
+            }
         }
         V cen0, cen1, cen2, cen3, v0, v1, v2, v3;
         v0 = wt_fused_vstage<T, K, 0>(w0, kk, cur, cen0);
-        if constexpr (!WA) buf[0][gl] = v0;
+        if constexpr (!WA) {
+            if (eh0) buf[0][gl] = v0;
+        }
         if constexpr (NS > 1) {
-            v1 = wt_fused_vstage<T, K, A1>(w1, kk, c1, cen1);
-            if constexpr (!WA) buf[A1][gl] = v1;
+            v1 = zero;
+            if (ev1) v1 = wt_fused_vstage<T, K, A1>(w1, kk, c1, cen1);
+            if constexpr (!WA) {
+                if (eh1) buf[A1][gl] = v1;
+            }
         }
         if constexpr (NS > 2) {
-            v2 = wt_fused_vstage<T, K, A2>(w2, kk, c2, cen2);
-            if constexpr (!WA) buf[A2][gl] = v2;
+            v2 = zero;
+            if (ev2) v2 = wt_fused_vstage<T, K, A2>(w2, kk, c2, cen2);
+            if constexpr (!WA) {
+                if (eh2) buf[A2][gl] = v2;
+            }
         }
         if constexpr (NS > 3) {
-            v3 = wt_fused_vstage<T, K, A3>(w3, kk, c3, cen3);
-            buf[A3][gl] = v3;
+            v3 = zero;
+            if (ev3) v3 = wt_fused_vstage<T, K, A3>(w3, kk, c3, cen3);
+            if (eh3) buf[A3][gl] = v3;
         }
-        if constexpr (!WA) __syncthreads();
-        V n0;
-        if constexpr (WA) n0 = wt_hfilter_dpp<K, (D <= 4 ? D : 4)>(v0);
-        else n0 = wt_hfilter_lds<T, K, D, NL>(buf[0], gl, v0);
-        const V d0 = f4_sub(cen0, n0);
-        if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
+        if constexpr (!WA) {
+            if (eh0) __syncthreads();                         // (no scale reads the LDS rows before step H0)
+        }
+        V n0 = zero, d0 = zero;
+        if (eh0) {
+            if constexpr (WA) n0 = wt_hfilter_dpp<K, (D <= 4 ? D : 4)>(v0);
+            else n0 = wt_hfilter_lds<T, K, D, NL>(buf[0], gl, v0);
+            d0 = f4_sub(cen0, n0);
+        }
+        if (es0) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
         if constexpr (HIST && PX == 4) {
             // the same predicate as the store of this row: chunk row k - (LAT_IN + LAG0) in [0, span)
             // (wave-uniform) and a lane that owns stored pixels
-            if ((unsigned)(k - (LAT_IN + LAG0)) < span && lane_store) {
+            if ((!PROL || k >= ST0) && (unsigned)(k - (LAT_IN + LAG0)) < span && lane_store) {
                 const uint32_t b[4] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z),
                                        __float_as_uint(d0.w)};
 #pragma unroll
@@ -618,25 +666,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                     if (FAST || x + j < g.W) atomicAdd(&lh[(b[j] & 0x7fffffffu) >> 20], 1u);
             }
         }
-        if constexpr (ST_ON && (NS == 1)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
+        if constexpr (NS == 1) {
+            if (esc) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n0);
+        }
         V d1 = zero, d2 = zero, d3 = zero, n1 = zero, n2 = zero, n3 = zero;
         if constexpr (NS > 1) {
-            if constexpr (WA) n1 = wt_hfilter_dpp<K, ((D << A1) <= 4 ? (D << A1) : 4)>(v1);
-            else n1 = wt_hfilter_lds<T, K, (D << A1), NL>(buf[A1], gl, v1);
-            d1 = f4_sub(cen1, n1);
-            if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
-            if constexpr (ST_ON && (NS == 2)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
+            if (eh1) {
+                if constexpr (WA) n1 = wt_hfilter_dpp<K, ((D << A1) <= 4 ? (D << A1) : 4)>(v1);
+                else n1 = wt_hfilter_lds<T, K, (D << A1), NL>(buf[A1], gl, v1);
+                d1 = f4_sub(cen1, n1);
+            }
+            if (es1) wt_bstore4v<WT_FUSED_W_AUX>(rw1, at(LAG1), d1);
+            if constexpr (NS == 2) {
+                if (esc) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n1);
+            }
             if constexpr (NS > 2) {
-                if constexpr (WA) n2 = wt_hfilter_dpp<K, ((D << A2) <= 4 ? (D << A2) : 4)>(v2);
-                else n2 = wt_hfilter_lds<T, K, (D << A2), NL>(buf[A2], gl, v2);
-                d2 = f4_sub(cen2, n2);
-                if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
-                if constexpr (ST_ON && (NS == 3)) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
+                if (eh2) {
+                    if constexpr (WA) n2 = wt_hfilter_dpp<K, ((D << A2) <= 4 ? (D << A2) : 4)>(v2);
+                    else n2 = wt_hfilter_lds<T, K, (D << A2), NL>(buf[A2], gl, v2);
+                    d2 = f4_sub(cen2, n2);
+                }
+                if (es2) wt_bstore4v<WT_FUSED_W_AUX>(rw2, at(LAG2), d2);
+                if constexpr (NS == 3) {
+                    if (esc) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n2);
+                }
                 if constexpr (NS > 3) {
-                    n3 = wt_hfilter_lds<T, K, (D << A3), NL>(buf[A3], gl, v3);
-                    d3 = f4_sub(cen3, n3);
-                    if constexpr (ST_ON) wt_bstore4v<WT_FUSED_W_AUX>(rw3, at(LAG3), d3);
-                    if constexpr (ST_ON) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n3);
+                    if (eh3) {
+                        n3 = wt_hfilter_lds<T, K, (D << A3), NL>(buf[A3], gl, v3);
+                        d3 = f4_sub(cen3, n3);
+                    }
+                    if (es3) wt_bstore4v<WT_FUSED_W_AUX>(rw3, at(LAG3), d3);
+                    if (esc) wt_bstore4v<WT_FUSED_C_AUX>(rc, at(LAGC), n3);
                     c3 = n2;
                 }
             }
@@ -651,10 +711,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                 V s1 = f4_add(old1, d1);                                  // row t - LAG1
                 V s2 = s1;
                 if constexpr (NS > 2) s2 = f4_add(old2, d2);              // row t - LAG2
-                ring[i1 * (NV + 1) + li] = s;
-                if constexpr (NS > 2) ring[(G1 + i2) * (NV + 1) + li] = s1;
+                // (a ring slot written at step k is read when the next scale's detail row of the same
+                //  image row comes out: needed from the step at which that row is a stored one)
+                if (es0) ring[i1 * (NV + 1) + li] = s;
+                if constexpr (NS > 2) {
+                    if (es1) ring[(G1 + i2) * (NV + 1) + li] = s1;
+                }
                 if constexpr (NS > 3) {
-                    ring[(G1 + G2 + i3) * (NV + 1) + li] = s2;
+                    if (es2) ring[(G1 + G2 + i3) * (NV + 1) + li] = s2;
                     s = f4_add(old3, d3);                                 // row t - LAG3
                 } else {
                     s = s2;
@@ -666,7 +730,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : (NS == 3 ? n2 : n3)));
             // the finished reconstruction is a write-once stream; an intermediate sum is re-read
             // by the next pass
-            if constexpr (ST_ON) wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
+            if (esc) wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
         }
         c1 = n0;
         koff += step_bytes;
@@ -688,36 +752,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     const int nexact = nsteps;
 #endif
     int kb0 = 0;
-#ifdef WT_FUSED_PEEL
-    // No plane stores before step LAT_IN + LAG0 >= U: the first trip through the body runs a copy
-    // of the steps WITHOUT store instructions (every one of them would be parked - dropped by the
-    // range check, but issued, addressed and counted: 9 % of a chunk's store instructions).
-    if constexpr (LAT_IN + LAG0 >= U) {
-#pragma unroll
-        for (int kk = 0; kk < U; ++kk) step(0, kk, std::false_type{});
-        kb0 = U;
-    }
-#endif
-    // The compiler sizes every `s_waitcnt vmcnt(N)` of the loop from the FEWEST vector-memory
-    // operations that can lie between a prefetch and its use on any path into that point - and on
-    // the path from here the PD prefetches would be back to back, while in the steady state a
-    // step's stores sit between them.  Without the padding below the first PD steps of every trip
-    // through the unrolled body wait with vmcnt(2..15), i.e. for the STORES of the previous steps
-    // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
-    // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
-    // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
+    if constexpr (PRO > 0) {
+        // the peeled prologue: PRO / U copies of the unrolled body with constant step numbers
+        // (compile-time recursion: the step number must be a constant in every copy; as a `#pragma
+        // unroll` loop around the early exit the body is NOT unrolled - the register window would
+        // land in scratch memory)
+        auto prologue = [&](auto self, auto ic) -> bool {
+            constexpr int KK = decltype(ic)::value;
+            if constexpr (KK < PRO) {
+                if (KK >= nexact) return true;               // a chunk shorter than the prologue
+                step(KK / U * U, KK % U, std::true_type{});
+                return self(self, std::integral_constant<int, KK + 1>{});
+            } else {
+                return false;
+            }
+        };
+        if (prologue(prologue, std::integral_constant<int, 0>{})) goto done;
+        kb0 = PRO;
+    } else {
+        // (no prologue: NS = 1, or -DWT_FUSED_NO_PROLOGUE)
+        // The compiler sizes every `s_waitcnt vmcnt(N)` of the loop from the FEWEST vector-memory
+        // operations that can lie between a prefetch and its use on any path into that point - and on
+        // the path from here the PD prefetches would be back to back, while in the steady state a
+        // step's stores sit between them.  Without the padding below the first PD steps of every trip
+        // through the unrolled body wait with vmcnt(2..15), i.e. for the STORES of the previous steps
+        // to be acknowledged (once per U steps the wave drains its store queue).  Issue as many parked
+        // stores (out-of-range offset: dropped by the range check, no memory traffic) as the steady
+        // state has behind the prefetches, so that every wait in the loop becomes vmcnt(~PD*ops/step).
 #ifndef WT_FUSED_NO_VMPAD
-    {
         constexpr int ST = NS + 1 + (SUM ? 1 : 0);          // stores per step
 #pragma unroll
         for (int i = 0; i < PD * ST; ++i) wt_bstore4v<0>(rc, WT_FUSED_PARKED + 16u * i, zero);   // distinct: not merged
-    }
 #endif
+    }
     for (int kb = kb0; kb < nsteps; kb += U) {
 #pragma unroll
         for (int kk = 0; kk < U; ++kk) {
             if (kb + kk >= nexact) goto done;
-            step(kb, kk, std::true_type{});
+            step(kb, kk, std::false_type{});
         }
     }
 done:;

@@ -1600,7 +1600,11 @@ __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows,
         const int r = (int)(item / nchunk), c = (int)(item - (int64_t)r * nchunk);
         const float *row = p + (int64_t)r * P4 * 4;
 #pragma unroll
+#ifdef WT_HIST_PLAIN_LOADS
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4 *>(row + 4 * min(c * 256 * U + 256 * u + (int)threadIdx.x, X4 - 1));
+#else
         for (int u = 0; u < U; ++u) v[u] = wt_ldnt4(row + 4 * min(c * 256 * U + 256 * u + (int)threadIdx.x, X4 - 1));
+#endif
     };
     auto bin = [&](int64_t item, const float4 (&v)[U]) {
         const int c = (int)(item % nchunk);
