@@ -315,6 +315,25 @@ int wt_filter2d_ex(wt_plan *plan, int src, int dst, const float *kernel, int kh,
                    int ax, int border, int flags);
 /* elementwise dst = a OP b: 0 a-b, 1 a+b, 2 a*b, 3 a/b, 4 (a+b)/b  (watroo/utils.py:259,280-281,288) */
 int wt_binary(wt_plan *plan, int op, int a, int b, int dst);
+/* Generic tap-list operator: atrous_convolution(image, kernel, bilateral_variance, s, mode) for
+ * ANY kernel and np.pad mode (watroo/wavelets.py:74-105) - what the tuned operators above do not
+ * take (non-separable kernels, even / large tap counts, borders other than 'symmetric').
+ *   var == WT_PLANE_NONE:  dst = [center_weight * I] + sum_t weights[t] * I_t      (tap order kept)
+ *   else (range weights):  dst = ([cw * I] + sum_t e_t I_t) / ([cw] + sum_t e_t),
+ *                          e_t = weights[t] * exp(-(I - I_t)^2 / var / 2)            (ref:97)
+ * I_t = the sample at offsets[3t .. 3t+2] = (dz, dy, dx); the border rule pad_mode (WT_PAD_*:
+ * np.pad's 'symmetric', 'reflect', 'edge', 'wrap', 'constant' with fill_value) applies per axis.
+ * depth = 0: an image (1 x N: a signal), Z > 0: a (Z, Y, X) cube stored as a (Z*Y) x X image.
+ * One sample per thread, taps read from a device list (<= 65536): a correctness path, not a
+ * tuned one.  The Python layer builds the list in the reference's tap order. */
+#define WT_PAD_SYMMETRIC 0
+#define WT_PAD_REFLECT 1
+#define WT_PAD_EDGE 2
+#define WT_PAD_WRAP 3
+#define WT_PAD_CONSTANT 4
+int wt_taps_conv(wt_plan *plan, int src, int var, int dst, const int32_t *offsets,
+                 const float *weights, int ntaps, float center_weight, int has_center,
+                 int depth, int pad_mode, float fill_value);
 /* multiresolution-support update of a residual plane (watroo/utils.py:263-276):
  * sig = significance(plane, tau); hard: mrs = persistent ? max(mrs,sig) : sig, plane *= mrs;
  * soft: mrs = persistent ? mrs*sig : sig, plane *= mrs**inv_pow */
@@ -361,6 +380,10 @@ int wt64_local_variance(wt_plan64 *plan, int src, int dst, int s, double f1, dou
  * taps_reversed as flag bit3 of wt_bilateral_conv */
 int wt64_bilateral_conv(wt_plan64 *plan, int src, int var, int dst, int s, int depth,
                         int taps_reversed);
+/* wt_taps_conv in float64 */
+int wt64_taps_conv(wt_plan64 *plan, int src, int var, int dst, const int32_t *offsets,
+                   const double *weights, int ntaps, double center_weight, int has_center,
+                   int depth, int pad_mode, double fill_value);
 /* device copy of a window between planes of two plans (crop of atrous_recursive, :405-406) */
 int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, int dst_plane, int64_t sy,
                      int64_t sx, int64_t dy, int64_t dx, int64_t rows, int64_t cols);

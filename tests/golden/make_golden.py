@@ -674,6 +674,92 @@ def g12_three_dimensional():
     save("g12_3d", "semantic(cv2 stand-in)", **out)
 
 
+
+def g21_general_operator():
+    """Round 3: what the HIP engine used to refuse.  (a) atrous_convolution (the reference's own numpy
+    loop, wavelets.py:74-105 - no cv2: HARD pin) with non-separable, rectangular and even-sized
+    kernels, every np.pad mode the engine implements, with and without the range weights, on
+    signals, images and cubes; (b) user-defined scaling functions with an EVEN number of taps and
+    with more than 15 taps through convolution() / AtrousTransform (cv2 stand-in: semantic pin;
+    1-D: scipy itself, hard)."""
+    import cv2 as _cv2
+    from watroo.wavelets import AbstractScalingFunction
+    out = {}
+    rng = np.random.default_rng(2100)
+    a = img((37, 53), 211)
+    sig = img((120,), 212)
+    cube = img((6, 9, 11), 213)
+    var = (np.abs(img((37, 53), 214)) + 0.3).astype(np.float32)
+    out["img"], out["sig"], out["cube"], out["var"] = a, sig, cube, var
+    kernels = {"k3x3": rng.random((3, 3)), "k3x5": rng.random((3, 5)), "k4x4": rng.random((4, 4)),
+               "k2x2": rng.random((2, 2)), "k5x1": rng.random((5, 1))}
+    for name, k in kernels.items():
+        kernels[name] = k / k.sum()
+        out[name] = kernels[name]
+    out["k1d4"] = rng.random(4)
+    out["k1d4"] /= out["k1d4"].sum()
+    out["k3d"] = rng.random((3, 3, 3))
+    out["k3d"] /= out["k3d"].sum()
+    _real = _cv2.filter2D
+
+    def _forbidden(*args, **kw):
+        raise AssertionError("hard-pin group must not call cv2.filter2D")
+    _cv2.filter2D = _forbidden
+    try:
+        for name, k in kernels.items():
+            for mode in ("symmetric", "reflect", "edge", "wrap", "constant"):
+                for s in (0, 2):
+                    out[f"ac_{name}_{mode}_s{s}"] = atrous_convolution(a, k, s=s, mode=mode)
+            out[f"acb_{name}_symmetric_s1"] = atrous_convolution(a, k, var, s=1)
+            out[f"acb_{name}_reflect_s1"] = atrous_convolution(a, k, var, s=1, mode="reflect")
+        out["ac_f64_k4x4_s1"] = atrous_convolution(a.astype(np.float64) * 1e3 + 7e5, kernels["k4x4"], s=1)
+        out["acb_f64_k3x3_s1"] = atrous_convolution(a.astype(np.float64), kernels["k3x3"], var.astype(np.float64), s=1,
+                                                    mode="edge")
+        for mode in ("symmetric", "reflect", "wrap"):
+            out[f"ac1_{mode}_s1"] = atrous_convolution(sig, out["k1d4"], s=1, mode=mode)
+            out[f"ac3_{mode}_s1"] = atrous_convolution(cube, out["k3d"], s=1, mode=mode)
+        out["acb3_symmetric_s0"] = atrous_convolution(cube, out["k3d"], np.float32(0.7), s=0)
+    finally:
+        _cv2.filter2D = _real
+
+    class Haar2(AbstractScalingFunction):
+        coefficients_1d = np.array([0.5, 0.5])
+        sigma_e_1d = np.array([0.7, 0.35, 0.18, 0.09, 0.045, 0.02])
+        sigma_e_2d = np.array([0.87, 0.22, 0.1, 0.05, 0.025, 0.012])
+        sigma_e_3d = np.array([0.95, 0.12, 0.04, 0.014, 0.005])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('haar2', *args, **kwargs)
+
+    class Even4(AbstractScalingFunction):
+        coefficients_1d = np.array([0.1, 0.4, 0.3, 0.2])
+        sigma_e_1d = np.array([0.7, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.9, 0.2, 0.09, 0.04, 0.02, 0.01])
+        sigma_e_3d = np.array([0.95, 0.12, 0.04, 0.014, 0.005])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('even4', *args, **kwargs)
+
+    class Long17(AbstractScalingFunction):
+        coefficients_1d = np.hanning(19)[1:-1] / np.hanning(19)[1:-1].sum()
+        sigma_e_1d = np.array([0.5, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.6, 0.2, 0.09, 0.04, 0.02, 0.01])
+        sigma_e_3d = np.array([0.7, 0.12, 0.04, 0.014, 0.005])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('long17', *args, **kwargs)
+
+    for name, cls in (("haar2", Haar2), ("even4", Even4), ("long17", Long17)):
+        out[f"{name}_taps"] = cls.coefficients_1d
+        out[f"{name}_conv2_s1"] = convolution(a, cls(2), s=1)
+        out[f"{name}_conv1_s2"] = convolution(sig, cls(1), s=2)
+        out[f"{name}_coef2_L3"] = AtrousTransform(cls)(a, 3).data
+        out[f"{name}_coef1_L2"] = AtrousTransform(cls)(sig, 2).data
+        out[f"{name}_den2"] = denoise(a.copy(), [5, 3], cls)
+    out["even4_coef3_L2"] = AtrousTransform(Even4)(cube, 2).data
+    out["even4_coef2_f64_L2"] = AtrousTransform(Even4)(a.astype(np.float64) + 1e4, 2).data
+    save("g21_general", "atrous_convolution: hard; scaling functions: 1-D hard, 2-D/3-D semantic(cv2 stand-in)", **out)
+
 if __name__ == "__main__":
     if "--only" in sys.argv:                      # e.g. --only g13_richardson_lucy_fft
         globals()[sys.argv[sys.argv.index("--only") + 1]]()
@@ -699,3 +785,4 @@ if __name__ == "__main__":
         g18_recursive_nd_bilateral()
         g19_custom_bilateral_nd()
         g20_float64()
+        g21_general_operator()

@@ -354,3 +354,75 @@ def test_exact_median_with_the_replicated_first_level_histogram(L, shape):
         plan.upload(0, a)
         assert plan.abs_median(0) == np.median(np.abs(a)), kind
     plan.close()
+
+
+# --------------------------------------------------------------------------- what used to be refused
+def test_general_atrous_convolution_vs_reference_golden(L):
+    """g21: atrous_convolution with non-separable / rectangular / even-sized kernels, the np.pad
+    modes 'symmetric', 'reflect', 'edge', 'wrap', 'constant', range weights, signals and cubes,
+    float32 and float64 - the generic tap-list operator (wt_taps_conv / wt64_taps_conv) against
+    the reference's own output (hard pin: its pure-numpy loop)."""
+    from conftest import load_golden
+    import wavelets_amd as WA
+    from wavelets_amd.wavelets import atrous_convolution
+    g = load_golden("g21_general")
+    a, sig, cube, var = g["img"], g["sig"], g["cube"], g["var"]
+    tol = 2e-6 * float(np.abs(a).max())
+    for name in ("k3x3", "k3x5", "k4x4", "k2x2", "k5x1"):
+        k = g[name]
+        for mode in ("symmetric", "reflect", "edge", "wrap", "constant"):
+            for s in (0, 2):
+                got = atrous_convolution(a, k, s=s, mode=mode)
+                assert got.dtype == np.float32
+                assert float(np.abs(got - g[f"ac_{name}_{mode}_s{s}"]).max()) <= tol, (name, mode, s)
+        for mode in ("symmetric", "reflect"):
+            got = atrous_convolution(a, k, var, s=1, mode=mode)
+            assert float(np.abs(got - g[f"acb_{name}_{mode}_s1"]).max()) <= 2e-5 * float(np.abs(a).max()), (name, mode)
+    a64 = a.astype(np.float64) * 1e3 + 7e5
+    got = atrous_convolution(a64, g["k4x4"], s=1)
+    assert got.dtype == np.float64 and float(np.abs(got - g["ac_f64_k4x4_s1"]).max()) <= 1e-12 * float(np.abs(a64).max())
+    got = atrous_convolution(a.astype(np.float64), g["k3x3"], var.astype(np.float64), s=1, mode="edge")
+    assert float(np.abs(got - g["acb_f64_k3x3_s1"]).max()) <= 1e-11 * float(np.abs(a).max())
+    for mode in ("symmetric", "reflect", "wrap"):
+        assert float(np.abs(atrous_convolution(sig, g["k1d4"], s=1, mode=mode) - g[f"ac1_{mode}_s1"]).max()) <= tol
+        assert float(np.abs(atrous_convolution(cube, g["k3d"], s=1, mode=mode) - g[f"ac3_{mode}_s1"]).max()) <= tol
+    got = atrous_convolution(cube, g["k3d"], np.float32(0.7), s=0)
+    assert float(np.abs(got - g["acb3_symmetric_s0"]).max()) <= 2e-5 * float(np.abs(cube).max())
+    out = np.empty_like(a)
+    assert atrous_convolution(a, g["k3x3"], s=1, mode="wrap", output=out) is out       # ref:78-79: written in place
+    with pytest.raises(NotImplementedError, match="linear_ramp"):
+        atrous_convolution(a, g["k3x3"], mode="linear_ramp")
+
+
+def test_scaling_functions_with_even_or_many_taps_vs_reference_golden(L):
+    """g21: user-defined AbstractScalingFunction subclasses with 2, 4 (even) and 17 taps through
+    convolution(), AtrousTransform and denoise - 1-D, 2-D, 3-D, float32 and float64."""
+    from conftest import load_golden
+    import wavelets_amd as WA
+    g = load_golden("g21_general")
+    a, sig, cube = g["img"], g["sig"], g["cube"]
+    tol = 2e-6 * float(np.abs(a).max())
+
+    def make(name, taps, e1, e2, e3):
+        class SF(WA.wavelets.AbstractScalingFunction):
+            coefficients_1d = np.asarray(taps)
+            sigma_e_1d, sigma_e_2d, sigma_e_3d = np.asarray(e1), np.asarray(e2), np.asarray(e3)
+
+            def __init__(self, *args, **kwargs):
+                super().__init__(name, *args, **kwargs)
+        return SF
+    e = {"haar2": ([0.7, 0.35, 0.18, 0.09, 0.045, 0.02], [0.87, 0.22, 0.1, 0.05, 0.025, 0.012], [0.95, 0.12, 0.04, 0.014, 0.005]),
+         "even4": ([0.7, 0.3, 0.2, 0.12, 0.08, 0.06], [0.9, 0.2, 0.09, 0.04, 0.02, 0.01], [0.95, 0.12, 0.04, 0.014, 0.005]),
+         "long17": ([0.5, 0.3, 0.2, 0.12, 0.08, 0.06], [0.6, 0.2, 0.09, 0.04, 0.02, 0.01], [0.7, 0.12, 0.04, 0.014, 0.005])}
+    for name in ("haar2", "even4", "long17"):
+        cls = make(name, g[f"{name}_taps"], *e[name])
+        assert float(np.abs(WA.convolution(a, cls(2), s=1) - g[f"{name}_conv2_s1"]).max()) <= tol, name
+        assert float(np.abs(WA.convolution(sig, cls(1), s=2) - g[f"{name}_conv1_s2"]).max()) <= tol, name
+        c = WA.AtrousTransform(cls)(a, 3)
+        assert c.data.dtype == np.float32 and float(np.abs(c.data - g[f"{name}_coef2_L3"]).max()) <= tol, name
+        assert float(np.abs(WA.AtrousTransform(cls)(sig, 2).data - g[f"{name}_coef1_L2"]).max()) <= tol, name
+        assert float(np.abs(WA.denoise(a.copy(), [5, 3], cls) - g[f"{name}_den2"]).max()) <= 5 * tol, name
+    cls = make("even4", g["even4_taps"], *e["even4"])
+    assert float(np.abs(WA.AtrousTransform(cls)(cube, 2).data - g["even4_coef3_L2"]).max()) <= 2e-6 * float(np.abs(cube).max())
+    c64 = WA.AtrousTransform(cls)(a.astype(np.float64) + 1e4, 2)
+    assert c64.data.dtype == np.float64 and float(np.abs(c64.data - g["even4_coef2_f64_L2"]).max()) <= 1e-11 * 1e4

@@ -462,3 +462,38 @@ def test_float64_and_integer_inputs_vs_reference():
     assert abs(c.get_noise() - g["noise"]) <= 1e-12 * g["noise"]
     close(c.significance(3.0, 1), g["sig_soft_s1"], 1e-12)
     close(O.generalized_anscombe(g["pos"]), g["ans_pos"], 1e-12)
+
+
+def test_g21_general_kernels_pad_modes_and_even_taps():
+    """g21 (round 3): the oracle's restatement of the reference's atrous_convolution loop for ANY
+    kernel / np.pad mode (non-separable, rectangular, even-sized; signals, images, cubes; with and
+    without range weights) is BIT-identical to the reference (hard pin: pure numpy), and
+    convolution_taps_nd / atrous_standard_taps_nd reproduce the reference's convolution() /
+    AtrousTransform for scaling functions with an even number of taps and with 17 taps (cv2
+    stand-in; 1-D: scipy itself)."""
+    g = load_golden("g21_general")
+    a, sig, cube, var = g["img"], g["sig"], g["cube"], g["var"]
+    for name in ("k3x3", "k3x5", "k4x4", "k2x2", "k5x1"):
+        k = g[name]
+        for mode in ("symmetric", "reflect", "edge", "wrap", "constant"):
+            for s in (0, 2):
+                np.testing.assert_array_equal(O.atrous_convolution_nd(a, k, None, s, mode), g[f"ac_{name}_{mode}_s{s}"])
+        for mode in ("symmetric", "reflect"):
+            got = O.atrous_convolution_nd(a, k, var, 1, mode)
+            np.testing.assert_allclose(got, g[f"acb_{name}_{mode}_s1"], rtol=0, atol=2e-6 * np.abs(a).max())
+    np.testing.assert_array_equal(O.atrous_convolution_nd(a.astype(np.float64) * 1e3 + 7e5, g["k4x4"], None, 1),
+                                  g["ac_f64_k4x4_s1"])
+    for mode in ("symmetric", "reflect", "wrap"):
+        np.testing.assert_array_equal(O.atrous_convolution_nd(sig, g["k1d4"], None, 1, mode), g[f"ac1_{mode}_s1"])
+        np.testing.assert_array_equal(O.atrous_convolution_nd(cube, g["k3d"], None, 1, mode), g[f"ac3_{mode}_s1"])
+    for name in ("haar2", "even4", "long17"):
+        taps = g[f"{name}_taps"]
+        tol = 2e-6 * float(np.abs(a).max())
+        np.testing.assert_allclose(O.convolution_taps_nd(a, taps, 1), g[f"{name}_conv2_s1"], rtol=0, atol=tol)
+        np.testing.assert_allclose(O.convolution_taps_nd(sig, taps, 2), g[f"{name}_conv1_s2"], rtol=0, atol=tol)
+        np.testing.assert_allclose(O.atrous_standard_taps_nd(a, 3, taps), g[f"{name}_coef2_L3"], rtol=0, atol=tol)
+        np.testing.assert_allclose(O.atrous_standard_taps_nd(sig, 2, taps), g[f"{name}_coef1_L2"], rtol=0, atol=tol)
+    np.testing.assert_allclose(O.atrous_standard_taps_nd(cube, 2, g["even4_taps"]), g["even4_coef3_L2"], rtol=0,
+                               atol=2e-6 * float(np.abs(cube).max()))
+    np.testing.assert_allclose(O.atrous_standard_taps_nd(a.astype(np.float64) + 1e4, 2, g["even4_taps"]),
+                               g["even4_coef2_f64_L2"], rtol=0, atol=1e-11 * 1e4)

@@ -113,6 +113,8 @@ SIGNATURES = {
     "wt_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp, _c.c_int, _c.c_int, _c.c_int]),
     "wt_filter2d_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _fp] + [_c.c_int] * 6),
     "wt_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_taps_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _fp, _c.c_int,
+                                _c.c_float, _c.c_int, _c.c_int, _c.c_int, _c.c_float]),
     "wt_mrs_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
                                  _c.c_int, _c.c_float]),
     "wt_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
@@ -133,6 +135,9 @@ SIGNATURES = {
                                        _c.c_int]),
     "wt64_copy_window": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64, _i64, _i64, _i64,
                                     _i64]),
+    "wt64_taps_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32),
+                                  _c.POINTER(_c.c_double), _c.c_int, _c.c_double, _c.c_int, _c.c_int, _c.c_int,
+                                  _c.c_double]),
     "wt64_abs_median": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt64_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int,
                                      _c.c_int, _c.c_int]),
@@ -620,6 +625,17 @@ class Plan:
         check(load().wt_binary(self._h, {"sub": 0, "add": 1, "mul": 2, "div": 3,
                                          "add_div": 4}[op], a, b, dst))
 
+    def taps_conv(self, src, var, dst, offsets, weights, center_weight=None, depth=0, pad_mode=0,
+                  fill_value=0.0):
+        """generic tap-list operator (wt_taps_conv): offsets (n, 3) int32 = (dz, dy, dx)"""
+        offs = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 3)
+        wts = np.ascontiguousarray(weights, dtype=np.float32).ravel()
+        assert len(offs) == len(wts)
+        check(load().wt_taps_conv(self._h, src, var, dst, offs.ctypes.data_as(_c.POINTER(_c.c_int32)),
+                                  wts.ctypes.data_as(_fp), len(wts),
+                                  0.0 if center_weight is None else float(center_weight),
+                                  int(center_weight is not None), depth, pad_mode, float(fill_value)))
+
     def mrs_update(self, plane, mrs_plane, tau, soft, noise_plane, persistent, inv_pow):
         check(load().wt_mrs_update(self._h, plane, mrs_plane, float(tau), int(soft), noise_plane,
                                    int(persistent), float(inv_pow)))
@@ -784,6 +800,16 @@ class Plan64:
     def binary(self, op, a, b, dst):
         code = {"add": 0, "sub": 1, "mul": 2, "div": 3, "add_div": 4}[op]
         check(load().wt64_binary(self._h, code, a, b, dst))
+
+    def taps_conv(self, src, var, dst, offsets, weights, center_weight=None, depth=0, pad_mode=0,
+                  fill_value=0.0):
+        offs = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 3)
+        wts = np.ascontiguousarray(weights, dtype=np.float64).ravel()
+        assert len(offs) == len(wts)
+        check(load().wt64_taps_conv(self._h, src, var, dst, offs.ctypes.data_as(_c.POINTER(_c.c_int32)),
+                                    wts.ctypes.data_as(_dp), len(wts),
+                                    0.0 if center_weight is None else float(center_weight),
+                                    int(center_weight is not None), depth, pad_mode, float(fill_value)))
 
     def copy(self, src, dst):
         self.copy_window_from(self, src, dst, 0, 0, 0, 0, self.H, self.W)

@@ -286,6 +286,7 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
     (void)hipFree(c->d_partials);
     (void)hipHostFree(c->h_pinned);
     (void)hipFree(c->d_psf);
+    if (c->d_taps) (void)hipFree(c->d_taps);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -2164,6 +2165,58 @@ extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, in
 {
     WtGuard guard_(ctx_of(p));
     return wt_filter2d_ex(p, src, dst, kernel, kh, kw, kh / 2, kw / 2, WT_BORDER_SYMMETRIC, flags);
+}
+
+// Tap list of the generic operator on the device: [ntaps x 3 int32 offsets][ntaps x weight]; the
+// previous list may still be in use by a kernel on the stream - the copy is stream-ordered.
+#define WT_MAX_TAPLIST 65536
+template <typename T>
+static int upload_taplist(wt_ctx *c, const int32_t *offs, const T *wts, int ntaps, const int32_t **d_offs, const T **d_wts)
+{
+    if (ntaps < 0 || ntaps > WT_MAX_TAPLIST) WT_FAIL("tap list of %d entries (0..%d supported)", ntaps, WT_MAX_TAPLIST);
+    const size_t need = (size_t)std::max(ntaps, 1);
+    if (c->d_taps_cap < need) {
+        WT_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_taps) (void)hipFree(c->d_taps);
+        c->d_taps = nullptr;
+        c->d_taps_cap = 0;
+        WT_HIP(hipMalloc(&c->d_taps, need * (3 * sizeof(int32_t) + sizeof(double))));
+        c->d_taps_cap = need;
+    }
+    char *base = (char *)c->d_taps;
+    // (pageable sources: hipMemcpyAsync stages them before it returns)
+    if (ntaps) {
+        WT_HIP(hipMemcpyAsync(base, offs, (size_t)ntaps * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        WT_HIP(hipMemcpyAsync(base + c->d_taps_cap * 3 * sizeof(int32_t), wts, (size_t)ntaps * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    }
+    *d_offs = (const int32_t *)base;
+    *d_wts = (const T *)(base + c->d_taps_cap * 3 * sizeof(int32_t));
+    return 0;
+}
+
+extern "C" int wt_taps_conv(wt_plan *p, int src, int var, int dst, const int32_t *offsets, const float *weights, int ntaps,
+                            float center_weight, int has_center, int depth, int pad_mode, float fill_value)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || (ntaps > 0 && (!offsets || !weights))) WT_FAIL("wt_taps_conv: null pointer");
+    if (p->nranks > 1) WT_FAIL("wt_taps_conv: the generic operator is single-GPU (whole images)");
+    if (src == dst || var == dst) WT_FAIL("wt_taps_conv: dst must differ from src and var");
+    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_CONSTANT) WT_FAIL("wt_taps_conv: unknown pad mode %d", pad_mode);
+    if (depth < 0 || (depth > 0 && p->g.nrows % depth)) WT_FAIL("wt_taps_conv: %d rows are not a multiple of depth %d", p->g.nrows, depth);
+    float *in = nullptr, *o = nullptr, *v = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, dst, &o));
+    if (var != WT_PLANE_NONE) WT_TRY(plane_base(p, var, &v));
+    const int32_t *d_offs = nullptr;
+    const float *d_wts = nullptr;
+    WT_TRY(upload_taplist<float>(p->ctx, offsets, weights, ntaps, &d_offs, &d_wts));
+    const int Z = depth > 0 ? depth : 1, Y = p->g.nrows / Z;
+    ProfScope ps(p->ctx, "wt_taps_kernel");
+    hipLaunchKernelGGL(wt_taps_kernel<float>, dim3((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)), dim3(256), 0, p->ctx->stream,
+                       (const float *)in, (const float *)v, o, p->g.W, p->g.P, Y, Z, d_offs, d_wts, ntaps, center_weight, has_center, pad_mode,
+                       fill_value);
+    WT_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst)

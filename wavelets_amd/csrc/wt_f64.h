@@ -1025,6 +1025,29 @@ extern "C" int wt64_bilateral_conv(wt_plan64 *p, int src, int var, int dst, int 
     return 0;
 }
 
+/* wt_taps_conv in float64 */
+extern "C" int wt64_taps_conv(wt_plan64 *p, int src, int var, int dst, const int32_t *offsets, const double *weights, int ntaps,
+                              double center_weight, int has_center, int depth, int pad_mode, double fill_value)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || (ntaps > 0 && (!offsets || !weights))) WT_FAIL("wt64_taps_conv: null pointer");
+    if (src == dst || var == dst) WT_FAIL("wt64_taps_conv: dst must differ from src and var");
+    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_CONSTANT) WT_FAIL("wt64_taps_conv: unknown pad mode %d", pad_mode);
+    if (depth < 0 || (depth > 0 && p->g.H % depth)) WT_FAIL("wt64_taps_conv: %d rows are not a multiple of depth %d", p->g.H, depth);
+    double *in = nullptr, *o = nullptr, *v = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    WT_TRY(plan64_base(p, dst, &o));
+    if (var != WT_PLANE_NONE) WT_TRY(plan64_base(p, var, &v));
+    const int32_t *d_offs = nullptr;
+    const double *d_wts = nullptr;
+    WT_TRY(upload_taplist<double>(p->ctx, offsets, weights, ntaps, &d_offs, &d_wts));
+    const int Z = depth > 0 ? depth : 1, Y = p->g.H / Z;
+    hipLaunchKernelGGL(wt_taps_kernel<double>, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, (const double *)v, o, p->g.W, p->g.P, Y, Z,
+                       d_offs, d_wts, ntaps, center_weight, has_center, pad_mode, fill_value);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
 /* dst[dst_plane][dy:dy+rows, dx:dx+cols] = src[src_plane][sy:sy+rows, sx:sx+cols] on the device (the
  * crop of atrous_recursive, watroo/wavelets.py:405-406) */
 extern "C" int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, int dst_plane, int64_t sy, int64_t sx, int64_t dy,

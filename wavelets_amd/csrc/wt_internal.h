@@ -96,6 +96,10 @@ struct wt_ctx {
     int partial_blocks = 0;
     void *h_pinned = nullptr;     // 64 KiB pinned host scratch
     float *d_psf = nullptr;       // PSF taps of wt_filter2d (<= 4096 floats)
+    // tap list of the generic operator (wt_taps_conv / wt64_taps_conv): 3 int32 offsets + one
+    // double-sized weight slot per tap, grown on demand
+    void *d_taps = nullptr;
+    size_t d_taps_cap = 0;        // taps
     // Marker a fused first pass leaves when it has histogrammed the first radix level of |plane| of
     // `prehist_plan` into d_hist (flag bit4 of wt_decompose / wt_decompose_pass).  wt_abs_median of
     // that plane then skips its first pass over the plane.  Dropped by any access to the plane

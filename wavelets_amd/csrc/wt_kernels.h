@@ -1403,6 +1403,70 @@ __global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic tap-list operator (round 3): the reference's atrous_convolution for ANY kernel and
+// np.pad mode (watroo/wavelets.py:74-105) - non-separable kernels, even or large tap counts,
+// 'symmetric' / 'reflect' / 'edge' / 'wrap' / 'constant' borders, with or without the range
+// weights, on signals (1 x N), images and (Z, Y, X) cubes stored as (Z*Y) x X images.
+//   plain:      out = kc * I + sum_t w_t * I_t                        (ref:79, 92-93; tap order kept)
+//   bilateral:  out = (kc * I + sum_t e_t * I_t) / (kc + sum_t e_t),  e_t = w_t * exp(-(I - I_t)^2 / var / 2)
+// I_t = the sample at offset (dz, dy, dx) under the border rule applied per axis.  One sample per
+// thread, taps from a device list: the fallback for everything the tuned kernels do not cover
+// (they take the separable built-in / user-defined taps under the symmetric border).
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int wt_pad_index(int i, int n, int mode)
+{
+    if ((unsigned)i < (unsigned)n) return i;
+    switch (mode) {
+        case WT_PAD_SYMMETRIC: return wt_refl(i, n);
+        case WT_PAD_REFLECT: {                           // d c b | a b c d | c b a  (no edge duplication)
+            if (n == 1) return 0;
+            const int p = 2 * n - 2;
+            int m = i % p;
+            if (m < 0) m += p;
+            return m < n ? m : p - m;
+        }
+        case WT_PAD_EDGE: return i < 0 ? 0 : n - 1;
+        case WT_PAD_WRAP: {
+            int m = i % n;
+            return m < 0 ? m + n : m;
+        }
+        default: return -1;                              // constant: the caller substitutes the fill value
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wt_taps_kernel(const T *in, const T *var, T *out, int W, int P, int Y, int Z,
+                                                      const int32_t *offs, const T *wts, int ntaps, T kc,
+                                                      int has_center, int mode, T cval)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int row = blockIdx.y; row < Z * Y; row += gridDim.y) {
+        const int z = row / Y, y = row - z * Y;
+        const T I = in[(int64_t)row * P + x];
+        T acc = has_center ? kc * I : (T)0, norm = has_center ? kc : (T)0;
+        const T iv = var ? var[(int64_t)row * P + x] : (T)1;
+        for (int t = 0; t < ntaps; ++t) {
+            const int zz = wt_pad_index(z + offs[3 * t], Z, mode);
+            const int yy = wt_pad_index(y + offs[3 * t + 1], Y, mode);
+            const int xx = wt_pad_index(x + offs[3 * t + 2], W, mode);
+            const T v = (zz < 0 || yy < 0 || xx < 0) ? cval : in[((int64_t)zz * Y + yy) * P + xx];
+            if (var) {
+                const T dlt = I - v;
+                const T e = wts[t] * exp(-(dlt * dlt) / iv / (T)2);     // ref:97
+                norm = norm + e;
+                acc = acc + v * e;
+            } else {
+                acc = acc + v * wts[t];                                  // ref:93
+            }
+        }
+        out[(int64_t)row * P + x] = var ? acc / norm : acc;
+    }
+}
+
 // elementwise binary ops of the RL iteration (watroo/utils.py:259,280-281,288)
 enum { WT_OP_SUB = 0, WT_OP_ADD = 1, WT_OP_MUL = 2, WT_OP_DIV = 3, WT_OP_ADD_DIV = 4 };
 __global__ __launch_bounds__(256) void wt_binary_kernel(const float *a, const float *b, float *dst,

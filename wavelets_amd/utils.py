@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
-from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of,
+from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of, _needs_generic,
                        _result_dtype, _taps_f64, _to_f32_image,
                        generalized_anscombe,
                        PLANE_INPUT)
@@ -77,7 +77,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
     """
     f64 = _result_dtype(data) == np.float64                           # float64 engine (ref:319-320)
-    if np.ndim(data) in (1, 3) or (f64 and np.ndim(data) == 2):
+    if np.ndim(data) in (1, 3) or (f64 and np.ndim(data) == 2) or _needs_generic(scaling_function):
         # signals, cubes and float64 images: the generic call sequence
         arr = np.asarray(data, np.float64 if f64 else np.float32)
         if anscombe:

@@ -173,6 +173,63 @@ def _taps_f64(scaling_function, ndim):
     return tuple(float(t) for t in (taps[::-1] if ndim == 1 else taps))
 
 
+_PAD_MODES = {"symmetric": 0, "reflect": 1, "edge": 2, "wrap": 3, "constant": 4}
+
+
+def _needs_generic(scaling_function):
+    """user-defined scaling functions the separable run-time-tap kernels do not take (an even
+    number of taps, or more than 15): served tap by tap through the generic operator"""
+    taps = np.asarray(getattr(scaling_function, "coefficients_1d", ()), dtype=np.float64).ravel()
+    return taps.size > 0 and (taps.size % 2 == 0 or taps.size > 15)
+
+
+def _reference_taps(kernel, s):
+    """Tap list of the reference's own loop (ref:76-94) for an n-D ``kernel`` at scale ``s``:
+    (centre weight, offsets (n, 3) as (dz, dy, dx), weights) in the reference's tap order - the
+    tap at kernel index i of an axis of size n reads the sample (n - 1 - i - n // 2) * 2**s away
+    (for an even n two taps land on the centre sample and none on one side, as in the reference)."""
+    k = np.asarray(kernel, dtype=np.float64)
+    hw = tuple(n // 2 for n in k.shape)
+    d = 2 ** s
+    offs, wts = [], []
+    for idx in np.ndindex(*k.shape):
+        if idx == hw:
+            continue
+        offs.append([0] * (3 - k.ndim) + [(n - 1 - i - h) * d for i, n, h in zip(idx, k.shape, hw)])
+        wts.append(k[idx])
+    return float(k[hw]), np.asarray(offs, dtype=np.int32).reshape(-1, 3), np.asarray(wts, dtype=np.float64)
+
+
+def _filter_taps(kernel, s, convolve=False):
+    """Tap list of convolution() (ref:35-69) for an n-D scaling-function kernel at scale ``s``: the
+    zero-stuffed kernel has n = (K - 1) * 2**s + 1 samples per axis and its centre is n // 2 (cv2's
+    default anchor, scipy's origin); cv2.filter2D correlates (2-D / 3-D: the sample at
+    i * 2**s - n // 2), scipy.ndimage.convolve convolves (1-D: the sample at n // 2 - i * 2**s)."""
+    k = np.asarray(kernel, dtype=np.float64)
+    d = 2 ** s
+    offs, wts = [], []
+    for idx in np.ndindex(*k.shape):
+        o = [i * d - ((n - 1) * d + 1) // 2 for i, n in zip(idx, k.shape)]
+        offs.append([0] * (3 - k.ndim) + ([-v for v in o] if convolve else o))
+        wts.append(k[idx])
+    return np.asarray(offs, dtype=np.int32).reshape(-1, 3), np.asarray(wts, dtype=np.float64)
+
+
+def _generic_plan(shape, f64, level=0):
+    rows, cols = _plane_shape(shape)
+    if f64:
+        return acquire_plan64(default_context(), rows, cols, (1.0,), level)
+    return acquire_plan(default_context(), rows, cols, _lib.B3SPLINE, level)
+
+
+def _generic_smooth(plan, scaling_function, ndim, shape, src, dst, s):
+    """conv_s through the generic tap-list operator: 'mirror' border for signals (ref:65-69),
+    BORDER_REFLECT = 'symmetric' otherwise (ref:39-63)"""
+    offs, wts = _filter_taps(scaling_function.kernel, s, convolve=ndim == 1)
+    plan.taps_conv(src, PLANE_NONE, dst, offs, wts, None, depth=shape[0] if ndim == 3 else 0,
+                   pad_mode=_PAD_MODES["reflect" if ndim == 1 else "symmetric"])
+
+
 def _plane_shape(shape):
     """(rows, cols) of the 2-D image an array of this shape is stored as: 1 x N, H x W, (Z*Y) x X"""
     if len(shape) == 1:
@@ -255,6 +312,21 @@ def convolution(arr, scaling_function, s=0, output=None):
     1 x N image under the engine's mirror border rule."""
     one_d = _is_1d(arr)
     three_d = np.ndim(arr) == 3
+    if _needs_generic(scaling_function) and np.ndim(arr) in (1, 2, 3):
+        # an even number of taps or more than 15: tap by tap (wt_taps_conv)
+        f64 = _is_f64(arr)
+        a = np.ascontiguousarray(arr, dtype=np.float64 if f64 else np.float32)
+        plan = _generic_plan(a.shape, f64)
+        try:
+            plan.upload(PLANE_INPUT, a.reshape(plan.shape))
+            _generic_smooth(plan, scaling_function, a.ndim, a.shape, PLANE_INPUT, PLANE_OUT, s)
+            res = plan.download(PLANE_OUT).reshape(a.shape).astype(_result_dtype(arr), copy=False)
+        finally:
+            release_plan(plan)
+        if output is None:
+            return res
+        output[...] = res
+        return output
     if _is_f64(arr) and np.ndim(arr) in (1, 2, 3):
         a = np.ascontiguousarray(arr, dtype=np.float64)
         plan = acquire_plan64(default_context(), *_plane_shape(a.shape),
@@ -324,37 +396,65 @@ def sdev_loc(image, scaling_function, s=0, variance=False):
 def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmetric",
                        output=None):
     """Dilated convolution, optionally range-weighted by ``bilateral_variance`` (ref:74-105).
-    ``kernel`` must be a SEPARABLE 2-D kernel - the outer product of an odd number (<= 15) of 1-D
-    taps with itself, which every AbstractScalingFunction kernel is (ref:170-173); ``mode`` must
-    be 'symmetric'."""
-    if mode != "symmetric":
-        raise NotImplementedError("the HIP engine implements mode='symmetric' only")
-    f64 = _is_f64(image) and np.ndim(image) == 2          # float64 engine (ref:319-320)
-    img = np.ascontiguousarray(image, dtype=np.float64) if f64 else _to_f32_image(image, "image")
+
+    2-D images with a SEPARABLE kernel (the outer product of an odd number <= 15 of 1-D taps with
+    itself - every AbstractScalingFunction kernel, ref:170-173) under ``mode='symmetric'`` run on
+    the tuned kernels.  Everything else the reference accepts - any ``kernel`` array of the image's
+    dimensionality (non-separable, even-sized, large), signals and cubes, and the np.pad modes
+    'symmetric', 'reflect', 'edge', 'wrap' and 'constant' - runs tap by tap on the generic
+    operator (wt_taps_conv), in the reference's tap order."""
+    if mode not in _PAD_MODES:
+        raise NotImplementedError(f"np.pad mode '{mode}' is not implemented in the HIP engine "
+                                  f"({', '.join(_PAD_MODES)} are)")
     kernel = np.asarray(kernel)
+    nd = np.ndim(image)
+    if nd not in (1, 2, 3) or kernel.ndim != nd:
+        raise ValueError("Unsupported number of dimensions")
+    f64 = _is_f64(image)                                  # float64 engine (ref:319-320)
     fam = None
-    for cls in (Triangle, B3spline):
-        k = cls(2).kernel
-        if kernel.shape == k.shape and np.allclose(kernel, k, rtol=1e-6, atol=0):
-            fam = cls._family
     flags = 0
+    if nd == 2 and mode == "symmetric":
+        for cls in (Triangle, B3spline):
+            k = cls(2).kernel
+            if kernel.shape == k.shape and np.allclose(kernel, k, rtol=1e-6, atol=0):
+                fam = cls._family
+        if fam is None:
+            # kernel = outer(t, t): t = centre row / sqrt(centre).  The reference's tap loop is a true
+            # convolution (ref:87-91) and the engine correlates: the plan gets the taps reversed and
+            # the range-weighted kernel is told so (wt_bilateral_conv flag bit 3).
+            k64 = np.asarray(kernel, dtype=np.float64)
+            ok = k64.shape[0] == k64.shape[1] and k64.shape[0] % 2 == 1 \
+                and k64.shape[0] <= 15 and k64[k64.shape[0] // 2, k64.shape[0] // 2] > 0
+            if ok:
+                hw = k64.shape[0] // 2
+                taps = k64[hw] / np.sqrt(k64[hw, hw])
+                ok = np.allclose(np.multiply.outer(taps, taps), k64, rtol=1e-6,
+                                 atol=1e-7 * np.abs(k64).max())
+            if ok:
+                fam = tuple(float(t) for t in taps[::-1])
+                flags = _lib.FLAG_TAPS_REVERSED
     if fam is None:
-        # kernel = outer(t, t): t = centre row / sqrt(centre).  The reference's tap loop is a true
-        # convolution (ref:87-91) and the engine correlates: the plan gets the taps reversed and
-        # the range-weighted kernel is told so (wt_bilateral_conv flag bit 3).
-        k64 = np.asarray(kernel, dtype=np.float64)
-        ok = k64.ndim == 2 and k64.shape[0] == k64.shape[1] and k64.shape[0] % 2 == 1 \
-            and k64.shape[0] <= 15 and k64[k64.shape[0] // 2, k64.shape[0] // 2] > 0
-        if ok:
-            hw = k64.shape[0] // 2
-            taps = k64[hw] / np.sqrt(k64[hw, hw])
-            ok = np.allclose(np.multiply.outer(taps, taps), k64, rtol=1e-6,
-                             atol=1e-7 * np.abs(k64).max())
-        if not ok:
-            raise NotImplementedError("kernel must be the outer product of an odd number (<= 15) "
-                                      "of 1-D taps with itself")
-        fam = tuple(float(t) for t in taps[::-1])
-        flags = _lib.FLAG_TAPS_REVERSED
+        # the general case: the reference's loop, tap by tap
+        a = np.ascontiguousarray(image, dtype=np.float64 if f64 else np.float32)
+        kc, offs, wts = _reference_taps(kernel, s)
+        plan = _generic_plan(a.shape, f64)
+        try:
+            plan.upload(PLANE_INPUT, a.reshape(plan.shape))
+            var_plane = PLANE_NONE
+            if bilateral_variance is not None:
+                var = np.broadcast_to(np.asarray(bilateral_variance, a.dtype), a.shape)
+                plan.upload(_TMP_PLANE, np.ascontiguousarray(var).reshape(plan.shape))
+                var_plane = _TMP_PLANE
+            plan.taps_conv(PLANE_INPUT, var_plane, PLANE_OUT, offs, wts, kc,
+                           depth=a.shape[0] if nd == 3 else 0, pad_mode=_PAD_MODES[mode])
+            res = plan.download(PLANE_OUT).reshape(a.shape)
+        finally:
+            release_plan(plan)
+        if output is None:
+            return res
+        output[...] = res
+        return output
+    img = np.ascontiguousarray(image, dtype=np.float64) if f64 else _to_f32_image(image, "image")
     if f64:
         if not isinstance(fam, tuple):                   # built-in family: its (symmetric) taps
             fam = _taps_f64(Triangle if fam == _lib.TRIANGLE else B3spline, 2)
@@ -746,6 +846,8 @@ class AtrousTransform:
 
         float64 / int inputs (computed in float64 by the reference, ref:297,319-320) run on the
         float64 engine."""
+        if np.ndim(arr) in (1, 2, 3) and _needs_generic(self.scaling_function_class):
+            return self._call_generic(arr, level, recursive)
         if _f64 and _is_f64(arr) and np.ndim(arr) in (1, 2, 3):
             if recursive:
                 return self._recursive(np.asarray(arr), level, self.scaling_function_class(np.ndim(arr)),
@@ -774,6 +876,30 @@ class AtrousTransform:
         coefficients._sum_valid = summed
         coefficients._host_sum = host_sum        # handed out once by np.sum(coefficients, axis=0)
         return coefficients
+
+    def _call_generic(self, arr, level, recursive):
+        """Standard algorithm (ref:408-444) for a user-defined scaling function with an even number
+        of taps or more than 15: every conv_s tap by tap through the generic operator, the detail
+        planes by subtraction; float32 or float64 planes as the input's type asks."""
+        if recursive or self.bilateral is not None:
+            raise NotImplementedError("scaling functions with an even number of taps or more than 15 "
+                                      "are served by the standard algorithm without bilateral filtering")
+        f64 = _is_f64(arr)
+        a = np.ascontiguousarray(arr, dtype=np.float64 if f64 else np.float32)
+        nd = a.ndim
+        scaling_function = self.scaling_function_class(nd)
+        plan = _generic_plan(a.shape, f64, level)
+        plan.upload(PLANE_INPUT, a.reshape(plan.shape))
+        cur = PLANE_INPUT
+        for s in range(level):
+            nxt = level if s == level - 1 else PLANE_SCRATCH(s & 1)
+            _generic_smooth(plan, scaling_function, nd, a.shape, cur, nxt, s)      # ref:432
+            plan.binary("sub", cur, nxt, s)                                        # ref:442
+            cur = nxt
+        if level == 0:
+            plan.decompose(PLANE_INPUT, 0)
+        return Coefficients(plan, scaling_function, None, _shape=a.shape if nd == 3 else None,
+                            _dtype=_result_dtype(arr))
 
     def _call_f64(self, arr, level, with_sum=False):
         """Standard algorithm in float64 (ref:408-444 on float64 / promoted input, ref:319-320):
