@@ -1674,10 +1674,25 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
         WT_HIP(hipEventRecord(e0, c->stream));
         WT_HIP(hipStreamWaitEvent(c->xfer_in, e0, 0));
         WT_HIP(hipStreamWaitEvent(c->xfer_out, e0, 0));
-        for (int y0 = 0; y0 < H; y0 += block_rows) {
-            const int y1 = std::min(H, y0 + block_rows);
-            // (rows that are contiguous on both sides go as ONE linear copy: the DMA engines' fast path)
-            if (in_stride == W && P == W)
+        // block boundaries: equal blocks, the last one cut into 1/2 + 1/4 + 1/4 (the tail of the call
+        // is the passes and the download of whatever came up last)
+        std::vector<int> cuts;
+        for (int y = 0; y < H; y += block_rows) cuts.push_back(y);
+        if (cuts.size() > 1 && H - cuts.back() > 192) {
+            const int yl = cuts.back(), n = H - yl, q = (n / 4 + 63) / 64 * 64;
+            if (n - 2 * q >= 64) {
+                cuts.push_back(yl + n - 2 * q);
+                cuts.push_back(H - q);
+            }
+        }
+        cuts.push_back(H);
+        // (rows that are contiguous on both sides go as ONE linear copy - the DMA engines' fast path -
+        //  when the piece is large: below ~16 MiB the linear path is the slow one, measured)
+        const size_t linear_min = (size_t)16 << 20;
+        for (size_t bi = 0; bi + 1 < cuts.size(); ++bi) {
+            const int y0 = cuts[bi], y1 = cuts[bi + 1];
+            if (y1 <= y0) continue;
+            if (in_stride == W && P == W && (size_t)(y1 - y0) * W * 4 >= linear_min)
                 WT_HIP(hipMemcpyAsync(up_b + (size_t)y0 * P, host_in + (size_t)y0 * in_stride, (size_t)(y1 - y0) * W * 4, hipMemcpyHostToDevice, c->xfer_in));
             else
                 WT_HIP(hipMemcpy2DAsync(up_b + (size_t)y0 * P, (size_t)P * 4, host_in + (size_t)y0 * in_stride, (size_t)in_stride * 4, (size_t)W * 4,
@@ -1712,7 +1727,7 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
                 WT_HIP(new_event(&ec));
                 WT_HIP(hipEventRecord(ec, c->stream));
                 WT_HIP(hipStreamWaitEvent(c->xfer_out, ec, 0));
-                if (out_stride == W && P == W)
+                if (out_stride == W && P == W && (size_t)(fin - out_done) * W * 4 >= linear_min)
                     WT_HIP(hipMemcpyAsync(host_out + (size_t)out_done * out_stride, down_b + (size_t)out_done * P, (size_t)(fin - out_done) * W * 4,
                                           hipMemcpyDeviceToHost, c->xfer_out));
                 else

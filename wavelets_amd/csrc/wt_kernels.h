@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void wt_lattice_kernel(ChainArgs a)
 // K1b  "row" kernel: the same single-scale operators for the dilations whose horizontal halo
 // fits a workgroup (hw*d <= 1/8 of its width).  A workgroup of NW waves marches down one chunk
 // of one polyphase chain like the fused pass: ONE coalesced 16-byte load per lane per row, the
-// row is shared through LDS (double-buffered, one barrier per row) and the K dilated taps are
+// row is shared through LDS (double-buffered, one barrier per PAIR of rows) and the K dilated taps are
 // LDS reads at lane offsets +-d/4, +-2d/4 (or the two adjacent lanes for d < 4) - instead of K
 // global loads per row.  Arithmetic is WtVert, i.e. bit-identical to the chain kernel.
 // ---------------------------------------------------------------------------------------------
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
 {
     constexpr int hw = K / 2;
     constexpr int NL = NW * 64;
-    __shared__ float4 rowbuf[2][NL];
+    __shared__ float4 rowbuf[2][2][NL];                  // [pair parity][row of the pair][lane]
     const ChainArgs &a = ra.c;
     const Geo g = a.g;
     const int d = a.d;
@@ -586,62 +586,76 @@ __global__ __launch_bounds__(NW * 64) void wt_row_kernel(RowArgs ra)
 
     WtVert<K, MODE, SMALL_D> vert;
     float4 raw[K];
-    // WT_ROW_PD rows in flight, in NAMED registers used in turn (the loop is unrolled by that many):
-    // a rotating array (pf0 = pf1; pf1 = load) makes the compiler copy the load it has just issued
-    // at the end of every iteration, i.e. wait for it at once - no prefetch left.  Four rows: the
-    // kernel sits at s_waitcnt / s_barrier for 72 % of its wave cycles with two (SQ_WAIT_ANY,
-    // profiles/r02_e), i.e. it is latency-bound at 16 waves per CU.
-#ifndef WT_ROW_PD
-#define WT_ROW_PD 4
-#endif
+    // Four rows in flight, in NAMED registers used in turn (the loop is unrolled by that many): a
+    // rotating array (pf0 = pf1; pf1 = load) makes the compiler copy the load it has just issued at
+    // the end of every iteration, i.e. wait for it at once - no prefetch left.
+    // TWO ROWS PER BARRIER (round 3): the kernel sat at s_waitcnt / s_barrier for 72 % of its wave
+    // cycles with one barrier per row (SQ_WAIT_ANY, profiles/r02_e) - four waves re-synchronising
+    // every ~130 VALU instructions.  A step now shares a PAIR of rows through LDS (two row buffers
+    // per parity) behind one barrier and filters both; same arithmetic per row, identical bits.
     float4 pfa = load_row(r0 - hw), pfb = load_row(r0 - hw + 1);
-#if WT_ROW_PD == 4
     float4 pfc = load_row(r0 - hw + 2), pfd = load_row(r0 - hw + 3);
-#endif
-    // steps t = r0-hw .. r1-1+hw ; step index k selects the LDS buffer
+    // steps t = r0-hw .. r1-1+hw ; the pair index selects the LDS buffers
     const int nsteps = (r1 - r0) + 2 * hw;
-    auto step = [&](const int k, const float4 cur) {
-        const int t = r0 - hw + k;
-        float4 *rowv = rowbuf[k & 1];
-        rowv[gl] = cur;
+    auto share = [&](const int k, const float4 cur0, const float4 cur1, const float4 *&rv0, const float4 *&rv1) {
+        float4 *w0 = rowbuf[(k >> 1) & 1][0], *w1 = rowbuf[(k >> 1) & 1][1];
+        w0[gl] = cur0;
+        w1[gl] = cur1;
         __syncthreads();
-        gather(rowv, cur, raw);
-        if (k < K - 1) {
-            // warm-up rows (uniform branch): fill the window
-            switch (k) {
-                case 0: vert.prime(0, raw, d); break;
-                case 1: vert.prime(1, raw, d); break;
-                case 2: if constexpr (K > 3) vert.prime(2, raw, d); break;
-                default: if constexpr (K > 3) vert.prime(3, raw, d); break;
-            }
-        } else {
-            const int r = t - hw;
-            vert.emit(raw, a, (int64_t)(q + d * r) * g.P, x, lane_ok);
-        }
+        rv0 = w0;
+        rv1 = w1;
     };
-    for (int k = 0; k < nsteps; k += WT_ROW_PD) {
+    auto emit_row = [&](const int k, const float4 *rowv, const float4 cur) {
+        gather(rowv, cur, raw);
+        vert.emit(raw, a, (int64_t)(q + d * (r0 - 2 * hw + k)) * g.P, x, lane_ok);   // row t - hw, t = r0 - hw + k
+    };
+    auto pair_emit = [&](const int k, const float4 cur0, const float4 cur1) {
+        const float4 *rv0, *rv1;
+        share(k, cur0, cur1, rv0, rv1);
+        emit_row(k, rv0, cur0);
+        if (k + 1 < nsteps) emit_row(k + 1, rv1, cur1);      // workgroup-uniform
+    };
+    // warm-up rows k = 0 .. K-2 fill the window: (K-1)/2 pairs with STATIC window indices (a switch on
+    // the run-time step number made the compiler index the window dynamically: scratch memory)
+    {
+        const float4 c0 = pfa, c1 = pfb;
+        pfa = load_row(r0 - hw + 4);
+        pfb = load_row(r0 - hw + 5);
+        const float4 *rv0, *rv1;
+        share(0, c0, c1, rv0, rv1);
+        gather(rv0, c0, raw);
+        vert.prime(0, raw, d);
+        gather(rv1, c1, raw);
+        vert.prime(1, raw, d);
+    }
+    {
+        const float4 c0 = pfc, c1 = pfd;
+        pfc = load_row(r0 - hw + 6);
+        pfd = load_row(r0 - hw + 7);
+        if constexpr (K > 3) {
+            const float4 *rv0, *rv1;
+            share(2, c0, c1, rv0, rv1);
+            gather(rv0, c0, raw);
+            vert.prime(2, raw, d);
+            gather(rv1, c1, raw);
+            vert.prime(3, raw, d);
+        } else {
+            pair_emit(2, c0, c1);                            // (nsteps >= 3: row 2 exists)
+        }
+    }
+    for (int k = 4; k < nsteps; k += 4) {
         {
-            const float4 cur = pfa;
-            pfa = load_row(r0 - hw + k + WT_ROW_PD);
-            step(k, cur);
+            const float4 c0 = pfa, c1 = pfb;
+            pfa = load_row(r0 - hw + k + 4);
+            pfb = load_row(r0 - hw + k + 5);
+            pair_emit(k, c0, c1);
         }
-        if (k + 1 < nsteps) {                            // workgroup-uniform
-            const float4 cur = pfb;
-            pfb = load_row(r0 - hw + k + 1 + WT_ROW_PD);
-            step(k + 1, cur);
+        if (k + 2 < nsteps) {                                // workgroup-uniform
+            const float4 c0 = pfc, c1 = pfd;
+            pfc = load_row(r0 - hw + k + 6);
+            pfd = load_row(r0 - hw + k + 7);
+            pair_emit(k + 2, c0, c1);
         }
-#if WT_ROW_PD == 4
-        if (k + 2 < nsteps) {
-            const float4 cur = pfc;
-            pfc = load_row(r0 - hw + k + 2 + WT_ROW_PD);
-            step(k + 2, cur);
-        }
-        if (k + 3 < nsteps) {
-            const float4 cur = pfd;
-            pfd = load_row(r0 - hw + k + 3 + WT_ROW_PD);
-            step(k + 3, cur);
-        }
-#endif
     }
 }
 
