@@ -1533,8 +1533,17 @@ static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t
         WT_HIP(hipEventRecord(c->ev_from_comm, c->comm_stream));
         return 0;
     };
+    // Overlapped schedule (round 3: every exchange hides, the first one included).  A pass needs its
+    // neighbours' rows only for the output rows within `halo` of a strip boundary.  So for every pass:
+    //   1. the exchange of the pass INPUT's halo rows starts on the communication stream (behind
+    //      everything queued so far, i.e. behind the previous pass),
+    //   2. the INTERIOR rows [halo, nrows - halo) - which read own rows only - are launched at once and
+    //      run beside the exchange (the launch leaves `overlap_reserve` CUs to the RCCL kernels),
+    //   3. the edge rows follow when the exchange has landed.
+    // Until round 2 a pass ran its edge rows FIRST and the next pass's exchange beside its interior,
+    // which left the exchange of the very first pass (the input image's 14 rows) with nothing to hide
+    // behind.  Same launches on the same row ranges, so the bits do not change.
     int cur = src;
-    bool pending = false;                                           // an exchange of `cur` is in flight
     for (int i = 0; i < np; ++i) {
         const int s0 = tr[3 * i], ns = tr[3 * i + 1];
         const bool last = s0 + ns == level;
@@ -1546,26 +1555,27 @@ static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t
             continue;
         }
         const int64_t halo = tr[3 * i + 2];
-        if (!pending && halo > 0) WT_TRY(exchange_async(cur, halo));
-        if (!dry && (pending || halo > 0)) WT_HIP(hipStreamWaitEvent(c->stream, c->ev_from_comm, 0));
-        pending = false;
-        const int64_t halo_next = i + 1 < np ? tr[3 * (i + 1) + 2] : 0;
         const int nrows = p->g.nrows;
-        const bool fused = ns > 1;
-        if (halo_next > 0 && fused && 2 * halo_next < nrows) {
+        const bool up = p->rank > 0, dn = p->rank + 1 < p->nranks;
+        // (a pass of one scale runs a fused kernel - and can take row ranges - only where one is built)
+        const bool ranged = ns > 1 || ((flags & 1) && !p->g.border && !p->ntaps && wt_fused_supported(p) && wt_fused_has_pass(s0, 1, p->family));
+        if (halo > 0 && ranged && (up || dn) && 2 * halo < nrows) {
+            WT_TRY(exchange_async(cur, halo));
             FusedRows edge, inner;
-            const bool up = p->rank > 0, dn = p->rank + 1 < p->nranks;
-            if (up) { edge.lo[edge.n] = 0; edge.hi[edge.n] = (int)halo_next; edge.n++; }
-            if (dn) { edge.lo[edge.n] = nrows - (int)halo_next; edge.hi[edge.n] = nrows; edge.n++; }
+            if (up) { edge.lo[edge.n] = 0; edge.hi[edge.n] = (int)halo; edge.n++; }
+            if (dn) { edge.lo[edge.n] = nrows - (int)halo; edge.hi[edge.n] = nrows; edge.n++; }
             inner.n = 1;
-            inner.lo[0] = up ? (int)halo_next : 0;
-            inner.hi[0] = dn ? nrows - (int)halo_next : nrows;
+            inner.lo[0] = up ? (int)halo : 0;
+            inner.hi[0] = dn ? nrows - (int)halo : nrows;
             inner.reserve = g_opt_overlap_reserve;
-            WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst, edge));
-            WT_TRY(exchange_async(nxt, halo_next));
             WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst, inner));
-            pending = true;
+            if (!dry) WT_HIP(hipStreamWaitEvent(c->stream, c->ev_from_comm, 0));
+            WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst, edge));
         } else {
+            if (halo > 0) {
+                WT_TRY(exchange_async(cur, halo));
+                if (!dry) WT_HIP(hipStreamWaitEvent(c->stream, c->ev_from_comm, 0));
+            }
             WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst));
         }
         cur = nxt;
@@ -1573,9 +1583,6 @@ static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t
     return 0;
 }
 
-// Decomposition and np.sum(planes, axis=0) in the same passes: every plane is still written,
-// but the sum is carried along (8*(L+2) -> 4*(L+2) + 8*(passes) B/pixel instead of re-reading
-// the L+1 planes).  Bit-identical to wt_decompose followed by wt_plane_sum (same plane order).
 extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int flags)
 {
     WtGuard guard_(ctx_of(p));
