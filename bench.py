@@ -536,7 +536,9 @@ def main():
                 "roofline": roofline,
                 "kernels": kernels,
             }
-            if full and world == 1 and config in ("headline", "cfg2"):
+            if full and world == 1 and config in ("headline", "cfg2") and not args.brief:
+                # (not under --brief: the PMC passes of tools/profile_round.sh average per dispatch, and
+                #  the pipelined host call launches the same kernels on row blocks)
                 # PCIe-inclusive rate (host numpy in, reconstruction out as a numpy array) - never
                 # `value`.  First call: the result's page-locked block is allocated; later calls
                 # reuse it from the host pool (wavelets_amd/_lib.py _HostPool), which is the steady

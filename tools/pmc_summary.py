@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def scope_name(kernel):
     """rocprof kernel name -> ProfScope name of wt_api.hip / wt_fused.h"""
-    m = re.match(r"void wt_fused_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel)
+    m = re.match(r"void wt_fused_kernel<(?:float, )?(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel)
     if m:
         _, ns, d, _, _, acc = map(int, m.groups())
         return f"{('wt_fused', 'wt_fused_acc', 'wt_fused_sum', 'wt_fused_hist')[acc]}<d{d}x{ns}>"
@@ -39,7 +39,7 @@ def scope_name(kernel):
 
 rows, traffic = [], {}
 for counter, sub in (("FETCH_SIZE", subdirs[0]), ("WRITE_SIZE", subdirs[1])):
-    acc = {}
+    acc, per_scope = {}, {}
     for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
@@ -49,8 +49,13 @@ for counter, sub in (("FETCH_SIZE", subdirs[0]), ("WRITE_SIZE", subdirs[1])):
     for k, (n, tot) in sorted(acc.items()):
         rows.append((counter, k, n, tot / n))
         if k.startswith("void wt_") or k.startswith("wt_"):
-            key = f"{scope_name(k)}@{config or side}"
-            traffic[key] = traffic.get(key, 0.0) + (2 if counter == "FETCH_SIZE" else 1) * tot / n * 1024
+            # several instantiations can share one profiling name (wt_row_kernel<wow> for d < 4 and
+            # d >= 4, the two histogram variants): average over ALL their dispatches
+            a = per_scope.setdefault(f"{scope_name(k)}@{config or side}", [0, 0.0])
+            a[0] += n
+            a[1] += tot
+    for key, (n, tot) in per_scope.items():
+        traffic[key] = traffic.get(key, 0.0) + (2 if counter == "FETCH_SIZE" else 1) * tot / n * 1024
 
 with open(prefix + "_pmc_summary.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "

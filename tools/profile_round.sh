@@ -1,22 +1,26 @@
 #!/bin/bash
-# End-of-session evidence: GPU tests, bench lines (headline + cfg2/3/5), rocprofv3 kernel stats and
-# the FETCH_SIZE / WRITE_SIZE passes.  Results under gpurun_out/final; copy the summaries to
-# profiles/ with tools/pmc_summary.py.  The profiled program sits directly behind `--` and is
-# told not to build (no child process under the profiler's preload).
+# End-of-session evidence: GPU tests, the default bench line (headline + cfg2/3/5), rocprofv3 kernel
+# stats and the FETCH_SIZE / WRITE_SIZE passes of every configuration.  Results under
+# gpurun_out/final; tools/pmc_summary.py turns the PMC passes into profiles/<tag>_pmc_summary*.csv and
+# profiles/traffic.json.  The profiled program sits directly behind `--` and is told not to build
+# (no child process under the profiler's preload).   usage: bash tools/profile_round.sh [skip-tests]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 rm -rf gpurun_out/final; mkdir -p gpurun_out/final
 python -c "import __graft_entry__ as e; e.build()"
-timeout -k 10 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/final/pytest_gpu.log
+if [ "$1" != "skip-tests" ]; then
+  timeout -k 10 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/final/pytest_gpu.log
+fi
 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
-for c in cfg2 cfg3 cfg5; do
-  timeout -k 10 600 python bench.py --config $c --no-build > gpurun_out/final/bench_$c.json 2> gpurun_out/final/bench_$c.err
-done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -- python3 $R/bench.py --steps 20 --no-cpu --no-build > $R/gpurun_out/final/rocprof_bench.log 2>&1
-for c in cfg2 cfg3 cfg5; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$c -- python3 $R/bench.py --config $c --steps 5 --no-cpu --no-build > $R/gpurun_out/final/rocprof_$c.log 2>&1
+for c in headline cfg2 cfg3 cfg5; do
+  steps=20; [ $c = cfg5 ] && steps=5
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$c -- python3 $R/bench.py --config $c --steps $steps --no-cpu --no-build --no-configs > $R/gpurun_out/final/rocprof_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/final/pmc_fetch_$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/final/pmc_write_$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
 done
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/final/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/final/pmc_write -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
-cd $R; cat gpurun_out/final/pytest_gpu.log | tail -2; cut -c1-300 gpurun_out/final/bench.json
+cd $R; cat gpurun_out/final/pytest_gpu.log 2>/dev/null | tail -2; cut -c1-300 gpurun_out/final/bench.json
+# keep only the small summary files of the rocprof runs (the merge back is capped at 64 MiB)
+find gpurun_out/final -name "*_kernel_trace.csv" -size +2M -delete
+find gpurun_out/final -name "*.db" -delete 2>/dev/null
+du -sh gpurun_out/final

@@ -361,8 +361,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     // bodies, at most two of them (code size); none for the single-scale passes
     // Built where the extra code does not cost registers the kernel does not have: the float D = 1
     // passes of up to three scales (B3 d1x3: 220 -> 240 VGPRs, no scratch).  The D = 8 three-scale
-    // passes sit at 256 VGPRs already and the four-scale / double variants spill with it (measured
-    // with -save-temps: 16 - 220 spilled registers), so they keep the plain march.
+    // passes sit at 256 VGPRs already and the four-scale / double variants spill with it (16 - 220
+    // spilled registers; still 21 with a single peeled trip, and gating only the horizontal filters
+    // and stores changes nothing), so they keep the plain march.
 #ifdef WT_FUSED_NO_PROLOGUE
     constexpr int PRO = 0;
 #else
