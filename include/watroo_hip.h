@@ -218,8 +218,8 @@ int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
  * soon as its rows and the pass's halo rows have arrived, finished rows of the reconstruction go
  * down while later blocks are still coming up (PCIe is full duplex): about one transfer leg
  * instead of two (8192^2: 10.2 -> ~6 ms).  Single-GPU plans with a fully fused schedule;
- * anything else (and wt_set_option("host_pipeline", 0)) runs the three legs in turn.  The host
- * buffers are page-locked for the duration of the call when they are not already.
+ * anything else (and wt_set_option("host_pipeline", 0)) runs the three legs in turn.  Host
+ * buffers are used as they are (pageable or page-locked; the runtime locks pages per copy).
  * Reference flow: watroo/utils.py:83-102 (numpy in, numpy out). */
 int wt_decompose_sum_host(wt_plan *plan, const float *host_in, int64_t in_stride, int level,
                           int dst, float *host_out, int64_t out_stride, int block_rows);

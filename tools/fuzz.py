@@ -5,7 +5,9 @@ Random (H, W, level, family) images: fused / per-scale (row + chain kernels) / c
 schedules against the C oracle; virtual row strips against the unsharded result (bitwise);
 recursive=True against the numpy oracle; the fused passes' fast addressing against the generic
 one (bitwise); and - round 2 - the bilateral transform and wow() (plain / bilateral, random keyword
-combinations, up to 9 scales) against the C-backed oracle.  Prints one line per failure and a summary.
+combinations, up to 9 scales) against the C-backed oracle; round 3: the float64 fused passes with the
+carried sum, the pipelined host-to-host call against the serial legs (bitwise, random block sizes) and
+the generic tap-list operator (random kernels, pad modes, dimensionalities).  One line per failure + a summary.
 
     python tools/fuzz.py [n_cases] [seed]
 """
@@ -29,6 +31,49 @@ def planes(plan, n):
     return np.stack([plan.download(s) for s in range(n)])
 
 
+TRACE = bool(os.environ.get("WT_FUZZ_TRACE"))
+
+
+def note(msg):
+    """WT_FUZZ_TRACE=1: one flushed line before every block of a case (to locate a GPU fault)"""
+    if TRACE:
+        print("    . " + msg, flush=True)
+
+
+def burn(rng, case):
+    """Consume exactly the random draws case `case` would make, without touching the GPU
+    (WT_FUZZ_FROM=n replays cases 0..n-1 this way, so that case n sees the same parameters)."""
+    kind = case % 4
+    H = int(rng.integers(1, 1600)) if kind else int(rng.integers(1, 64))
+    Wd = int(rng.integers(1, 3000)) if kind != 1 else int(rng.integers(1, 64))
+    level = int(rng.integers(1, 10))
+    fam = ("b3spline", "triangle")[int(rng.integers(0, 2))]
+    rng.standard_normal((H, Wd))
+    rng.integers(2, 6), rng.integers(0, 2)
+    cls = W.B3spline if fam == "b3spline" else W.Triangle
+    if case % 3 == 0 and H >= 24 and Wd >= 24 and H * Wd <= 1500000:
+        rng.uniform(0.5, 2.0), rng.integers(0, 3), rng.integers(0, 2), rng.integers(0, 3), rng.integers(0, 3)
+    if H * Wd >= 2:
+        lev = min(level, len(cls(2).sigma_e()) - 1)
+        rng.choice([0., 1., 2., 3., 5.], int(rng.integers(1, lev + 1)))
+        rng.integers(0, 2)
+    if case % 7 == 3:
+        Hp, Wp = int(rng.integers(1100, 2600)), int(rng.integers(500, 1030)) * 4
+        rng.integers(2, 7)
+        rng.standard_normal((Hp, Wp))
+        rng.choice([0, 128, 192, 256, 320, 512, 1024])
+    if case % 6 == 2:
+        nd = int(rng.integers(1, 4))
+        shp = {1: (int(rng.integers(5, 400)),), 2: (int(rng.integers(3, 90)), int(rng.integers(3, 120))),
+               3: (int(rng.integers(2, 9)), int(rng.integers(2, 20)), int(rng.integers(2, 30)))}[nd]
+        rng.random(tuple(int(rng.integers(1, 6)) for _ in range(nd)))
+        rng.standard_normal(shp)
+        rng.choice(["symmetric", "reflect", "edge", "wrap", "constant"])
+        rng.integers(0, 3)
+        if rng.integers(0, 2):
+            rng.standard_normal(shp)
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -36,9 +81,13 @@ def main():
     ctx = L.default_context()
     cref.build()
     fails = 0
+    first = int(os.environ.get("WT_FUZZ_FROM", "0"))
     for case in range(n_cases):
+        if case < first:
+            burn(rng, case)
+            continue
         kind = case % 4
-        if case % 10 == 0:
+        if case % 10 == 0 or TRACE:
             print(f"... case {case} of {n_cases}, {fails} failures so far", flush=True)
         H = int(rng.integers(1, 1600)) if kind else int(rng.integers(1, 64))
         Wd = int(rng.integers(1, 3000)) if kind != 1 else int(rng.integers(1, 64))
@@ -48,8 +97,10 @@ def main():
         ref = cref.decompose(a, level, fam)
         tol = 1e-5 * max(1.0, float(np.abs(a).max()))
         tag = f"case {case}: {H}x{Wd} L={level} {fam}"
+        note(tag)
         got = {}
         for name, flags, row in (("fused", L.FLAG_FUSED, 1), ("perscale", 0, 1), ("chain", 0, 0)):
+            note("schedule " + name)
             L.set_option("row_kernel", row)
             plan = L.Plan(ctx, H, Wd, FAM[fam], level)
             plan.upload(L.PLANE_INPUT, a)
@@ -78,6 +129,7 @@ def main():
         k = int(rng.integers(2, 6))
         fused = bool(rng.integers(0, 2))
         if H >= k and required_halo(FAM[fam], level, fused) <= H // k:
+            note(f"{k} virtual strips, fused={fused}")
             flags = L.FLAG_FUSED if fused else 0
             plans = []
             for r, (row0, n) in enumerate(partition_rows(H, k)):
@@ -110,6 +162,7 @@ def main():
                 p.close()
         # fast vs generic addressing of the fused passes (bitwise)
         if Wd % 4 == 0:
+            note("fast vs generic addressing")
             outs = {}
             for mode in (1, 0):
                 L.set_option("fused_fast", mode)
@@ -128,6 +181,7 @@ def main():
             b = (a + 3 * np.sin(np.arange(Wd, dtype=np.float32) / 11.)[None, :]).astype(np.float32)
             lev = max(1, min(level, int(np.log2(min(H, Wd))) - 2, len(cls(2).sigma_e(bilateral=1)) - 1))
             sb = float(rng.uniform(0.5, 2.0))
+            note(f"bilateral transform lev={lev}")
             got_b = W.AtrousTransform(cls, bilateral=sb)(b, lev).data
             ref_b = cref.decompose_bilateral(b, lev, fam, sb)
             e = float(np.abs(got_b - ref_b).max())
@@ -142,6 +196,7 @@ def main():
             if rng.integers(0, 3) == 0:
                 kw["preserve_variance"] = True
             cp = lambda d: {k: (list(v) if isinstance(v, list) else v) for k, v in d.items()}
+            note(f"wow {kw}")
             rec_w, coef_w = W.wow(b.copy(), cls, **cp(kw))
             ref_r, ref_p = cref.wow(b.copy(), fam, **cp(kw))
             bad = np.abs(coef_w.data - ref_p) > 2e-4 * max(1.0, float(np.abs(ref_p).max())) + 2e-4 * np.abs(ref_p)
@@ -162,6 +217,7 @@ def main():
         if H * Wd >= 2:
             cls = W.B3spline if fam == "b3spline" else W.Triangle
             lev = min(level, len(cls(2).sigma_e()) - 1)
+            note(f"get_noise / denoise lev={lev}")
             c = W.AtrousTransform(cls)(a, lev)
             n_got = c.get_noise()
             n_ref = np.median(np.abs(ref[0])) / 0.6745 / cls(2).sigma_e()[0]
@@ -173,6 +229,7 @@ def main():
             nsig = int(rng.integers(1, lev + 1))
             sig = [float(x) for x in rng.choice([0., 1., 2., 3., 5.], nsig)]
             soft = bool(rng.integers(0, 2))
+            note(f"denoise sigma={sig} soft={soft}")
             got_d = W.denoise(a, sig, cls, soft_threshold=soft)
             cd = O.Coeffs(cref.decompose(a, len(sig), fam), fam)
             cd.denoise(sig, soft_threshold=soft)
@@ -187,6 +244,7 @@ def main():
             cls = W.B3spline if fam == "b3spline" else W.Triangle
             lev = min(level, 6)
             a64 = (a.astype(np.float64) * 37.0 + 1e4) if case % 4 else a.astype(np.float64)
+            note(f"float64 transform lev={lev}")
             c64 = W.AtrousTransform(cls)(a64, lev)
             r64 = O.atrous_standard(a64, lev, fam)
             e = float(np.abs(c64.data - r64).max())
@@ -201,7 +259,66 @@ def main():
             if not e <= 1e-11 * max(1.0, float(np.abs(a64).max())):
                 fails += 1
                 print(f"FAIL {tag}: float64 denoise max err {e:.3e}")
+        # round 3: float64 fused passes - wt64_decompose_sum (sum carried through the passes) against
+        # wt64_plane_sum over the same planes (bitwise) and against the generic kernels / the oracle
+        if case % 2 == 1 and H * Wd <= 1500000:
+            cls = W.B3spline if fam == "b3spline" else W.Triangle
+            lev = min(level, 8)
+            a64 = a.astype(np.float64) * 11.0 + 3e3
+            note(f"float64 decompose_sum lev={lev}")
+            p64 = L.Plan64(ctx, H, Wd, tuple(float(t) for t in cls.coefficients_1d), lev)
+            p64.upload(L.PLANE_INPUT, a64)
+            fused64 = p64.decompose_sum(L.PLANE_INPUT, lev, L.PLANE_OUT)
+            pl = np.stack([p64.download(s_) for s_ in range(lev + 1)])
+            car = p64.download(L.PLANE_OUT).copy()
+            p64.plane_sum(0, lev + 1, L.PLANE_SCRATCH(7))
+            r64 = O.atrous_standard(a64, lev, fam)
+            e = float(np.abs(pl - r64).max())
+            if not np.array_equal(car, p64.download(L.PLANE_SCRATCH(7))) or not e <= 1e-12 * float(np.abs(a64).max()):
+                fails += 1
+                print(f"FAIL {tag}: float64 decompose_sum (fused={fused64}) max err {e:.3e} or carried sum != plane sum")
+            p64.close()
+        # round 3: the pipelined host-to-host call against the serial legs (bitwise), random block sizes
+        if case % 7 == 3:
+            Hp, Wp = int(rng.integers(1100, 2600)), int(rng.integers(500, 1030)) * 4
+            lev = int(rng.integers(2, 7))
+            big = rng.standard_normal((Hp, Wp)).astype(np.float32)
+            plan = L.Plan(ctx, Hp, Wp, FAM[fam], lev)
+            blk = int(rng.choice([0, 128, 192, 256, 320, 512, 1024]))
+            note(f"pipelined host call {Hp}x{Wp} L={lev} blk={blk}")
+            got_p = plan.decompose_sum_host(big, lev, L.PLANE_OUT, block_rows=blk).copy()
+            pl_p = planes(plan, lev + 1)
+            L.set_option("host_pipeline", 0)
+            ref_p = plan.decompose_sum_host(big, lev, L.PLANE_OUT).copy()
+            L.set_option("host_pipeline", 1)
+            if not (np.array_equal(got_p, ref_p) and np.array_equal(pl_p, planes(plan, lev + 1))):
+                fails += 1
+                print(f"FAIL case {case}: pipelined host call {Hp}x{Wp} L={lev} {fam} block_rows={blk} != serial legs")
+            plan.close()
+        # round 3: the generic tap-list operator - random kernels / pad modes / dimensionalities
+        if case % 6 == 2:
+            nd = int(rng.integers(1, 4))
+            shp = {1: (int(rng.integers(5, 400)),), 2: (int(rng.integers(3, 90)), int(rng.integers(3, 120))),
+                   3: (int(rng.integers(2, 9)), int(rng.integers(2, 20)), int(rng.integers(2, 30)))}[nd]
+            ker = rng.random(tuple(int(rng.integers(1, 6)) for _ in range(nd)))
+            ker /= ker.sum()
+            img_g = rng.standard_normal(shp).astype(np.float32)
+            mode = str(rng.choice(["symmetric", "reflect", "edge", "wrap", "constant"]))
+            s_g = int(rng.integers(0, 3))
+            if mode in ("symmetric", "reflect", "wrap") and any((k // 2) * 2 ** s_g > 3 * n for k, n in zip(ker.shape, shp)):
+                s_g = 0
+            var_g = (np.abs(rng.standard_normal(shp)) + 0.2).astype(np.float32) if rng.integers(0, 2) else None
+            from wavelets_amd.wavelets import atrous_convolution
+            note(f"generic operator {shp} kernel {ker.shape} {mode} s={s_g}")
+            got_g = atrous_convolution(img_g, ker, var_g, s=s_g, mode=mode)
+            ref_g = O.atrous_convolution_nd(img_g, ker.astype(np.float32), var_g, s_g, mode)
+            e = float(np.abs(got_g - ref_g).max())
+            if not e <= (3e-5 if var_g is not None else 3e-6) * max(1.0, float(np.abs(img_g).max())):
+                fails += 1
+                print(f"FAIL case {case}: atrous_convolution {shp} kernel {ker.shape} mode={mode} s={s_g} "
+                      f"var={'yes' if var_g is not None else 'no'} max err {e:.3e}")
         if case % 5 == 0 and H * Wd < 400000 and level <= 6:
+            note("recursive")
             r = W.AtrousTransform(W.B3spline if fam == "b3spline" else W.Triangle)(a, level, recursive=True)
             e = float(np.abs(r.data - O.atrous_recursive(a, level, fam)).max())
             if not e <= tol:

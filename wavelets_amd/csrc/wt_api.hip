@@ -913,12 +913,19 @@ extern "C" int wt_plane_ptr(wt_plan *p, int plane, void **dev_ptr)
 // =============================================================================================
 // host <-> device, copies
 // =============================================================================================
-// Host transfers.  Large user buffers are pinned for the duration of the call
-// (hipHostRegister) so the copy is one DMA at PCIe rate instead of a staged pageable copy;
-// WT_PIN_THRESHOLD (bytes, default 4 MiB; 0 disables) sets the cut-over.
+// Host transfers.  Caller-owned (pageable) buffers are handed to the runtime as they are: it locks
+// the pages for the duration of a copy by itself and reaches the same 56-57 GB/s as page-locked
+// memory on this platform (tools/bench_pcie_pipe.py).  Rounds 1-2 additionally registered large
+// user buffers for the duration of the call (hipHostRegister / hipHostUnregister around the
+// copy); that is OFF by default since round 3: with it a long randomised run (tools/fuzz.py, 140
+// cases, multi-megabyte numpy arrays carved from the C heap once glibc has raised its mmap
+// threshold) ended twice in "Memory access fault by GPU ... on address <host heap address>" at
+// different places, and ran clean twice without it - registering and unregistering ranges of the
+// process heap that the allocator later trims or hands out again is not something the runtime
+// tolerates.  WT_PIN_THRESHOLD=<bytes> switches the registration back on for experiments.
 static size_t pin_threshold()
 {
-    static const long long v = getenv("WT_PIN_THRESHOLD") ? atoll(getenv("WT_PIN_THRESHOLD")) : (4ll << 20);
+    static const long long v = getenv("WT_PIN_THRESHOLD") ? atoll(getenv("WT_PIN_THRESHOLD")) : 0;
     return (size_t)v;
 }
 
@@ -2206,10 +2213,15 @@ static int upload_taplist(wt_ctx *c, const int32_t *offs, const T *wts, int ntap
         c->d_taps_cap = need;
     }
     char *base = (char *)c->d_taps;
-    // (pageable sources: hipMemcpyAsync stages them before it returns)
+    // The list comes from caller-owned pageable memory that may be freed the moment this call returns
+    // (temporaries of the Python layer), and the previous list may still be read by a kernel on the
+    // stream: drain the stream, then copy SYNCHRONOUSLY.  (An asynchronous copy from such memory is a
+    // use-after-free in waiting: a GPU memory fault on a host heap address showed up once in a long
+    // fuzz run.)  The generic operator is a correctness path; the drain costs microseconds.
     if (ntaps) {
-        WT_HIP(hipMemcpyAsync(base, offs, (size_t)ntaps * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        WT_HIP(hipMemcpyAsync(base + c->d_taps_cap * 3 * sizeof(int32_t), wts, (size_t)ntaps * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        WT_HIP(hipStreamSynchronize(c->stream));
+        WT_HIP(hipMemcpy(base, offs, (size_t)ntaps * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(base + c->d_taps_cap * 3 * sizeof(int32_t), wts, (size_t)ntaps * sizeof(T), hipMemcpyHostToDevice));
     }
     *d_offs = (const int32_t *)base;
     *d_wts = (const T *)(base + c->d_taps_cap * 3 * sizeof(int32_t));

@@ -1088,7 +1088,10 @@ extern "C" int wt64_filter2d(wt_plan64 *p, int src, int dst, const double *kerne
         p->psf = (double *)q;
         p->psf_cap = n;
     }
-    WT_HIP(hipMemcpyAsync(p->psf, kernel, n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    // caller-owned pageable memory: drain the stream (the previous PSF may still be in use) and copy
+    // synchronously - see upload_taplist
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    WT_HIP(hipMemcpy(p->psf, kernel, n * sizeof(double), hipMemcpyHostToDevice));
     WT_HIP(hipStreamSynchronize(p->ctx->stream));        // the host buffer may be pageable and short-lived
     hipLaunchKernelGGL(wt64_filter2d_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, o, p->g, (const double *)p->psf, kh, kw,
                        ay, ax, border == WT_BORDER_PERIODIC);
