@@ -2,7 +2,8 @@
 # End-of-session evidence: GPU tests, the default bench line (headline + cfg2/3/5), rocprofv3 kernel
 # stats and the FETCH_SIZE / WRITE_SIZE passes of every configuration.  Results under
 # gpurun_out/final; tools/pmc_summary.py turns the PMC passes into profiles/<tag>_pmc_summary*.csv and
-# profiles/traffic.json.  The profiled program sits directly behind `--` and is told not to build
+# profiles/traffic.json (clear the LOCAL gpurun_out/final first: gpurun merges, old runs would mix in).
+# The profiled program sits directly behind `--` and is told not to build
 # (no child process under the profiler's preload).   usage: bash tools/profile_round.sh [skip-tests]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
@@ -15,7 +16,9 @@ python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 cd /tmp && export TMPDIR=/tmp
 for c in headline cfg2 cfg3 cfg5; do
   steps=20; [ $c = cfg5 ] && steps=5
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$c -- python3 $R/bench.py --config $c --steps $steps --no-cpu --no-build --no-configs > $R/gpurun_out/final/rocprof_$c.log 2>&1
+  # (--brief: no PCIe leg - the pipelined host call launches the same kernels on row blocks, which
+  #  would pull the per-kernel averages down - no CPU baseline, no other configs)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$c -- python3 $R/bench.py --config $c --steps $steps --no-cpu --no-build --brief > $R/gpurun_out/final/rocprof_$c.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/final/pmc_fetch_$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/final/pmc_write_$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
 done
