@@ -292,12 +292,13 @@ def _shutdown():
     otherwise destroys planes after the runtime's own static destructors ran)."""
     _host_pool.close()
     objs = list(_live)
-    for o in objs:
-        if isinstance(o, (Plan, Plan64)):
-            o.close()
-    for o in objs:
-        if isinstance(o, Context):
-            o.close()
+    for kind in ((Plan, Plan64), (Context,)):
+        for o in objs:
+            if isinstance(o, kind):
+                try:
+                    o.close()
+                except Exception:           # (interpreter exit: report nothing, keep releasing)
+                    pass
     _default_ctx.clear()
     del _pool[:]
 
