@@ -303,7 +303,9 @@ int wt_bilateral3d_conv(wt_plan *plan, int src, int var, int dst, int s, int dep
 /* ---- Richardson-Lucy support (watroo/utils.py:222-290) -------------- */
 /* cv2.filter2D(src, -1, kernel, dst, (-1,-1), 0, BORDER_REFLECT) with a small arbitrary kernel
  * (watroo/utils.py:257,286): correlation, anchor = kernel centre.  `kernel` is a host pointer
- * to kh*kw floats (<= 4096 taps). */
+ * to kh*kw floats.  Up to 4096 taps run as one LDS-tiled launch; larger PSFs (the reference has
+ * no size limit; up to 2^22 taps here) are applied in bands of rows / columns that accumulate
+ * (O(kh*kw) per pixel: the direct form, not an FFT). */
 int wt_filter2d(wt_plan *plan, int src, int dst, const float *kernel, int kh, int kw, int flags);
 /* General form: explicit anchor (ay, ax) and border WT_BORDER_SYMMETRIC or WT_BORDER_PERIODIC.
  * The periodic border with anchor k/2 (correlation) or k-1-k/2 (flipped kernel = convolution)

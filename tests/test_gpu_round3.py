@@ -426,3 +426,32 @@ def test_scaling_functions_with_even_or_many_taps_vs_reference_golden(L):
     assert float(np.abs(WA.AtrousTransform(cls)(cube, 2).data - g["even4_coef3_L2"]).max()) <= 2e-6 * float(np.abs(cube).max())
     c64 = WA.AtrousTransform(cls)(a.astype(np.float64) + 1e4, 2)
     assert c64.data.dtype == np.float64 and float(np.abs(c64.data - g["even4_coef2_f64_L2"]).max()) <= 1e-11 * 1e4
+
+
+def test_psf_beyond_4096_taps_runs_in_bands(L):
+    """wt_filter2d with PSFs larger than one LDS-tiled launch takes (65 x 65 = 4225 taps, 9 x 600,
+    130 x 40): bands of rows / columns that accumulate, symmetric and periodic borders, against the
+    oracle's direct correlation; and richardson_lucy with such a PSF against the oracle's."""
+    from oracle import atrous_numpy as O
+    import wavelets_amd as WA
+    rng = np.random.default_rng(9)
+    img = rng.standard_normal((150, 700), dtype=np.float32)
+    plan = L.Plan(L.default_context(), 150, 700, L.B3SPLINE, 1)
+    plan.upload(L.PLANE_INPUT, img)
+    for kh, kw in ((65, 65), (9, 600), (130, 40), (64, 64)):
+        k = rng.random((kh, kw)).astype(np.float32)
+        k /= k.sum()
+        plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, k)
+        ref = O.filter2d_reflect(img.astype(np.float64), k.astype(np.float64))
+        assert float(np.abs(plan.download(L.PLANE_OUT) - ref).max()) <= 2e-6 * float(np.abs(img).max()) * 4, (kh, kw)
+        plan.filter2d(L.PLANE_INPUT, L.PLANE_OUT, k, anchor=(kh // 2, kw // 2), periodic=True)
+        ref = O.filter2d_periodic(img.astype(np.float64), k.astype(np.float64), (kh // 2, kw // 2))
+        assert float(np.abs(plan.download(L.PLANE_OUT) - ref).max()) <= 2e-6 * float(np.abs(img).max()) * 4, (kh, kw, "periodic")
+    plan.close()
+    yy, xx = np.mgrid[-32:33, -32:33]
+    psf = np.exp(-(yy ** 2 + xx ** 2) / (2 * 6.0 ** 2)).astype(np.float32)
+    psf /= psf.sum()
+    data = (np.abs(rng.standard_normal((128, 160), dtype=np.float32)) * 5 + 20).astype(np.float32)
+    got = WA.richardson_lucy(data, psf, iterations=3, denoise_coefficients=[3, 1])
+    ref = O.richardson_lucy(data, psf, iterations=3, denoise_coefficients=[3, 1])
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))

@@ -255,6 +255,7 @@ extern "C" int wt_ctx_create(int device, wt_ctx **out)
     c->partial_blocks = kPartialBlocks;
     WT_HIP(hipHostMalloc(&c->h_pinned, 65536, hipHostMallocDefault));
     WT_HIP(hipMalloc(&c->d_psf, 4096 * sizeof(float)));
+    c->d_psf_cap = 4096;
     *out = c;
     return 0;
 }
@@ -2155,7 +2156,7 @@ extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel,
 {
     WtGuard guard_(ctx_of(p));
     if (!p || !kernel) WT_FAIL("wt_filter2d: null pointer");
-    if (kh < 1 || kw < 1 || kh * kw > 4096) WT_FAIL("wt_filter2d: kernel %d x %d unsupported (<= 4096 taps)", kh, kw);
+    if (kh < 1 || kw < 1 || (int64_t)kh * kw > (1 << 22)) WT_FAIL("wt_filter2d: kernel %d x %d unsupported (up to 2^22 taps)", kh, kw);
     if (ay < 0 || ay >= kh || ax < 0 || ax >= kw) WT_FAIL("wt_filter2d: anchor (%d, %d) outside the %d x %d kernel", ay, ax, kh, kw);
     if (src == dst) WT_FAIL("wt_filter2d: src and dst must differ");
     if (border != WT_BORDER_SYMMETRIC && border != WT_BORDER_PERIODIC) WT_FAIL("wt_filter2d: border %d unsupported (symmetric or periodic)", border);
@@ -2163,8 +2164,6 @@ extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel,
     const bool wrap = border == WT_BORDER_PERIODIC;
     if (wrap && (p->nranks > 1 || p->g.row0 != 0 || p->g.nrows != p->g.H))
         WT_FAIL("wt_filter2d: the periodic border needs a whole-image plan");
-    const size_t lds = (size_t)(WT_F2D_TW + kw - 1) * (WT_F2D_TH + kh - 1) * sizeof(float);
-    if (lds > 160 * 1024) WT_FAIL("wt_filter2d: kernel %d x %d needs %zu B of LDS", kh, kw, lds);
     const int reach = std::max(ay, kh - 1 - ay);
     if (p->nranks > 1 && reach > p->g.halo) WT_FAIL("wt_filter2d: kernel needs %d halo rows, plan has %d", reach, p->g.halo);
     wt_ctx *c = p->ctx;
@@ -2172,19 +2171,49 @@ extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel,
     WT_TRY(plane_base(p, src, &in));
     WT_TRY(plane_base(p, dst, &o));
     WT_TRY(maybe_exchange(p, src, reach, flags));
-    // the taps travel through pinned memory so the copy is ordered on the stream
+    const size_t ntaps = (size_t)kh * kw;
+    // the taps come from caller-owned memory: drain the stream (the previous PSF may still be read),
+    // copy synchronously (small PSFs through the pinned scratch, as before)
     WT_HIP(hipStreamSynchronize(c->stream));
-    memcpy(c->h_pinned, kernel, (size_t)kh * kw * sizeof(float));
-    WT_HIP(hipMemcpyAsync(c->d_psf, c->h_pinned, (size_t)kh * kw * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (ntaps > c->d_psf_cap) {
+        (void)hipFree(c->d_psf);
+        c->d_psf = nullptr;
+        c->d_psf_cap = 0;
+        WT_HIP(hipMalloc(&c->d_psf, ntaps * sizeof(float)));
+        c->d_psf_cap = ntaps;
+    }
+    if (ntaps * sizeof(float) <= 65536) {
+        memcpy(c->h_pinned, kernel, ntaps * sizeof(float));
+        WT_HIP(hipMemcpyAsync(c->d_psf, c->h_pinned, ntaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else {
+        WT_HIP(hipMemcpy(c->d_psf, kernel, ntaps * sizeof(float), hipMemcpyHostToDevice));
+    }
     dim3 grid((p->g.W + WT_F2D_TW - 1) / WT_F2D_TW, (p->g.nrows + WT_F2D_TH - 1) / WT_F2D_TH), block(64, 4);
     if (grid.y > 65535u) WT_FAIL("wt_filter2d: strip too tall");
+    // Bands (round 3: the reference has no PSF size limit, watroo/utils.py:245-257): a launch takes a
+    // window of at most 4096 taps whose LDS tile fits 96 KB; the windows tile the PSF and every launch
+    // after the first accumulates.  A PSF that fits is one launch, as before.
+    const int bw = std::min(kw, 512);
+    int bh = std::max(1, std::min(kh, 4096 / bw));
+    while (bh > 1 && (size_t)(WT_F2D_TW + bw - 1) * (WT_F2D_TH + bh - 1) * sizeof(float) > 96 * 1024) --bh;
+    const size_t lds = (size_t)(WT_F2D_TW + bw - 1) * (WT_F2D_TH + bh - 1) * sizeof(float);
     ProfScope ps(c, "wt_filter2d_kernel");
-    if (wrap) {
-        if (lds > 64 * 1024) WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(wt_filter2d_kernel<true>, grid, block, lds, c->stream, in, o, p->g, c->d_psf, kh, kw, ay, ax);
-    } else {
-        if (lds > 64 * 1024) WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(wt_filter2d_kernel<false>, grid, block, lds, c->stream, in, o, p->g, c->d_psf, kh, kw, ay, ax);
+    bool first = true;
+    for (int i0 = 0; i0 < kh; i0 += bh) {
+        for (int j0 = 0; j0 < kw; j0 += bw) {
+            const int h = std::min(bh, kh - i0), w = std::min(bw, kw - j0);
+            const float *sub = c->d_psf + (size_t)i0 * kw + j0;
+            #define WT_F2D_LAUNCH(WRAP, ACC)                                                                                        \
+                do {                                                                                                                 \
+                    if (lds > 64 * 1024)                                                                                             \
+                        WT_HIP(hipFuncSetAttribute((const void *)wt_filter2d_kernel<WRAP, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    hipLaunchKernelGGL((wt_filter2d_kernel<WRAP, ACC>), grid, block, lds, c->stream, (const float *)in, o, p->g, sub, kw, h, w, ay - i0, ax - j0); \
+                } while (0)
+            if (wrap) { if (first) WT_F2D_LAUNCH(true, false); else WT_F2D_LAUNCH(true, true); }
+            else { if (first) WT_F2D_LAUNCH(false, false); else WT_F2D_LAUNCH(false, true); }
+            #undef WT_F2D_LAUNCH
+            first = false;
+        }
     }
     WT_HIP(hipGetLastError());
     return 0;

@@ -1092,7 +1092,6 @@ extern "C" int wt64_filter2d(wt_plan64 *p, int src, int dst, const double *kerne
     // synchronously - see upload_taplist
     WT_HIP(hipStreamSynchronize(p->ctx->stream));
     WT_HIP(hipMemcpy(p->psf, kernel, n * sizeof(double), hipMemcpyHostToDevice));
-    WT_HIP(hipStreamSynchronize(p->ctx->stream));        // the host buffer may be pageable and short-lived
     hipLaunchKernelGGL(wt64_filter2d_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, o, p->g, (const double *)p->psf, kh, kw,
                        ay, ax, border == WT_BORDER_PERIODIC);
     WT_HIP(hipGetLastError());

@@ -95,7 +95,8 @@ struct wt_ctx {
     double *d_partials = nullptr; // reduction partials
     int partial_blocks = 0;
     void *h_pinned = nullptr;     // 64 KiB pinned host scratch
-    float *d_psf = nullptr;       // PSF taps of wt_filter2d (<= 4096 floats)
+    float *d_psf = nullptr;       // PSF taps of wt_filter2d (grown on demand)
+    size_t d_psf_cap = 0;         // floats
     // tap list of the generic operator (wt_taps_conv / wt64_taps_conv): 3 int32 offsets + one
     // double-sized weight slot per tap, grown on demand
     void *d_taps = nullptr;

@@ -1380,9 +1380,12 @@ __device__ __forceinline__ int wt_wrap(int i, int n)
     return m < 0 ? m + n : m;
 }
 
-template <bool WRAP>
+// (round 3) psf_pitch / ACCUM: a PSF beyond 4096 taps (or beyond the LDS tile) is applied in bands of
+// rows and columns - each launch takes a kh x kw window of the full PSF (row pitch psf_pitch) with the
+// anchor shifted into the window's frame (it may then lie outside the window) and adds to `out`
+template <bool WRAP, bool ACCUM>
 __global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float *out, Geo g,
-                                                          const float *psf, int kh, int kw, int ay, int ax)
+                                                          const float *psf, int psf_pitch, int kh, int kw, int ay, int ax)
 {
     extern __shared__ float tile[];
     const int tw = WT_F2D_TW + kw - 1, th = WT_F2D_TH + kh - 1;
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < kh; ++i)
         for (int j = 0; j < kw; ++j) {
-            const float k = psf[i * kw + j];
+            const float k = psf[i * psf_pitch + j];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[r] = fmaf(k, tile[(threadIdx.y * 4 + r + i) * tw + threadIdx.x + j], acc[r]);
@@ -1412,7 +1415,7 @@ __global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ly = ly0 + threadIdx.y * 4 + r;
-            if (ly < g.nrows) out[(int64_t)ly * g.P + x] = acc[r];
+            if (ly < g.nrows) out[(int64_t)ly * g.P + x] = ACCUM ? out[(int64_t)ly * g.P + x] + acc[r] : acc[r];
         }
     }
 }
