@@ -598,6 +598,31 @@ def main():
                           "kernels": o["kernels"],
                           "cpu_baseline": o.get("cpu_baseline")}
         out["configs"] = extra
+        # the reference's DEFAULT dtype (README flows are float64, ref wavelets.py:297,319-320): the
+        # headline workload in float64 on the fused double passes (wt64_decompose_sum) - not a
+        # BASELINE.json configuration, reported beside them
+        try:
+            import wavelets_amd as WA
+            p64 = _lib.Plan64(ctx, 8192, 8192, tuple(float(t) for t in WA.B3spline.coefficients_1d), LEVEL)
+            p64.upload(PLANE_INPUT, make_strip(8192, 8192, seed=0).astype(np.float64))
+            for _ in range(5):
+                fused64 = p64.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT)
+            ctx.sync()
+            n64 = max(5, min(args.steps, 20))
+            ctx.timer_start()
+            for _ in range(n64):
+                p64.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT)
+            ms64 = ctx.timer_stop() / n64
+            p64.close()
+            bpp64 = 16.0 * (LEVEL + 2)                               # SURVEY 8(d) at 8 bytes per sample
+            out["float64"] = {"workload": "8192x8192 float64, b3spline L=6, decompose (7 planes in HBM) + plane sum "
+                                          "(wt64_decompose_sum); device-resident",
+                              "value": round(8192 * 8192 / ms64 / 1e3, 1), "unit": "Mpix/s",
+                              "ms_per_step": round(ms64, 4), "fused_passes": bool(fused64),
+                              "bytes_per_pixel": bpp64,
+                              "frac_of_hbm_peak": round(bpp64 * 8192 * 8192 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception as e:                                       # never lose the headline line over the extra
+            out["float64"] = {"error": repr(e)}
     if out is not None:
         brief = out.pop("_brief")
         emit(brief if args.brief else json.dumps(out))

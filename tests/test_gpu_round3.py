@@ -180,6 +180,8 @@ def test_bench_default_line_carries_every_config():
     assert set(out["configs"]) == {"cfg2", "cfg3", "cfg5"}
     for name, c in out["configs"].items():
         assert c["value"] > 0 and c["ms_per_step"] > 0 and c["bytes_per_pixel"] > 0 and c["dominant_kernel"]
+    f64 = out["float64"]                                     # the reference's default dtype, beside the configs
+    assert f64.get("fused_passes") is True and f64["value"] > 20000 and f64["bytes_per_pixel"] == 128.0
     rf = out["roofline"]
     assert rf["kernel"] == "wt_fused_kernel" and 0 < rf["frac"] < 1.2
     if rf["traffic"] is not None:
