@@ -1,0 +1,68 @@
+"""CPU checks of the host logic behind the generic tap-list operator (wt_taps_conv): the tap lists
+the Python layer builds (wavelets_amd.wavelets._reference_taps / _filter_taps) are applied here by a
+numpy model of wt_taps_kernel (same border rules per axis) and must reproduce the oracle's
+restatements of the reference - atrous_convolution for any kernel / np.pad mode
+(watroo/wavelets.py:74-105) and convolution() for even or long tap vectors (:35-69)."""
+import numpy as np
+import pytest
+
+from oracle import atrous_numpy as O
+from wavelets_amd.wavelets import _PAD_MODES, _filter_taps, _reference_taps
+
+
+def pad_index(i, n, mode):
+    """wt_pad_index of wt_kernels.h"""
+    i = np.asarray(i)
+    if mode == "symmetric":
+        m = np.mod(i, 2 * n)
+        return np.where(m < n, m, 2 * n - 1 - m)
+    if mode == "reflect":
+        if n == 1:
+            return np.zeros_like(i)
+        m = np.mod(i, 2 * n - 2)
+        return np.where(m < n, m, 2 * n - 2 - m)
+    if mode == "edge":
+        return np.clip(i, 0, n - 1)
+    if mode == "wrap":
+        return np.mod(i, n)
+    return np.where((i >= 0) & (i < n), i, -1)              # constant
+
+
+def apply_taps(a, center, offs, wts, mode, fill=0.0):
+    """numpy model of wt_taps_kernel (plain form) on a 1-, 2- or 3-D array"""
+    a3 = a.reshape((1,) * (3 - a.ndim) + a.shape)
+    Z, Y, X = a3.shape
+    zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    acc = (center * a3).astype(a.dtype) if center is not None else np.zeros_like(a3)
+    for (dz, dy, dx), w in zip(offs, wts):
+        iz, iy, ix = pad_index(zz + dz, Z, mode), pad_index(yy + dy, Y, mode), pad_index(xx + dx, X, mode)
+        ok = (iz >= 0) & (iy >= 0) & (ix >= 0)
+        v = np.where(ok, a3[np.maximum(iz, 0), np.maximum(iy, 0), np.maximum(ix, 0)], a.dtype.type(fill))
+        acc = acc + v * a.dtype.type(w)
+    return acc.reshape(a.shape)
+
+
+@pytest.mark.parametrize("mode", sorted(_PAD_MODES))
+@pytest.mark.parametrize("shape,kshape", [((40,), (4,)), ((23, 31), (3, 5)), ((17, 19), (4, 2)), ((5, 9, 11), (3, 3, 2))])
+def test_reference_tap_list_reproduces_the_reference_loop(shape, kshape, mode):
+    rng = np.random.default_rng(len(shape) * 100 + kshape[0])
+    a = rng.standard_normal(shape)
+    k = rng.random(kshape)
+    for s in (0, 1, 2):
+        kc, offs, wts = _reference_taps(k, s)
+        got = apply_taps(a, kc, offs, wts, mode)
+        np.testing.assert_allclose(got, O.atrous_convolution_nd(a, k, None, s, mode), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("taps", [[0.5, 0.5], [0.1, 0.4, 0.3, 0.2], list(np.hanning(19)[1:-1] / np.hanning(19)[1:-1].sum())])
+def test_filter_tap_list_reproduces_convolution_for_even_and_long_taps(taps):
+    rng = np.random.default_rng(len(taps))
+    t = np.asarray(taps)
+    for a in (rng.standard_normal(90), rng.standard_normal((29, 37)), rng.standard_normal((6, 9, 13))):
+        kern = t
+        for _ in range(a.ndim - 1):
+            kern = np.multiply.outer(kern, t)
+        for s in (0, 1, 2):
+            offs, wts = _filter_taps(kern, s, convolve=a.ndim == 1)
+            got = apply_taps(a, None, offs, wts, "reflect" if a.ndim == 1 else "symmetric")
+            np.testing.assert_allclose(got, O.convolution_taps_nd(a, t, s), rtol=0, atol=1e-12)
