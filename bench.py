@@ -581,8 +581,12 @@ def main():
         # every other single-GPU BASELINE.json configuration, timed in the same run
         extra = {}
         for cfg in ("cfg2", "cfg3", "cfg5"):
-            o = run_workload(cfg, max(5, min(args.steps, 20)) if cfg != "cfg5" else 5,
-                             args.warmup, full=False)
+            try:
+                o = run_workload(cfg, max(5, min(args.steps, 20)) if cfg != "cfg5" else 5,
+                                 args.warmup, full=False)
+            except Exception as e:          # never lose the headline line over an extra configuration
+                extra[cfg] = {"error": repr(e)}
+                continue
             r = o["roofline"] or {}
             extra[cfg] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"],
                           "ms_per_step": o["ms_per_step"], "steps": o["steps"],
