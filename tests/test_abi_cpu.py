@@ -133,3 +133,27 @@ def test_header_is_plain_c_and_a_c_client_links():
     assert r.returncode in (0, 3), r.stdout + r.stderr
     if r.returncode == 3:
         assert "no HIP device" in r.stderr
+
+
+def test_no_kernel_uses_scratch_memory_or_spills(tmp_path):
+    """Every kernel of libwatroo_hip.so keeps its working set in registers: no private (scratch)
+    segment, no spilled VGPRs.  The marching kernels hold sliding windows in register arrays indexed
+    by fully unrolled loops; an innocent edit (a run-time switch around a window update, a loop the
+    compiler declines to unroll) silently moves a window to scratch memory and costs 10x - this
+    happened twice in round 3.  Reads the kernel metadata of the embedded gfx950 code object."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("ROCm LLVM tools not installed")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert objs, "no device code object in the library"
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / objs[0])],
+                           check=True, capture_output=True, text=True).stdout
+    kernels = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)",
+                         notes, flags=re.S)
+    assert len(kernels) > 200
+    bad = [(n, int(sc), int(sp)) for n, sc, sp in kernels if int(sc) or int(sp)]
+    assert not bad, f"kernels with scratch / spills: {bad[:5]}"
