@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 4
+#define WT_ABI_VERSION 5
 
 typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
 typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */

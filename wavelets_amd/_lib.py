@@ -174,7 +174,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = res, args
-            if L.wt_abi_version() != 4:
+            if L.wt_abi_version() != 5:
                 raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
             _lib = L
     return _lib
