@@ -569,6 +569,35 @@ def main():
                                                    budget=15.0 if full else 5.0)
             out["_brief"] = f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
                 f"{k}={v['avg_ms']}" for k, v in kernels.items())
+        if world > 1:
+            # Halo self-check over the real transport (outside the timed region, every rank): a linear
+            # ramp in y is reproduced exactly by the smoothing filters (symmetric taps, unit gain) away
+            # from the image's own top / bottom border, so every detail plane must vanish there - unless
+            # a strip boundary was filtered with missing, stale or misplaced neighbour rows.  Rows within
+            # the transform's reach of a global border (reflection is not linear) are cropped off.
+            reach = sum(h for _, _, h in sched)
+            ramp = (np.arange(row0, row0 + nrows, dtype=np.float32)[:, None]
+                    * np.ones((1, W), dtype=np.float32))
+            plan.upload(PLANE_INPUT, ramp)
+            del ramp
+            plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+            top = reach if rank == 0 else 0
+            bot = reach if rank == world - 1 else 0
+            worst = 0.0
+            if nrows - top - bot > 0:
+                sub = _lib.Plan(ctx, nrows - top - bot, W, fam, 0)
+                for s_ in range(level):
+                    sub.crop_from(plan, s_, PLANE_INPUT, top, 0)
+                    _, _, lo, hi = sub.reduce(PLANE_INPUT)
+                    worst = max(worst, abs(lo), abs(hi))
+                sub.close()
+            import torch
+            t = torch.tensor([worst], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if out is not None:
+                # (float32 rounding of values up to H: a few ulp of 3e4; a wrong halo row shows as O(1..H))
+                out["halo_selfcheck"] = {"input": "f(y, x) = y", "max_abs_detail_off_the_global_border": float(t[0]),
+                                         "bound": 0.05, "ok": bool(float(t[0]) <= 0.05)}
         if coefficients is not None:
             coefficients._plan = None                 # the plan is ours, not the pool's
         plan.close()
