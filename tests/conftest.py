@@ -57,3 +57,36 @@ def plane_bound(s, amax):
 
 def recon_bound(amax, denoised=False):
     return (5.8e-6 if denoised else 3.9e-6) * float(amax) / _REF_AMAX
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(cmd, env, tag, timeout=600):
+    """Run a multi-process command (torch.distributed.run rendezvous + RCCL bootstrap over loopback
+    sockets).  A launcher-level failure - non-zero exit WITHOUT a result line, seen once in a dozen
+    runs on the shared boxes - is retried once on a fresh port; the output of a failed attempt is
+    kept under gpurun_out/ either way.  A run that completes and reports wrong results is never
+    retried."""
+    import subprocess
+    r = None
+    for attempt in (0, 1):
+        if "--master-port" in cmd:
+            cmd = list(cmd)
+            cmd[cmd.index("--master-port") + 1] = str(free_port())
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        if r.returncode == 0:
+            return r
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"ranks_failure_{tag}_{attempt}.log"), "w") as f:
+                f.write(r.stdout[-20000:] + "\n---- stderr ----\n" + r.stderr[-40000:])
+        except OSError:
+            pass
+        if "mismatch" in r.stdout or any(ln.startswith("{") for ln in r.stdout.splitlines()):
+            return r                     # it ran to the end: a real failure
+    return r

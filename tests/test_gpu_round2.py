@@ -147,9 +147,9 @@ def test_bench_self_launches_two_ranks_on_the_shared_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu",
-                        "--size", "2048", "--steps", "3", "--warmup", "1", "--no-cpu"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    from conftest import run_ranks
+    r = run_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu",
+                   "--size", "2048", "--steps", "3", "--warmup", "1", "--no-cpu"], env, "bench2")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

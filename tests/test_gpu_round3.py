@@ -125,34 +125,7 @@ def test_cfg4_32768_eight_strips_equal_unsharded():
     assert "8 virtual strips vs unsharded: max |difference| over all planes = 0.0" in r.stdout
 
 
-def _run_ranks(cmd, env, tag):
-    """Run a multi-process command (torch.distributed.run rendezvous + RCCL bootstrap over loopback
-    sockets).  A launcher-level failure - non-zero exit WITHOUT a result line, seen once in a dozen
-    runs on the shared boxes - is retried once on a fresh port; the output of a failed attempt is
-    kept under gpurun_out/ either way.  A run that completes and reports wrong results is never
-    retried."""
-    for attempt in (0, 1):
-        if "--master-port" in cmd:
-            cmd = list(cmd)
-            cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-        if r.returncode == 0:
-            return r
-        try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", f"ranks_failure_{tag}_{attempt}.log"), "w") as f:
-                f.write(r.stdout[-20000:] + "\n---- stderr ----\n" + r.stderr[-40000:])
-        except OSError:
-            pass
-        if "mismatch" in r.stdout or any(ln.startswith("{") for ln in r.stdout.splitlines()):
-            return r                     # it ran to the end: a real failure
-    return r
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from conftest import free_port as _free_port, run_ranks as _run_ranks  # noqa: E402
 
 
 def test_real_rccl_four_ranks_share_the_gpu():

@@ -221,7 +221,8 @@ def test_real_rccl_ranks_share_the_gpu(nranks, shape):
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tools", "check_rccl_ranks.py"), "--shape", str(shape[0]), str(shape[1])]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    from conftest import run_ranks
+    r = run_ranks(cmd, env, f"ranks{nranks}", timeout=420)
     assert r.returncode == 0 and "0 mismatches in total" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
