@@ -456,3 +456,41 @@ def test_psf_beyond_4096_taps_runs_in_bands(L):
     got = WA.richardson_lucy(data, psf, iterations=3, denoise_coefficients=[3, 1])
     ref = O.richardson_lucy(data, psf, iterations=3, denoise_coefficients=[3, 1])
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))
+
+
+def test_float64_fused_8192_vs_generic_engine_on_the_device(L):
+    """The float64 headline workload at full size (8192^2, B3spline, 6 scales; 512 MiB planes): the
+    fused double passes against the generic one-kernel-per-scale float64 engine (itself pinned by
+    g20 and the oracle at small sizes), every plane compared ON THE DEVICE (subtract + reduce) at
+    1e-13 * max|input|; the carried sum equals the input to 1e-12 (perfect reconstruction) and is
+    bit-identical to wt64_plane_sum over the fused planes."""
+    import wavelets_amd as WA
+    side, level = 8192, 6
+    rng = np.random.default_rng(7)
+    plan = L.Plan64(L.default_context(), side, side, tuple(float(t) for t in WA.B3spline.coefficients_1d), level)
+    a = rng.standard_normal((side, side)) * 4.0 + 1e3
+    amax = float(np.abs(a).max())
+    plan.upload(L.PLANE_INPUT, a)
+    del a
+    assert plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT)
+    keep = [L.PLANE_SCRATCH(8 + s) for s in range(level + 1)]
+    for s in range(level + 1):
+        plan.copy(s, keep[s])                                 # the fused planes, set aside
+    D = L.PLANE_SCRATCH(20)
+    plan.binary("sub", L.PLANE_OUT, L.PLANE_INPUT, D)
+    _, _, lo, hi = plan.reduce(D)
+    assert max(abs(lo), abs(hi)) <= 1e-12 * amax, (lo, hi)
+    plan.plane_sum(0, level + 1, D)
+    plan.binary("sub", L.PLANE_OUT, D, D)
+    _, _, lo, hi = plan.reduce(D)
+    assert lo == 0.0 and hi == 0.0                            # carried sum == plane sum, bitwise
+    try:
+        L.set_option("fused64", 0)
+        plan.decompose(L.PLANE_INPUT, level)
+    finally:
+        L.set_option("fused64", 1)
+    for s in range(level + 1):
+        plan.binary("sub", s, keep[s], D)
+        _, _, lo, hi = plan.reduce(D)
+        assert max(abs(lo), abs(hi)) <= 1e-13 * amax, (s, lo, hi)
+    plan.close()
