@@ -363,9 +363,9 @@ int wt64_upload(wt_plan64 *plan, int plane, const double *host, int64_t host_pit
 int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
 /* AtrousTransform.atrous_standard (watroo/wavelets.py:408-444).  Images (depth 0) under the
  * symmetric border with the taps of a built-in family run the FUSED multi-scale passes of the
- * float32 engine instantiated for double (two pixels per lane; wavelets_amd/csrc/wt_fused.h)
- * when the size admits them (W even and at least the widest pass's x halo, H at least the
- * pass's row reach); everything else runs one generic kernel per scale.
+ * float32 engine instantiated for double (two pixels per lane; wavelets_amd/csrc/wt_fused.h),
+ * any width and height (H >= 2; scales beyond the fused passes: one generic kernel each);
+ * signals, cubes, user-defined taps and non-default borders run one generic kernel per scale.
  * wt_set_option("fused64", 0) forces the generic kernels (A/B; results agree to rounding: the
  * fused passes filter columns first, the generic kernels rows first). */
 int wt64_decompose(wt_plan64 *plan, int src, int level, int depth);

@@ -243,24 +243,44 @@ def test_float64_fused_passes_vs_generic_and_oracle(L, H, W, fam, level):
     plan.close()
 
 
-def test_float64_shapes_that_keep_the_generic_kernels(L):
-    """Odd widths, images narrower than a pass's halo, user-defined taps and non-default borders are
-    served by the generic float64 kernels: wt64_decompose_sum says so and the planes match the oracle."""
+def test_float64_odd_widths_small_images_and_deep_schedules(L):
+    """Odd widths and images smaller than a pass's halo run the fused float64 passes on the generic
+    (gather / multi-bounce) addressing; schedules deeper than the fused passes (B3 L = 9: scale 8) mix
+    fused passes with one generic kernel per remaining scale (the sum then takes the two-step form);
+    user-defined taps and 1 x N signals keep the generic engine.  Planes vs the float64 oracle at
+    1e-13, fused vs generic engine at 1e-13, carried sum == plane sum bitwise."""
     from oracle import atrous_numpy as O
     import wavelets_amd as WA
     taps = tuple(float(t) for t in WA.B3spline.coefficients_1d)
-    for H, W, level in ((64, 95, 3), (40, 10, 3), (100, 64, 6)):
+    for H, W, level, fused_sum in ((64, 95, 3, True), (40, 10, 3, True), (100, 64, 6, True), (3, 7, 2, True),
+                                   (301, 1001, 6, True), (600, 533, 9, False), (2, 2, 2, True), (5, 4, 1, False)):
         a = np.random.default_rng(H + W).standard_normal((H, W)) + 50.0
+        amax = float(np.abs(a).max())
         plan = L.Plan64(L.default_context(), H, W, taps, level)
         plan.upload(L.PLANE_INPUT, a)
-        assert not plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT)
+        assert plan.decompose_sum(L.PLANE_INPUT, level, L.PLANE_OUT) == fused_sum, (H, W, level)
+        got = [plan.download(s).copy() for s in range(level + 1)]
+        car = plan.download(L.PLANE_OUT).copy()
+        plan.plane_sum(0, level + 1, L.PLANE_SCRATCH(5))
+        np.testing.assert_array_equal(car, plan.download(L.PLANE_SCRATCH(5)))
         ref = O.atrous_standard(a, level, "b3spline")
+        try:
+            L.set_option("fused64", 0)
+            plan.decompose(L.PLANE_INPUT, level)
+            gen = [plan.download(s).copy() for s in range(level + 1)]
+        finally:
+            L.set_option("fused64", 1)
         for s in range(level + 1):
-            assert float(np.abs(plan.download(s) - ref[s]).max()) <= 1e-13 * float(np.abs(a).max())
-        np.testing.assert_allclose(plan.download(L.PLANE_OUT), a, rtol=0, atol=1e-12 * float(np.abs(a).max()))
+            assert float(np.abs(got[s] - ref[s]).max()) <= 1e-13 * amax, (H, W, level, s)
+            assert float(np.abs(got[s] - gen[s]).max()) <= 1e-13 * amax, (H, W, level, s)
+        np.testing.assert_allclose(car, a, rtol=0, atol=1e-12 * amax)
         plan.close()
     plan = L.Plan64(L.default_context(), 128, 128, (0.2, 0.6, 0.2), 3)      # not a built-in family
     plan.upload(L.PLANE_INPUT, np.ones((128, 128)))
+    assert not plan.decompose_sum(L.PLANE_INPUT, 3, L.PLANE_OUT)
+    plan.close()
+    plan = L.Plan64(L.default_context(), 1, 300, taps, 3)                   # a signal: row filter only
+    plan.upload(L.PLANE_INPUT, np.random.default_rng(1).standard_normal((1, 300)))
     assert not plan.decompose_sum(L.PLANE_INPUT, 3, L.PLANE_OUT)
     plan.close()
 

@@ -660,9 +660,9 @@ extern "C" int wt64_smooth(wt_plan64 *p, int src, int dst, int s, int square_inp
 // fused multi-scale passes in float64 (round 3): wt_fused_kernel instantiated for double - a lane
 // owns two pixels (double2 = the same 16 bytes per access and the same register window as the
 // float4 passes), same polyphase march, LDS row exchange, delay rings and fixed-descriptor stores.
-// Served: images under the symmetric border whose taps are one of the built-in families and whose
-// size admits the fast addressing (W even, W >= the widest pass's x halo, H >= D * (rows of input
-// beyond a stored row + 1)); everything else keeps the generic per-scale kernels above.
+// Served: images (H >= 2) under the symmetric border whose taps are one of the built-in families and
+// whose schedule is all fused passes; signals, cubes, user-defined taps, the borders of the recursive
+// algorithm and schedules with per-scale passes (L > 8) keep the generic per-scale kernels above.
 // ---------------------------------------------------------------------------------------------
 static int g_opt_fused64 = getenv("WT_NO_FUSED64") ? 0 : 1;      // wt_set_option("fused64", 0/1)
 static void wt_set_fused64(int on) { g_opt_fused64 = on; }
@@ -675,22 +675,25 @@ static int fused64_family(const wt_plan64 *p)
     return -1;
 }
 
-// every pass of the fused schedule for `level` scales exists and takes the fast addressing
-static bool fused64_ok(const wt_plan64 *p, int level, int depth, int32_t *tr, int *np)
+// every pass of the fused schedule for `level` scales exists (any width and height: images that do
+// not admit the fast addressing - odd widths, sizes below a pass's halo - take the generic one, as in
+// float32)
+static bool fused64_ok(const wt_plan64 *p, int level, int depth, int32_t *tr, int *np, bool *all_fused)
 {
     const int fam = fused64_family(p);
-    if (!g_opt_fused64 || fam < 0 || depth != 0 || p->g.border != 0 || level < 1 || (p->g.W & 1)) return false;
+    *all_fused = false;
+    if (!g_opt_fused64 || fam < 0 || depth != 0 || p->g.border != 0 || level < 1) return false;
+    if (p->g.H < 2) return false;                        // 1 x N: a signal (row filter only) - generic kernels
     if (!wt_fused_supported_bytes((int64_t)p->g.P * 8)) return false;
     if (wt_schedule(fam, level, 1, tr, 32, np)) return false;
-    const int hw = p->ntaps / 2;
+    bool all = true, any = false;
     for (int i = 0; i < *np; ++i) {
-        const int s0 = tr[3 * i], ns = tr[3 * i + 1], D = 1 << s0;
-        if (!wt_fused_has_pass(s0, ns, fam)) return false;
-        const int lat = hw * ((1 << ns) - 1);
-        const int HX = (lat * D + 15) / 16 * 16;
-        if (p->g.W < HX || p->g.H < D * (lat + 1)) return false;
+        const bool has = wt_fused_has_pass(tr[3 * i], tr[3 * i + 1], fam);
+        all = all && has;
+        any = any || has;
     }
-    return true;
+    *all_fused = all;
+    return any;                                          // (scales beyond the fused passes: one generic kernel each)
 }
 
 template <int K, int ACC>
@@ -729,6 +732,17 @@ static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int 
         const int s0 = tr[3 * i], ns = tr[3 * i + 1];
         const bool last = s0 + ns == level;
         const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+        if (!wt_fused_has_pass(s0, ns, b3 ? WT_B3SPLINE : WT_TRIANGLE)) {
+            // a scale beyond the fused passes (the schedule gives those one scale per pass)
+            if (with_sum || ns != 1) WT_FAIL("float64 schedule: pass (%d, %d) has no fused kernel", s0, ns);
+            double *ci = nullptr, *co = nullptr, *w = nullptr;
+            WT_TRY(plan64_base(p, cur, &ci));
+            WT_TRY(plan64_base(p, nxt, &co));
+            WT_TRY(plan64_base(p, s0, &w));
+            WT_TRY(smooth64(p, ci, co, w, s0, 0, 0));
+            cur = nxt;
+            continue;
+        }
         FusedArgsT<double> a{};
         double *in = nullptr;
         WT_TRY(plan64_base(p, cur, &in));
@@ -773,7 +787,8 @@ extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
     {
         int32_t tr[3 * 32];
         int np = 0;
-        if (fused64_ok(p, level, depth, tr, &np)) return fused64_run(p, src, level, tr, np, false, WT_PLANE_NONE);
+        bool all = false;
+        if (fused64_ok(p, level, depth, tr, &np, &all)) return fused64_run(p, src, level, tr, np, false, WT_PLANE_NONE);
     }
     int cur = src;
     for (int s = 0; s < level; ++s) {
@@ -804,7 +819,8 @@ extern "C" int wt64_decompose_sum(wt_plan64 *p, int src, int level, int dst, int
         WT_FAIL("wt64_decompose_sum: scratch planes 0/1 are used internally");
     int32_t tr[3 * 32];
     int np = 0;
-    const bool fused = fused64_ok(p, level, 0, tr, &np);
+    bool all = false;
+    const bool fused = fused64_ok(p, level, 0, tr, &np, &all) && all;    // the sum rides only if every pass is fused
     if (fused_out) *fused_out = fused ? 1 : 0;
     if (fused) return fused64_run(p, src, level, tr, np, true, dst);
     WT_TRY(wt64_decompose(p, src, level, 0));

@@ -915,15 +915,8 @@ static int wt_fused_launch_t(PLAN *p, const FusedArgsT<T> &base, const char *nam
     ProfScope ps(p->ctx, name);
     // fast addressing: aligned groups reflect onto aligned groups and no index reflects twice
     const bool fast = g_opt_fused_fast && g.W % PX == 0 && g.W >= HX && g.H >= D * (hw * ((1 << NS) - 1) + 1);
-    if constexpr (sizeof(T) == 8) {
-        // float64: only the fast addressing is built (wt64_decompose checks the conditions up front and
-        // keeps the generic per-scale kernels for every other shape)
-        if (!fast) WT_FAIL("float64 fused pass: image %d x %d does not admit the fast addressing", g.H, g.W);
-        hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
-    } else {
-        if (fast) hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
-        else hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, false>), grid, block, 0, p->ctx->stream, a);
-    }
+    if (fast) hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
+    else hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }
