@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the launcher plumbing (gloo rendezvous, RCCL communicator) even "
                          "with one rank (plumbing check on a 1-GPU box)")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="testing: skip the halo exchange of multi-rank runs (wrong results at strip "
+                         "boundaries - the halo self-check must then report ok = false)")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="testing on a 1-GPU box: all ranks use device 0 and each gets its own "
                          "NCCL_HOSTID, so RCCL treats them as separate hosts (socket transport)")
@@ -328,6 +331,8 @@ def main():
         else:
             plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
         flags = 0 if args.unfused else _lib.FLAG_FUSED
+        if args.no_exchange:
+            flags |= _lib.FLAG_NO_EXCHANGE
         two_call = args.two_call or args.unfused
         coefficients = None
 

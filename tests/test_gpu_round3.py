@@ -514,3 +514,18 @@ def test_float64_fused_8192_vs_generic_engine_on_the_device(L):
         _, _, lo, hi = plan.reduce(D)
         assert max(abs(lo), abs(hi)) <= 1e-13 * amax, (s, lo, hi)
     plan.close()
+
+
+def test_halo_selfcheck_of_the_bench_detects_a_missing_exchange():
+    """The ramp self-check of `bench.py --gpus N` is only worth something if it FAILS when the
+    neighbours' rows are wrong: with --no-exchange (halo margins never filled) it must say so."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--size", "2048",
+           "--steps", "2", "--warmup", "1", "--no-cpu", "--no-exchange"]
+    r = _run_ranks(cmd, env, "bench2_noexchange")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    chk = out["halo_selfcheck"]
+    assert chk["ok"] is False and chk["max_abs_detail_off_the_global_border"] > 1.0, chk
