@@ -7,11 +7,17 @@
     N = 1 : 8192 x 8192 float32 N(0,1), B3spline, 6 scales: decompose (7 planes materialised in
             HBM) + plane sum; input already resident in HBM when the timed region starts.
     N > 1 : BASELINE config 4: one 32768 x 32768 image split into N row strips, halo rows
-            exchanged with the strip neighbours over RCCL before every pass.  `python bench.py
-            --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
-            itself (as a CHILD process, before anything touches the GPU) when it is not already
-            running under it; torch.distributed (gloo) is only the launcher plumbing:
-            rendezvous, broadcast of the RCCL unique id, barrier, MAX over ranks.
+            exchanged with the strip neighbours over RCCL before every pass.  One process per GPU.
+            `python bench.py --gpus N` starts its N ranks itself (child processes, before anything
+            touches the GPU; wavelets_amd/launch.py) unless it already runs as a rank (RANK /
+            WORLD_SIZE in the environment: `python -m torch.distributed.run ... bench.py --gpus N`,
+            the driver's command).  Either way the ranks rendezvous over a local socket - the 128-
+            byte RCCL unique id, barriers and the MAX over ranks - and NO rank imports torch: N = 1
+            and N > 1 run on the same (system) ROCm stack.  --launcher torch restores the round-3
+            plumbing (torch.distributed / gloo in every rank).  The line carries per-pass
+            exchange / interior / edge times, the step time with the overlap switched off, and an
+            A/B of the strip planes' placement (plain hipMalloc vs scattered 2-MiB chunks); a
+            wall-clock limit (--time-limit) kills a hung launch and reports it as JSON.
 --config cfg2 | cfg3 | cfg5  (N = 1; the other BASELINE.json configs, same JSON shape)
     cfg2  4096^2 B3spline L=6 decompose + reconstruct
     cfg3  8192^2 Triangle L=8 + denoise([5,3,2]) soft threshold + reconstruct
@@ -189,20 +195,113 @@ def cpu_baseline(config, side, family, level, budget=15.0):
 
 
 def self_launch(args, argv):
-    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child
-    process (never exec: nothing here has touched the GPU yet, and nothing will), forward the
-    child's output (rank 0 prints the one JSON line) and its return code."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    """`python bench.py --gpus N` outside any launcher: start the N ranks as child processes (never
+    exec: nothing here has touched the GPU yet, and nothing will), forward rank 0's one JSON line
+    and the return code.  A rank that fails, or the wall-clock limit, ends every rank's process
+    group; if no result line has come out by then this process prints {"error": ...} instead."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    if args.launcher == "torch":
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + argv
+        try:
+            return subprocess.run(cmd, env=env, timeout=args.time_limit).returncode
+        except subprocess.TimeoutExpired:
+            print(json.dumps({"error": f"time limit of {args.time_limit:.0f} s exceeded", "n_gpus": args.gpus}))
+            return 124
+    from wavelets_amd import launch
+    if not args.no_build:
+        # build once, before the ranks start (they must not race for the library) and in a child of
+        # its own: this process never loads the HIP library
+        rc = subprocess.run([sys.executable, "-c", "import __graft_entry__ as e; e.build()"], cwd=ROOT, env=env).returncode
+        if rc != 0:
+            print(json.dumps({"error": f"__graft_entry__.build() failed with code {rc}", "n_gpus": args.gpus}))
+            return rc
+    seen = []
+    rc, reason = launch.spawn(args.gpus, [sys.executable, os.path.abspath(__file__)] + argv + ["--no-build"],
+                              time_limit=args.time_limit, env=env, tee_rank0=seen)
+    if rc != 0 and not any(ln.startswith("{") for ln in seen):
+        print(json.dumps({"error": reason, "n_gpus": args.gpus, "launcher": "stdlib"}))
+    return rc
+
+
+class TorchGroup:
+    """--launcher torch: the collectives of wavelets_amd.launch.SocketGroup over torch.distributed
+    (gloo).  Imports torch - and with it torch's bundled ROCm runtime - into the rank."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def bcast(self, obj, src=0):
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out if self.rank == 0 else None
+
+    def allreduce(self, value, op=max):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, value)
+        return op(out)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+def source_digest():
+    """sha1 over the kernel sources (wavelets_amd/csrc + include), comments and whitespace removed:
+    what profiles/traffic.json is tied to - PMC bytes per launch describe the kernels they were
+    measured on (tools/pmc_summary.py stores the digest, tests/test_abi_cpu.py compares)."""
+    import hashlib
+    import re
+    h = hashlib.sha1()
+    files = [os.path.join(ROOT, "include", "watroo_hip.h")]
+    csrc = os.path.join(ROOT, "wavelets_amd", "csrc")
+    files += [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))]
+    for f in files:
+        text = open(f, encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(os.path.basename(f).encode())
+        h.update("".join(text.split()).encode())
+    return h.hexdigest()
+
+
+def load_traffic(path=None, digest=None, lib_overridden=None):
+    """(db, stale_reason): the PMC traffic table, and why it must not be used (None: usable).  The
+    table is stale when it was measured on other kernel sources than the ones the loaded library
+    was built from, or when a different library was put in place (WATROO_HIP_LIB)."""
+    path = path or os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return {}, "profiles/traffic.json is missing"
+    db = json.load(open(path))
+    meta = db.get("_meta") or {}
+    if lib_overridden is None:
+        lib_overridden = bool(os.environ.get("WATROO_HIP_LIB"))
+    if lib_overridden:
+        return db, "WATROO_HIP_LIB overrides the library the table was measured on"
+    if not meta.get("source_digest"):
+        return db, "profiles/traffic.json carries no source digest"
+    if meta["source_digest"] != (digest or source_digest()):
+        return db, ("profiles/traffic.json was measured on other kernel sources (digest "
+                    f"{meta['source_digest'][:12]}): re-run tools/profile_round.sh")
+    return db, None
 
 
 def main():
@@ -235,6 +334,14 @@ def main():
     ap.add_argument("--shared-gpu", action="store_true",
                     help="testing on a 1-GPU box: all ranks use device 0 and each gets its own "
                          "NCCL_HOSTID, so RCCL treats them as separate hosts (socket transport)")
+    ap.add_argument("--launcher", choices=("stdlib", "torch"), default="stdlib",
+                    help="plumbing between the ranks: local socket (default; no rank imports torch) or "
+                         "torch.distributed / gloo as in round 3")
+    ap.add_argument("--time-limit", type=float, default=900.0,
+                    help="wall-clock limit of a multi-rank run in seconds: at the limit every rank is "
+                         "killed and a JSON line says so (the last complete measurement, if there is one)")
+    ap.add_argument("--no-scatter-ab", action="store_true",
+                    help="multi-rank runs: skip the A/B of the strip planes' placement (plain hipMalloc only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -267,42 +374,63 @@ def main():
     if world > 1 and args.config != "headline":
         sys.exit("--config cfg2/cfg3/cfg5 are single-GPU workloads")
 
-    # ORDER MATTERS: torch wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 /
-    # librccl).  If libwatroo_hip.so pulls in the system ROCm first and torch is imported
-    # afterwards, the process ends up with TWO HSA runtimes and whichever initialises second
-    # sees "no ROCm-capable device".  Importing torch first makes the dynamic loader resolve
-    # our library's sonames to the already-loaded (torch) copies: one consistent stack.
-    dist = None
+    # The plumbing between the ranks.  Default: a local socket (wavelets_amd/launch.py) - no rank
+    # imports torch, so N = 1 and N > 1 run on the same system ROCm stack; under the driver's
+    # `python -m torch.distributed.run` torch lives in the launcher process only.
+    # --launcher torch: torch.distributed (gloo) in every rank.  ORDER MATTERS there: torch wheels
+    # bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 / librccl).  If libwatroo_hip.so
+    # pulls in the system ROCm first and torch is imported afterwards, the process ends up with TWO
+    # HSA runtimes and whichever initialises second sees "no ROCm-capable device"; importing torch
+    # first makes the dynamic loader resolve our library's sonames to the already-loaded copies.
+    state = {"result": None, "main_done": False}       # what the watchdog reports at the time limit
+    dog = None
+    if world > 1:
+        from wavelets_amd.launch import Watchdog
+
+        def on_expire():
+            sys.stderr.write(f"[bench rank {rank}] time limit of {args.time_limit:.0f} s exceeded\n")
+            if rank == 0:
+                if state["result"] is not None:
+                    state["result"]["time_limit_hit"] = (f"{args.time_limit:.0f} s: this is the last complete "
+                                                         "measurement; a later phase of the run did not finish")
+                    state["result"].pop("_brief", None)
+                    emit(json.dumps(state["result"]))
+                else:
+                    emit(json.dumps({"error": f"time limit of {args.time_limit:.0f} s exceeded before the first "
+                                              "complete measurement", "n_gpus": world, "launcher": args.launcher}))
+        # (a little ahead of the launcher's own limit, so that the stored result gets out; a rank that
+        #  has finished the main measurement leaves with code 0)
+        dog = Watchdog(max(5.0, args.time_limit - 20.0), on_expire,
+                       code=lambda: 0 if state["main_done"] else 124)
+    group = None
     if world > 1 or args.force_dist:
-        import torch  # noqa: F401  (before anything loads libwatroo_hip.so)
-        import torch.distributed as dist
+        if args.launcher == "torch":
+            import torch  # noqa: F401  (before anything loads libwatroo_hip.so)
+            group = TorchGroup(rank, world)
+        else:
+            from wavelets_amd.launch import SocketGroup
+            group = SocketGroup(rank, world, op_timeout=args.time_limit)
     if rank == 0 and not args.no_build:
         import __graft_entry__ as entry
         entry.build()
-    if dist is not None:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        dist.barrier()
+    if group is not None:
+        group.barrier()
     from wavelets_amd import _lib
     from wavelets_amd._lib import PLANE_INPUT, PLANE_OUT
 
+    if os.environ.get("WT_BENCH_REPORT_MODULES"):     # (tests: what this rank has imported before its first GPU call)
+        sys.stderr.write(f"[bench rank {rank}] torch_in_sys_modules={'torch' in sys.modules}\n")
     ctx = _lib.Context(local_rank)
     rccl_ranks = 1
-    if dist is not None:
-        def bcast(obj, src):
-            box = [obj]
-            dist.broadcast_object_list(box, src=src)
-            return box[0]
+    if group is not None:
         from wavelets_amd.parallel import init_comm
-        init_comm(ctx, rank, world, bcast)
+        init_comm(ctx, rank, world, group.bcast)
         rccl_ranks = ctx.comm_info()[1]          # what ncclCommCount says, not what we asked for
         if args.force_dist:
             assert ctx.comm_selftest(1 << 20), "RCCL self-test failed"
 
-    traffic_db = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # from rocprofv3 --pmc passes
-    if os.path.exists(tpath):
-        traffic_db = json.load(open(tpath))
+    traffic_db, traffic_stale = load_traffic()                    # from rocprofv3 --pmc passes
+    traffic_meta = traffic_db.get("_meta") or {}
 
     def run_workload(config, steps, warmup, full):
         """Time `steps` steps of BASELINE configuration `config`; returns the JSON object (rank 0)
@@ -321,45 +449,50 @@ def main():
         if rank == world - 1:
             nrows = H - row0
         fam = {"b3spline": _lib.B3SPLINE, "triangle": _lib.TRIANGLE}[family]
-        plan = _lib.Plan(ctx, H, W, fam, level, row0=row0, nrows=nrows, rank=rank, nranks=world)
         if config == "cfg5":
             # the cfg5 image of tools/bench_configs.py: noise on a smooth structure (pure noise has
-            # no edges for the bilateral weights to act on)
-            img0 = make_strip(nrows, W, seed=0) + 3 * np.sin(np.arange(W, dtype=np.float32) / 50.)[None, :]
-            plan.upload(PLANE_INPUT, img0.astype(np.float32))
-            del img0
+            # no edges for the bilateral weights to act on); the workload string says so
+            img0 = (make_strip(nrows, W, seed=0)
+                    + 3 * np.sin(np.arange(W, dtype=np.float32) / 50.)[None, :]).astype(np.float32)
         else:
-            plan.upload(PLANE_INPUT, make_strip(nrows, W, seed=rank))
+            img0 = make_strip(nrows, W, seed=rank)
         flags = 0 if args.unfused else _lib.FLAG_FUSED
         if args.no_exchange:
             flags |= _lib.FLAG_NO_EXCHANGE
         two_call = args.two_call or args.unfused
-        coefficients = None
+        sched = _lib.schedule(fam, level, not args.unfused)
+        my_pix = float(nrows) * W
 
-        if config in ("headline", "cfg2"):
-            def step():
-                if two_call:
-                    plan.decompose(PLANE_INPUT, level, flags)
-                    plan.plane_sum(0, level + 1, PLANE_OUT)
-                else:   # same outputs (planes + reconstruction, bit-identical), sum carried along
-                    plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
-        elif config == "cfg3":
+        def make_plan():
+            plan = _lib.Plan(ctx, H, W, fam, level, row0=row0, nrows=nrows, rank=rank, nranks=world)
+            plan.upload(PLANE_INPUT, img0)
+            return plan
+
+        def make_step(plan):
+            """(step, coefficients): one pass of the hot path over the image on `plan`"""
+            if config in ("headline", "cfg2"):
+                def step():
+                    if two_call:
+                        plan.decompose(PLANE_INPUT, level, flags)
+                        plan.plane_sum(0, level + 1, PLANE_OUT)
+                    else:   # same outputs (planes + reconstruction, bit-identical), sum carried along
+                        plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+                return step, None
             import wavelets_amd as WA
-            coefficients = WA.Coefficients(plan, WA.Triangle(2))
+            if config == "cfg3":
+                coefficients = WA.Coefficients(plan, WA.Triangle(2))
+                from wavelets_amd.wavelets import _decompose_denoise_sum
+                transform = WA.AtrousTransform(WA.Triangle)
 
-            from wavelets_amd.wavelets import _decompose_denoise_sum
-            transform = WA.AtrousTransform(WA.Triangle)
-
-            def step():         # transform, Coefficients.denoise([5,3,2]), np.sum(coefficients, axis=0)
-                coefficients.noise = None                      # lazy MAD estimate, every step
-                if two_call:
-                    plan.decompose(PLANE_INPUT, level, flags)
-                    coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
-                else:           # the same three results with the threshold step between the passes
-                    _decompose_denoise_sum(transform, plan, level, coefficients, [5, 3, 2],
-                                           soft_threshold=True, write_back=True)
-        else:
-            import wavelets_amd as WA
+                def step():     # transform, Coefficients.denoise([5,3,2]), np.sum(coefficients, axis=0)
+                    coefficients.noise = None                      # lazy MAD estimate, every step
+                    if two_call:
+                        plan.decompose(PLANE_INPUT, level, flags)
+                        coefficients._denoise_sum([5, 3, 2], soft_threshold=True, write_back=True)
+                    else:       # the same three results with the threshold step between the passes
+                        _decompose_denoise_sum(transform, plan, level, coefficients, [5, 3, 2],
+                                               soft_threshold=True, write_back=True)
+                return step, coefficients
             from wavelets_amd import utils as WU
             transform = WA.AtrousTransform(WA.B3spline, bilateral=[1] * (level + 1))
             coefficients = WA.Coefficients(plan, WA.B3spline(2), [1] * (level + 1))
@@ -368,144 +501,210 @@ def main():
                 transform._run(plan, level)
                 coefficients.noise = None
                 WU._wow_device(coefficients, level, [], True, [5, 2], True, False, 3.2, None, None, 0)
+            return step, coefficients
 
         def fence():
             ctx.sync()
-            if dist is not None:
-                dist.barrier()
+            if group is not None:
+                group.barrier()
             ctx.sync()
 
-        # Untimed spin-up: the GPU idles at 94 MHz and its clocks ramp over the first milliseconds of
-        # work; W = 3 warm-up steps are only 2.5 ms.  Run the same step for a quarter of a second so
-        # that the timed region starts at steady clocks (measured: K = 5 reads 4 % low otherwise).
-        if dist is None:
-            t_spin = time.perf_counter()
-            while time.perf_counter() - t_spin < args.spinup:
-                for _ in range(20 if config in ("headline", "cfg2") else 2):
+        def timed(step, nsteps):
+            """nsteps steps between two fences; (seconds - MAX over the ranks -, device ms of this rank)"""
+            fence()
+            t0 = time.perf_counter()
+            ctx.timer_start()
+            for _ in range(nsteps):
+                step()
+            dev_ms = ctx.timer_stop()
+            fence()
+            elapsed = time.perf_counter() - t0
+            if group is not None:
+                elapsed = float(group.allreduce(elapsed, max))
+            return elapsed, dev_ms
+
+        def measure(step, nsteps, spin=True):
+            """spin-up, warm-up, the timed region, then `nprof` more steps under the live per-kernel
+            profiler (HIP events on the launch streams)"""
+            # Untimed spin-up: the GPU idles at 94 MHz and its clocks ramp over the first milliseconds of
+            # work; W = 3 warm-up steps are only 2.5 ms.  Run the same step for a quarter of a second so
+            # that the timed region starts at steady clocks (measured: K = 5 reads 4 % low otherwise).
+            if group is None and spin:
+                t_spin = time.perf_counter()
+                while time.perf_counter() - t_spin < args.spinup:
+                    for _ in range(20 if config in ("headline", "cfg2") else 2):
+                        step()
+                    ctx.sync()
+            elif spin and args.spinup > 0:
+                # every rank must issue the same number of halo exchanges: a fixed count, not a clock
+                for _ in range(60):
                     step()
                 ctx.sync()
-        elif args.spinup > 0:
-            # every rank must issue the same number of halo exchanges: a fixed count, not a clock
-            for _ in range(60):
+            for _ in range(warmup):
                 step()
-            ctx.sync()
-        for _ in range(warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        ctx.timer_start()
-        for _ in range(steps):
-            step()
-        dev_ms = ctx.timer_stop()
-        fence()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-            t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t[0])
-
-        ms_per_step = elapsed / steps * 1e3
-        value = H * W * steps / elapsed / 1e6
-
-        # ---- live per-kernel timing (HIP events on the launch stream) for the roofline figure
-        ctx.profile(True)
-        ctx.profile_reset()
-        nprof = max(3, min(steps, 10))
-        for _ in range(nprof):
-            step()
-        prof = ctx.profile_entries()
-        ctx.profile(False)
-        roofline = None
-        kernels = {}
-        my_pix = float(nrows) * W
-        sched = _lib.schedule(fam, level, not args.unfused)
-
-        def algo_bytes(name, calls):
-            """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
-            fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
-            its bytes are per STEP; every other kernel's are per launch."""
-            bpp = algorithmic_bytes_per_pixel(name, level, interleaved=any(
-                k.startswith("wt_fused_hist") for k in prof), n_fold=sched[0][1] if sched else 3)
-            if bpp is None:
-                return None
-            return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)
+            elapsed, dev_ms = timed(step, nsteps)
+            ctx.profile(True)
+            ctx.profile_reset()
+            nprof = max(3, min(nsteps, 10))
+            for _ in range(nprof):
+                step()
+            raw = ctx.profile_entries()
+            ctx.profile(False)
+            return {"elapsed": elapsed, "dev_ms": dev_ms, "steps": nsteps, "prof_raw": raw, "nprof": nprof}
 
         def pmc_bytes(name):
             """HBM bytes per launch of `name` at this image size from profiles/traffic.json (the
-            rocprofv3 --pmc passes of an earlier run of the same command; None: not recorded)."""
-            if world > 1 or H != W:
+            rocprofv3 --pmc passes of an earlier run of the same command on the SAME kernel sources;
+            None: not recorded, or the table is stale)."""
+            if world > 1 or H != W or traffic_stale:
+                return None
+            sizes = traffic_meta.get("image") or {}
+            if config in sizes and list(sizes[config]) != [H, W]:
                 return None
             return traffic_db.get(f"{name}@{config}", traffic_db.get(f"{name}@{side}") if config == "headline" else None)
 
-        step_traffic, traffic_complete = 0.0, True
-        for name, (calls, ms) in prof.items():
-            ab = algo_bytes(name, calls)
-            tb = pmc_bytes(name)
-            kernels[name] = {"calls_per_step": calls // nprof,
-                             "avg_ms": round(ms / calls, 4),
-                             "algorithmic_GBs": None if ab is None else round(ab / (ms * 1e-3) / 1e9, 1)}
-            if tb is not None:
-                kernels[name]["hbm_GBs"] = round(tb * calls / (ms * 1e-3) / 1e9, 1)
-                step_traffic += tb * calls / nprof
-            elif ms / nprof > 0.002 and not name.startswith("rccl"):   # (select steps etc. move nothing)
-                traffic_complete = False
-        # Dominant kernel = the SOURCE kernel with the largest total time.  The fused passes are
-        # instantiations of one kernel (wt_fused_kernel<..., D=1> and <..., D=8>; rocprof lists them
-        # as two rows), so the roofline entry describes them together: per launch algorithmic bytes /
-        # average launch duration over the instantiations.
-        groups = {}
-        for n, (c, ms) in prof.items():
-            ab = algo_bytes(n, c)
-            if ab is None:
-                continue
-            key = "wt_fused_kernel" if n.startswith("wt_fused") else n.split("<")[0]
-            f = groups.setdefault(key, {"ms": 0.0, "calls": 0, "bytes": 0.0, "members": [], "pmc": 0.0,
-                                        "pmc_ok": True})
-            f["ms"] += ms
-            f["calls"] += c
-            f["bytes"] += ab
-            f["members"].append(n)
-            tb = pmc_bytes(n)
-            if tb is None:
-                f["pmc_ok"] = False
-            else:
-                f["pmc"] += tb * c
-        if groups:
-            dom = max(groups, key=lambda k: groups[k]["ms"])
-            f = groups[dom]
-            achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-            have_pmc = f["pmc_ok"] and f["pmc"] > 0
-            roofline = {"bound": "hbm", "kernel": dom, "instantiations": sorted(f["members"]),
-                        "launches_per_step": f["calls"] // nprof,
-                        "avg_launch_ms": round(f["ms"] / f["calls"], 4),
-                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "achieved_is": "SURVEY 8(d) algorithmic bytes / measured launch time "
-                                       "(throughput-equivalent, not bytes on the HBM interface)",
-                        "traffic": round(f["pmc"] / f["calls"]) if have_pmc else None,
-                        "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
-                                          "WRITE_SIZE passes of an earlier run of this command; "
-                                          "not re-measured here)" if have_pmc else None,
-                        "hbm_achieved_GBs": round(f["pmc"] / (f["ms"] * 1e-3) / 1e9, 1) if have_pmc else None,
-                        "hbm_achieved": round(f["pmc"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                        if have_pmc else None}
-            if dom.startswith("wt_bilateral"):
-                # SURVEY 8(d): the bilateral operator is VALU / transcendental bound - K*K-1 taps of
-                # (sub, mul, fma into the exponent, v_exp, two fmas) + variance + normalisation per
-                # pixel and scale: ~10 flop per tap + 40.  HBM stays the `bound` the schema knows;
-                # the vector-ALU fraction is reported beside it.
-                taps = 24 if family == "b3spline" else 8
-                flops = (10.0 * taps + 40.0) * my_pix * f["calls"]
-                roofline["valu"] = {"algorithmic_flop_per_pixel_scale": 10.0 * taps + 40.0,
-                                    "achieved_TFLOPs": round(flops / (f["ms"] * 1e-3) / 1e12, 1),
-                                    "peak_TFLOPs": VALU_PEAK_TFLOPS,
-                                    "frac": round(flops / (f["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+        def report(m):
+            """the JSON object of measurement `m` (every rank computes its per-pass times; rank 0 returns
+            the object, the others None)"""
+            elapsed, nsteps, nprof = m["elapsed"], m["steps"], m["nprof"]
+            ms_per_step = elapsed / nsteps * 1e3
+            value = H * W * nsteps / elapsed / 1e6
+            # The two parts of a split pass (multi-GPU: "<kernel>/interior", "<kernel>/edge") and the
+            # per-pass exchanges ("rccl_halo_exchange/pass<i>") are timed under their own names: merged
+            # here into one entry per kernel, kept apart for the per-pass table.
+            prof, parts, exch = {}, {}, {}
+            for name, (calls, ms) in m["prof_raw"].items():
+                base, _, part = name.partition("/")
+                if base == "rccl_halo_exchange" and part.startswith("pass"):
+                    exch[int(part[4:])] = (calls, ms)
+                elif part:
+                    parts.setdefault(base, {})[part] = (calls, ms)
+                c0, m0 = prof.get(base, (0, 0.0))
+                # (a split pass counts once per step: its launches are the parts of ONE pass)
+                prof[base] = (c0 + (calls if part in ("", "interior") or base == "rccl_halo_exchange" else 0), m0 + ms)
+            for base, pp in parts.items():          # (an edge-only pass - strips thinner than 2 halos - cannot occur: run_schedule)
+                if "interior" not in pp:
+                    prof[base] = (prof[base][0] + pp["edge"][0], prof[base][1])
+            interleaved = any(k.startswith("wt_fused_hist") for k in prof)
 
-        out = None
-        if rank == 0:
+            def algo_bytes(name, calls):
+                """algorithmic bytes `name` moved during the nprof profiled steps (None: not priced).  A
+                fused pass may be launched in several parts (multi-GPU: edge rows, then interior rows):
+                its bytes are per STEP; every other kernel's are per launch."""
+                bpp = algorithmic_bytes_per_pixel(name, level, interleaved=interleaved,
+                                                  n_fold=sched[0][1] if sched else 3)
+                if bpp is None:
+                    return None
+                return bpp * my_pix * (nprof if name.startswith("wt_fused") else calls)
+
+            kernels = {}
+            step_traffic, traffic_complete = 0.0, True
+            for name, (calls, ms) in prof.items():
+                ab = algo_bytes(name, calls)
+                tb = pmc_bytes(name)
+                kernels[name] = {"calls_per_step": calls // nprof,
+                                 "avg_ms": round(ms / max(calls, 1), 4),
+                                 "algorithmic_GBs": None if ab is None else round(ab / (ms * 1e-3) / 1e9, 1)}
+                if name in parts:
+                    kernels[name]["parts_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in parts[name].items()}
+                if tb is not None:
+                    kernels[name]["hbm_GBs"] = round(tb * calls / (ms * 1e-3) / 1e9, 1)
+                    step_traffic += tb * calls / nprof
+                elif ms / nprof > 0.002 and not name.startswith("rccl"):   # (select steps etc. move nothing)
+                    traffic_complete = False
+            # Dominant kernel = the SOURCE kernel with the largest total time.  The fused passes are
+            # instantiations of one kernel (wt_fused_kernel<..., D=1> and <..., D=8>; rocprof lists them
+            # as two rows), so the roofline entry describes them together: per launch algorithmic bytes /
+            # average launch duration over the instantiations.
+            groups = {}
+            for n, (c, ms) in prof.items():
+                ab = algo_bytes(n, c)
+                if ab is None:
+                    continue
+                key = "wt_fused_kernel" if n.startswith("wt_fused") else n.split("<")[0]
+                f = groups.setdefault(key, {"ms": 0.0, "calls": 0, "bytes": 0.0, "members": [], "pmc": 0.0,
+                                            "pmc_ok": True})
+                f["ms"] += ms
+                f["calls"] += c
+                f["bytes"] += ab
+                f["members"].append(n)
+                tb = pmc_bytes(n)
+                if tb is None:
+                    f["pmc_ok"] = False
+                else:
+                    f["pmc"] += tb * c
+            roofline = None
+            if groups:
+                dom = max(groups, key=lambda k: groups[k]["ms"])
+                f = groups[dom]
+                achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+                have_pmc = f["pmc_ok"] and f["pmc"] > 0
+                roofline = {"bound": "hbm", "kernel": dom, "instantiations": sorted(f["members"]),
+                            "launches_per_step": f["calls"] // nprof,
+                            "avg_launch_ms": round(f["ms"] / f["calls"], 4),
+                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "achieved_is": "SURVEY 8(d) algorithmic bytes / measured launch time "
+                                           "(throughput-equivalent, not bytes on the HBM interface)",
+                            "traffic": round(f["pmc"] / f["calls"]) if have_pmc else None,
+                            "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                              "WRITE_SIZE passes of an earlier run of this command on the "
+                                              "same kernel sources; not re-measured here)" if have_pmc else None,
+                            "hbm_achieved_GBs": round(f["pmc"] / (f["ms"] * 1e-3) / 1e9, 1) if have_pmc else None,
+                            "hbm_achieved": round(f["pmc"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                            if have_pmc else None}
+                if traffic_stale and world == 1:
+                    roofline["traffic_stale"] = True
+                    roofline["traffic_stale_reason"] = traffic_stale
+                if dom.startswith("wt_bilateral"):
+                    # SURVEY 8(d): the bilateral operator is VALU / transcendental bound - K*K-1 taps of
+                    # (sub, mul, fma into the exponent, v_exp, two fmas) + variance + normalisation per
+                    # pixel and scale: ~10 flop per tap + 40.  HBM stays the `bound` the schema knows;
+                    # the vector-ALU fraction is reported beside it.
+                    taps = 24 if family == "b3spline" else 8
+                    flops = (10.0 * taps + 40.0) * my_pix * f["calls"]
+                    roofline["valu"] = {"algorithmic_flop_per_pixel_scale": 10.0 * taps + 40.0,
+                                        "achieved_TFLOPs": round(flops / (f["ms"] * 1e-3) / 1e12, 1),
+                                        "peak_TFLOPs": VALU_PEAK_TFLOPS,
+                                        "frac": round(flops / (f["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+
+            # ---- multi-GPU: what every pass of the schedule cost on this rank (live events, both streams)
+            strip_passes = None
+            if world > 1:
+                mine = []
+                for i, (s0, ns, halo) in enumerate(sched):
+                    tag = f"<d{1 << s0}x{ns}>"
+                    base = next((n for n in prof if n.startswith("wt_fused") and n.endswith(tag)), None)
+                    e = {"scales": [s0, s0 + ns], "halo_rows": halo, "kernel": base,
+                         "exchange_bytes_per_neighbour": halo * W * 4}
+                    if i in exch:
+                        e["exchange_ms"] = round(exch[i][1] / max(exch[i][0], 1), 4)
+                    pp = parts.get(base, {})
+                    if "interior" in pp:
+                        e["interior_ms"] = round(pp["interior"][1] / max(pp["interior"][0], 1), 4)
+                    if "edge" in pp:
+                        e["edge_ms"] = round(pp["edge"][1] / max(pp["edge"][0], 1), 4)
+                    if base and not pp:
+                        e["whole_ms"] = round(prof[base][1] / max(prof[base][0], 1), 4)
+                    mine.append(e)
+                if "rccl_halo_exchange" in m["prof_raw"]:        # serial order (overlap off): not per pass
+                    c_, ms_ = m["prof_raw"]["rccl_halo_exchange"]
+                    mine.append({"serial_exchanges_per_step": c_ // nprof, "serial_exchange_ms_per_step": round(ms_ / nprof, 4)})
+                allp = group.gather(mine)
+                if rank == 0:
+                    strip_passes = {"rank0": mine, "max_over_ranks": []}
+                    for i in range(len(sched)):
+                        mx = {"scales": mine[i]["scales"]}
+                        for key in ("exchange_ms", "interior_ms", "edge_ms", "whole_ms"):
+                            vals = [p[i][key] for p in allp if i < len(p) and key in p[i]]
+                            if vals:
+                                mx[key] = max(vals)
+                        strip_passes["max_over_ranks"].append(mx)
+
+            if rank != 0:
+                return None
             bpp_whole = whole_path_bytes_per_pixel(config, level)
-            whole_job_GBs = bpp_whole * H * W * steps / elapsed / 1e9
+            whole_job_GBs = bpp_whole * H * W * nsteps / elapsed / 1e9
             metric = {"headline": f"Mpix/s decompose+sum, {H}x{W} f32 B3spline 6 scales; %HBM roofline"
                                   if (world > 1 or side != 8192) else
                                   "Mpix/s decompose+sum, 8192^2 f32 B3spline 6 scales; %HBM roofline",
@@ -520,28 +719,89 @@ def main():
                 whole["hbm_achieved_GBs"] = round(step_traffic / (ms_per_step * 1e-3) / 1e9, 1)
                 whole["hbm_achieved"] = round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 whole["hbm_traffic_source"] = "profiles/traffic.json (PMC passes, not re-measured here)"
+            elif traffic_stale and world == 1:
+                whole["hbm_achieved"] = None
+                whole["traffic_stale"] = True
+            data = ("np.random.default_rng(0).standard_normal + 3*sin(x/50) along the columns (noise on a smooth "
+                    "structure: the bilateral weights need edges)" if config == "cfg5"
+                    else "np.random.default_rng(seed).standard_normal")
             out = {
                 "metric": metric,
-                "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": steps,
+                "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": nsteps,
                 "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
                 "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{H}x{W} float32 np.random.default_rng(seed).standard_normal, "
+                "config": {"workload": f"{H}x{W} float32 {data}, "
                                        f"{family} L={level}, " + what.format(n=level + 1)
                                        + "; device-resident"
                                        + ("" if world == 1 else f"; {world} row strips, RCCL halo "
                                           "exchange per pass"),
                            "name": config, "image": [H, W], "levels": level, "family": family,
                            "fused": not args.unfused, "sum_in_passes": not two_call,
-                           "schedule": _lib.schedule(fam, level, not args.unfused),
+                           "schedule": sched,
                            "parallelism": f"strips{world}"},
                 "rccl_ranks": rccl_ranks,
-                "device_ms_per_step": round(dev_ms / steps, 4),
+                "device_ms_per_step": round(m["dev_ms"] / nsteps, 4),
                 "whole_path": whole,
                 "roofline": roofline,
                 "kernels": kernels,
             }
-            if full and world == 1 and config in ("headline", "cfg2") and not args.brief:
+            if world > 1:
+                out["launcher"] = {"plumbing": args.launcher,
+                                   "torch_imported_in_ranks": "torch" in sys.modules,
+                                   "started_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                                   else ("bench.py (wavelets_amd.launch.spawn)" if "WT_RDZV" in os.environ else "other")}
+                out["strip_passes"] = strip_passes
+            out["_brief"] = f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
+                f"{k}={v['avg_ms']}" for k, v in kernels.items())
+            return out
+
+        def halo_check(plan):
+            """Halo self-check over the real transport (outside the timed region, every rank): a linear
+            ramp in y is reproduced exactly by the smoothing filters (symmetric taps, unit gain) away
+            from the image's own top / bottom border, so every detail plane must vanish there - unless
+            a strip boundary was filtered with missing, stale or misplaced neighbour rows.  Rows within
+            the transform's reach of a global border (reflection is not linear) are cropped off.
+            Returns the JSON entry (the same on every rank)."""
+            worst, check_err = 0.0, None
+            try:                         # (a failing check must not cost the timing line: every rank
+                reach = sum(h for _, _, h in sched)          #  still reaches the all-reduce below)
+                ramp = (np.arange(row0, row0 + nrows, dtype=np.float32)[:, None]
+                        * np.ones((1, W), dtype=np.float32))
+                plan.upload(PLANE_INPUT, ramp)
+                del ramp
+                plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+                top = reach if rank == 0 else 0
+                bot = reach if rank == world - 1 else 0
+                if nrows - top - bot > 0:
+                    sub = _lib.Plan(ctx, nrows - top - bot, W, fam, 0)
+                    for s_ in range(level):
+                        sub.crop_from(plan, s_, PLANE_INPUT, top, 0)
+                        _, _, lo, hi = sub.reduce(PLANE_INPUT)
+                        worst = max(worst, abs(lo), abs(hi))
+                    sub.close()
+            except Exception as e:
+                worst, check_err = 1e30, repr(e)
+            worst = float(group.allreduce(worst, max))
+            # (float32 rounding of values up to H: a few ulp of 3e4; a wrong halo row shows as O(1..H))
+            entry = {"input": "f(y, x) = y", "max_abs_detail_off_the_global_border": worst,
+                     "bound": 0.05, "ok": bool(worst <= 0.05)}
+            if check_err:
+                entry[f"error_on_rank_{rank}"] = check_err
+            return entry
+
+        plan = make_plan()
+        step, coefficients = make_step(plan)
+        m = measure(step, steps)
+        out = report(m)
+
+        def release(pl, co):
+            if co is not None:
+                co._plan = None                       # the plan is ours, not the pool's
+            pl.close()
+
+        if world == 1:
+            if out is not None and full and config in ("headline", "cfg2") and not args.brief:
                 # (not under --brief: the PMC passes of tools/profile_round.sh average per dispatch, and
                 #  the pipelined host call launches the same kernels on row blocks)
                 # PCIe-inclusive rate (host numpy in, reconstruction out as a numpy array) - never
@@ -569,48 +829,70 @@ def main():
                 recon = plan.download(PLANE_OUT)
                 out["pcie_inclusive_serial_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
                 del recon
-            if world == 1 and not args.no_cpu and not args.brief:
+            if out is not None and not args.no_cpu and not args.brief:
                 out["cpu_baseline"] = cpu_baseline(config, side, family, level,
                                                    budget=15.0 if full else 5.0)
-            out["_brief"] = f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
-                f"{k}={v['avg_ms']}" for k, v in kernels.items())
-        if world > 1:
-            # Halo self-check over the real transport (outside the timed region, every rank): a linear
-            # ramp in y is reproduced exactly by the smoothing filters (symmetric taps, unit gain) away
-            # from the image's own top / bottom border, so every detail plane must vanish there - unless
-            # a strip boundary was filtered with missing, stale or misplaced neighbour rows.  Rows within
-            # the transform's reach of a global border (reflection is not linear) are cropped off.
-            worst, check_err = 0.0, None
-            try:                         # (a failing check must not cost the timing line: every rank
-                reach = sum(h for _, _, h in sched)          #  still reaches the all-reduce below)
-                ramp = (np.arange(row0, row0 + nrows, dtype=np.float32)[:, None]
-                        * np.ones((1, W), dtype=np.float32))
-                plan.upload(PLANE_INPUT, ramp)
-                del ramp
-                plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
-                top = reach if rank == 0 else 0
-                bot = reach if rank == world - 1 else 0
-                if nrows - top - bot > 0:
-                    sub = _lib.Plan(ctx, nrows - top - bot, W, fam, 0)
-                    for s_ in range(level):
-                        sub.crop_from(plan, s_, PLANE_INPUT, top, 0)
-                        _, _, lo, hi = sub.reduce(PLANE_INPUT)
-                        worst = max(worst, abs(lo), abs(hi))
-                    sub.close()
+            release(plan, coefficients)
+            return out
+
+        # ------------------------------------------------------------------ multi-GPU extras
+        # (1) the same steps with the exchanges in serial order on the compute stream (no overlap)
+        ab_steps = max(3, min(steps, 10))
+        overlap = {"default": "on", "ms_per_step_on": round(m["elapsed"] / steps * 1e3, 4)}
+        try:
+            _lib.set_option("overlap", 0)
+            for _ in range(3):
+                step()
+            e_off, _ = timed(step, ab_steps)
+            overlap["ms_per_step_off"] = round(e_off / ab_steps * 1e3, 4)
+            overlap["steps_off"] = ab_steps
+        finally:
+            _lib.set_option("overlap", 1)
+        # (2) the ramp check of the halo exchange on the plan that was timed
+        check = halo_check(plan)
+        planes_ab = {"chosen": "hipMalloc", "hipMalloc_ms_per_step": round(m["elapsed"] / steps * 1e3, 4)}
+        if out is not None:
+            out["overlap"] = overlap
+            out["halo_selfcheck"] = check
+            out["strip_planes"] = planes_ab
+            state["result"] = out                     # from here on the time limit reports THIS line
+        group.barrier()
+        state["main_done"] = True
+        release(plan, coefficients)
+        # (3) strip planes over scattered 2-MiB chunks (what single-GPU plans use) instead of
+        # plain hipMalloc: measured AFTER the line above is safe, guarded by the same ramp check on the
+        # mapped planes over the real transport; the faster placement becomes the reported value.
+        if not args.no_scatter_ab and not args.no_exchange:
+            try:
+                _lib.set_option("scatter_strips", 1)
+                plan2 = make_plan()
+                mapped = plan2.memory()[1]
+                ok2 = bool(group.allreduce(mapped > 0, all))
+                if not ok2:
+                    planes_ab["scattered"] = "not available (planes below 8 MiB, or no virtual-memory API)"
+                    plan2.close()
+                else:
+                    check2 = halo_check(plan2)
+                    planes_ab["scattered_halo_selfcheck_ok"] = check2["ok"]
+                    if check2["ok"]:
+                        plan2.upload(PLANE_INPUT, img0)
+                        step2, _ = make_step(plan2)
+                        m2 = measure(step2, steps)
+                        planes_ab["scattered_ms_per_step"] = round(m2["elapsed"] / steps * 1e3, 4)
+                        if m2["elapsed"] < 0.99 * m["elapsed"]:
+                            out2 = report(m2)
+                            if out2 is not None:
+                                planes_ab["chosen"] = "scattered"
+                                out2["overlap"] = dict(overlap, note="measured on the hipMalloc'ed planes")
+                                out2["halo_selfcheck"] = check2
+                                out2["strip_planes"] = planes_ab
+                                out = out2
+                                state["result"] = out
+                    plan2.close()
             except Exception as e:
-                worst, check_err = 1e30, repr(e)
-            import torch
-            t = torch.tensor([worst], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            if out is not None:
-                # (float32 rounding of values up to H: a few ulp of 3e4; a wrong halo row shows as O(1..H))
-                out["halo_selfcheck"] = {"input": "f(y, x) = y", "max_abs_detail_off_the_global_border": float(t[0]),
-                                         "bound": 0.05, "ok": bool(float(t[0]) <= 0.05)}
-                if check_err:
-                    out["halo_selfcheck"]["error_on_rank_0"] = check_err
-        if coefficients is not None:
-            coefficients._plan = None                 # the plan is ours, not the pool's
-        plan.close()
+                planes_ab["scattered_error"] = repr(e)
+            finally:
+                _lib.set_option("scatter_strips", 0)
         return out
 
     out = run_workload(args.config, args.steps, args.warmup, full=True)
@@ -671,9 +953,11 @@ def main():
     if out is not None:
         brief = out.pop("_brief")
         emit(brief if args.brief else json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if dog is not None:
+        dog.cancel()
+    if group is not None:
+        group.barrier()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -111,9 +111,14 @@ int wt_plan_info(wt_plan *plan, int64_t out[8]);
  * plane of host transfers, mapped chunks, idle chunks), out[1] = bytes of planes mapped over
  * scattered 2-MiB chunks, out[2] = bytes of idle chunks (created in groups, not yet mapped:
  * wt_plan_trim gives them back), out[3] = 1 when this context has stopped scattering planes
- * because the virtual-memory API failed on it (wt_last_error then holds the failing call; the
- * fused passes run ~20 % slower on physically contiguous planes). */
+ * because the virtual-memory API failed on it (wt_ctx_scatter_status names the failing call; the
+ * fused passes run ~20 % slower on physically contiguous planes).  Leaves
+ * wt_last_error alone. */
 int wt_plan_memory(wt_plan *plan, int64_t out[4]);
+/* *disabled = 1 when the context has fallen back to plain hipMalloc per plane; `reason` (up to
+ * `cap` bytes, may be NULL) then names the HIP call that failed when it happened.  The fallback
+ * is also announced once on stderr.  (No reference counterpart: device-memory management.) */
+int wt_ctx_scatter_status(wt_ctx *ctx, int *disabled, char *reason, int cap);
 /* Release the plan's idle physical chunks (a plan keeps up to three planes' worth after its last
  * plane was allocated).  The Python plan pool calls this when a plan is handed back. */
 int wt_plan_trim(wt_plan *plan);

@@ -112,6 +112,63 @@ def test_bench_algorithmic_byte_shares_add_up():
     assert f("wt_fused_sum<d1x3>", 3) == 8 * 5       # single pass, L = 3
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_traffic_table_is_tied_to_the_kernel_sources(tmp_path):
+    """profiles/traffic.json (PMC bytes per launch) describes the kernels it was measured on:
+    bench.load_traffic refuses a table whose source digest differs from the sources the library is
+    built from (bench.py then reports traffic / hbm_achieved as null with traffic_stale: true), a
+    table without a digest, and any table when WATROO_HIP_LIB puts another library in place."""
+    import json
+    bench = _bench_module()
+    d = bench.source_digest()
+    assert len(d) == 40 and d == bench.source_digest()
+    good = tmp_path / "good.json"
+    good.write_text(json.dumps({"_meta": {"source_digest": d, "image": {"headline": [8192, 8192]}}, "k@headline": 5}))
+    db, stale = bench.load_traffic(str(good), lib_overridden=False)
+    assert stale is None and db["k@headline"] == 5
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({"_meta": {"source_digest": "0" * 40}, "k@headline": 5}))
+    assert "other kernel sources" in bench.load_traffic(str(bad), lib_overridden=False)[1]
+    old = tmp_path / "old.json"
+    old.write_text(json.dumps({"k@headline": 5}))
+    assert "no source digest" in bench.load_traffic(str(old), lib_overridden=False)[1]
+    assert "WATROO_HIP_LIB" in bench.load_traffic(str(good), lib_overridden=True)[1]
+    assert "missing" in bench.load_traffic(str(tmp_path / "none.json"), lib_overridden=False)[1]
+
+
+def test_source_digest_ignores_comments_and_layout_only(tmp_path, monkeypatch):
+    bench = _bench_module()
+    import shutil
+    root = tmp_path / "r"
+    shutil.copytree(os.path.join(ROOT, "wavelets_amd", "csrc"), root / "wavelets_amd" / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    d0 = bench.source_digest()
+    f = root / "wavelets_amd" / "csrc" / "wt_internal.h"
+    f.write_text("// a new comment\n/* and a block\n comment */\n" + f.read_text().replace("    ", "\t"))
+    assert bench.source_digest() == d0
+    f.write_text(f.read_text().replace("int num_cus = 256;", "int num_cus = 255;"))
+    assert bench.source_digest() != d0
+
+
+def test_committed_traffic_table_matches_the_current_sources():
+    """The committed table must have been measured on the committed kernels: after a kernel edit,
+    re-run tools/profile_round.sh on a GPU box and commit profiles/traffic.json with it."""
+    bench = _bench_module()
+    db, stale = bench.load_traffic(lib_overridden=False)
+    assert stale is None, stale
+    sizes = db["_meta"]["image"]
+    for cfg, (side, _, _, _) in bench.CONFIGS.items():
+        assert sizes.get(cfg) == [side, side], (cfg, sizes.get(cfg))
+
+
 def _build_abi_demo():
     import subprocess
     import __graft_entry__ as entry

@@ -205,25 +205,21 @@ def test_large_geometry_device_side_checks():
 @pytest.mark.parametrize("nranks,shape", [(2, (1536, 1100)), (3, (1200, 520))])
 def test_real_rccl_ranks_share_the_gpu(nranks, shape):
     """The production RCCL sequence with REAL ranks (tools/check_rccl_ranks.py): one process per
-    rank under torch.distributed.run, unique-id broadcast, ncclCommInitRank, grouped
+    rank started by wavelets_amd.launch (no torch in any rank: the system ROCm stack, as in the
+    bench), unique-id broadcast over a local socket, ncclCommInitRank, grouped
     ncclSend/ncclRecv of the halo rows on the compute stream before every pass, all-reduced
     histograms / moments.  The box has one GPU, so every rank gets its own NCCL_HOSTID: RCCL
     treats them as separate hosts and carries the rows over its socket transport.  Each rank
     compares planes, reconstruction, noise and denoised sum bit for bit with the unsharded plan."""
-    import socket
-    import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "tools", "check_rccl_ranks.py"), "--shape", str(shape[0]), str(shape[1])]
+    cmd = [_sys.executable, os.path.join(root, "tools", "check_rccl_ranks.py"), "--ranks", str(nranks),
+           "--shape", str(shape[0]), str(shape[1])]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     from conftest import run_ranks
     r = run_ranks(cmd, env, f"ranks{nranks}", timeout=420)
     assert r.returncode == 0 and "0 mismatches in total" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "torch not imported" in r.stdout
 
 
 @pytest.mark.parametrize("fam_name,level,nrows,W,rank,nranks", [

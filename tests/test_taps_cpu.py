@@ -66,3 +66,50 @@ def test_filter_tap_list_reproduces_convolution_for_even_and_long_taps(taps):
             offs, wts = _filter_taps(kern, s, convolve=a.ndim == 1)
             got = apply_taps(a, None, offs, wts, "reflect" if a.ndim == 1 else "symmetric")
             np.testing.assert_allclose(got, O.convolution_taps_nd(a, t, s), rtol=0, atol=1e-12)
+
+
+class _Even4(__import__("wavelets_amd").wavelets.AbstractScalingFunction):        # (module level: picklable)
+    coefficients_1d = np.array([0.1, 0.4, 0.3, 0.2])
+    sigma_e_1d = sigma_e_2d = sigma_e_3d = np.array([0.9, 0.2, 0.09, 0.04])
+
+    def __init__(self, *args, **kwargs):
+        super().__init__("even4", *args, **kwargs)
+
+
+def test_generic_tap_coefficients_reacquire_a_storage_plan_when_they_lost_theirs(monkeypatch):
+    """Coefficients of a scaling function with an even number of taps (or more than 15) live on a
+    storage-only plan of the generic operator.  A copy, an unpickled object or Coefficients(ndarray,
+    sf) has no plan: the first device operation must acquire that storage plan again instead of
+    asking the tuned engine for a family it does not have (_taps_f64 / _family_of raise
+    NotImplementedError for such taps).  No GPU here: the plan pool is replaced by a recorder."""
+    import copy
+    import pickle
+    from wavelets_amd import wavelets as WV
+
+    Even4 = _Even4
+    calls = []
+
+    class FakePlan:
+        nranks = 1
+
+        def __init__(self, kind, *a):
+            calls.append((kind,) + a)
+            self.uploaded = []
+
+        def upload(self, plane, host):
+            self.uploaded.append((plane, host.shape, host.dtype))
+
+    monkeypatch.setattr(WV, "default_context", lambda: "ctx")
+    monkeypatch.setattr(WV, "acquire_plan", lambda ctx, H, W, fam, lvl: FakePlan("f32", H, W, fam, lvl))
+    monkeypatch.setattr(WV, "acquire_plan64", lambda ctx, H, W, taps, lvl: FakePlan("f64", H, W, taps, lvl))
+    monkeypatch.setattr(WV, "release_plan", lambda plan: None)
+    for dtype, kind in ((np.float32, "f32"), (np.float64, "f64")):
+        for shape, hw in (((3, 10, 12), (10, 12)), ((3, 40), (1, 40)), ((3, 4, 5, 6), (20, 6))):
+            sf = Even4(len(shape) - 1)
+            c = WV.Coefficients(np.zeros(shape, dtype), sf)
+            for obj in (c, copy.deepcopy(c), copy.copy(c), pickle.loads(pickle.dumps(c))):
+                del calls[:]
+                plan = obj._device()                       # what denoise / significance / sum call first
+                assert calls == [(kind,) + hw + ((WV._lib.B3SPLINE if kind == "f32" else (1.0,)), 2)], calls
+                assert [u[0] for u in plan.uploaded] == [0, 1, 2] and plan.uploaded[0][1] == hw
+                obj._plan = None

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Real multi-rank check of the RCCL strip path on a box with ONE GPU.
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-        --master-port 29533 tools/check_rccl_ranks.py [--shape 1536 1100]
+    python tools/check_rccl_ranks.py --ranks 2 [--shape 1536 1100]
+
+starts the ranks itself (wavelets_amd/launch.py: child processes, a local socket for the unique id,
+a wall-clock limit; no rank imports torch - the same plumbing and the same system ROCm stack as
+bench.py --gpus N).  It also runs as a rank of somebody else's launcher (RANK / WORLD_SIZE in the
+environment, e.g. `python -m torch.distributed.run --nproc-per-node 2 ... tools/check_rccl_ranks.py`),
+and --launcher torch uses torch.distributed (gloo) between the ranks as rounds 1-3 did.
 
 RCCL refuses two ranks of one communicator on the same device ("Duplicate GPU detected"), so
 every rank gets its own NCCL_HOSTID: RCCL then believes the ranks live on different hosts and
@@ -34,7 +39,34 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", type=int, nargs=2, default=[1536, 1100])
     ap.add_argument("--own-gpu", action="store_true")
+    ap.add_argument("--ranks", type=int, default=0, help="start this many ranks (not needed under a launcher)")
+    ap.add_argument("--launcher", choices=("stdlib", "torch"), default="stdlib")
+    ap.add_argument("--time-limit", type=float, default=400.0)
     args = ap.parse_args()
+    if "RANK" not in os.environ:
+        if args.ranks < 1:
+            sys.exit("not running as a rank: pass --ranks N")
+        import subprocess
+        from wavelets_amd import launch
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        rc = subprocess.run([sys.executable, "-c", "import __graft_entry__ as e; e.build()"], cwd=ROOT, env=env).returncode
+        if rc:
+            sys.exit(rc)
+        if args.launcher == "torch":
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.ranks}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.run(cmd, env=env, timeout=args.time_limit).returncode)
+        rc, reason = launch.spawn(args.ranks, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                  time_limit=args.time_limit, env=env)
+        if rc:
+            print(f"check_rccl_ranks: FAILED ({reason})")
+        sys.exit(rc)
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,13 +76,19 @@ def main():
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
     import numpy as np
-    import torch  # noqa: F401  (first: one ROCm runtime per process, see bench.py)
-    import torch.distributed as dist
+    if args.launcher == "torch":
+        import torch  # noqa: F401  (first: one ROCm runtime per process, see bench.py)
+        sys.path.insert(0, ROOT)
+        from bench import TorchGroup
+        group, dog = TorchGroup(rank, world), None
+    else:
+        from wavelets_amd.launch import SocketGroup, Watchdog
+        dog = Watchdog(args.time_limit, lambda: sys.stderr.write(f"[rank {rank}] time limit exceeded\n"))
+        group = SocketGroup(rank, world, op_timeout=args.time_limit)
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dist.barrier()
+    group.barrier()
     from wavelets_amd import _lib as L
     from wavelets_amd.parallel import init_comm, StripTransform
     from wavelets_amd.wavelets import B3spline, Triangle
@@ -59,12 +97,7 @@ def main():
     os.environ["WATROO_HIP_DEVICE"] = str(dev)     # the unsharded reference (default context) on the same GPU
     ctx = L.Context(dev)
 
-    def bcast(obj, src):
-        box = [obj]
-        dist.broadcast_object_list(box, src=src)
-        return box[0]
-
-    init_comm(ctx, rank, world, bcast)
+    init_comm(ctx, rank, world, group.bcast)
     assert ctx.comm_selftest(1 << 18), "ring send/recv + all-reduce self-test failed"
 
     H, W = args.shape
@@ -170,14 +203,16 @@ def main():
 
     ctx.sync()
     bad = [n for n, ok in checks if not ok]
-    flag = torch.tensor([len(bad)], dtype=torch.int64)
-    dist.all_reduce(flag)
+    nbad = int(group.allreduce(len(bad), sum))
     if rank == 0:
-        print(f"check_rccl_ranks: {world} ranks, image {H}x{W}, {len(checks)} comparisons per "
-              f"rank, {int(flag[0])} mismatches in total")
-    dist.barrier()
-    dist.destroy_process_group()
-    sys.exit(1 if int(flag[0]) else 0)
+        print(f"check_rccl_ranks: {world} ranks ({args.launcher} plumbing, torch "
+              f"{'imported' if 'torch' in sys.modules else 'not imported'}), image {H}x{W}, {len(checks)} comparisons per "
+              f"rank, {nbad} mismatches in total", flush=True)
+    group.barrier()
+    group.close()
+    if dog is not None:
+        dog.cancel()
+    sys.exit(1 if nbad else 0)
 
 
 if __name__ == "__main__":

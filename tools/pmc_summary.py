@@ -66,6 +66,24 @@ with open(prefix + "_pmc_summary.csv", "w") as f:
         f.write(f'{c},"{k}",{n},{v:.1f}\n')
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 old = json.load(open(tpath)) if os.path.exists(tpath) else {}
+# The table is tied to the kernel sources it was measured on (bench.source_digest: csrc + header,
+# comments and whitespace removed) and to the image size of every configuration: bench.py reports
+# `traffic` / `hbm_achieved` as null with `traffic_stale: true` when either differs, and
+# tests/test_abi_cpu.py fails on a committed table that no longer matches the sources.  Entries
+# measured on other sources are dropped when the digest changes.
+sys.path.insert(0, ROOT)
+from bench import source_digest, CONFIGS  # noqa: E402
+digest = source_digest()
+meta = old.get("_meta") or {}
+if meta.get("source_digest") != digest:
+    old = {}
+    meta = {"source_digest": digest, "image": {}}
+meta.setdefault("image", {})[config or "headline"] = [side, side]
+if not config:
+    meta["image"][str(side)] = [side, side]
+meta["note"] = ("HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, one counter per pass; "
+                "tools/profile_round.sh), keys '<profiling name>@<config>'")
+old["_meta"] = meta
 old.update({k: round(v) for k, v in traffic.items()})
 json.dump(old, open(tpath, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: round(v) for k, v in traffic.items()}, indent=1))

@@ -63,6 +63,7 @@ SIGNATURES = {
     "wt_plan_info": (_c.c_int, [_vp, _c.POINTER(_i64)]),
     "wt_plan_memory": (_c.c_int, [_vp, _c.POINTER(_i64)]),
     "wt_plan_trim": (_c.c_int, [_vp]),
+    "wt_ctx_scatter_status": (_c.c_int, [_vp, _c.POINTER(_c.c_int), _c.c_char_p, _c.c_int]),
     "wt_schedule": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.c_int,
                                _c.POINTER(_c.c_int)]),
     "wt_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
@@ -229,6 +230,14 @@ class Context:
         out = (_i64 * 2)()
         check(load().wt_device_memory(self._h, out))
         return int(out[0]), int(out[1])
+
+    def scatter_status(self):
+        """(disabled, reason): whether this context has fallen back from planes over scattered
+        chunks to plain hipMalloc, and the HIP call that failed when it did."""
+        d = _c.c_int(0)
+        buf = _c.create_string_buffer(256)
+        check(load().wt_ctx_scatter_status(self._h, _c.byref(d), buf, 256))
+        return bool(d.value), buf.value.decode("utf-8", "replace")
 
     def timer_start(self):
         check(load().wt_timer_start(self._h))
@@ -863,7 +872,16 @@ def release_plan(plan):
     evicted = []
     fam = ("f64",) + plan.family if isinstance(plan, Plan64) else plan.family
     if isinstance(plan, Plan):
-        plan.trim()               # idle physical chunks (up to three planes' worth) go back now
+        try:
+            plan.trim()           # idle physical chunks (up to three planes' worth) go back now
+        except WatrooHipError:
+            # a plan whose chunks cannot be released is not pooled (it would be handed out again with
+            # its state unknown): closed here, and the error goes to the caller
+            try:
+                plan.close()
+            except WatrooHipError:
+                pass
+            raise
     with _pool_lock:
         _pool.append(((id(plan.ctx), plan.H, plan.W, fam, plan.max_level), plan))
         total = sum(_plan_bytes(p) for _, p in _pool)
@@ -871,5 +889,11 @@ def release_plan(plan):
             _, old = _pool.pop(0)
             total -= _plan_bytes(old)
             evicted.append(old)
-    for old in evicted:
-        old.close()
+    first_error = None
+    for old in evicted:           # every evicted plan is closed, whatever the ones before it did
+        try:
+            old.close()
+        except WatrooHipError as e:
+            first_error = first_error or e
+    if first_error is not None:
+        raise first_error

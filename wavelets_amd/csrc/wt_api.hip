@@ -381,6 +381,9 @@ static int g_opt_tri4 = getenv("WT_NO_TRI4") ? 0 : 1;
 // planes over shuffled physical chunks (plan_alloc): chunks are created in groups worth this many
 // planes; 0 = plain hipMalloc per plane (contiguous planes: interop through wt_plane_ptr)
 static int g_opt_scatter = getenv("WT_SCATTER") ? atoi(getenv("WT_SCATTER")) : 4;
+// strip plans (nranks > 1) too: wt_set_option("scatter_strips", 1) / WT_SCATTER_STRIPS=1; bench.py --gpus N
+// measures both placements on the real transport and keeps the faster
+static int g_opt_scatter_strips = getenv("WT_SCATTER_STRIPS") ? atoi(getenv("WT_SCATTER_STRIPS")) : 0;
 
 extern "C" int wt_schedule(int family, int level, int fused, int32_t *triples, int cap, int *n_passes)
 {
@@ -568,8 +571,7 @@ static int plan_alloc(wt_plan *p, float **slot)
     // Strip plans keep plain hipMalloc unless WT_SCATTER_STRIPS=1: RCCL reads and writes the planes
     // of a strip, and its xGMI transport has never run on mapped memory here (the socket transport
     // of the one-GPU rank test has, green) - the one multi-GPU measurement must not hinge on it.
-    static const int scatter_strips = getenv("WT_SCATTER_STRIPS") ? atoi(getenv("WT_SCATTER_STRIPS")) : 0;
-    if (!raw && scatter > 0 && !p->ctx->vmm_disabled && need >= ((size_t)8 << 20) && (p->nranks == 1 || scatter_strips)) {
+    if (!raw && scatter > 0 && !p->ctx->vmm_disabled && need >= ((size_t)8 << 20) && (p->nranks == 1 || g_opt_scatter_strips)) {
         std::string why;
         hipError_t err = hipSuccess;
         if (vmm_plane_alloc(p, need, scatter, &raw, why, err)) {
@@ -582,8 +584,11 @@ static int plan_alloc(wt_plan *p, float **slot)
                 p->ctx->vmm_disabled = true;
                 p->ctx->vmm_reason = why;
             }
-            if (getenv("WT_VERBOSE")) fprintf(stderr, "watroo_hip: plane not scattered on device %d (%s)%s\n", p->ctx->device, why.c_str(),
-                                              err != hipErrorOutOfMemory ? "; scattering disabled for this context" : "");
+            // the permanent fallback is announced once per context, unconditionally (the fused passes
+            // are ~20 % slower on contiguous planes); transient out-of-memory only under WT_VERBOSE
+            if (err != hipErrorOutOfMemory || getenv("WT_VERBOSE"))
+                fprintf(stderr, "watroo_hip: plane not scattered on device %d (%s)%s\n", p->ctx->device, why.c_str(),
+                        err != hipErrorOutOfMemory ? "; scattered planes disabled for this context: plain hipMalloc from now on" : "");
             raw = nullptr;
         }
     }
@@ -706,8 +711,19 @@ extern "C" int wt_plan_memory(wt_plan *p, int64_t out[4])
     out[0] = (int64_t)(p->raw_bytes + mapped + idle);
     out[1] = (int64_t)mapped;
     out[2] = (int64_t)idle;
-    out[3] = p->ctx->vmm_disabled ? 1 : 0;
-    if (p->ctx->vmm_disabled) wt_set_error("scattered planes disabled on this context: %s", p->ctx->vmm_reason.c_str());
+    out[3] = p->ctx->vmm_disabled ? 1 : 0;      // why: wt_ctx_scatter_status
+    return 0;
+}
+
+// Whether the planes of this context's plans are still mapped over scattered chunks, and if not, the
+// call that made the context fall back to plain hipMalloc (kept from the moment it happened; the
+// thread's wt_last_error is left alone).
+extern "C" int wt_ctx_scatter_status(wt_ctx *c, int *disabled, char *reason, int cap)
+{
+    WtGuard guard_(ctx_of(c));
+    if (!c || !disabled) WT_FAIL("wt_ctx_scatter_status: null pointer");
+    *disabled = c->vmm_disabled ? 1 : 0;
+    if (reason && cap > 0) snprintf(reason, (size_t)cap, "%s", c->vmm_reason.c_str());
     return 0;
 }
 
@@ -1057,7 +1073,7 @@ extern "C" int wt_halo_exchange_local(wt_plan *upper, wt_plan *lower, int plane,
 }
 
 // st == nullptr: the context's compute stream
-static int halo_exchange_on(wt_plan *p, int plane, int64_t rows, hipStream_t st)
+static int halo_exchange_on(wt_plan *p, int plane, int64_t rows, hipStream_t st, const char *prof_name = "rccl_halo_exchange")
 {
     if (!p) WT_FAIL("wt_halo_exchange: null plan");
     if (p->nranks == 1 || rows == 0) return 0;
@@ -1071,7 +1087,7 @@ static int halo_exchange_on(wt_plan *p, int plane, int64_t rows, hipStream_t st)
     WT_TRY(plane_base(p, plane, &b));
     const size_t P = (size_t)p->g.P, cnt = (size_t)rows * P;
     const int up = p->rank - 1, dn = p->rank + 1;
-    ProfScope ps(c, "rccl_halo_exchange", st);
+    ProfScope ps(c, prof_name, st);
     WT_NCCL(g_rccl.GroupStart());
     if (up >= 0) {
         WT_NCCL(g_rccl.Send(b, cnt, NCCL_FLOAT32, up, c->comm, st));
@@ -1203,6 +1219,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "host_pipeline")) { g_opt_host_pipeline = value != 0; return 0; }
     if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
+    if (!strcmp(name, "scatter_strips")) { g_opt_scatter_strips = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
 }
 
@@ -1533,11 +1550,13 @@ static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t
     const bool multi = p->nranks > 1 && !(flags & 2);
     const bool dry = g_opt_split_dry && p->nranks > 1 && (flags & 2);
     const bool overlap = dry || (multi && g_opt_overlap && c->comm_stream);
-    auto exchange_async = [&](int plane, int64_t rows) -> int {     // after everything queued on the compute stream so far
+    auto exchange_async = [&](int plane, int64_t rows, int pass) -> int {     // after everything queued on the compute stream so far
         if (dry) return 0;
         WT_HIP(hipEventRecord(c->ev_to_comm, c->stream));
         WT_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_to_comm, 0));
-        WT_TRY(halo_exchange_on(p, plane, rows, c->comm_stream));
+        char nm[40];
+        snprintf(nm, sizeof nm, "rccl_halo_exchange/pass%d", pass);
+        WT_TRY(halo_exchange_on(p, plane, rows, c->comm_stream, nm));
         WT_HIP(hipEventRecord(c->ev_from_comm, c->comm_stream));
         return 0;
     };
@@ -1568,8 +1587,10 @@ static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t
         // (a pass of one scale runs a fused kernel - and can take row ranges - only where one is built)
         const bool ranged = ns > 1 || ((flags & 1) && !p->g.border && !p->ntaps && wt_fused_supported(p) && wt_fused_has_pass(s0, 1, p->family));
         if (halo > 0 && ranged && (up || dn) && 2 * halo < nrows) {
-            WT_TRY(exchange_async(cur, halo));
+            WT_TRY(exchange_async(cur, halo, i));
             FusedRows edge, inner;
+            edge.part = 2;
+            inner.part = 1;
             if (up) { edge.lo[edge.n] = 0; edge.hi[edge.n] = (int)halo; edge.n++; }
             if (dn) { edge.lo[edge.n] = nrows - (int)halo; edge.hi[edge.n] = nrows; edge.n++; }
             inner.n = 1;
@@ -1581,7 +1602,7 @@ static int run_schedule(wt_plan *p, int src, int level, int flags, const int32_t
             WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst, edge));
         } else {
             if (halo > 0) {
-                WT_TRY(exchange_async(cur, halo));
+                WT_TRY(exchange_async(cur, halo, i));
                 if (!dry) WT_HIP(hipStreamWaitEvent(c->stream, c->ev_from_comm, 0));
             }
             WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags | 2, acc, i == 0, dst));
@@ -1643,7 +1664,8 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
     const int H = p->g.nrows, P = p->g.P, W = p->g.W;
     int32_t tr[3 * 32];
     int np = 0;
-    bool pipe = g_opt_host_pipeline && p->nranks == 1 && level > 0 && !p->g.border && !p->ntaps && wt_fused_supported(p);
+    bool pipe = g_opt_host_pipeline && p->nranks == 1 && p->g.row0 == 0 && p->g.nrows == p->g.H && level > 0 && !p->g.border && !p->ntaps &&
+                wt_fused_supported(p);
     if (pipe) {
         WT_TRY(wt_schedule(p->family, level, 1, tr, 32, &np));
         for (int i = 0; i < np; ++i) pipe = pipe && wt_fused_has_pass(tr[3 * i], tr[3 * i + 1], p->family);
@@ -2241,7 +2263,10 @@ static int upload_taplist(wt_ctx *c, const int32_t *offs, const T *wts, int ntap
         WT_HIP(hipMalloc(&c->d_taps, need * (3 * sizeof(int32_t) + sizeof(double))));
         c->d_taps_cap = need;
     }
+    // layout: [cap x 8-byte weight slots][cap x 3 int32 offsets] - the weights first, so that double
+    // weights are 8-byte aligned whatever the capacity (hipMalloc returns 256-byte aligned blocks)
     char *base = (char *)c->d_taps;
+    char *offs_base = base + c->d_taps_cap * sizeof(double);
     // The list comes from caller-owned pageable memory that may be freed the moment this call returns
     // (temporaries of the Python layer), and the previous list may still be read by a kernel on the
     // stream: drain the stream, then copy SYNCHRONOUSLY.  (An asynchronous copy from such memory is a
@@ -2249,11 +2274,11 @@ static int upload_taplist(wt_ctx *c, const int32_t *offs, const T *wts, int ntap
     // fuzz run.)  The generic operator is a correctness path; the drain costs microseconds.
     if (ntaps) {
         WT_HIP(hipStreamSynchronize(c->stream));
-        WT_HIP(hipMemcpy(base, offs, (size_t)ntaps * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
-        WT_HIP(hipMemcpy(base + c->d_taps_cap * 3 * sizeof(int32_t), wts, (size_t)ntaps * sizeof(T), hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(offs_base, offs, (size_t)ntaps * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(base, wts, (size_t)ntaps * sizeof(T), hipMemcpyHostToDevice));
     }
-    *d_offs = (const int32_t *)base;
-    *d_wts = (const T *)(base + c->d_taps_cap * 3 * sizeof(int32_t));
+    *d_offs = (const int32_t *)offs_base;
+    *d_wts = (const T *)base;
     return 0;
 }
 

@@ -819,6 +819,7 @@ struct FusedRows {
     int n = 0;
     int lo[2] = {0, 0}, hi[2] = {0, 0};
     int reserve = 0;
+    int part = 0;      // profiling label of a split pass (multi-GPU): 1 = "/interior", 2 = "/edge"
 };
 
 // S = element type (float: wt_plan, double: wt_plan64 - both carry `ctx` and the geometry `g`)
@@ -912,7 +913,10 @@ static int wt_fused_launch_t(PLAN *p, const FusedArgsT<T> &base, const char *nam
     const int64_t gy = (int64_t)D * chunks;
     if (gy > 65535) WT_FAIL("fused pass: grid too large");
     dim3 grid(nx, (unsigned)gy, nranges), block(NL);
-    ProfScope ps(p->ctx, name);
+    // (the two parts of a split pass are timed under their own names: bench.py reports per-pass
+    //  exchange / interior / edge times of the multi-GPU schedule)
+    const std::string pname = std::string(name) + (rows.part == 1 ? "/interior" : rows.part == 2 ? "/edge" : "");
+    ProfScope ps(p->ctx, pname.c_str());
     // fast addressing: aligned groups reflect onto aligned groups and no index reflects twice
     const bool fast = g_opt_fused_fast && g.W % PX == 0 && g.W >= HX && g.H >= D * (hw * ((1 << NS) - 1) + 1);
     if (fast) hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);

@@ -587,7 +587,12 @@ class Coefficients:
         run inside an operation use ``self._plan`` directly."""
         if self._plan is None:
             H, W = self._plane_hw()
-            if self._dtype == np.float64:
+            if _needs_generic(self.scaling_function):
+                # scaling functions with an even number of taps or more than 15 run on the generic
+                # tap-list operator: their planes live on a storage-only plan (the plan's own taps are
+                # never used), which is what a copy / an unpickled / a hand-built object needs back
+                self._plan = _generic_plan(self._shape, self._dtype == np.float64, self._nplanes - 1)
+            elif self._dtype == np.float64:
                 self._plan = acquire_plan64(default_context(), H, W,
                                             _taps_f64(self.scaling_function, self._ndim), self._nplanes - 1)
             else:
