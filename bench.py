@@ -273,7 +273,7 @@ def source_digest():
     h = hashlib.sha1()
     files = [os.path.join(ROOT, "include", "watroo_hip.h")]
     csrc = os.path.join(ROOT, "wavelets_amd", "csrc")
-    files += [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))]
+    files += [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if os.path.isfile(os.path.join(csrc, f))]
     for f in files:
         text = open(f, encoding="utf-8").read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)

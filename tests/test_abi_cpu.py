@@ -206,11 +206,13 @@ def test_no_kernel_uses_scratch_memory_or_spills(tmp_path):
     so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
     subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], check=True, capture_output=True)
     objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
-    assert objs, "no device code object in the library"
-    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / objs[0])],
-                           check=True, capture_output=True, text=True).stdout
-    kernels = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)",
-                         notes, flags=re.S)
-    assert len(kernels) > 200
+    assert len(objs) == 15, f"expected one device code object per translation unit, found {len(objs)}"
+    kernels = []
+    for obj in objs:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / obj)],
+                               check=True, capture_output=True, text=True).stdout
+        kernels += re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)",
+                              notes, flags=re.S)
+    assert len(kernels) > 200 and len(set(k[0] for k in kernels)) == len(kernels)
     bad = [(n, int(sc), int(sp)) for n, sc, sp in kernels if int(sc) or int(sp)]
     assert not bad, f"kernels with scratch / spills: {bad[:5]}"

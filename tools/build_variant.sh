@@ -1,10 +1,14 @@
 #!/bin/bash
-# tools/build_variant.sh NAME [-DFLAG ...] : hipcc build of libwatroo_hip.so into variants/NAME.so
-# (A/B libraries for tools/try_variants.sh; select one with WATROO_HIP_LIB=variants/NAME.so)
+# tools/build_variant.sh NAME [-DFLAG ...] : build of libwatroo_hip.so into variants/NAME.so with extra
+# compiler flags (A/B libraries for tools/try_variants.sh; select one with WATROO_HIP_LIB=variants/NAME.so)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p variants
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -Wall -Wno-unused-function "$@" \
-    -o variants/$name.so wavelets_amd/csrc/wt_api.hip -ldl
-echo built variants/$name.so
+python - "$name" "$@" <<'PY'
+import sys
+import __graft_entry__ as e
+name, flags = sys.argv[1], sys.argv[2:]
+e.build(force=True, extra_flags=flags, lib=f"variants/{name}.so")
+print(f"built variants/{name}.so")
+PY

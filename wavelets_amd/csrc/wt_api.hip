@@ -8,7 +8,7 @@
 
 #include "wt_internal.h"
 #include "wt_kernels.h"
-#include "wt_fused.h"
+#include "wt_fused_decl.h"
 
 // =============================================================================================
 // errors
@@ -1189,6 +1189,8 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
 }
 
 // tuning / A-B switches (wt_set_option)
+// 0 forces the generic addressing of the fused passes (read by the launch code of every wt_fused_tu.hip unit)
+int g_opt_fused_fast = getenv("WT_FUSED_NO_FAST") ? 0 : 1;
 static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
 static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
 static int g_opt_bilateral2 = getenv("WT_NO_BILATERAL2") ? 0 : 1;   // 2-pixel bilateral kernel

@@ -10,24 +10,6 @@
 // Included at the end of wt_api.hip (one translation unit).
 #pragma once
 
-#define WT64_NUM_SCRATCH 32
-#define WT64_MAX_TAPS 15
-
-struct wt_plan64 {
-    wt_ctx *ctx = nullptr;
-    Geo g{};                                   // P = pitch in doubles (even)
-    int max_level = 0;
-    double taps[WT64_MAX_TAPS] = {0};
-    int ntaps = 0;
-    std::vector<double *> coef;
-    double *input = nullptr, *out = nullptr;
-    double *scratch[WT64_NUM_SCRATCH] = {nullptr};
-    double *tmp[3] = {nullptr, nullptr, nullptr};   // private temporaries of the filters (no plane id)
-    double *psf = nullptr;                          // PSF taps of wt64_filter2d
-    size_t psf_cap = 0;
-    std::vector<void *> allocs;
-};
-
 struct Taps64 {
     double k[WT64_MAX_TAPS];
     int n;
@@ -718,33 +700,6 @@ static bool fused64_ok(const wt_plan64 *p, int level, int depth, int32_t *tr, in
     return any;                                          // (scales beyond the fused passes: one generic kernel each)
 }
 
-template <int K, int ACC>
-static int fused64_dispatch(wt_plan64 *p, const FusedArgsT<double> &a, int s0, int ns)
-{
-    typedef double T;
-    static const char *pre[3] = {"wt64_fused", "wt64_fused_acc", "wt64_fused_sum"};
-    static char names[3][16][32];
-    auto nm = [&](int slot, const char *tag) -> const char * {
-        if (!names[ACC][slot][0]) snprintf(names[ACC][slot], sizeof names[ACC][slot], "%s<%s>", pre[ACC], tag);
-        return names[ACC][slot];
-    };
-    const FusedRows rows;
-    // Workgroup shapes as the float passes: 4 waves at D = 1 (512 pixels per row step), 8 waves for
-    // the dilated passes (1024 pixels, x halo 112 / 48 / 192 px per side).
-    if constexpr (K == 3) {
-        if (s0 == 0 && ns == 4) return wt_fused_launch_t<T, K, 4, 1, 4, 4, ACC>(p, a, nm(7, "d1x4"), rows);
-        if (s0 == 4 && ns == 4) return wt_fused_launch_t<T, K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, nm(8, "d16x4"), rows);
-    }
-    if (s0 == 0 && ns == 3) return wt_fused_launch_t<T, K, 3, 1, 4, 4, ACC>(p, a, nm(0, "d1x3"), rows);
-    if (s0 == 0 && ns == 2) return wt_fused_launch_t<T, K, 2, 1, 4, 4, ACC>(p, a, nm(1, "d1x2"), rows);
-    if (s0 == 3 && ns == 3) return wt_fused_launch_t<T, K, 3, 8, 8, 4, ACC>(p, a, nm(2, "d8x3"), rows);
-    if (s0 == 3 && ns == 2) return wt_fused_launch_t<T, K, 2, 8, 8, 4, ACC>(p, a, nm(3, "d8x2"), rows);
-    if (s0 == 6 && ns == 2) return wt_fused_launch_t<T, K, 2, 64, 8, 4, ACC>(p, a, nm(4, "d64x2"), rows);
-    if (s0 == 3 && ns == 1) return wt_fused_launch_t<T, K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(5, "d8x1"), rows);
-    if (s0 == 6 && ns == 1) return wt_fused_launch_t<T, K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(6, "d64x1"), rows);
-    WT_FAIL("float64 fused pass (first scale %d, %d scales) is not built", s0, ns);
-}
-
 // the fused schedule: planes 0..level, optionally the plane sum carried through the passes into dst
 static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int np, bool with_sum, int dst)
 {
@@ -780,9 +735,10 @@ static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int 
             a.p_in = i == 0 ? nullptr : a.p_out;
         }
         int rc;
-        if (acc == 2) rc = b3 ? fused64_dispatch<5, 2>(p, a, s0, ns) : fused64_dispatch<3, 2>(p, a, s0, ns);
-        else if (acc == 1) rc = b3 ? fused64_dispatch<5, 1>(p, a, s0, ns) : fused64_dispatch<3, 1>(p, a, s0, ns);
-        else rc = b3 ? fused64_dispatch<5, 0>(p, a, s0, ns) : fused64_dispatch<3, 0>(p, a, s0, ns);
+        const FusedRows rows;      // (whole passes: the float64 engine is single-GPU)
+        if (acc == 2) rc = b3 ? wt_fused_tu_f64_k5_acc2(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc2(p, a, s0, ns, rows);
+        else if (acc == 1) rc = b3 ? wt_fused_tu_f64_k5_acc1(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc1(p, a, s0, ns, rows);
+        else rc = b3 ? wt_fused_tu_f64_k5_acc0(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc0(p, a, s0, ns, rows);
         WT_TRY(rc);
         cur = nxt;
     }

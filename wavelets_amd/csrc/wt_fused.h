@@ -40,10 +40,9 @@
 #include <type_traits>
 
 #include "wt_internal.h"
-#include "wt_kernels.h"
+#include "wt_device.h"
+#include "wt_fused_decl.h"
 
-#define WT_FUSED_MAX_SCALES 4      // four only for the 3-tap family (register window 2 * 15 float4)
-#define WT_FUSED_MAX_FIRST_SCALE 3
 
 // Element type of a pass (round 3): float - a lane owns 4 adjacent pixels - or double - 2 pixels.
 // Either way a lane moves 16 bytes per access and the register window costs the same VGPRs, so the
@@ -75,33 +74,6 @@ __device__ __forceinline__ double2 wt_vrev(double2 v) { return make_double2(v.y,
 __device__ __forceinline__ void wt_vfence(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void wt_vfence(double2 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 
-template <typename T>
-struct FusedArgsT {
-    const T *in;                           // c_{s0}, local row 0
-    T *out_c;                              // c_{s0+NS}
-    T *out_w[3];                           // w_{s0+a}, a < 3 (the fourth plane of a four-scale pass: out_w3, last field)
-    Geo g;
-    int Vx;       // valid (stored) pixels per x-strip, multiple of 32
-    int S;        // chain steps stored per chunk
-    int chunks;   // chunks per chain
-    // accumulate variants (ACC != 0): the plane sum np.sum(planes, axis=0) carried through the
-    // passes in plane order - p_in = w_0 + ... + w_{s0-1} (nullptr for the first pass),
-    // p_out = p_in + w_{s0} + ... + w_{s0+NS-1} (+ c_{s0+NS} in the last pass); may alias p_in
-    const T *p_in;
-    T *p_out;
-    // rows stored by this launch: up to two ranges [rlo, rhi) of strip-local rows (blockIdx.z);
-    // a whole pass is the single range [0, nrows).  Splitting a pass into its edge rows and its
-    // interior lets the halo exchange of the NEXT pass overlap with the interior (multi-GPU).
-    int rlo[2], rhi[2];
-    // ACC == 3 (plain pass + first level of the exact-median select): 2048-bin histogram of the top
-    // 11 magnitude bits of the first detail plane's stored pixels, added to these global bins
-    uint32_t *hist;
-    int debug;    // ablation switches (WT_FUSED_DEBUG): 1 = drop stores,
-                  // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
-                  // not issue the predicated-off stores
-    T *out_w3;      // w_{s0+3} of a four-scale pass (3-tap family); LAST on purpose: the older fields keep their offsets
-};
-typedef FusedArgsT<float> FusedArgs;
 
 template <typename T, int K, int SHIFT_PX, int NLANES>
 __device__ __forceinline__ typename WtVec<T>::V wt_hfilter_lds(const typename WtVec<T>::V *vrow, int gl, typename WtVec<T>::V own)
@@ -804,24 +776,6 @@ done:;
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// The fused march addresses the rows of a chunk with 31-bit byte offsets (fixed store
-// descriptors): the shortest chunk of the widest-dilation pass (D = 64: ~48 steps of 64 rows)
-// must stay below 2 GiB, i.e. rows up to ~174 000 pixels.  Wider images take the per-scale kernels.
-static inline bool wt_fused_supported(const wt_plan *p) { return (int64_t)p->g.P * 4 * 64 * 48 < ((int64_t)1 << 31); }
-static inline bool wt_fused_supported_bytes(int64_t pitch_bytes) { return pitch_bytes * 64 * 48 < ((int64_t)1 << 31); }
-
-// Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = compute units the chunk
-// search leaves free (for the RCCL kernels of an exchange running beside the launch).
-// A/B switch (wt_set_option "fused_fast"): 0 forces the generic addressing of the fused passes
-static int g_opt_fused_fast = getenv("WT_FUSED_NO_FAST") ? 0 : 1;
-
-struct FusedRows {
-    int n = 0;
-    int lo[2] = {0, 0}, hi[2] = {0, 0};
-    int reserve = 0;
-    int part = 0;      // profiling label of a split pass (multi-GPU): 1 = "/interior", 2 = "/edge"
-};
-
 // S = element type (float: wt_plan, double: wt_plan64 - both carry `ctx` and the geometry `g`)
 template <typename T, int K, int NS, int D, int NW, int PD, int ACC, typename PLAN>
 static int wt_fused_launch_t(PLAN *p, const FusedArgsT<T> &base, const char *name, const FusedRows &rows)
@@ -971,30 +925,30 @@ static int wt_fused_dispatch_acc(wt_plan *p, const FusedArgs &a, int s0, int ns,
     WT_FAIL("fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
-static inline bool wt_fused_has_pass(int s0, int ns, int family = WT_B3SPLINE)
+// the float64 passes (wt_plan64; called from wt_f64.h through wt_fused_tu.hip)
+template <int K, int ACC>
+static int wt_fused64_dispatch_acc(wt_plan64 *p, const FusedArgsT<double> &a, int s0, int ns, const FusedRows &rows)
 {
-    if (family == WT_TRIANGLE && ns == 4 && (s0 == 0 || s0 == 4)) return true;
-    if (ns == 1 && (s0 == 3 || s0 == 6)) return true;    // the single scale that ends a 4- or 7-scale schedule
-    return (s0 == 0 && (ns == 2 || ns == 3)) || (s0 == 3 && (ns == 2 || ns == 3)) || (s0 == 6 && ns == 2);
+    typedef double T;
+    static const char *pre[3] = {"wt64_fused", "wt64_fused_acc", "wt64_fused_sum"};
+    static char names[3][16][32];
+    auto nm = [&](int slot, const char *tag) -> const char * {
+        if (!names[ACC][slot][0]) snprintf(names[ACC][slot], sizeof names[ACC][slot], "%s<%s>", pre[ACC], tag);
+        return names[ACC][slot];
+    };
+    // Workgroup shapes as the float passes: 4 waves at D = 1 (512 pixels per row step), 8 waves for
+    // the dilated passes (1024 pixels, x halo 112 / 48 / 192 px per side).
+    if constexpr (K == 3) {
+        if (s0 == 0 && ns == 4) return wt_fused_launch_t<T, K, 4, 1, 4, 4, ACC>(p, a, nm(7, "d1x4"), rows);
+        if (s0 == 4 && ns == 4) return wt_fused_launch_t<T, K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, nm(8, "d16x4"), rows);
+    }
+    if (s0 == 0 && ns == 3) return wt_fused_launch_t<T, K, 3, 1, 4, 4, ACC>(p, a, nm(0, "d1x3"), rows);
+    if (s0 == 0 && ns == 2) return wt_fused_launch_t<T, K, 2, 1, 4, 4, ACC>(p, a, nm(1, "d1x2"), rows);
+    if (s0 == 3 && ns == 3) return wt_fused_launch_t<T, K, 3, 8, 8, 4, ACC>(p, a, nm(2, "d8x3"), rows);
+    if (s0 == 3 && ns == 2) return wt_fused_launch_t<T, K, 2, 8, 8, 4, ACC>(p, a, nm(3, "d8x2"), rows);
+    if (s0 == 6 && ns == 2) return wt_fused_launch_t<T, K, 2, 64, 8, 4, ACC>(p, a, nm(4, "d64x2"), rows);
+    if (s0 == 3 && ns == 1) return wt_fused_launch_t<T, K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(5, "d8x1"), rows);
+    if (s0 == 6 && ns == 1) return wt_fused_launch_t<T, K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(6, "d64x1"), rows);
+    WT_FAIL("float64 fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 
-// acc: see wt_fused_dispatch_acc; p_in / p_out only for acc != 0
-static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns,
-                           int acc = 0, const float *p_in = nullptr, float *p_out = nullptr,
-                           const FusedRows &rows = FusedRows(), uint32_t *hist = nullptr)
-{
-    FusedArgs a{};
-    a.in = in;
-    a.out_c = out_c;
-    for (int i = 0; i < ns && i < 3; ++i) a.out_w[i] = out_w[i];
-    a.out_w3 = ns > 3 ? out_w[3] : nullptr;
-    a.g = p->g;
-    a.p_in = p_in;
-    a.p_out = p_out;
-    a.hist = hist;
-    const bool b3 = p->family == WT_B3SPLINE;
-    if (acc == 3) return b3 ? wt_fused_dispatch_acc<5, 3>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 3>(p, a, s0, ns, rows);
-    if (acc == 1) return b3 ? wt_fused_dispatch_acc<5, 1>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 1>(p, a, s0, ns, rows);
-    if (acc == 2) return b3 ? wt_fused_dispatch_acc<5, 2>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 2>(p, a, s0, ns, rows);
-    return b3 ? wt_fused_dispatch_acc<5, 0>(p, a, s0, ns, rows) : wt_fused_dispatch_acc<3, 0>(p, a, s0, ns, rows);
-}

@@ -153,6 +153,25 @@ struct wt_plan {
     float taps[WT_MAX_CUSTOM_TAPS] = {0};
 };
 
+// float64 engine (wt_f64.h): double planes; the fused double passes (wt_fused_tu.hip) launch on it too
+#define WT64_NUM_SCRATCH 32
+#define WT64_MAX_TAPS 15
+
+struct wt_plan64 {
+    wt_ctx *ctx = nullptr;
+    Geo g{};                                   // P = pitch in doubles (even)
+    int max_level = 0;
+    double taps[WT64_MAX_TAPS] = {0};
+    int ntaps = 0;
+    std::vector<double *> coef;
+    double *input = nullptr, *out = nullptr;
+    double *scratch[WT64_NUM_SCRATCH] = {nullptr};
+    double *tmp[3] = {nullptr, nullptr, nullptr};   // private temporaries of the filters (no plane id)
+    double *psf = nullptr;                          // PSF taps of wt64_filter2d
+    size_t psf_cap = 0;
+    std::vector<void *> allocs;
+};
+
 // Profiling bracket: records events around a kernel launch when ctx->profiling.
 struct ProfScope {
     wt_ctx *ctx;

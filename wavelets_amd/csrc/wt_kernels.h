@@ -8,104 +8,7 @@
 #include <type_traits>
 
 #include "wt_internal.h"
-
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
-// Symmetric reflection with edge duplication and any number of bounces:
-// cv2.BORDER_REFLECT (watroo/wavelets.py:45) == np.pad 'symmetric' (watroo/wavelets.py:77).
-__device__ __forceinline__ int wt_refl(int i, int n)
-{
-    if ((unsigned)i < (unsigned)n) return i;
-    const int p = 2 * n;
-    int m = i % p;
-    if (m < 0) m += p;
-    return m < n ? m : p - 1 - m;
-}
-
-// Border rule of the reference's RECURSIVE algorithm (watroo/wavelets.py:354-390): each
-// polyphase sub-array (offset o, stride d) is filtered on its own with BORDER_REFLECT, i.e. an
-// out-of-range index reflects inside its own residue class:  i = o + d j  ->  o + d refl(j, n_o).
-__device__ __forceinline__ int wt_refl_b(int i, int n, int d, int border)
-{
-    if ((unsigned)i < (unsigned)n) return i;
-    if (border == 0) return wt_refl(i, n);
-    if (border == 2) {
-        // scipy.ndimage 'mirror' (1-D branch of convolution(), watroo/wavelets.py:66-69):
-        // reflection about the centre of the edge sample, d c b | a b c d | c b a
-        if (n == 1) return 0;
-        const int p = 2 * n - 2;
-        int m = i % p;
-        if (m < 0) m += p;
-        return m < n ? m : p - m;
-    }
-    int o = i % d;
-    if (o < 0) o += d;
-    const int j = (i - o) / d;
-    const int n_o = (n - o + d - 1) / d;
-    if (border == 3) {
-        // 'mirror' inside the residue class: the 1-D branch of convolution() applied to the
-        // sub-arrays of atrous_recursive (watroo/wavelets.py:66-69 under :354-390)
-        if (n_o == 1) return o;
-        const int p = 2 * n_o - 2;
-        int m = j % p;
-        if (m < 0) m += p;
-        return o + d * (m < n_o ? m : p - m);
-    }
-    return o + d * wt_refl(j, n_o);
-}
-
-template <int K>
-__device__ __forceinline__ constexpr float wt_tap(int i)
-{
-    // Triangle (watroo/wavelets.py:239) and B3spline (watroo/wavelets.py:268) 1-D taps:
-    // dyadic rationals, exact in fp32.
-    if (K == 3) return i == 1 ? 0.5f : 0.25f;
-    return (i == 2) ? 0.375f : ((i == 1 || i == 3) ? 0.25f : 0.0625f);
-}
-
-template <int K>
-__device__ __forceinline__ constexpr float wt_tap_log2(int i)
-{
-    // log2 of the taps: 1/4, 1/2 (Triangle); 1/16, 1/4, 3/8 (B3spline)
-    if (K == 3) return i == 1 ? -1.f : -2.f;
-    return (i == 2) ? -1.4150374992788438f : ((i == 1 || i == 3) ? -2.f : -4.f);
-}
-
-__device__ __forceinline__ float4 f4_mul(float4 a, float4 b)
-{
-    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
-}
-__device__ __forceinline__ float4 f4_scale(float k, float4 a)
-{
-    return make_float4(k * a.x, k * a.y, k * a.z, k * a.w);
-}
-__device__ __forceinline__ float4 f4_fma(float k, float4 a, float4 c)
-{
-    return make_float4(fmaf(k, a.x, c.x), fmaf(k, a.y, c.y), fmaf(k, a.z, c.z), fmaf(k, a.w, c.w));
-}
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b)
-{
-    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-__device__ __forceinline__ float4 f4_sub(float4 a, float4 b)
-{
-    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-}
-
-// a / b for the two divisions of the bilateral kernels (b = the weight sum in [k_c, 1], or a
-// variance >= 1e-20): v_rcp_f32, one Newton step on the reciprocal and one residual correction of
-// the quotient - 6 instructions instead of the ~10 of the IEEE sequence (v_div_scale x2, v_rcp,
-// 4 fma, v_div_fmas, v_div_fixup), the same result except for rare 1-ulp cases (no scaling is
-// needed: neither operand is near the ends of the exponent range).  Bilateral outputs are a
-// stated-tolerance path (2e-5 * max|input|), not a bit-exact one.
-__device__ __forceinline__ float wt_div_nr(float a, float b)
-{
-    float r = __builtin_amdgcn_rcpf(b);
-    r = fmaf(fmaf(-b, r, 1.0f), r, r);
-    const float q = a * r;
-    return fmaf(fmaf(-b, q, a), r, q);
-}
+#include "wt_device.h"
 
 // Row pointer for GLOBAL row gy (any integer): reflect on the global image, then map into
 // this strip's buffer (rows outside the strip live in the halo margins).
@@ -1595,7 +1498,6 @@ __global__ __launch_bounds__(256) void wt_fill_kernel(float *dst, int64_t n4, fl
 // One histogram pass per digit (11 + 10 + 10 bits); LDS-privatised bins, one global atomic per
 // non-empty bin per block.  Pixels in the pitch padding (x >= W) are masked.
 // ---------------------------------------------------------------------------------------------
-#define WT_HIST_BINS 2048
 // Selection state kept on the device between the passes of the radix select (wt_abs_median): the
 // passes chain on the stream without a host round trip; the host reads the state once at the end.
 struct WtSelectState {
