@@ -950,6 +950,46 @@ def main():
                               "frac_of_hbm_peak": round(bpp64 * 8192 * 8192 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         except Exception as e:                                       # never lose the headline line over the extra
             out["float64"] = {"error": repr(e)}
+        # ... and BASELINE configs[2] in float64: 8192^2 Triangle L = 8 + denoise([5,3,2]) + sum on the
+        # float64 engine (fused double passes, the first one histogramming |w_0|; exact median on the
+        # gathered list; wt64_denoise_sum between the passes).  SURVEY 8(d) at 8 bytes per sample: 216 B/pixel.
+        try:
+            import wavelets_amd as WA
+            from wavelets_amd.wavelets import _decompose_denoise_sum
+            p64 = _lib.Plan64(ctx, 8192, 8192, tuple(float(t) for t in WA.Triangle.coefficients_1d), 8)
+            p64.upload(PLANE_INPUT, make_strip(8192, 8192, seed=0).astype(np.float64))
+            c64 = WA.Coefficients(p64, WA.Triangle(2))
+            tr64 = WA.AtrousTransform(WA.Triangle)
+
+            def step64():
+                c64.noise = None
+                _decompose_denoise_sum(tr64, p64, 8, c64, [5, 3, 2], soft_threshold=True, write_back=True)
+            for _ in range(3):
+                step64()
+            ctx.sync()
+            n64 = max(5, min(args.steps, 20))
+            t64 = time.perf_counter()
+            for _ in range(n64):
+                step64()
+            ctx.sync()
+            ms64 = (time.perf_counter() - t64) / n64 * 1e3
+            ctx.profile(True)
+            ctx.profile_reset()
+            for _ in range(3):
+                step64()
+            k64 = {k: round(ms / 3, 4) for k, (calls, ms) in ctx.profile_entries().items()}
+            ctx.profile(False)
+            c64._plan = None
+            p64.close()
+            bpp = 2.0 * whole_path_bytes_per_pixel("cfg3", 8)
+            out["float64_cfg3"] = {"workload": "8192x8192 float64, triangle L=8, decompose + MAD noise + denoise([5,3,2]) soft "
+                                               "+ plane sum (BASELINE configs[2] on the float64 engine); device-resident",
+                                   "value": round(8192 * 8192 / ms64 / 1e3, 1), "unit": "Mpix/s",
+                                   "ms_per_step": round(ms64, 4), "steps": n64, "bytes_per_pixel": bpp,
+                                   "frac_of_hbm_peak": round(bpp * 8192 * 8192 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "kernels_ms_per_step": k64}
+        except Exception as e:
+            out["float64_cfg3"] = {"error": repr(e)}
     if out is not None:
         brief = out.pop("_brief")
         emit(brief if args.brief else json.dumps(out))

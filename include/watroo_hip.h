@@ -374,6 +374,17 @@ int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
  * wt_set_option("fused64", 0) forces the generic kernels (A/B; results agree to rounding: the
  * fused passes filter columns first, the generic kernels rows first). */
 int wt64_decompose(wt_plan64 *plan, int src, int level, int depth);
+/* the same with flags: bit4 (16) = where the first pass is a fused one it also histograms the first
+ * radix level of |w_0| (as flag bit4 of wt_decompose): a wt64_abs_median(plan, 0) that follows -
+ * Coefficients.get_noise, watroo/wavelets.py:126-127 - then reads the plane once less */
+int wt64_decompose_ex(wt_plan64 *plan, int src, int level, int depth, int flags);
+/* Pass-level entry points of the fused float64 schedule (wt_schedule; as wt_decompose_pass /
+ * wt_decompose_pass_sum / wt_plan_fused_ok): they let the caller place Coefficients.denoise between
+ * the passes (watroo/utils.py:95-98: transform, denoise, sum) */
+int wt64_plan_fused_ok(wt_plan64 *plan, int level, int *ok);
+int wt64_decompose_pass(wt_plan64 *plan, int cur, int nxt, int s0, int ns, int flags);
+int wt64_decompose_pass_sum(wt_plan64 *plan, int cur, int nxt, int s0, int ns, int sum_plane,
+                            int first, int last);
 /* wt_decompose_sum in float64: planes 0..level and np.sum(planes, axis=0) (plane order) -> dst,
  * the sum carried through the fused passes where they apply (*fused = 1), else transform +
  * wt64_plane_sum (*fused = 0; fused may be NULL). */
@@ -394,7 +405,10 @@ int wt64_taps_conv(wt_plan64 *plan, int src, int var, int dst, const int32_t *of
 /* device copy of a window between planes of two plans (crop of atrous_recursive, :405-406) */
 int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, int dst_plane, int64_t sy,
                      int64_t sx, int64_t dy, int64_t dx, int64_t rows, int64_t cols);
-/* np.median(np.abs(plane)) (watroo/wavelets.py:127): exact 63-bit radix select */
+/* np.median(np.abs(plane)) (watroo/wavelets.py:127): exact select on the 63-bit keys - two radix
+ * levels (the first may ride on the transform, wt64_decompose_ex), then the keys of the selected bin
+ * are gathered and one workgroup finishes on that list; radix passes to the end where the bin does
+ * not fit the list (ties) */
 int wt64_abs_median(wt_plan64 *plan, int plane, double *median);
 /* mode 0: dst = Coefficients.significance (watroo/wavelets.py:129-143); mode 1: dst = src * (wgt *
  * significance) (Coefficients.denoise with dst = src, :145-149).  tau <= 0: significance one;
@@ -403,6 +417,11 @@ int wt64_significance(wt_plan64 *plan, int src, int dst, double tau, double wgt,
                       int noise_plane, int mode);
 /* np.sum(planes[first..first+count), axis=0) in plane order (watroo/utils.py:98) */
 int wt64_plane_sum(wt_plan64 *plan, int first, int count, int dst);
+/* wt_denoise_sum in float64: Coefficients.denoise over the first n_den planes (tau[k] <= 0: weight
+ * only) fused with the plane sum of planes [first, first + count) -> dst (watroo/wavelets.py:145-149,
+ * utils.py:98); write_back stores the thresholded planes */
+int wt64_denoise_sum(wt_plan64 *plan, int first, int count, int dst, int n_den, const double *tau,
+                     const double *wgt, int soft, int noise_plane, int write_back);
 /* dst = a OP b: 0 add, 1 sub, 2 mul, 3 div, 4 (a+b)/b */
 int wt64_binary(wt_plan64 *plan, int op, int a, int b, int dst);
 /* the operators of utils.wow without bilateral filtering (watroo/utils.py:157-217) in float64:

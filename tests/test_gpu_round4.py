@@ -154,3 +154,140 @@ def test_generic_tap_coefficients_survive_copy_and_pickle(L, dtype):
         np.testing.assert_array_equal(np.asarray(c.data), want)
         np.testing.assert_array_equal(np.sum(c, axis=0), want_sum)
         assert c.data.dtype == dtype
+
+
+# --------------------------------------------------------------------------- float64 (the reference's default dtype)
+def _plan64(L, img, taps, level):
+    p = L.Plan64(L.default_context(), img.shape[0], img.shape[1], taps, level)
+    p.upload(L.PLANE_INPUT, img)
+    return p
+
+
+B3_TAPS = (1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16)
+TRI_TAPS = (1 / 4, 1 / 2, 1 / 4)
+
+
+def test_float64_erf_of_the_threshold_kernels_vs_scipy(L):
+    """wt_erf64 (branch-free: one degree-26 polynomial + expm1) against scipy.special.erf over the whole
+    range, tiny arguments and the clamp included: absolute error <= 1e-15 (the float64 parity bound of
+    the golden tests is 1e-12)."""
+    from scipy.special import erf
+    y = np.concatenate([np.linspace(0, 7, 40000), 10.0 ** np.linspace(-300, 0, 3000), [0.0, 5.999, 6.0, 6.001, 30.0, 1e300]])
+    y = np.concatenate([y, -y])
+    img = np.resize(y, (64, 2048)).astype(np.float64)
+    p = _plan64(L, img, B3_TAPS, 1)
+    p.significance(L.PLANE_INPUT, L.PLANE_OUT, 1.0, True)            # erf(|v| / 1)
+    got = p.download(L.PLANE_OUT)
+    assert float(np.abs(got - erf(np.abs(img))).max()) <= 1e-15
+    assert got[img == 0].max() == 0.0 and got.max() <= 1.0
+    tiny = np.abs(img) < 1e-3
+    rel = np.abs(got[tiny & (img != 0)] / erf(np.abs(img[tiny & (img != 0)])) - 1)
+    assert float(rel.max()) <= 1e-13                                 # expm1 keeps small arguments relative
+    p.significance(L.PLANE_INPUT, L.PLANE_OUT, 0.5, False)           # hard threshold
+    np.testing.assert_array_equal(p.download(L.PLANE_OUT), (np.abs(img) > 0.5).astype(np.float64))
+    p.close()
+
+
+@pytest.mark.parametrize("shape,taps,level", [((300, 517), B3_TAPS, 5), ((257, 1024), TRI_TAPS, 8), ((64, 33), B3_TAPS, 2)])
+def test_float64_denoise_sum_kernel_equals_the_two_step_form_bitwise(L, shape, taps, level):
+    """wt64_denoise_sum (thresholds + plane sum in one kernel) against wt64_significance per plane and
+    wt64_plane_sum: planes (written back or not) and the sum, bit for bit; soft and hard thresholds, a
+    weight-only plane (tau = 0), a noise map."""
+    img = (rnd(shape, 11) * 3 + 100).astype(np.float64)
+    nz = (1.0 + 0.3 * np.abs(rnd(shape, 12))).astype(np.float64)
+    for soft in (True, False):
+        for noise_plane in (L.PLANE_NONE, L.PLANE_SCRATCH(7)):
+            a, b = _plan64(L, img, taps, level), _plan64(L, img, taps, level)
+            for p in (a, b):
+                p.decompose(L.PLANE_INPUT, level)
+                if noise_plane != L.PLANE_NONE:
+                    p.upload(noise_plane, nz)
+            taus, wgts = [1.7, 0.0, 0.4][:min(3, level)], [1.0, 0.5, 2.0][:min(3, level)]
+            for s, (t, w) in enumerate(zip(taus, wgts)):
+                a.denoise(s, t, w, soft, noise_plane)                  # (tau = 0: weight only)
+            a.plane_sum(0, level + 1, L.PLANE_OUT)
+            keep = [b.download(s).copy() for s in range(level + 1)]
+            b.denoise_sum(level + 1, taus, wgts, soft, noise_plane, write_back=False)
+            np.testing.assert_array_equal(b.download(L.PLANE_OUT).view(np.uint64), a.download(L.PLANE_OUT).view(np.uint64))
+            for s in range(level + 1):
+                np.testing.assert_array_equal(b.download(s), keep[s])  # untouched without write_back
+            b.denoise_sum(level + 1, taus, wgts, soft, noise_plane, write_back=True)
+            for s in range(level + 1):
+                np.testing.assert_array_equal(b.download(s).view(np.uint64), a.download(s).view(np.uint64))
+            np.testing.assert_array_equal(b.download(L.PLANE_OUT).view(np.uint64), a.download(L.PLANE_OUT).view(np.uint64))
+            a.close()
+            b.close()
+
+
+@pytest.mark.parametrize("case", ["gauss_even", "gauss_odd", "quantised", "constant", "two_values", "tiny", "wide_range",
+                                  "upper_in_next_bin"])
+def test_float64_median_select_is_exact(L, case):
+    """np.median(np.abs(plane)) in float64 must be exact for any data: continuous planes take the
+    gathered-list finish (two radix levels, one collect pass, one workgroup), planes with ties whose bin
+    does not fit the list fall back to the radix passes; with and without the first level riding on the
+    transform's first pass (flag bit4), both list and radix paths forced."""
+    rng = np.random.default_rng(7)
+    if case == "gauss_even":
+        img = rng.standard_normal((1024, 2048))
+    elif case == "gauss_odd":
+        img = rng.standard_normal((333, 1001)) * 1e-3 + 5.0
+    elif case == "quantised":
+        img = np.round(rng.standard_normal((2048, 2048)) * 3)          # ~10 distinct magnitudes: 4M ties
+    elif case == "constant":
+        img = np.full((1500, 1500), -2.5)
+    elif case == "two_values":
+        img = np.where(rng.random((1200, 1100)) < 0.5, 1.0, 1.0 + 2.0 ** -40)
+    elif case == "tiny":
+        img = rng.standard_normal((3, 2))
+    elif case == "wide_range":
+        img = rng.standard_normal((512, 512)) * 10.0 ** rng.integers(-200, 200, (512, 512))
+    else:   # the lower median is the largest key of its level-2 bin: the upper one is not in the list
+        img = np.abs(rng.standard_normal((600, 1000)))
+        s = np.sort(img.ravel())
+        lo = s[img.size // 2 - 1]
+        hi = np.float64(np.frombuffer((np.float64(lo).view(np.uint64) | np.uint64((1 << 41) - 1)).tobytes(), np.float64)[0])
+        img = np.where(img > lo, np.maximum(img, hi * (1 + 2.0 ** -10)), img)     # nothing else left in lo's bin above lo
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    want = np.median(np.abs(img))
+    p = _plan64(L, img, B3_TAPS, 0)
+    try:
+        for use_list in (1, 0):
+            L.set_option("select64_list", use_list)
+            assert p.abs_median(L.PLANE_INPUT) == want, use_list
+    finally:
+        L.set_option("select64_list", 1)
+    p.close()
+    # through the public API: the transform's first pass histograms |w_0| (fused images), then get_noise
+    import wavelets_amd as WA
+    if min(img.shape) >= 2:
+        c = WA.AtrousTransform(WA.B3spline)(img, 3)
+        w0 = np.array(c.data[0], copy=True)
+        assert c.get_noise() == np.median(np.abs(w0)) / 0.6745 / c.sigma_e[0]
+        c2 = WA.AtrousTransform(WA.Triangle)(img, 4)
+        c2.data[0][...] = c2.data[0] * 0.5                              # an edited mirror: the riding histogram is stale
+        assert c2.get_noise() == np.median(np.abs(c2.data[0])) / 0.6745 / c2.sigma_e[0]
+
+
+def test_float64_denoise_interleaved_equals_the_plain_sequence(L):
+    """utils.denoise of a float64 image places the threshold step between the fused passes
+    (wt64_decompose_pass + histogram, wt64_denoise_sum, wt64_decompose_pass_sum): the same operations in
+    the same order as transform -> Coefficients.denoise -> np.sum(axis=0), so identical bits; and within
+    1e-12 of the numpy oracle."""
+    import wavelets_amd as WA
+    from oracle import atrous_numpy as O
+    img = (rnd((1024, 1536), 5) * 4 + 1e3).astype(np.float64)
+    for cls, name, sig in ((WA.Triangle, "triangle", [5, 3, 2, 0, 0, 0, 0, 0]), (WA.B3spline, "b3spline", [5, 3]),
+                           (WA.B3spline, "b3spline", [4, 0, 2, 0, 0, 0])):
+        for soft in (True, False):
+            got = WA.denoise(img, list(sig), cls, soft_threshold=soft)
+            c = WA.AtrousTransform(cls)(img, len(sig))
+            c.denoise(list(sig), soft_threshold=soft)
+            want = np.sum(c, axis=0)
+            assert got.dtype == np.float64
+            np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
+            ref = O.denoise(img.copy(), list(sig), name, soft_threshold=soft)
+            if soft:          # (a hard threshold can flip on a last-bit difference of a coefficient)
+                assert float(np.abs(got - ref).max()) <= 1e-12 * float(np.abs(img).max())
+    got = WA.denoise(np.abs(img), [5, 3, 1], WA.B3spline, anscombe=True)
+    ref = O.denoise(np.abs(img).copy(), [5, 3, 1], "b3spline", anscombe=True)
+    assert float(np.abs(got - ref).max()) <= 1e-11 * float(np.abs(img).max())

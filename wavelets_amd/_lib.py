@@ -151,6 +151,13 @@ SIGNATURES = {
     "wt64_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
                                     _c.c_double, _c.c_double]),
     "wt64_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_double]),
+    "wt64_decompose_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_plan_fused_ok": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_int)]),
+    "wt64_decompose_pass": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_decompose_pass_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int]),
+    "wt64_denoise_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double),
+                                    _c.POINTER(_c.c_double), _c.c_int, _c.c_int, _c.c_int]),
     "wt64_reduce": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt64_filter2d": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_int,
                                  _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -729,11 +736,27 @@ class Plan64:
     def set_border(self, border):
         check(load().wt64_plan_set_border(self._h, int(border)))
 
+    _BUILTIN = {(0.25, 0.5, 0.25): TRIANGLE, (0.0625, 0.25, 0.375, 0.25, 0.0625): B3SPLINE}
+
+    @property
+    def fused_family(self):
+        """TRIANGLE / B3SPLINE when the taps are a built-in family's (fused passes), else None"""
+        return self._BUILTIN.get(self.family)
+
     def fused_ok(self, level):
-        return False              # (the float32-only interleavings of the Python layer stay off)
+        """True when the whole schedule of `level` scales runs as fused passes (wt64_plan_fused_ok)."""
+        ok = _c.c_int(0)
+        check(load().wt64_plan_fused_ok(self._h, level, _c.byref(ok)))
+        return bool(ok.value)
 
     def decompose(self, src, level, flags=0):
-        check(load().wt64_decompose(self._h, src, level, 0))
+        check(load().wt64_decompose_ex(self._h, src, level, 0, flags & FLAG_MEDIAN_HIST))
+
+    def decompose_pass(self, cur, nxt, s0, ns, flags=FLAG_FUSED):
+        check(load().wt64_decompose_pass(self._h, cur, nxt, s0, ns, flags & FLAG_MEDIAN_HIST))
+
+    def decompose_pass_sum(self, cur, nxt, s0, ns, flags, sum_plane, first, last):
+        check(load().wt64_decompose_pass_sum(self._h, cur, nxt, s0, ns, sum_plane, int(first), int(last)))
 
     def decompose_sum(self, src, level, dst=PLANE_OUT, flags=0):
         """Transform + np.sum(planes, axis=0) -> dst; True when the sum rode in the fused passes."""
@@ -797,12 +820,12 @@ class Plan64:
         return tuple(out)
 
     def denoise_sum(self, n, taus, wgts, soft, noise_plane=PLANE_NONE, write_back=True, dst=PLANE_OUT):
-        """Coefficients.denoise over the first len(taus) planes, then the plane sum (two steps
-        here; the planes are always written back)."""
-        for s, (tau, wgt) in enumerate(zip(taus, wgts)):
-            if tau > 0 or wgt != 1:
-                self.denoise(s, tau, wgt, soft, noise_plane)
-        self.plane_sum(0, n, dst)
+        """Coefficients.denoise over the first len(taus) planes fused with the plane sum of planes
+        0..n-1 -> dst (wt64_denoise_sum); tau <= 0: no threshold on that plane (weight only)."""
+        k = len(taus)
+        t = (_c.c_double * max(k, 1))(*[float(v) for v in taus])
+        w = (_c.c_double * max(k, 1))(*[float(v) for v in wgts])
+        check(load().wt64_denoise_sum(self._h, 0, n, dst, k, t, w, int(soft), noise_plane, int(write_back)))
 
     def plane_sum(self, first, count, dst=PLANE_OUT):
         check(load().wt64_plane_sum(self._h, first, count, dst))

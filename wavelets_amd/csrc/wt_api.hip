@@ -231,7 +231,7 @@ extern "C" int wt_ctx_comm_info(wt_ctx *ctx, int *rank, int *nranks)
 // =============================================================================================
 // context
 // =============================================================================================
-static const int kPartialBlocks = 1024;
+static const int kPartialBlocks = 2048;     // 8 blocks of wt_reduce_kernel per CU
 
 extern "C" int wt_ctx_create(int device, wt_ctx **out)
 {
@@ -288,6 +288,7 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
     (void)hipHostFree(c->h_pinned);
     (void)hipFree(c->d_psf);
     if (c->d_taps) (void)hipFree(c->d_taps);
+    if (c->d_cand) (void)hipFree(c->d_cand);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1204,6 +1205,7 @@ static int g_opt_overlap_reserve = getenv("WT_OVERLAP_RESERVE") ? atoi(getenv("W
 static int g_opt_split_dry = 0;
 
 static void wt_set_fused64(int on);     // wt_f64.h (included at the end of this file)
+static void wt_set_select64_list(int on);
 // wt_decompose_sum_host: pipeline the PCIe legs with the passes (0: upload, passes, download in turn)
 static int g_opt_host_pipeline = getenv("WT_NO_HOST_PIPELINE") ? 0 : 1;
 
@@ -1220,6 +1222,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "tri4")) { g_opt_tri4 = value != 0; return 0; }
     if (!strcmp(name, "host_pipeline")) { g_opt_host_pipeline = value != 0; return 0; }
     if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
+    if (!strcmp(name, "select64_list")) { wt_set_select64_list(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "scatter_strips")) { g_opt_scatter_strips = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
@@ -2352,7 +2355,8 @@ extern "C" int wt_reduce(wt_plan *p, int plane, double out[4])
     wt_ctx *c = p->ctx;
     float *b = nullptr;
     WT_TRY(plane_base(p, plane, &b));
-    const int blocks = std::min(p->g.nrows, c->partial_blocks);
+    // (work items: (row, chunk of 4096 pixels) pairs)
+    const int blocks = (int)std::min<int64_t>((int64_t)p->g.nrows * ((p->g.W + 4095) / 4096), c->partial_blocks);
     double *dout = c->d_partials + (size_t)c->partial_blocks * 4;
     {
         ProfScope ps(c, "wt_reduce_kernel");

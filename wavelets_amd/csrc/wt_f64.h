@@ -184,25 +184,111 @@ __global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const
     }
 }
 
+// erf(y) for y >= 0 in double precision, branch-free (round 4).  The library erf evaluates one of
+// several ranges per lane - a wave pays for all of them, ~200 double-precision operations per sample,
+// which bounded the float64 threshold kernels at 0.40 of the HBM rate.  Here
+//     erf(y) = -expm1(a),   a = -y * (r(t) + y) = log(erfc(y)),   t = y / 3 - 1,   y clamped to 6
+// (erfc(6) = 2e-17), r ONE degree-26 polynomial (tools/make_erf64.py: weighted Chebyshev fit against
+// 50-digit mpmath values), and expm1 written out: a = n ln2 + x, |x| <= ln2 / 2,
+// expm1(a) = 2^n (1 + x q(x)) - 1 with q of degree 12, so that -expm1(a) = (1 - 2^n) - 2^n x q(x) in one
+// FMA - exact for n = 0, i.e. small arguments keep their relative accuracy.  ~50 FMAs per sample, no
+// division, no branch.  Measured against mpmath on [1e-300, 6.5]: absolute error <= 2.3e-16, relative
+// <= 2.7e-14 (the float64 parity bound of the tests is 1e-12).  erf(0) = 0 exactly; NaN stays NaN.
+// The coefficients live in constant memory, NOT in the instruction stream: a 64-bit literal cannot be
+// an operand of v_fma_f64, so with constexpr tables every Horner step was a v_mov_b64 + v_fmac_f64
+// pair (150 moves per two samples); scalar loads put them in SGPR pairs, which v_fma_f64 reads directly.
+__constant__ double WT_ERF64_Q[27] = {0x1.259bcee7098c9p-1, -0x1.142c68ccd863dp-2, 0x1.2293b824c872dp-3, -0x1.33ec0d4b613eap-4,
+                                      0x1.3c837774a376ap-5, -0x1.32f7d405cccfap-6, 0x1.0ee44d87ebd23p-7, -0x1.93aca6b315f22p-9,
+                                      0x1.84922d81926a0p-11, 0x1.3fd374d9a6dcdp-13, -0x1.8d18e3e4439d9p-12, 0x1.63d73d5b4b8bap-12,
+                                      -0x1.e1bf08c08a3fap-13, 0x1.22e8a9c630114p-13, -0x1.19446361f8e4fp-14, -0x1.49050d2260ba0p-22,
+                                      0x1.86930026aa01cp-20, 0x1.287c357a01b50p-15, 0x1.14679d6bb6ed4p-16, -0x1.d2963129dd6bep-15,
+                                      -0x1.4bd1e396300c0p-16, 0x1.2e935cbc2a44fp-15, 0x1.8e87fa9480c7fp-16, -0x1.122db495799f0p-16,
+                                      -0x1.813c9c90f35cap-17, 0x1.c52e5511ca2c2p-19, 0x1.147aa0cdd9e8cp-19};
+// 1 / k!, k = 1 .. 13
+__constant__ double WT_ERF64_F[13] = {1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                      1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+__device__ __forceinline__ double wt_erf64(double y)
+{
+    const double *Q = WT_ERF64_Q, *F = WT_ERF64_F;
+    y = y > 6.0 ? 6.0 : y;
+    const double t = fma(y, 1.0 / 3.0, -1.0);
+    double r = Q[26];
+#pragma unroll
+    for (int k = 25; k >= 0; --k) r = fma(r, t, Q[k]);
+    const double a = -(y * (r + y));                         // log(erfc(y)), in [-38.5, 0]
+    const double n = __builtin_rint(a * 0x1.71547652b82fep+0);
+    double x = fma(n, -0x1.62e42fefa39efp-1, a);
+    x = fma(n, -0x1.abc9e3b39803fp-56, x);
+    double q = F[12];
+#pragma unroll
+    for (int k = 11; k >= 0; --k) q = fma(q, x, F[k]);
+    const double s = ldexp(1.0, (int)n);
+    return fma(-s, x * q, 1.0 - s);
+}
+
+// significance of one sample (watroo/wavelets.py:137-141): erf(|v / tt|) or |v| > tt
+__device__ __forceinline__ double wt_sig64(double v, double tt, int soft)
+{
+    return soft ? wt_erf64(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
+}
+// the same with the reciprocal of a scalar threshold (the kernels form 1 / tau once per thread: the
+// argument of erf then differs from the quotient by at most one rounding, 1e-16 relative)
+__device__ __forceinline__ double wt_sig64_inv(double v, double tt, double inv_tt, int soft)
+{
+    return soft ? wt_erf64(fabs(v) * inv_tt) : (fabs(v) > tt ? 1.0 : 0.0);
+}
+
 // Coefficients.significance / denoise (watroo/wavelets.py:129-149): mode 0: dst = significance;
 // mode 1: dst = c * (wgt * significance).  tau <= 0: significance one.  noise: optional per-pixel map
-// that multiplies tau (:133).
-// (one sample per thread: the erf of a double is what bounds this kernel - two samples per thread with
-//  16-byte accesses ran 0.48 ms per 8192^2 plane instead of 0.34)
-__global__ __launch_bounds__(256) void wt64_signif_kernel(const double *c, const double *noise, double *dst, int W, int P, int nrows,
-                                                          double tau, double wgt, int soft, int mode)
+// that multiplies tau (:133).  A lane owns two samples (16-byte accesses; planes are contiguous with an
+// even pitch, n2 = double2 groups of the plane) - with wt_erf64 the kernel is a memory stream.
+__global__ __launch_bounds__(256) void wt64_signif_kernel(const double *c, const double *noise, double *dst, int64_t n2, double tau,
+                                                          double wgt, int soft, int mode)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
-        const int64_t o = (int64_t)y * P + x;
-        const double v = c[o];
-        double sg = 1.0;
+    const double inv_tau = 1.0 / tau;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const double2 v = reinterpret_cast<const double2 *>(c)[i];
+        double2 sg = make_double2(1.0, 1.0);
         if (tau > 0.0) {
-            const double tt = noise ? tau * noise[o] : tau;
-            sg = soft ? erf(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
+            if (noise) {
+                const double2 nz = reinterpret_cast<const double2 *>(noise)[i];
+                sg = make_double2(wt_sig64(v.x, tau * nz.x, soft), wt_sig64(v.y, tau * nz.y, soft));
+            } else {
+                sg = make_double2(wt_sig64_inv(v.x, tau, inv_tau, soft), wt_sig64_inv(v.y, tau, inv_tau, soft));
+            }
         }
-        dst[o] = mode ? v * (wgt * sg) : sg;
+        reinterpret_cast<double2 *>(dst)[i] = mode ? make_double2(v.x * (wgt * sg.x), v.y * (wgt * sg.y)) : sg;
+    }
+}
+
+// Coefficients.denoise over the first n_den planes fused with np.sum(planes, axis=0) (wt_denoise_sum in
+// float64): plane k < n_den becomes c * (wgt_k * significance_k) - the expression of wt64_signif_kernel,
+// identical bits - and is written back if asked; the sum runs in plane order.
+struct DenoiseSum64Args {
+    double *p[32];
+    double tau[32], inv_tau[32], wgt[32];      // inv_tau = 1 / tau (IEEE division on the host, as the kernels' own)
+    int n, n_den, soft, write_back;
+};
+__global__ __launch_bounds__(256) void wt64_denoise_sum_kernel(DenoiseSum64Args a, const double *noise, double *dst, int64_t n2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        double2 nz = make_double2(1.0, 1.0);
+        if (noise) nz = reinterpret_cast<const double2 *>(noise)[i];
+        double2 acc = make_double2(0.0, 0.0);
+        for (int k = 0; k < a.n; ++k) {
+            double2 v = reinterpret_cast<const double2 *>(a.p[k])[i];
+            if (k < a.n_den) {
+                double2 sg = make_double2(1.0, 1.0);
+                if (a.tau[k] > 0.0) {
+                    if (noise) sg = make_double2(wt_sig64(v.x, a.tau[k] * nz.x, a.soft), wt_sig64(v.y, a.tau[k] * nz.y, a.soft));
+                    else sg = make_double2(wt_sig64_inv(v.x, a.tau[k], a.inv_tau[k], a.soft), wt_sig64_inv(v.y, a.tau[k], a.inv_tau[k], a.soft));
+                }
+                v = make_double2(v.x * (a.wgt[k] * sg.x), v.y * (a.wgt[k] * sg.y));
+                if (a.write_back) reinterpret_cast<double2 *>(a.p[k])[i] = v;
+            }
+            acc = k == 0 ? v : make_double2(acc.x + v.x, acc.y + v.y);
+        }
+        reinterpret_cast<double2 *>(dst)[i] = acc;
     }
 }
 
@@ -218,7 +304,7 @@ __global__ __launch_bounds__(256) void wt64_wow_kernel(double *c, const double *
         double t = c[o];
         if (tau > 0.0) {
             const double tt = noise ? tau * noise[o] : tau;
-            t = t * (soft ? erf(fabs(t / tt)) : (fabs(t) > tt ? 1.0 : 0.0));
+            t = t * wt_sig64(t, tt, soft);
         }
         if (gamma) gamma[o] = gamma[o] + t;
         double q = factor;
@@ -252,20 +338,35 @@ __global__ __launch_bounds__(256) void wt64_fill_kernel(double *dst, int W, int 
     for (int y = blockIdx.y; y < nrows; y += gridDim.y) dst[(int64_t)y * P + x] = value;
 }
 
-// {sum, sumsq, min, max}: per-block partials over whole rows, folded by wt_reduce_final_kernel
+// {sum, sumsq, min, max}: per-block partials over whole rows, folded by wt_reduce_final_kernel; four
+// 16-byte loads in flight per thread feeding independent accumulators (folded in a fixed order)
 __global__ __launch_bounds__(256) void wt64_reduce_kernel(const double *p, int nrows, int P, int W, double *partials)
 {
-    double s = 0.0, s2 = 0.0, mn = INFINITY, mx = -INFINITY;
+    constexpr int U = 4;
+    double sa[U] = {0.0, 0.0, 0.0, 0.0}, sb[U] = {0.0, 0.0, 0.0, 0.0}, mn = INFINITY, mx = -INFINITY;
+    const int X2 = (W + 1) / 2;
     for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
         const double *row = p + (int64_t)r * P;
-        for (int x = threadIdx.x; x < W; x += 256) {
-            const double t = row[x];
-            s += t;
-            s2 = fma(t, t, s2);
-            mn = fmin(mn, t);
-            mx = fmax(mx, t);
+        for (int x2 = threadIdx.x; x2 < X2; x2 += 256 * U) {
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2 *>(row + 2 * min(x2 + 256 * u, X2 - 1));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int xx = x2 + 256 * u;
+                const double e[2] = {v[u].x, v[u].y};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (xx < X2 && 2 * xx + k < W) {
+                        sa[u] += e[k];
+                        sb[u] = fma(e[k], e[k], sb[u]);
+                        mn = fmin(mn, e[k]);
+                        mx = fmax(mx, e[k]);
+                    }
+            }
         }
     }
+    double s = (sa[0] + sa[1]) + (sa[2] + sa[3]), s2 = (sb[0] + sb[1]) + (sb[2] + sb[3]);
     __shared__ double red[4][4];
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_down(s, off);
@@ -319,7 +420,7 @@ __global__ __launch_bounds__(256) void wt64_mrs_kernel(double *c, double *mrs, c
         double sg = 1.0;
         if (tau > 0.0) {
             const double tt = noise ? tau * noise[o] : tau;
-            sg = soft ? erf(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
+            sg = wt_sig64(v, tt, soft);
         }
         double m = mrs[o];
         if (soft) {
@@ -337,16 +438,16 @@ struct Sum64Args {
     const double *p[32];
     int n;
 };
-// np.sum(planes, axis=0) in plane order (watroo/utils.py:98)
-__global__ __launch_bounds__(256) void wt64_plane_sum_kernel(Sum64Args a, double *dst, int W, int P, int nrows)
+// np.sum(planes, axis=0) in plane order (watroo/utils.py:98); a lane owns two samples (16-byte accesses)
+__global__ __launch_bounds__(256) void wt64_plane_sum_kernel(Sum64Args a, double *dst, int64_t n2)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
-        const int64_t o = (int64_t)y * P + x;
-        double acc = a.p[0][o];
-        for (int k = 1; k < a.n; ++k) acc += a.p[k][o];
-        dst[o] = acc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        double2 acc = reinterpret_cast<const double2 *>(a.p[0])[i];
+        for (int k = 1; k < a.n; ++k) {
+            const double2 v = reinterpret_cast<const double2 *>(a.p[k])[i];
+            acc = make_double2(acc.x + v.x, acc.y + v.y);
+        }
+        reinterpret_cast<double2 *>(dst)[i] = acc;
     }
 }
 
@@ -392,11 +493,63 @@ __global__ __launch_bounds__(256) void wt64_var_kernel(const double *mean, const
 // selection state on the device like the float32 select.
 struct Select64State {
     unsigned long long k, cum_le, prefix;
-    uint32_t failed, pad;
+    uint32_t failed, pad;         // failed: 1 = rank not found (NaN input), 2 = candidate list too small (fall back to the radix passes)
+    unsigned long long bin_count; // elements in the bin the last step selected (what a collect pass would gather)
+    unsigned long long upper;     // list select: smallest key above the lower median (~0: not among the candidates)
 };
 
-// (round 3: 16-byte accesses - a lane reads a double2 - and four of them in flight per thread: the
-//  one-double-per-lane loop streamed at 3.6 TB/s, 8-byte accesses run at 0.54-0.70 of the 16-byte rate)
+// Read stream over the valid samples of a plane for the select kernels: work items are (row, chunk of
+// 256 * 4 double2) pairs dealt round-robin to the blocks; the four 16-byte loads of the NEXT item are
+// issued before the current item is consumed (8 loads in flight per thread - the one-item loop of round
+// 3 streamed at 4.2 TB/s, with a full drain between a row's chunks).  f(key[8], ok[8]) sees the 63-bit
+// magnitude keys of a thread's eight samples of an item and which of them are valid samples.
+template <typename F>
+__device__ __forceinline__ void wt64_scan_keys(const double *p, int nrows, int P, int W, F &&f)
+{
+    constexpr int U = 4;
+    const int X2 = (W + 1) / 2;                          // double2 groups per row (rows are 16-byte aligned: P even)
+    const int nchunk = (X2 + 256 * U - 1) / (256 * U);
+    const int64_t nitems = (int64_t)nrows * nchunk;
+    auto load = [&](int64_t item, double2 (&v)[U]) {
+        const int r = (int)(item / nchunk), c = (int)(item - (int64_t)r * nchunk);
+        const double *row = p + (int64_t)r * P;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            typedef double nt2d __attribute__((ext_vector_type(2)));
+            const nt2d t = __builtin_nontemporal_load(reinterpret_cast<const nt2d *>(row + 2 * min(c * 256 * U + 256 * u + (int)threadIdx.x, X2 - 1)));
+            v[u] = make_double2(t.x, t.y);
+        }
+    };
+    auto consume = [&](int64_t item, const double2 (&v)[U]) {
+        const int c = (int)(item % nchunk);
+        unsigned long long key[2 * U];
+        bool ok[2 * U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int xx = c * 256 * U + 256 * u + (int)threadIdx.x;
+            const double e[2] = {v[u].x, v[u].y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                key[2 * u + k] = (unsigned long long)__double_as_longlong(e[k]) & 0x7fffffffffffffffull;
+                ok[2 * u + k] = xx < X2 && 2 * xx + k < W;
+            }
+        }
+        f(key, ok);
+    };
+    double2 va[U], vb[U];
+    int64_t item = blockIdx.x;
+    if (item < nitems) load(item, va);
+    while (item < nitems) {                              // two items per trip: no register copies
+        const int64_t i1 = item + gridDim.x, i2 = i1 + gridDim.x;
+        if (i1 < nitems) load(i1, vb);
+        consume(item, va);
+        if (i1 >= nitems) break;
+        if (i2 < nitems) load(i2, va);
+        consume(i1, vb);
+        item = i2;
+    }
+}
+
 __global__ __launch_bounds__(256) void wt64_hist_kernel(const double *p, int nrows, int P, int W, unsigned long long prefix_mask,
                                                         const Select64State *st, int shift, uint32_t bin_mask, uint32_t *hist)
 {
@@ -404,25 +557,11 @@ __global__ __launch_bounds__(256) void wt64_hist_kernel(const double *p, int nro
     __shared__ uint32_t lh[WT_HIST_BINS];
     for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256) lh[i] = 0;
     __syncthreads();
-    const int X2 = (W + 1) / 2;                          // double2 groups per row (rows are 16-byte aligned: P even)
-    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const double *row = p + (int64_t)r * P;
-        for (int x2 = threadIdx.x; x2 < X2; x2 += 256 * 4) {
-            double2 v[4];
+    wt64_scan_keys(p, nrows, P, W, [&](const unsigned long long (&w)[8], const bool (&ok)[8]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double2 *>(row + 2 * min(x2 + 256 * u, X2 - 1));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int xx = x2 + 256 * u;
-                const double e[2] = {v[u].x, v[u].y};
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const unsigned long long w = (unsigned long long)__double_as_longlong(e[k]) & 0x7fffffffffffffffull;
-                    if (xx < X2 && 2 * xx + k < W && (w & prefix_mask) == prefix_val) atomicAdd(&lh[(uint32_t)(w >> shift) & bin_mask], 1u);
-                }
-            }
-        }
-    }
+        for (int j = 0; j < 8; ++j)
+            if (ok[j] && (w[j] & prefix_mask) == prefix_val) atomicAdd(&lh[(uint32_t)(w[j] >> shift) & bin_mask], 1u);
+    });
     __syncthreads();
     for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256)
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
@@ -458,6 +597,7 @@ __global__ __launch_bounds__(256) void wt64_select_step_kernel(uint32_t *hist, S
                 st->k = k - cum;
                 st->cum_le = cum_le + cum + (last ? h[i] : 0);
                 st->prefix = prefix | ((unsigned long long)(b0 + i) << shift);
+                st->bin_count = h[i];
                 break;
             }
             cum += h[i];
@@ -467,24 +607,142 @@ __global__ __launch_bounds__(256) void wt64_select_step_kernel(uint32_t *hist, S
     for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;
 }
 
+// Round 4: after two radix levels (22 of the 63 bits) the selected bin of a continuous plane holds a
+// few ten thousand elements (8192^2 Gaussian: ~2e-4 of them).  Instead of four more passes over the
+// plane, ONE pass gathers those elements' keys into a list (this kernel) and one workgroup finishes
+// the select on the list (below) - lower AND upper median, so the extra pass for the upper median of an
+// even count disappears too.  A bin that does not fit the list (ties: constant or quantised data) is
+// left alone: bin_count > cap, nothing is gathered, the host continues with the radix passes.
+__global__ __launch_bounds__(256) void wt64_collect_kernel(const double *p, int nrows, int P, int W, unsigned long long prefix_mask,
+                                                           const Select64State *st, unsigned long long *list, unsigned long long cap)
+{
+    if (st->bin_count > cap || st->failed) return;
+    const unsigned long long prefix_val = st->prefix & prefix_mask;
+    unsigned long long *count = list + cap;              // the counter word sits behind the list
+    // Hits are staged in LDS and leave with ONE global atomic per block: appends through a single global
+    // counter serialise (~6 ns each - 14 000 of them doubled the time of this pass at 8192^2).  A block
+    // that overflows its stage (bins near the list's capacity) appends the rest directly.
+    constexpr int STAGE = 1024;
+    __shared__ unsigned long long stage[STAGE];
+    __shared__ unsigned int n_staged;
+    __shared__ unsigned long long base;
+    if (threadIdx.x == 0) n_staged = 0;
+    __syncthreads();
+    wt64_scan_keys(p, nrows, P, W, [&](const unsigned long long (&w)[8], const bool (&ok)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ok[j] && (w[j] & prefix_mask) == prefix_val) {
+                const unsigned int i = atomicAdd(&n_staged, 1u);
+                if (i < STAGE) {
+                    stage[i] = w[j];
+                } else {
+                    const unsigned long long slot = atomicAdd(count, 1ull);
+                    if (slot < cap) list[slot] = w[j];
+                }
+            }
+    });
+    __syncthreads();
+    const unsigned int n = min(n_staged, (unsigned int)STAGE);
+    if (threadIdx.x == 0 && n) base = atomicAdd(count, (unsigned long long)n);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += 256)
+        if (base + i < cap) list[base + i] = stage[i];
+}
+
+// One workgroup finishes the select on the gathered keys: radix levels over the remaining `bits_left`
+// bits (11 per level, LDS bins), then the smallest key above the result (the upper median of an even
+// count).  State in / out as wt64_select_step_kernel; failed = 2 when nothing was gathered.
+__global__ __launch_bounds__(1024) void wt64_list_select_kernel(const unsigned long long *list, unsigned long long cap, Select64State *st,
+                                                                int bits_left)
+{
+    __shared__ uint32_t lh[WT_HIST_BINS];
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long sh_k, sh_cum, sh_prefix;
+    __shared__ int sh_found;
+    if (st->failed) return;
+    const unsigned long long n = list[cap];
+    if (st->bin_count > cap || n != st->bin_count) {     // (not gathered, or the counts disagree: let the host fall back)
+        if (threadIdx.x == 0) st->failed = 2;
+        return;
+    }
+    unsigned long long k = st->k, cum_le = st->cum_le, prefix = st->prefix;
+    unsigned long long known = ~((1ull << bits_left) - 1ull) & 0x7fffffffffffffffull;   // bits fixed so far
+    int left = bits_left;
+    while (left > 0) {
+        const int nb = left >= 11 ? 11 : left, shift = left - nb, nbins = 1 << nb;
+        for (int i = threadIdx.x; i < WT_HIST_BINS; i += 1024) lh[i] = 0;
+        __syncthreads();
+        for (unsigned long long i = threadIdx.x; i < n; i += 1024) {
+            const unsigned long long w = list[i];
+            if ((w & known) == (prefix & known)) atomicAdd(&lh[(uint32_t)(w >> shift) & (uint32_t)(nbins - 1)], 1u);
+        }
+        __syncthreads();
+        // two bins per thread, inclusive scan over the threads' sums
+        const uint32_t h0 = lh[2 * threadIdx.x], h1 = lh[2 * threadIdx.x + 1];
+        part[threadIdx.x] = (unsigned long long)h0 + h1;
+        if (threadIdx.x == 0) sh_found = 0;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned long long incl = part[threadIdx.x], excl = incl - h0 - h1;
+        if (k >= excl && k < incl) {
+            const bool second = k >= excl + h0;
+            const unsigned long long cum = excl + (second ? h0 : 0);
+            sh_k = k - cum;
+            sh_cum = cum_le + cum + (shift == 0 ? (second ? h1 : h0) : 0);
+            sh_prefix = prefix | ((unsigned long long)(2 * threadIdx.x + (second ? 1 : 0)) << shift);
+            sh_found = 1;
+        }
+        __syncthreads();
+        if (!sh_found) {
+            if (threadIdx.x == 0) st->failed = 1;
+            return;
+        }
+        k = sh_k; cum_le = sh_cum; prefix = sh_prefix;
+        known |= (unsigned long long)(nbins - 1) << shift;
+        left -= nb;
+        __syncthreads();
+    }
+    // smallest gathered key above the result
+    unsigned long long best = ~0ull;
+    for (unsigned long long i = threadIdx.x; i < n; i += 1024) {
+        const unsigned long long w = list[i];
+        if (w > prefix && w < best) best = w;
+    }
+    part[threadIdx.x] = best;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off && part[threadIdx.x + off] < part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->k = k; st->cum_le = cum_le; st->prefix = prefix;
+        st->upper = part[0];
+    }
+}
+
 __global__ __launch_bounds__(256) void wt64_min_greater_kernel(const double *p, int nrows, int P, int W, unsigned long long than,
                                                                unsigned long long *result)
 {
     unsigned long long best = ~0ull;
-    const int X2 = (W + 1) / 2;
-    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const double *row = p + (int64_t)r * P;
-        for (int x2 = threadIdx.x; x2 < X2; x2 += 256) {
-            const double2 v = *reinterpret_cast<const double2 *>(row + 2 * x2);
-            const double e[2] = {v.x, v.y};
+    wt64_scan_keys(p, nrows, P, W, [&](const unsigned long long (&w)[8], const bool (&ok)[8]) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const unsigned long long w = (unsigned long long)__double_as_longlong(e[k]) & 0x7fffffffffffffffull;
-                if (2 * x2 + k < W && w > than && w < best) best = w;
-            }
-        }
+        for (int j = 0; j < 8; ++j)
+            if (ok[j] && w[j] > than && w[j] < best) best = w[j];
+    });
+    // one global atomic per block
+    __shared__ unsigned long long wb[256];
+    wb[threadIdx.x] = best;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off && wb[threadIdx.x + off] < wb[threadIdx.x]) wb[threadIdx.x] = wb[threadIdx.x + off];
+        __syncthreads();
     }
-    if (best != ~0ull) atomicMin(result, best);
+    if (threadIdx.x == 0 && wb[0] != ~0ull) atomicMin(result, wb[0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -498,6 +756,7 @@ static int plan64_base(wt_plan64 *p, int id, double **base)
     else if (id == WT_PLANE_OUT) slot = &p->out;
     else if (id <= WT_PLANE_SCRATCH(0) && id > WT_PLANE_SCRATCH(WT64_NUM_SCRATCH)) slot = &p->scratch[-3 - id];
     else WT_FAIL("float64 plan: invalid plane id %d (max_level %d)", id, p->max_level);
+    if (p->ctx->prehist_plan == p && p->ctx->prehist_plane == id) p->ctx->prehist_plan = nullptr;   // plane touched
     if (!*slot) {
         void *q = nullptr;
         WT_HIP(hipSetDevice(p->ctx->device));
@@ -524,6 +783,9 @@ static int plan64_tmp(wt_plan64 *p, int i, double **base)
 
 static inline wt_ctx *ctx_of(wt_plan64 *p) { return p ? p->ctx : nullptr; }
 static inline dim3 grid64(const wt_plan64 *p) { return dim3((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)); }
+// flat pointwise kernels: planes are contiguous (pitch even, 16-byte aligned rows): double2 groups of a plane
+static inline int64_t plan64_n2(const wt_plan64 *p) { return (int64_t)p->g.nrows * p->g.P / 2; }
+static inline int flat_grid64(const wt_plan64 *p) { return (int)std::min<int64_t>((plan64_n2(p) + 255) / 256, 256 * 16); }
 static Taps64 taps64(const wt_plan64 *p)
 {
     Taps64 t{};
@@ -561,6 +823,7 @@ extern "C" int wt64_plan_destroy(wt_plan64 *p)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) return 0;
+    if (p->ctx->prehist_plan == p) p->ctx->prehist_plan = nullptr;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     for (void *q : p->allocs) (void)hipFree(q);
@@ -700,8 +963,63 @@ static bool fused64_ok(const wt_plan64 *p, int level, int depth, int32_t *tr, in
     return any;                                          // (scales beyond the fused passes: one generic kernel each)
 }
 
+// one fused pass: scales [s0, s0 + ns) of plane cur -> detail planes s0.. and plane nxt; acc 0 plain,
+// 1 / 2 carrying the plane sum in sum_plane (2: last pass), 3 plain + first level of the median select
+static int fused64_pass(wt_plan64 *p, int cur, int nxt, int s0, int ns, int acc, bool first_of_sum, int sum_plane)
+{
+    const int fam = fused64_family(p);
+    if (fam < 0 || !wt_fused_has_pass(s0, ns, fam)) WT_FAIL("float64 pass (%d, %d): no fused kernel for these taps / scales", s0, ns);
+    if (p->g.border != 0 || p->g.H < 2 || !wt_fused_supported_bytes((int64_t)p->g.P * 8)) WT_FAIL("float64 pass: the fused passes need an image under the symmetric border");
+    if (s0 < 0 || s0 + ns - 1 > p->max_level || ns < 1) WT_FAIL("float64 pass: scales [%d,%d) outside the plan (max_level %d)", s0, s0 + ns, p->max_level);
+    if (cur == nxt || (cur >= s0 && cur < s0 + ns) || (nxt >= s0 && nxt < s0 + ns)) WT_FAIL("float64 pass: input / output planes alias the detail planes of the pass");
+    const bool b3 = fam == WT_B3SPLINE;
+    FusedArgsT<double> a{};
+    double *in = nullptr;
+    WT_TRY(plan64_base(p, cur, &in));
+    a.in = in;
+    WT_TRY(plan64_base(p, nxt, &a.out_c));
+    for (int k = 0; k < ns && k < 3; ++k) WT_TRY(plan64_base(p, s0 + k, &a.out_w[k]));
+    if (ns > 3) WT_TRY(plan64_base(p, s0 + 3, &a.out_w3));
+    a.g = p->g;
+    if (acc == 1 || acc == 2) {
+        if (first_of_sum != (s0 == 0)) WT_FAIL("float64 pass: first must be set for the pass that starts at scale 0 and only for it");
+        WT_TRY(plan64_base(p, sum_plane, &a.p_out));
+        a.p_in = first_of_sum ? nullptr : a.p_out;
+    }
+    const FusedRows rows;          // (whole passes: the float64 engine is single-GPU)
+    if (acc == 3) {
+        if (s0 != 0) WT_FAIL("float64 pass: the histogram variant exists for the first pass only");
+        a.hist = p->ctx->d_hist;
+        p->ctx->prehist_ran = true;
+        return b3 ? wt_fused_tu_f64_k5_acc3(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc3(p, a, s0, ns, rows);
+    }
+    if (acc == 2) return b3 ? wt_fused_tu_f64_k5_acc2(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc2(p, a, s0, ns, rows);
+    if (acc == 1) return b3 ? wt_fused_tu_f64_k5_acc1(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc1(p, a, s0, ns, rows);
+    return b3 ? wt_fused_tu_f64_k5_acc0(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc0(p, a, s0, ns, rows);
+}
+
+// flag bit4 of wt64_decompose_ex / wt64_decompose_pass: the first pass also histograms the exponent
+// field of |w_0| (first level of wt64_abs_median's select); same marker protocol as the float32 engine
+static int prehist64_begin(wt_plan64 *p, int flags)
+{
+    p->ctx->prehist_ran = false;
+    if (flags & 16) {
+        p->ctx->prehist_plan = nullptr;
+        WT_HIP(hipMemsetAsync(p->ctx->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), p->ctx->stream));
+    }
+    return 0;
+}
+static void prehist64_end(wt_plan64 *p)
+{
+    if (p->ctx->prehist_ran) {
+        p->ctx->prehist_plan = p;
+        p->ctx->prehist_plane = 0;
+    }
+    p->ctx->prehist_ran = false;
+}
+
 // the fused schedule: planes 0..level, optionally the plane sum carried through the passes into dst
-static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int np, bool with_sum, int dst)
+static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int np, bool with_sum, int dst, int flags = 0)
 {
     const bool b3 = fused64_family(p) == WT_B3SPLINE;
     int cur = src;
@@ -720,26 +1038,8 @@ static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int 
             cur = nxt;
             continue;
         }
-        FusedArgsT<double> a{};
-        double *in = nullptr;
-        WT_TRY(plan64_base(p, cur, &in));
-        a.in = in;
-        WT_TRY(plan64_base(p, nxt, &a.out_c));
-        for (int k = 0; k < ns && k < 3; ++k) WT_TRY(plan64_base(p, s0 + k, &a.out_w[k]));
-        if (ns > 3) WT_TRY(plan64_base(p, s0 + 3, &a.out_w3));
-        a.g = p->g;
-        int acc = 0;
-        if (with_sum) {
-            acc = last ? 2 : 1;
-            WT_TRY(plan64_base(p, dst, &a.p_out));
-            a.p_in = i == 0 ? nullptr : a.p_out;
-        }
-        int rc;
-        const FusedRows rows;      // (whole passes: the float64 engine is single-GPU)
-        if (acc == 2) rc = b3 ? wt_fused_tu_f64_k5_acc2(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc2(p, a, s0, ns, rows);
-        else if (acc == 1) rc = b3 ? wt_fused_tu_f64_k5_acc1(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc1(p, a, s0, ns, rows);
-        else rc = b3 ? wt_fused_tu_f64_k5_acc0(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc0(p, a, s0, ns, rows);
-        WT_TRY(rc);
+        const int acc = with_sum ? (last ? 2 : 1) : ((flags & 16) && s0 == 0 ? 3 : 0);
+        WT_TRY(fused64_pass(p, cur, nxt, s0, ns, acc, i == 0, dst));
         cur = nxt;
     }
     return 0;
@@ -747,7 +1047,16 @@ static int fused64_run(wt_plan64 *p, int src, int level, const int32_t *tr, int 
 
 /* AtrousTransform.atrous_standard in float64 (watroo/wavelets.py:408-444): planes 0..level-1 detail,
  * plane level smooth, from plane src (left intact).  depth as above. */
+extern "C" int wt64_decompose_ex(wt_plan64 *p, int src, int level, int depth, int flags);
 extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
+{
+    WtGuard guard_(ctx_of(p));
+    return wt64_decompose_ex(p, src, level, depth, 0);
+}
+
+/* wt64_decompose with flags: bit4 (16) = where the first pass is a fused one it also histograms the
+ * first radix level of |w_0| for a wt64_abs_median(plan, 0) that follows (as flag bit4 of wt_decompose) */
+extern "C" int wt64_decompose_ex(wt_plan64 *p, int src, int level, int depth, int flags)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_decompose: null plan");
@@ -766,7 +1075,12 @@ extern "C" int wt64_decompose(wt_plan64 *p, int src, int level, int depth)
         int32_t tr[3 * 32];
         int np = 0;
         bool all = false;
-        if (fused64_ok(p, level, depth, tr, &np, &all)) return fused64_run(p, src, level, tr, np, false, WT_PLANE_NONE);
+        if (fused64_ok(p, level, depth, tr, &np, &all)) {
+            WT_TRY(prehist64_begin(p, flags));
+            WT_TRY(fused64_run(p, src, level, tr, np, false, WT_PLANE_NONE, flags));
+            prehist64_end(p);
+            return 0;
+        }
     }
     int cur = src;
     for (int s = 0; s < level; ++s) {
@@ -803,6 +1117,39 @@ extern "C" int wt64_decompose_sum(wt_plan64 *p, int src, int level, int dst, int
     if (fused) return fused64_run(p, src, level, tr, np, true, dst);
     WT_TRY(wt64_decompose(p, src, level, 0));
     return wt64_plane_sum(p, 0, level + 1, dst);
+}
+
+/* Would wt64_decompose_sum(plan, ., level, .) carry the sum through fused passes (wt_plan_fused_ok)? */
+extern "C" int wt64_plan_fused_ok(wt_plan64 *p, int level, int *ok)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !ok) WT_FAIL("wt64_plan_fused_ok: null pointer");
+    int32_t tr[3 * 32];
+    int np = 0;
+    bool all = false;
+    *ok = (level >= 1 && level <= p->max_level && fused64_ok(p, level, 0, tr, &np, &all) && all) ? 1 : 0;
+    return 0;
+}
+
+/* One pass of the fused schedule in float64 (wt_decompose_pass): scales [s0, s0 + ns) of plane cur ->
+ * detail planes s0 .. s0 + ns - 1 and plane nxt; flags bit4: also histogram |w_0| (s0 = 0 only) */
+extern "C" int wt64_decompose_pass(wt_plan64 *p, int cur, int nxt, int s0, int ns, int flags)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_decompose_pass: null plan");
+    WT_TRY(prehist64_begin(p, flags));
+    WT_TRY(fused64_pass(p, cur, nxt, s0, ns, (flags & 16) && s0 == 0 ? 3 : 0, false, WT_PLANE_NONE));
+    prehist64_end(p);
+    return 0;
+}
+
+/* wt_decompose_pass_sum in float64: the pass also carries np.sum(planes, axis=0) in sum_plane */
+extern "C" int wt64_decompose_pass_sum(wt_plan64 *p, int cur, int nxt, int s0, int ns, int sum_plane, int first, int last)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_decompose_pass_sum: null plan");
+    if (sum_plane == cur || sum_plane == nxt || (sum_plane >= s0 && sum_plane < s0 + ns)) WT_FAIL("wt64_decompose_pass_sum: the sum plane aliases a plane of the pass");
+    return fused64_pass(p, cur, nxt, s0, ns, last ? 2 : 1, first != 0, sum_plane);
 }
 
 /* sdev_loc(image, sf, s, variance) (watroo/wavelets.py:24-32), times f1 then f2 */
@@ -847,8 +1194,9 @@ extern "C" int wt64_significance(wt_plan64 *p, int src, int dst, double tau, dou
     WT_TRY(plan64_base(p, src, &c));
     WT_TRY(plan64_base(p, dst, &d));
     if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
-    hipLaunchKernelGGL(wt64_signif_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)c, (const double *)nz, d, p->g.W, p->g.P, p->g.nrows,
-                       tau, wgt, soft, mode);
+    ProfScope ps(p->ctx, "wt64_signif_kernel");
+    hipLaunchKernelGGL(wt64_signif_kernel, dim3(flat_grid64(p)), dim3(256), 0, p->ctx->stream, (const double *)c, (const double *)nz, d, plan64_n2(p), tau,
+                       wgt, soft, mode);
     WT_HIP(hipGetLastError());
     return 0;
 }
@@ -867,7 +1215,36 @@ extern "C" int wt64_plane_sum(wt_plan64 *p, int first, int count, int dst)
     }
     double *d = nullptr;
     WT_TRY(plan64_base(p, dst, &d));
-    hipLaunchKernelGGL(wt64_plane_sum_kernel, grid64(p), dim3(256), 0, p->ctx->stream, a, d, p->g.W, p->g.P, p->g.nrows);
+    ProfScope ps(p->ctx, "wt64_plane_sum_kernel");
+    hipLaunchKernelGGL(wt64_plane_sum_kernel, dim3(flat_grid64(p)), dim3(256), 0, p->ctx->stream, a, d, plan64_n2(p));
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* wt_denoise_sum in float64 (Coefficients.denoise over the first n_den planes + np.sum(planes, axis=0),
+ * watroo/wavelets.py:145-149, utils.py:98): planes [first, first + count) -> dst; tau[k] <= 0: no
+ * threshold on plane k (its weight still applies); write_back: store the thresholded planes */
+extern "C" int wt64_denoise_sum(wt_plan64 *p, int first, int count, int dst, int n_den, const double *tau, const double *wgt, int soft,
+                                int noise_plane, int write_back)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_denoise_sum: null plan");
+    if (count < 1 || count > 32 || first < 0 || first + count - 1 > p->max_level) WT_FAIL("wt64_denoise_sum: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
+    if (n_den < 0 || n_den > count) WT_FAIL("wt64_denoise_sum: n_den %d outside [0,%d]", n_den, count);
+    if (n_den > 0 && (!tau || !wgt)) WT_FAIL("wt64_denoise_sum: null tau / wgt");
+    DenoiseSum64Args a{};
+    a.n = count; a.n_den = n_den; a.soft = soft; a.write_back = write_back;
+    for (int i = 0; i < count; ++i) {
+        WT_TRY(plan64_base(p, first + i, &a.p[i]));
+        a.tau[i] = i < n_den ? tau[i] : 0.0;
+        a.inv_tau[i] = a.tau[i] > 0.0 ? 1.0 / a.tau[i] : 0.0;
+        a.wgt[i] = i < n_den ? wgt[i] : 1.0;
+    }
+    double *d = nullptr, *nz = nullptr;
+    WT_TRY(plan64_base(p, dst, &d));
+    if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
+    ProfScope ps(p->ctx, "wt64_denoise_sum_kernel");
+    hipLaunchKernelGGL(wt64_denoise_sum_kernel, dim3(flat_grid64(p)), dim3(256), 0, p->ctx->stream, a, (const double *)nz, d, plan64_n2(p));
     WT_HIP(hipGetLastError());
     return 0;
 }
@@ -885,12 +1262,20 @@ extern "C" int wt64_anscombe(wt_plan64 *p, int src, int dst, double alpha, doubl
     return 0;
 }
 
-/* np.median(np.abs(plane)) in float64 (watroo/wavelets.py:127): exact */
+/* np.median(np.abs(plane)) in float64 (watroo/wavelets.py:127): exact.
+ * Round 4: two radix levels of 11 bits (the first one rides on the transform's first fused pass when
+ * flag bit4 asked for it), then ONE pass gathers the keys of the selected bin - a few ten thousand on
+ * continuous data - and one workgroup finishes the select on that list, upper median of an even count
+ * included: two or three reads of the plane instead of six or seven.  Bins that do not fit the list
+ * (ties: constant or quantised data) continue with the radix passes as before. */
+static int g_opt_select64_list = getenv("WT_NO_SELECT64_LIST") ? 0 : 1;      // wt_set_option("select64_list", 0/1): A/B and tests
+static void wt_set_select64_list(int on) { g_opt_select64_list = on; }
 extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
 {
     WtGuard guard_(ctx_of(p));
     if (!p || !median) WT_FAIL("wt64_abs_median: null pointer");
     wt_ctx *c = p->ctx;
+    const bool pre = c->prehist_plan == p && c->prehist_plane == plane;
     c->prehist_plan = nullptr;                                   // the bins are shared with the float32 select
     double *b = nullptr;
     WT_TRY(plan64_base(p, plane, &b));
@@ -898,35 +1283,88 @@ extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
     const int64_t klo = (N - 1) / 2;
     Select64State *st = (Select64State *)(c->d_hist + WT_HIST_BINS + 16);
     Select64State *hst = (Select64State *)c->h_pinned;
-    hst->k = (unsigned long long)klo; hst->cum_le = 0; hst->prefix = 0; hst->failed = 0; hst->pad = 0;
+    memset(hst, 0, sizeof *hst);
+    hst->k = (unsigned long long)klo;
+    hst->upper = ~0ull;
     WT_HIP(hipMemcpyAsync(st, hst, sizeof(Select64State), hipMemcpyHostToDevice, c->stream));
-    WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+    if (!pre) WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
     const int shifts[6] = {52, 41, 30, 19, 8, 0};
     const int bits[6] = {11, 11, 11, 11, 11, 8};
+    // (work items are (row, chunk of 2048 samples) pairs: the grid is sized to the device, 8 blocks per CU)
+    static const int hist_bpc = getenv("WT_HIST64_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("WT_HIST64_BLOCKS_PER_CU"))) : 8;
+    const int hgrid = (int)std::min<int64_t>((int64_t)p->g.nrows * ((p->g.W + 2047) / 2048), (int64_t)hist_bpc * c->num_cus);
     unsigned long long mask = 0;
-    for (int i = 0; i < 6; ++i) {
+    auto level = [&](int i, bool have_hist) -> int {
         const uint32_t bin_mask = (1u << bits[i]) - 1u;
-        hipLaunchKernelGGL(wt64_hist_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W,
-                           mask, (const Select64State *)st, shifts[i], bin_mask, c->d_hist);
+        if (!have_hist) {
+            ProfScope ps(c, "wt64_hist_kernel");
+            hipLaunchKernelGGL(wt64_hist_kernel, dim3(hgrid), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, mask,
+                               (const Select64State *)st, shifts[i], bin_mask, c->d_hist);
+        }
         hipLaunchKernelGGL(wt64_select_step_kernel, dim3(1), dim3(256), 0, c->stream, c->d_hist, st, (int)bin_mask + 1, shifts[i], i == 5);
         mask |= (unsigned long long)bin_mask << shifts[i];
+        WT_HIP(hipGetLastError());
+        return 0;
+    };
+    auto read_state = [&](Select64State *out) -> int {
+        WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(Select64State), hipMemcpyDeviceToHost, c->stream));
+        WT_HIP(hipStreamSynchronize(c->stream));
+        *out = *(const Select64State *)((const char *)c->h_pinned + 64);
+        return 0;
+    };
+    WT_TRY(level(0, pre));
+    WT_TRY(level(1, false));
+    Select64State res{};
+    bool listed = false;
+    if (g_opt_select64_list) {
+        const size_t cap = (size_t)1 << 20;
+        if (!c->d_cand) {
+            WT_HIP(hipMalloc(&c->d_cand, (cap + 1) * sizeof(unsigned long long)));
+            c->d_cand_cap = cap;
+        }
+        WT_HIP(hipMemsetAsync(c->d_cand + c->d_cand_cap, 0, sizeof(unsigned long long), c->stream));
+        {
+            ProfScope ps(c, "wt64_collect_kernel");
+            hipLaunchKernelGGL(wt64_collect_kernel, dim3(hgrid), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, mask,
+                               (const Select64State *)st, c->d_cand, (unsigned long long)c->d_cand_cap);
+        }
+        hipLaunchKernelGGL(wt64_list_select_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)c->d_cand,
+                           (unsigned long long)c->d_cand_cap, st, 41);
+        WT_HIP(hipGetLastError());
+        WT_TRY(read_state(&res));
+        listed = res.failed == 0;
+        if (res.failed == 2) {                                   // the bin did not fit the list: the state is untouched
+            hst->failed = 0;
+            WT_HIP(hipMemcpyAsync(&st->failed, &hst->failed, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        }
     }
-    WT_HIP(hipGetLastError());
-    WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(Select64State), hipMemcpyDeviceToHost, c->stream));
-    WT_HIP(hipStreamSynchronize(c->stream));
-    const Select64State res = *(const Select64State *)((const char *)c->h_pinned + 64);
+    if (!listed) {
+        if (res.failed == 1) WT_FAIL("wt64_abs_median: rank %lld not found (NaN input?)", (long long)klo);
+        for (int i = 2; i < 6; ++i) WT_TRY(level(i, false));
+        WT_TRY(read_state(&res));
+        res.upper = ~0ull;
+    }
     if (res.failed) WT_FAIL("wt64_abs_median: rank %lld not found (NaN input?)", (long long)klo);
     const unsigned long long ulo = res.prefix;
     unsigned long long uhi = ulo;
     if ((N & 1) == 0 && (int64_t)res.cum_le < klo + 2) {
-        unsigned long long *r = (unsigned long long *)(c->d_hist + WT_HIST_BINS + 32);
-        WT_HIP(hipMemsetAsync(r, 0xff, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(wt64_min_greater_kernel, dim3(std::min(p->g.nrows, 2048)), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, ulo, r);
-        WT_HIP(hipGetLastError());
-        WT_HIP(hipMemcpyAsync(c->h_pinned, r, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        WT_HIP(hipStreamSynchronize(c->stream));
-        uhi = *(const unsigned long long *)c->h_pinned;
-        if (uhi == ~0ull) WT_FAIL("wt64_abs_median: upper median not found");
+        // the upper median is the smallest element above the lower one: among the gathered keys, or -
+        // when the lower median is the largest of them / nothing was gathered - one more pass
+        uhi = res.upper;
+        if (uhi == ~0ull) {
+            unsigned long long *r = (unsigned long long *)(c->d_hist + WT_HIST_BINS + 32);
+            WT_HIP(hipMemsetAsync(r, 0xff, sizeof(unsigned long long), c->stream));
+            {
+                ProfScope ps(c, "wt64_min_greater_kernel");
+                hipLaunchKernelGGL(wt64_min_greater_kernel, dim3(hgrid), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P,
+                                   p->g.W, ulo, r);
+            }
+            WT_HIP(hipGetLastError());
+            WT_HIP(hipMemcpyAsync(c->h_pinned, r, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            WT_HIP(hipStreamSynchronize(c->stream));
+            uhi = *(const unsigned long long *)c->h_pinned;
+            if (uhi == ~0ull) WT_FAIL("wt64_abs_median: upper median not found");
+        }
     }
     double lo, hi;
     memcpy(&lo, &ulo, 8);
@@ -990,8 +1428,11 @@ extern "C" int wt64_reduce(wt_plan64 *p, int plane, double out[4])
     WT_TRY(plan64_base(p, plane, &b));
     const int blocks = std::min(p->g.nrows, c->partial_blocks);
     double *dout = c->d_partials + (size_t)c->partial_blocks * 4;
-    hipLaunchKernelGGL(wt64_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, c->d_partials);
-    hipLaunchKernelGGL(wt_reduce_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->d_partials, blocks, dout);
+    {
+        ProfScope ps(c, "wt64_reduce_kernel");
+        hipLaunchKernelGGL(wt64_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, c->d_partials);
+        hipLaunchKernelGGL(wt_reduce_final_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->d_partials, blocks, dout);
+    }
     WT_HIP(hipGetLastError());
     WT_HIP(hipMemcpyAsync(c->h_pinned, dout, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     WT_HIP(hipStreamSynchronize(c->stream));

@@ -262,6 +262,9 @@ __device__ __forceinline__ double2 wt_from_v4u(wt_v4u t, double2)
 #ifndef WT_FUSED_C_AUX
 #define WT_FUSED_C_AUX 0
 #endif
+#ifndef WT_FUSED_R_AUX
+#define WT_FUSED_R_AUX WT_FUSED_W_AUX   // the finished reconstruction (last pass of a carried sum)
+#endif
 
 // Vertical half of one scale of one step: push `cur` (a row of c_{s0+A}) into the window and
 // return the vertically filtered row (centred hw*2^A steps back); `cen` = matching row of
@@ -311,7 +314,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     constexpr bool SUM = ACC == 1 || ACC == 2;
     constexpr bool HIST = ACC == 3;
     static_assert(!HIST || D == 1, "the histogram variant exists for the first pass only");
-    static_assert(!HIST || PX == 4, "the histogram variant is float32 (the float64 select has 63-bit keys)");
     static_assert(NS <= 3 || K == 3, "four scales per pass: 3-tap family only");
     constexpr int hw = K / 2;
     constexpr int KM = K - 1;
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                     pv = pa[kk % PD];
                     pa[kk % PD] = load_acc(PD);
                 }
-                wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), pv);
+                wt_bstore4v<(ACC == 2 ? WT_FUSED_R_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), pv);
             }
             koff += step_bytes;
             return;
@@ -628,15 +630,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             d0 = f4_sub(cen0, n0);
         }
         if (es0) wt_bstore4v<WT_FUSED_W_AUX>(rw0, at(LAG0), d0);
-        if constexpr (HIST && PX == 4) {
+        if constexpr (HIST) {
             // the same predicate as the store of this row: chunk row k - (LAT_IN + LAG0) in [0, span)
             // (wave-uniform) and a lane that owns stored pixels
             if ((!PROL || k >= ST0) && (unsigned)(k - (LAT_IN + LAG0)) < span && lane_store) {
-                const uint32_t b[4] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z),
-                                       __float_as_uint(d0.w)};
+                if constexpr (PX == 4) {
+                    const uint32_t b[4] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z),
+                                           __float_as_uint(d0.w)};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (FAST || x + j < g.W) atomicAdd(&lh[(b[j] & 0x7fffffffu) >> 20], 1u);
+                    for (int j = 0; j < 4; ++j)
+                        if (FAST || x + j < g.W) atomicAdd(&lh[(b[j] & 0x7fffffffu) >> 20], 1u);
+                } else {
+                    // double: the top 11 bits of the 63-bit magnitude are the exponent field (first level
+                    // of wt64_abs_median's select)
+                    const unsigned long long b[2] = {(unsigned long long)__double_as_longlong(d0.x),
+                                                     (unsigned long long)__double_as_longlong(d0.y)};
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (FAST || x + j < g.W) atomicAdd(&lh[(uint32_t)((b[j] & 0x7fffffffffffffffull) >> 52)], 1u);
+                }
             }
         }
         if constexpr (NS == 1) {
@@ -703,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             if constexpr (ACC == 2) s = f4_add(s, NS == 1 ? n0 : (NS == 2 ? n1 : (NS == 3 ? n2 : n3)));
             // the finished reconstruction is a write-once stream; an intermediate sum is re-read
             // by the next pass
-            if (esc) wt_bstore4v<(ACC == 2 ? WT_FUSED_W_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
+            if (esc) wt_bstore4v<(ACC == 2 ? WT_FUSED_R_AUX : WT_FUSED_P_AUX)>(rp, at(LAGC), s);
         }
         c1 = n0;
         koff += step_bytes;
@@ -930,8 +942,8 @@ template <int K, int ACC>
 static int wt_fused64_dispatch_acc(wt_plan64 *p, const FusedArgsT<double> &a, int s0, int ns, const FusedRows &rows)
 {
     typedef double T;
-    static const char *pre[3] = {"wt64_fused", "wt64_fused_acc", "wt64_fused_sum"};
-    static char names[3][16][32];
+    static const char *pre[4] = {"wt64_fused", "wt64_fused_acc", "wt64_fused_sum", "wt64_fused_hist"};
+    static char names[4][16][32];
     auto nm = [&](int slot, const char *tag) -> const char * {
         if (!names[ACC][slot][0]) snprintf(names[ACC][slot], sizeof names[ACC][slot], "%s<%s>", pre[ACC], tag);
         return names[ACC][slot];
@@ -940,15 +952,19 @@ static int wt_fused64_dispatch_acc(wt_plan64 *p, const FusedArgsT<double> &a, in
     // the dilated passes (1024 pixels, x halo 112 / 48 / 192 px per side).
     if constexpr (K == 3) {
         if (s0 == 0 && ns == 4) return wt_fused_launch_t<T, K, 4, 1, 4, 4, ACC>(p, a, nm(7, "d1x4"), rows);
-        if (s0 == 4 && ns == 4) return wt_fused_launch_t<T, K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, nm(8, "d16x4"), rows);
+        if constexpr (ACC != 3) {
+            if (s0 == 4 && ns == 4) return wt_fused_launch_t<T, K, 4, 16, (ACC == 0 ? 8 : 7), (ACC == 0 ? 4 : 2), ACC>(p, a, nm(8, "d16x4"), rows);
+        }
     }
     if (s0 == 0 && ns == 3) return wt_fused_launch_t<T, K, 3, 1, 4, 4, ACC>(p, a, nm(0, "d1x3"), rows);
     if (s0 == 0 && ns == 2) return wt_fused_launch_t<T, K, 2, 1, 4, 4, ACC>(p, a, nm(1, "d1x2"), rows);
-    if (s0 == 3 && ns == 3) return wt_fused_launch_t<T, K, 3, 8, 8, 4, ACC>(p, a, nm(2, "d8x3"), rows);
-    if (s0 == 3 && ns == 2) return wt_fused_launch_t<T, K, 2, 8, 8, 4, ACC>(p, a, nm(3, "d8x2"), rows);
-    if (s0 == 6 && ns == 2) return wt_fused_launch_t<T, K, 2, 64, 8, 4, ACC>(p, a, nm(4, "d64x2"), rows);
-    if (s0 == 3 && ns == 1) return wt_fused_launch_t<T, K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(5, "d8x1"), rows);
-    if (s0 == 6 && ns == 1) return wt_fused_launch_t<T, K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(6, "d64x1"), rows);
+    if constexpr (ACC != 3) {      // (the histogram variant exists for the first pass only)
+        if (s0 == 3 && ns == 3) return wt_fused_launch_t<T, K, 3, 8, 8, 4, ACC>(p, a, nm(2, "d8x3"), rows);
+        if (s0 == 3 && ns == 2) return wt_fused_launch_t<T, K, 2, 8, 8, 4, ACC>(p, a, nm(3, "d8x2"), rows);
+        if (s0 == 6 && ns == 2) return wt_fused_launch_t<T, K, 2, 64, 8, 4, ACC>(p, a, nm(4, "d64x2"), rows);
+        if (s0 == 3 && ns == 1) return wt_fused_launch_t<T, K, 1, 8, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(5, "d8x1"), rows);
+        if (s0 == 6 && ns == 1) return wt_fused_launch_t<T, K, 1, 64, 8, (K == 5 ? 4 : 2), ACC>(p, a, nm(6, "d64x1"), rows);
+    }
     WT_FAIL("float64 fused pass (first scale %d, %d scales) is not built", s0, ns);
 }
 

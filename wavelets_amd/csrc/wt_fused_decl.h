@@ -1,7 +1,7 @@
 // Host-side interface of the fused multi-scale passes (wt_fused.h): argument block, row ranges, which
 // passes exist, and the entry points of the translation units the instantiations are compiled in.
 // The 200-odd instantiations of wt_fused_kernel take minutes to compile in one piece; they are built
-// as one group per (element type, taps, variant) in wt_fused_tu.hip - 14 translation units that
+// as one group per (element type, taps, variant) in wt_fused_tu.hip - 16 translation units that
 // compile side by side - and wt_api.hip sees only the functions declared here.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -75,8 +75,8 @@ WT_FUSED_TU_DECL(3, 0) WT_FUSED_TU_DECL(3, 1) WT_FUSED_TU_DECL(3, 2) WT_FUSED_TU
 #undef WT_FUSED_TU_DECL
 #define WT_FUSED_TU_DECL(K, ACC)                                                                                       \
     int wt_fused_tu_f64_k##K##_acc##ACC(wt_plan64 *p, const FusedArgsT<double> &a, int s0, int ns, const FusedRows &rows);
-WT_FUSED_TU_DECL(5, 0) WT_FUSED_TU_DECL(5, 1) WT_FUSED_TU_DECL(5, 2)
-WT_FUSED_TU_DECL(3, 0) WT_FUSED_TU_DECL(3, 1) WT_FUSED_TU_DECL(3, 2)
+WT_FUSED_TU_DECL(5, 0) WT_FUSED_TU_DECL(5, 1) WT_FUSED_TU_DECL(5, 2) WT_FUSED_TU_DECL(5, 3)
+WT_FUSED_TU_DECL(3, 0) WT_FUSED_TU_DECL(3, 1) WT_FUSED_TU_DECL(3, 2) WT_FUSED_TU_DECL(3, 3)
 #undef WT_FUSED_TU_DECL
 
 // acc: see wt_fused_dispatch_acc; p_in / p_out only for acc != 0

@@ -105,9 +105,12 @@ struct wt_ctx {
     // `prehist_plan` into d_hist (flag bit4 of wt_decompose / wt_decompose_pass).  wt_abs_median of
     // that plane then skips its first pass over the plane.  Dropped by any access to the plane
     // through plane_base (conservative: reads too), by any wt_abs_median and with the plan.
-    struct wt_plan *prehist_plan = nullptr;
+    const void *prehist_plan = nullptr;          // a wt_plan or a wt_plan64
     int prehist_plane = 0;
     bool prehist_ran = false;     // set by the launch of the histogram variant (per entry point)
+    // candidate list of the float64 median select (wt64_abs_median): 64-bit keys + a counter word
+    unsigned long long *d_cand = nullptr;
+    size_t d_cand_cap = 0;        // keys
     // scattered planes (plan_alloc): cleared PER CONTEXT when the virtual-memory API fails on this
     // device (plain hipMalloc from then on); the reason is kept for wt_plan_memory / wt_last_error
     bool vmm_disabled = false;

@@ -1660,28 +1660,58 @@ __global__ __launch_bounds__(256) void wt_min_greater_kernel(const float *p, int
 // K7  {sum, sumsq, min, max}: fp64 sums, deterministic two-stage reduction (per-block partials
 // over whole rows, then one block folds them in a fixed order).  Rows are walked with 2-D
 // indices (no 64-bit modulo per element); min/max are taken in fp32, which is exact.
+// Round 4: four 16-byte loads in flight per thread feeding four independent accumulator sets (folded
+// in a fixed order at the end), nontemporal loads, 8 blocks per CU - the one-load loop with its
+// dependent fp64 chains kept 16 KB in flight per CU and streamed at 0.52 of the HBM rate.
 __global__ __launch_bounds__(256) void wt_reduce_kernel(const float *p, int nrows, int P4, int W,
                                                         double *partials)
 {
-    double s = 0.0, s2 = 0.0;
+    constexpr int U = 4;
+    double sa[U] = {0.0, 0.0, 0.0, 0.0}, sb[U] = {0.0, 0.0, 0.0, 0.0};
     float mn = INFINITY, mx = -INFINITY;
-    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const float4 *row = reinterpret_cast<const float4 *>(p) + (int64_t)r * P4;
-        for (int x4 = threadIdx.x; x4 * 4 < W; x4 += 256) {
-            const float4 v = row[x4];
-            const float b[4] = {v.x, v.y, v.z, v.w};
-            const int nv = min(4, W - x4 * 4);
+    const int X4 = (W + 3) >> 2;
+    // work items are (row, chunk of 256 * U float4) pairs dealt round-robin to the blocks (a fixed
+    // assignment: deterministic sums); the loads of the NEXT item are issued before the current one is
+    // folded - 8 loads of 16 B in flight per thread, as in the select passes
+    const int nchunk = (X4 + 256 * U - 1) / (256 * U);
+    const int64_t nitems = (int64_t)nrows * nchunk;
+    auto load = [&](int64_t item, float4 (&v)[U]) {
+        const int r = (int)(item / nchunk), c = (int)(item - (int64_t)r * nchunk);
+        const float *row = p + (int64_t)r * P4 * 4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = wt_ldnt4(row + 4 * min(c * 256 * U + 256 * u + (int)threadIdx.x, X4 - 1));
+    };
+    auto fold = [&](int64_t item, const float4 (&v)[U]) {
+        const int c = (int)(item % nchunk);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int xx = c * 256 * U + 256 * u + (int)threadIdx.x;
+            const int nv = xx < X4 ? min(4, W - xx * 4) : 0;
+            const float b[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < nv) {
                     const double t = (double)b[k];
-                    s += t;
-                    s2 = fma(t, t, s2);
+                    sa[u] += t;
+                    sb[u] = fma(t, t, sb[u]);
                     mn = fminf(mn, b[k]);
                     mx = fmaxf(mx, b[k]);
                 }
         }
+    };
+    float4 va[U], vb[U];
+    int64_t item = blockIdx.x;
+    if (item < nitems) load(item, va);
+    while (item < nitems) {
+        const int64_t i1 = item + gridDim.x, i2 = i1 + gridDim.x;
+        if (i1 < nitems) load(i1, vb);
+        fold(item, va);
+        if (i1 >= nitems) break;
+        if (i2 < nitems) load(i2, va);
+        fold(i1, vb);
+        item = i2;
     }
+    double s = (sa[0] + sa[1]) + (sa[2] + sa[3]), s2 = (sb[0] + sb[1]) + (sb[2] + sb[3]);
     __shared__ double red[4][2];
     __shared__ float redf[4][2];
     for (int off = 32; off > 0; off >>= 1) {

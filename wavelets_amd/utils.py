@@ -11,7 +11,7 @@ import warnings
 import numpy as np
 
 from . import _lib
-from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, default_context
+from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, acquire_plan64, default_context
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of, _needs_generic,
                        _result_dtype, _taps_f64, _to_f32_image,
                        generalized_anscombe,
@@ -77,6 +77,25 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
     """
     f64 = _result_dtype(data) == np.float64                           # float64 engine (ref:319-320)
+    if f64 and np.ndim(data) == 2 and bilateral is None and not _needs_generic(scaling_function):
+        # float64 images: the same interleaving as float32 below on the float64 engine - fused passes,
+        # the first one histogramming |w_0|, thresholds + start of the sum in one kernel
+        # (wt64_denoise_sum), the later passes carrying the sum
+        img = np.ascontiguousarray(data, dtype=np.float64)
+        level = len(weights)
+        transform = AtrousTransform(scaling_function)
+        sf = scaling_function(2)
+        plan = acquire_plan64(default_context(), img.shape[0], img.shape[1], _taps_f64(sf, 2), level)
+        plan.upload(PLANE_INPUT, img)
+        if anscombe:
+            plan.anscombe(PLANE_INPUT, PLANE_INPUT)                       # ref:93-94
+        coefficients = Coefficients(plan, sf, None)
+        coefficients.noise = noise                                        # ref:96
+        _decompose_denoise_sum(transform, plan, level, coefficients, weights,
+                               soft_threshold=soft_threshold, write_back=False)
+        if anscombe:
+            plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)             # ref:99-100
+        return plan.download(PLANE_OUT)
     if np.ndim(data) in (1, 3) or (f64 and np.ndim(data) == 2) or _needs_generic(scaling_function):
         # signals, cubes and float64 images: the generic call sequence
         arr = np.asarray(data, np.float64 if f64 else np.float32)

@@ -780,9 +780,11 @@ def _decompose_denoise_sum(transform, plan, level, coefficients, sigma, weights=
         weights = (1,) * len(sigma)
     entries = list(zip(range(level + 1), sigma, weights))                 # zip truncation, ref:148
     n_den = max([scl + 1 for scl, sig, wgt in entries if sig != 0 or wgt != 1], default=0)
-    sched = _lib.schedule(plan.family, level, True) if not plan.custom else []
+    # (float64 plans: the fused passes serve the built-in families' taps, wt64_decompose_pass)
+    fam = plan.fused_family if isinstance(plan, Plan64) else (None if plan.custom else plan.family)
+    sched = _lib.schedule(fam, level, True) if fam is not None else []
     k, covered = 0, 0
-    if transform.bilateral is None and not plan.custom and level > 0 and plan.fused_ok(level):
+    if transform.bilateral is None and fam is not None and level > 0 and plan.fused_ok(level):
         while k < len(sched) and (covered < n_den or k == 0):
             covered += sched[k][1]
             k += 1
@@ -927,7 +929,8 @@ class AtrousTransform:
             elif nd == 2 and with_sum and level > 0:
                 summed = plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT) or True   # (two-step form: the sum is there too)
             else:
-                plan.decompose(PLANE_INPUT, level)
+                # (images: the first fused pass also histograms |w_0| for a get_noise() that may follow)
+                plan.decompose(PLANE_INPUT, level, _lib.FLAG_MEDIAN_HIST if nd == 2 else 0)
             plan.set_border(0)
             c = Coefficients(plan, scaling_function, self.bilateral,
                              _shape=a.shape if nd == 3 else None, _dtype=np.float64)
