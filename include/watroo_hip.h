@@ -341,6 +341,21 @@ int wt_binary(wt_plan *plan, int op, int a, int b, int dst);
 int wt_taps_conv(wt_plan *plan, int src, int var, int dst, const int32_t *offsets,
                  const float *weights, int ntaps, float center_weight, int has_center,
                  int depth, int pad_mode, float fill_value);
+/* The same with the two border rules of the RECURSIVE algorithm (watroo/wavelets.py:330-406: every
+ * polyphase sub-array of stride `dilation` is filtered on its own with the base operator, i.e. an
+ * out-of-range index is extended inside its own residue class modulo `dilation`): symmetric
+ * (cv2.BORDER_REFLECT per sub-array, images and cubes) or scipy's 'mirror' (signals).  `dilation`
+ * is ignored by the np.pad modes above. */
+#define WT_PAD_POLY_SYMMETRIC 5
+#define WT_PAD_POLY_MIRROR 6
+int wt_taps_conv_ex(wt_plan *plan, int src, int var, int dst, const int32_t *offsets,
+                    const float *weights, int ntaps, float center_weight, int has_center,
+                    int depth, int pad_mode, float fill_value, int dilation);
+/* sdev_loc's last step (watroo/wavelets.py:27-32) from the two smoothed moments: dst = (meansq -
+ * mean^2, values <= 0 -> 1e-20, optionally sqrt) * f1 * f2 - for callers that form conv(I) and
+ * conv(I^2) themselves (scaling functions the tuned wt_local_variance does not take) */
+int wt_variance_from_moments(wt_plan *plan, int mean, int meansq, int dst, float f1, float f2,
+                             int take_sqrt);
 /* multiresolution-support update of a residual plane (watroo/utils.py:263-276):
  * sig = significance(plane, tau); hard: mrs = persistent ? max(mrs,sig) : sig, plane *= mrs;
  * soft: mrs = persistent ? mrs*sig : sig, plane *= mrs**inv_pow */
@@ -398,10 +413,15 @@ int wt64_local_variance(wt_plan64 *plan, int src, int dst, int s, double f1, dou
  * taps_reversed as flag bit3 of wt_bilateral_conv */
 int wt64_bilateral_conv(wt_plan64 *plan, int src, int var, int dst, int s, int depth,
                         int taps_reversed);
-/* wt_taps_conv in float64 */
+/* wt_taps_conv / wt_taps_conv_ex / wt_variance_from_moments in float64 */
 int wt64_taps_conv(wt_plan64 *plan, int src, int var, int dst, const int32_t *offsets,
                    const double *weights, int ntaps, double center_weight, int has_center,
                    int depth, int pad_mode, double fill_value);
+int wt64_taps_conv_ex(wt_plan64 *plan, int src, int var, int dst, const int32_t *offsets,
+                      const double *weights, int ntaps, double center_weight, int has_center,
+                      int depth, int pad_mode, double fill_value, int dilation);
+int wt64_variance_from_moments(wt_plan64 *plan, int mean, int meansq, int dst, double f1, double f2,
+                               int take_sqrt);
 /* device copy of a window between planes of two plans (crop of atrous_recursive, :405-406) */
 int wt64_copy_window(wt_plan64 *src, int src_plane, wt_plan64 *dst, int dst_plane, int64_t sy,
                      int64_t sx, int64_t dy, int64_t dx, int64_t rows, int64_t cols);

@@ -59,6 +59,12 @@ def recon_bound(amax, denoised=False):
     return (5.8e-6 if denoised else 3.9e-6) * float(amax) / _REF_AMAX
 
 
+# Small-fixture bounds (round 4; the golden groups g0 / g1, ragged shapes, the random shape sweep):
+# 4 x the errors measured on MI355X (gpurun_out/parity_errors.log of round 4; until then 1e-5 and 2e-5).
+SMALL_PLANES = 8e-7          # planes / single-scale operators, times max|input| (measured 2.0e-7 at worst: ragged shapes)
+SMALL_RECON = 5.2e-7          # np.sum(planes, axis=0) against the input image (measured 1.3e-7)
+
+
 def free_port():
     import socket
     with socket.socket() as s:

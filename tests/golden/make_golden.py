@@ -760,6 +760,78 @@ def g21_general_operator():
     out["even4_coef2_f64_L2"] = AtrousTransform(Even4)(a.astype(np.float64) + 1e4, 2).data
     save("g21_general", "atrous_convolution: hard; scaling functions: 1-D hard, 2-D/3-D semantic(cv2 stand-in)", **out)
 
+def g22_remaining_refusals():
+    """Round 4: the last cases the HIP engine refused.  (a) atrous_convolution under the np.pad modes
+    the engine does not implement on the device ('linear_ramp', 'maximum', 'mean', 'median', 'minimum':
+    the reference hands `mode` to np.pad, wavelets.py:77) - the reference's own numpy loop, cv2
+    forbidden: HARD pin.  (b) bilateral and recursive transforms with scaling functions of an even
+    number of taps or more than 15 (wavelets.py:330-406, 433-440): signals / images / cubes (cv2
+    stand-in for convolution(): semantic pin; 1-D: scipy itself)."""
+    import cv2 as _cv2
+    from watroo.wavelets import AbstractScalingFunction
+    out = {}
+    rng = np.random.default_rng(2200)
+    a = img((41, 58), 221)
+    sig = img((150,), 222)
+    cube = img((9, 12, 10), 223)
+    var = (np.abs(img((41, 58), 224)) + 0.3).astype(np.float32)
+    out["img"], out["sig"], out["cube"], out["var"] = a, sig, cube, var
+    k33, k42 = rng.random((3, 3)), rng.random((4, 2))
+    out["k3x3"], out["k4x2"] = k33 / k33.sum(), k42 / k42.sum()
+    out["k1d3"] = np.array([0.2, 0.5, 0.3])
+    _real = _cv2.filter2D
+
+    def _forbidden(*args, **kw):
+        raise AssertionError("hard-pin group must not call cv2.filter2D")
+    _cv2.filter2D = _forbidden
+    try:
+        for mode in ("linear_ramp", "maximum", "mean", "median", "minimum"):
+            for name in ("k3x3", "k4x2"):
+                for s in (0, 2):
+                    out[f"ac_{name}_{mode}_s{s}"] = atrous_convolution(a, out[name], s=s, mode=mode)
+            out[f"acb_k3x3_{mode}_s1"] = atrous_convolution(a, out["k3x3"], var, s=1, mode=mode)
+            out[f"ac1_{mode}_s1"] = atrous_convolution(sig, out["k1d3"], s=1, mode=mode)
+        out["ac_f64_k4x2_mean_s1"] = atrous_convolution(a.astype(np.float64) * 1e3 + 7e5, out["k4x2"], s=1, mode="mean")
+    finally:
+        _cv2.filter2D = _real
+
+    class Even4(AbstractScalingFunction):
+        coefficients_1d = np.array([0.1, 0.4, 0.3, 0.2])
+        sigma_e_1d = np.array([0.7, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.9, 0.2, 0.09, 0.04, 0.02, 0.01])
+        sigma_e_3d = np.array([0.95, 0.12, 0.04, 0.014, 0.005])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('even4', *args, **kwargs)
+
+    class Long17(AbstractScalingFunction):
+        coefficients_1d = np.hanning(19)[1:-1] / np.hanning(19)[1:-1].sum()
+        sigma_e_1d = np.array([0.5, 0.3, 0.2, 0.12, 0.08, 0.06])
+        sigma_e_2d = np.array([0.6, 0.2, 0.09, 0.04, 0.02, 0.01])
+        sigma_e_3d = np.array([0.7, 0.12, 0.04, 0.014, 0.005])
+
+        def __init__(self, *args, **kwargs):
+            super().__init__('long17', *args, **kwargs)
+
+    small = img((12, 14), 225)                     # (Long17's 3-D bilateral kernel has 17^3 taps: a small cube)
+    out["small"] = small
+    for name, cls in (("even4", Even4), ("long17", Long17)):
+        out[f"{name}_taps"] = cls.coefficients_1d
+        out[f"{name}_bil2_L3"] = AtrousTransform(cls, bilateral=1)(a, 3).data
+        out[f"{name}_bil2_scaled_L2"] = AtrousTransform(cls, bilateral=[1.5, 0.7], bilateral_scaling=True)(a, 2).data
+        out[f"{name}_bil1_L2"] = AtrousTransform(cls, bilateral=2)(sig, 2).data
+        out[f"{name}_rec2_L3"] = AtrousTransform(cls)(a, 3, recursive=True).data
+        out[f"{name}_rec1_L3"] = AtrousTransform(cls)(sig, 3, recursive=True).data
+        out[f"{name}_recbil2_L2"] = AtrousTransform(cls, bilateral=1)(a, 2, recursive=True).data
+        out[f"{name}_recbil1_L2"] = AtrousTransform(cls, bilateral=1)(sig, 2, recursive=True).data
+    out["even4_bil3_L2"] = AtrousTransform(Even4, bilateral=1)(cube, 2).data
+    out["even4_rec3_L2"] = AtrousTransform(Even4)(cube, 2, recursive=True).data
+    out["even4_recbil3_L2"] = AtrousTransform(Even4, bilateral=1)(cube, 2, recursive=True).data
+    out["even4_rec2_f64_L3"] = AtrousTransform(Even4)(a.astype(np.float64) + 1e4, 3, recursive=True).data
+    out["even4_bil2_f64_L2"] = AtrousTransform(Even4, bilateral=1)(a.astype(np.float64) + 1e4, 2).data
+    save("g22_refusals", "atrous_convolution pad modes: hard; transforms: 1-D hard, 2-D/3-D semantic(cv2 stand-in)", **out)
+
+
 if __name__ == "__main__":
     if "--only" in sys.argv:                      # e.g. --only g13_richardson_lucy_fft
         globals()[sys.argv[sys.argv.index("--only") + 1]]()
@@ -786,3 +858,4 @@ if __name__ == "__main__":
         g19_custom_bilateral_nd()
         g20_float64()
         g21_general_operator()
+        g22_remaining_refusals()

@@ -291,3 +291,84 @@ def test_float64_denoise_interleaved_equals_the_plain_sequence(L):
     got = WA.denoise(np.abs(img), [5, 3, 1], WA.B3spline, anscombe=True)
     ref = O.denoise(np.abs(img).copy(), [5, 3, 1], "b3spline", anscombe=True)
     assert float(np.abs(got - ref).max()) <= 1e-11 * float(np.abs(img).max())
+
+
+# --------------------------------------------------------------------------- the last refusals (g22)
+def _sf(name, taps, e1, e2, e3):
+    import wavelets_amd as WA
+
+    class SF(WA.wavelets.AbstractScalingFunction):
+        coefficients_1d = np.asarray(taps)
+        sigma_e_1d, sigma_e_2d, sigma_e_3d = np.asarray(e1), np.asarray(e2), np.asarray(e3)
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(name, *args, **kwargs)
+    return SF
+
+
+def test_remaining_np_pad_modes_of_atrous_convolution_vs_reference_golden(L):
+    """g22 (hard pin: the reference's own numpy loop): atrous_convolution under np.pad's 'linear_ramp',
+    'maximum', 'mean', 'median' and 'minimum' - the border is synthesised by np.pad as in the reference
+    (wavelets.py:77), the taps run on the generic operator - plain and range-weighted, signals and
+    images, float32 and float64; unknown modes raise np.pad's ValueError."""
+    from conftest import load_golden
+    from wavelets_amd import atrous_convolution
+    g = load_golden("g22_refusals")
+    a, sig, var = g["img"], g["sig"], g["var"]
+    tol = 2e-6 * float(np.abs(a).max())
+    for mode in ("linear_ramp", "maximum", "mean", "median", "minimum"):
+        for name in ("k3x3", "k4x2"):
+            for s in (0, 2):
+                got = atrous_convolution(a, g[name], s=s, mode=mode)
+                assert got.dtype == np.float32 and got.shape == a.shape
+                assert float(np.abs(got - g[f"ac_{name}_{mode}_s{s}"]).max()) <= tol, (mode, name, s)
+        assert float(np.abs(atrous_convolution(a, g["k3x3"], var, s=1, mode=mode) - g[f"acb_k3x3_{mode}_s1"]).max()) <= 10 * tol
+        assert float(np.abs(atrous_convolution(sig, g["k1d3"], s=1, mode=mode) - g[f"ac1_{mode}_s1"]).max()) <= tol
+    a64 = a.astype(np.float64) * 1e3 + 7e5
+    got = atrous_convolution(a64, g["k4x2"], s=1, mode="mean")
+    assert got.dtype == np.float64 and float(np.abs(got - g["ac_f64_k4x2_mean_s1"]).max()) <= 1e-12 * 7e5
+    out = np.empty_like(a)
+    assert atrous_convolution(a, g["k3x3"], s=1, mode="median", output=out) is out
+    np.testing.assert_allclose(out, g["ac_k3x3_median_s1"] if "ac_k3x3_median_s1" in g.files else
+                               atrous_convolution(a, g["k3x3"], s=1, mode="median"), rtol=0, atol=tol)
+
+
+def test_bilateral_and_recursive_transforms_with_even_or_long_taps_vs_reference_golden(L):
+    """g22: AtrousTransform(cls, bilateral=...) and recursive=True for scaling functions with 4 (even)
+    and 17 taps - refused until round 3 - on signals, images and cubes, float32 and float64, against the
+    unmodified reference's output (wavelets.py:330-406, 433-440)."""
+    from conftest import load_golden
+    import wavelets_amd as WA
+    g = load_golden("g22_refusals")
+    a, sig, cube = g["img"], g["sig"], g["cube"]
+    amax = float(np.abs(a).max())
+    e = {"even4": ([0.7, 0.3, 0.2, 0.12, 0.08, 0.06], [0.9, 0.2, 0.09, 0.04, 0.02, 0.01], [0.95, 0.12, 0.04, 0.014, 0.005]),
+         "long17": ([0.5, 0.3, 0.2, 0.12, 0.08, 0.06], [0.6, 0.2, 0.09, 0.04, 0.02, 0.01], [0.7, 0.12, 0.04, 0.014, 0.005])}
+
+    def check(c, ref, tol, what):
+        assert c.data.shape == ref.shape and c.data.dtype == ref.dtype, what
+        d = float(np.abs(c.data - ref).max())
+        assert d <= tol, f"{what}: {d:.3e} > {tol:.3e}"
+    plain, bil = 3e-6 * amax, 1e-4 * amax           # (bilateral errors chain through the scales: 2e-5 per scale x 5)
+    for name in ("even4", "long17"):
+        cls = _sf(name, g[f"{name}_taps"], *e[name])
+        check(WA.AtrousTransform(cls, bilateral=1)(a, 3), g[f"{name}_bil2_L3"], bil, f"{name} bilateral 2-D")
+        check(WA.AtrousTransform(cls, bilateral=[1.5, 0.7], bilateral_scaling=True)(a, 2), g[f"{name}_bil2_scaled_L2"], bil,
+              f"{name} bilateral scaled")
+        check(WA.AtrousTransform(cls, bilateral=2)(sig, 2), g[f"{name}_bil1_L2"], bil, f"{name} bilateral 1-D")
+        check(WA.AtrousTransform(cls)(a, 3, recursive=True), g[f"{name}_rec2_L3"], plain, f"{name} recursive 2-D")
+        check(WA.AtrousTransform(cls)(sig, 3, recursive=True), g[f"{name}_rec1_L3"], plain, f"{name} recursive 1-D")
+        check(WA.AtrousTransform(cls, bilateral=1)(a, 2, recursive=True), g[f"{name}_recbil2_L2"], bil, f"{name} recursive bilateral 2-D")
+        check(WA.AtrousTransform(cls, bilateral=1)(sig, 2, recursive=True), g[f"{name}_recbil1_L2"], bil, f"{name} recursive bilateral 1-D")
+    cls = _sf("even4", g["even4_taps"], *e["even4"])
+    check(WA.AtrousTransform(cls, bilateral=1)(cube, 2), g["even4_bil3_L2"], bil, "bilateral 3-D")
+    check(WA.AtrousTransform(cls)(cube, 2, recursive=True), g["even4_rec3_L2"], plain, "recursive 3-D")
+    check(WA.AtrousTransform(cls, bilateral=1)(cube, 2, recursive=True), g["even4_recbil3_L2"], bil, "recursive bilateral 3-D")
+    a64 = a.astype(np.float64) + 1e4
+    check(WA.AtrousTransform(cls)(a64, 3, recursive=True), g["even4_rec2_f64_L3"], 1e-11 * 1e4, "recursive float64")
+    check(WA.AtrousTransform(cls, bilateral=1)(a64, 2), g["even4_bil2_f64_L2"], 1e-10 * 1e4, "bilateral float64")
+    # the Coefficients of such a transform are ordinary ones
+    c = WA.AtrousTransform(cls)(a, 3, recursive=True)
+    assert np.isfinite(c.get_noise())
+    c.denoise([5, 3])
+    assert np.sum(c, axis=0).shape == a.shape

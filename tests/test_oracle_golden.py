@@ -497,3 +497,39 @@ def test_g21_general_kernels_pad_modes_and_even_taps():
                                atol=2e-6 * float(np.abs(cube).max()))
     np.testing.assert_allclose(O.atrous_standard_taps_nd(a.astype(np.float64) + 1e4, 2, g["even4_taps"]),
                                g["even4_coef2_f64_L2"], rtol=0, atol=1e-11 * 1e4)
+
+
+def test_g22_remaining_pad_modes_bilateral_and_recursive_with_even_or_long_taps():
+    """g22 (round 4): (a) atrous_convolution under np.pad's 'linear_ramp', 'maximum', 'mean', 'median',
+    'minimum' - the reference's own numpy loop with cv2 forbidden: the oracle matches bit for bit;
+    (b) bilateral and recursive transforms of scaling functions with 4 and 17 taps (signals, images,
+    cubes, float64): the oracle's restatements atrous_standard_bilateral_taps_nd /
+    atrous_recursive_taps_nd against the reference's output (1-D: scipy itself; 2-D / 3-D: cv2
+    stand-in, so float rounding of the correlate differs - a few ulp)."""
+    g = load_golden("g22_refusals")
+    a, sig, cube, var = g["img"], g["sig"], g["cube"], g["var"]
+    for mode in ("linear_ramp", "maximum", "mean", "median", "minimum"):
+        for name in ("k3x3", "k4x2"):
+            for s in (0, 2):
+                np.testing.assert_array_equal(O.atrous_convolution_nd(a, g[name], None, s, mode), g[f"ac_{name}_{mode}_s{s}"])
+        np.testing.assert_allclose(O.atrous_convolution_nd(a, g["k3x3"], var, 1, mode), g[f"acb_k3x3_{mode}_s1"], rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(O.atrous_convolution_nd(sig, g["k1d3"], None, 1, mode), g[f"ac1_{mode}_s1"])
+    np.testing.assert_array_equal(O.atrous_convolution_nd(a.astype(np.float64) * 1e3 + 7e5, g["k4x2"], None, 1, "mean"),
+                                  g["ac_f64_k4x2_mean_s1"])
+    tol = 3e-6 * float(np.abs(a).max())
+    for name in ("even4", "long17"):
+        t = g[f"{name}_taps"]
+        close(O.atrous_standard_bilateral_taps_nd(a, 3, t, 1), g[f"{name}_bil2_L3"], tol)
+        close(O.atrous_standard_bilateral_taps_nd(a, 2, t, [1.5, 0.7], True), g[f"{name}_bil2_scaled_L2"], tol)
+        close(O.atrous_standard_bilateral_taps_nd(sig, 2, t, 2), g[f"{name}_bil1_L2"], tol)
+        close(O.atrous_recursive_taps_nd(a, 3, t), g[f"{name}_rec2_L3"], tol)
+        close(O.atrous_recursive_taps_nd(sig, 3, t), g[f"{name}_rec1_L3"], tol)
+        close(O.atrous_recursive_taps_nd(a, 2, t, 1), g[f"{name}_recbil2_L2"], tol)
+        close(O.atrous_recursive_taps_nd(sig, 2, t, 1), g[f"{name}_recbil1_L2"], tol)
+    t = g["even4_taps"]
+    close(O.atrous_standard_bilateral_taps_nd(cube, 2, t, 1), g["even4_bil3_L2"], tol)
+    close(O.atrous_recursive_taps_nd(cube, 2, t), g["even4_rec3_L2"], tol)
+    close(O.atrous_recursive_taps_nd(cube, 2, t, 1), g["even4_recbil3_L2"], tol)
+    a64 = a.astype(np.float64) + 1e4
+    close(O.atrous_recursive_taps_nd(a64, 3, t), g["even4_rec2_f64_L3"], 1e-11 * 1e4)
+    close(O.atrous_standard_bilateral_taps_nd(a64, 2, t, 1), g["even4_bil2_f64_L2"], 1e-10 * 1e4)

@@ -19,6 +19,7 @@ PLANE_INPUT, PLANE_OUT, PLANE_NONE = -1, -2, -1000
 NUM_SCRATCH = 32
 FLAG_FUSED, FLAG_NO_EXCHANGE, FLAG_SEPARATE_VARIANCE, FLAG_TAPS_REVERSED = 1, 2, 4, 8
 FLAG_MEDIAN_HIST = 16     # wt_decompose_pass: the pass histograms |w_0| for the next wt_abs_median
+PAD_POLY_SYMMETRIC, PAD_POLY_MIRROR = 5, 6     # wt_taps_conv_ex: the border rules of the recursive algorithm
 
 
 def PLANE_SCRATCH(i):
@@ -116,6 +117,9 @@ SIGNATURES = {
     "wt_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_taps_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _fp, _c.c_int,
                                 _c.c_float, _c.c_int, _c.c_int, _c.c_int, _c.c_float]),
+    "wt_taps_conv_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _fp, _c.c_int,
+                                   _c.c_float, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_int]),
+    "wt_variance_from_moments": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_int]),
     "wt_mrs_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
                                  _c.c_int, _c.c_float]),
     "wt_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
@@ -139,6 +143,10 @@ SIGNATURES = {
     "wt64_taps_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32),
                                   _c.POINTER(_c.c_double), _c.c_int, _c.c_double, _c.c_int, _c.c_int, _c.c_int,
                                   _c.c_double]),
+    "wt64_taps_conv_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32),
+                                     _c.POINTER(_c.c_double), _c.c_int, _c.c_double, _c.c_int, _c.c_int, _c.c_int,
+                                     _c.c_double, _c.c_int]),
+    "wt64_variance_from_moments": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int]),
     "wt64_abs_median": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double)]),
     "wt64_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int,
                                      _c.c_int, _c.c_int]),
@@ -643,15 +651,21 @@ class Plan:
                                          "add_div": 4}[op], a, b, dst))
 
     def taps_conv(self, src, var, dst, offsets, weights, center_weight=None, depth=0, pad_mode=0,
-                  fill_value=0.0):
-        """generic tap-list operator (wt_taps_conv): offsets (n, 3) int32 = (dz, dy, dx)"""
+                  fill_value=0.0, dilation=1):
+        """generic tap-list operator (wt_taps_conv_ex): offsets (n, 3) int32 = (dz, dy, dx); dilation:
+        the stride of the polyphase pad modes (5 / 6)"""
         offs = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 3)
         wts = np.ascontiguousarray(weights, dtype=np.float32).ravel()
         assert len(offs) == len(wts)
-        check(load().wt_taps_conv(self._h, src, var, dst, offs.ctypes.data_as(_c.POINTER(_c.c_int32)),
-                                  wts.ctypes.data_as(_fp), len(wts),
-                                  0.0 if center_weight is None else float(center_weight),
-                                  int(center_weight is not None), depth, pad_mode, float(fill_value)))
+        check(load().wt_taps_conv_ex(self._h, src, var, dst, offs.ctypes.data_as(_c.POINTER(_c.c_int32)),
+                                     wts.ctypes.data_as(_fp), len(wts),
+                                     0.0 if center_weight is None else float(center_weight),
+                                     int(center_weight is not None), depth, pad_mode, float(fill_value),
+                                     int(dilation)))
+
+    def variance_from_moments(self, mean, meansq, dst, f1=1.0, f2=1.0, take_sqrt=False):
+        """sdev_loc's last step (ref wavelets.py:27-32) from conv(I) and conv(I^2)"""
+        check(load().wt_variance_from_moments(self._h, mean, meansq, dst, f1, f2, int(take_sqrt)))
 
     def mrs_update(self, plane, mrs_plane, tau, soft, noise_plane, persistent, inv_pow):
         check(load().wt_mrs_update(self._h, plane, mrs_plane, float(tau), int(soft), noise_plane,
@@ -835,14 +849,18 @@ class Plan64:
         check(load().wt64_binary(self._h, code, a, b, dst))
 
     def taps_conv(self, src, var, dst, offsets, weights, center_weight=None, depth=0, pad_mode=0,
-                  fill_value=0.0):
+                  fill_value=0.0, dilation=1):
         offs = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 3)
         wts = np.ascontiguousarray(weights, dtype=np.float64).ravel()
         assert len(offs) == len(wts)
-        check(load().wt64_taps_conv(self._h, src, var, dst, offs.ctypes.data_as(_c.POINTER(_c.c_int32)),
-                                    wts.ctypes.data_as(_dp), len(wts),
-                                    0.0 if center_weight is None else float(center_weight),
-                                    int(center_weight is not None), depth, pad_mode, float(fill_value)))
+        check(load().wt64_taps_conv_ex(self._h, src, var, dst, offs.ctypes.data_as(_c.POINTER(_c.c_int32)),
+                                       wts.ctypes.data_as(_dp), len(wts),
+                                       0.0 if center_weight is None else float(center_weight),
+                                       int(center_weight is not None), depth, pad_mode, float(fill_value),
+                                       int(dilation)))
+
+    def variance_from_moments(self, mean, meansq, dst, f1=1.0, f2=1.0, take_sqrt=False):
+        check(load().wt64_variance_from_moments(self._h, mean, meansq, dst, f1, f2, int(take_sqrt)))
 
     def copy(self, src, dst):
         self.copy_window_from(self, src, dst, 0, 0, 0, 0, self.H, self.W)

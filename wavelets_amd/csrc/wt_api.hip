@@ -2291,10 +2291,35 @@ extern "C" int wt_taps_conv(wt_plan *p, int src, int var, int dst, const int32_t
                             float center_weight, int has_center, int depth, int pad_mode, float fill_value)
 {
     WtGuard guard_(ctx_of(p));
+    if (pad_mode > WT_PAD_CONSTANT) WT_FAIL("wt_taps_conv: unknown pad mode %d (the polyphase modes take a dilation: wt_taps_conv_ex)", pad_mode);
+    return wt_taps_conv_ex(p, src, var, dst, offsets, weights, ntaps, center_weight, has_center, depth, pad_mode, fill_value, 1);
+}
+
+extern "C" int wt_variance_from_moments(wt_plan *p, int mean, int meansq, int dst, float f1, float f2, int take_sqrt)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_variance_from_moments: null plan");
+    float *m = nullptr, *q = nullptr, *d = nullptr;
+    WT_TRY(plane_base(p, mean, &m));
+    WT_TRY(plane_base(p, meansq, &q));
+    WT_TRY(plane_base(p, dst, &d));
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_var_moments_kernel");
+    hipLaunchKernelGGL(wt_var_moments_kernel, dim3(flat_grid(n4)), dim3(256), 0, p->ctx->stream, (const float *)m, (const float *)q, d, n4, f1, f2,
+                       take_sqrt);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_taps_conv_ex(wt_plan *p, int src, int var, int dst, const int32_t *offsets, const float *weights, int ntaps,
+                               float center_weight, int has_center, int depth, int pad_mode, float fill_value, int dilation)
+{
+    WtGuard guard_(ctx_of(p));
     if (!p || (ntaps > 0 && (!offsets || !weights))) WT_FAIL("wt_taps_conv: null pointer");
+    if (dilation < 1) WT_FAIL("wt_taps_conv: dilation %d must be positive", dilation);
     if (p->nranks > 1) WT_FAIL("wt_taps_conv: the generic operator is single-GPU (whole images)");
     if (src == dst || var == dst) WT_FAIL("wt_taps_conv: dst must differ from src and var");
-    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_CONSTANT) WT_FAIL("wt_taps_conv: unknown pad mode %d", pad_mode);
+    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_POLY_MIRROR) WT_FAIL("wt_taps_conv: unknown pad mode %d", pad_mode);
     if (depth < 0 || (depth > 0 && p->g.nrows % depth)) WT_FAIL("wt_taps_conv: %d rows are not a multiple of depth %d", p->g.nrows, depth);
     float *in = nullptr, *o = nullptr, *v = nullptr;
     WT_TRY(plane_base(p, src, &in));
@@ -2307,7 +2332,7 @@ extern "C" int wt_taps_conv(wt_plan *p, int src, int var, int dst, const int32_t
     ProfScope ps(p->ctx, "wt_taps_kernel");
     hipLaunchKernelGGL(wt_taps_kernel<float>, dim3((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)), dim3(256), 0, p->ctx->stream,
                        (const float *)in, (const float *)v, o, p->g.W, p->g.P, Y, Z, d_offs, d_wts, ntaps, center_weight, has_center, pad_mode,
-                       fill_value);
+                       fill_value, dilation);
     WT_HIP(hipGetLastError());
     return 0;
 }

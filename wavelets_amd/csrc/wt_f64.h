@@ -1461,13 +1461,38 @@ extern "C" int wt64_bilateral_conv(wt_plan64 *p, int src, int var, int dst, int 
 }
 
 /* wt_taps_conv in float64 */
+extern "C" int wt64_taps_conv_ex(wt_plan64 *p, int src, int var, int dst, const int32_t *offsets, const double *weights, int ntaps,
+                                 double center_weight, int has_center, int depth, int pad_mode, double fill_value, int dilation);
 extern "C" int wt64_taps_conv(wt_plan64 *p, int src, int var, int dst, const int32_t *offsets, const double *weights, int ntaps,
                               double center_weight, int has_center, int depth, int pad_mode, double fill_value)
 {
     WtGuard guard_(ctx_of(p));
+    if (pad_mode > WT_PAD_CONSTANT) WT_FAIL("wt64_taps_conv: unknown pad mode %d (the polyphase modes take a dilation: wt64_taps_conv_ex)", pad_mode);
+    return wt64_taps_conv_ex(p, src, var, dst, offsets, weights, ntaps, center_weight, has_center, depth, pad_mode, fill_value, 1);
+}
+
+extern "C" int wt64_variance_from_moments(wt_plan64 *p, int mean, int meansq, int dst, double f1, double f2, int take_sqrt)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_variance_from_moments: null plan");
+    double *m = nullptr, *q = nullptr, *d = nullptr;
+    WT_TRY(plan64_base(p, mean, &m));
+    WT_TRY(plan64_base(p, meansq, &q));
+    WT_TRY(plan64_base(p, dst, &d));
+    hipLaunchKernelGGL(wt64_var_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)m, (const double *)q, d, p->g.W, p->g.P, p->g.nrows, f1, f2,
+                       take_sqrt);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt64_taps_conv_ex(wt_plan64 *p, int src, int var, int dst, const int32_t *offsets, const double *weights, int ntaps,
+                                 double center_weight, int has_center, int depth, int pad_mode, double fill_value, int dilation)
+{
+    WtGuard guard_(ctx_of(p));
     if (!p || (ntaps > 0 && (!offsets || !weights))) WT_FAIL("wt64_taps_conv: null pointer");
+    if (dilation < 1) WT_FAIL("wt64_taps_conv: dilation %d must be positive", dilation);
     if (src == dst || var == dst) WT_FAIL("wt64_taps_conv: dst must differ from src and var");
-    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_CONSTANT) WT_FAIL("wt64_taps_conv: unknown pad mode %d", pad_mode);
+    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_POLY_MIRROR) WT_FAIL("wt64_taps_conv: unknown pad mode %d", pad_mode);
     if (depth < 0 || (depth > 0 && p->g.H % depth)) WT_FAIL("wt64_taps_conv: %d rows are not a multiple of depth %d", p->g.H, depth);
     double *in = nullptr, *o = nullptr, *v = nullptr;
     WT_TRY(plan64_base(p, src, &in));
@@ -1478,7 +1503,7 @@ extern "C" int wt64_taps_conv(wt_plan64 *p, int src, int var, int dst, const int
     WT_TRY(upload_taplist<double>(p->ctx, offsets, weights, ntaps, &d_offs, &d_wts));
     const int Z = depth > 0 ? depth : 1, Y = p->g.H / Z;
     hipLaunchKernelGGL(wt_taps_kernel<double>, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, (const double *)v, o, p->g.W, p->g.P, Y, Z,
-                       d_offs, d_wts, ntaps, center_weight, has_center, pad_mode, fill_value);
+                       d_offs, d_wts, ntaps, center_weight, has_center, pad_mode, fill_value, dilation);
     WT_HIP(hipGetLastError());
     return 0;
 }

@@ -1335,10 +1335,15 @@ __global__ __launch_bounds__(256) void wt_filter2d_kernel(const float *in, float
 // (they take the separable built-in / user-defined taps under the symmetric border).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int wt_pad_index(int i, int n, int mode)
+// d: the dilation of the polyphase modes (the border rules of atrous_recursive, whose sub-arrays of
+// stride d are each extended on their own: WT_PAD_POLY_SYMMETRIC / WT_PAD_POLY_MIRROR = wt_refl_b's
+// border rules 1 / 3); unused by the np.pad modes
+__device__ __forceinline__ int wt_pad_index(int i, int n, int mode, int d = 1)
 {
     if ((unsigned)i < (unsigned)n) return i;
     switch (mode) {
+        case WT_PAD_POLY_SYMMETRIC: return wt_refl_b(i, n, d, 1);
+        case WT_PAD_POLY_MIRROR: return wt_refl_b(i, n, d, 3);
         case WT_PAD_SYMMETRIC: return wt_refl(i, n);
         case WT_PAD_REFLECT: {                           // d c b | a b c d | c b a  (no edge duplication)
             if (n == 1) return 0;
@@ -1359,7 +1364,7 @@ __device__ __forceinline__ int wt_pad_index(int i, int n, int mode)
 template <typename T>
 __global__ __launch_bounds__(256) void wt_taps_kernel(const T *in, const T *var, T *out, int W, int P, int Y, int Z,
                                                       const int32_t *offs, const T *wts, int ntaps, T kc,
-                                                      int has_center, int mode, T cval)
+                                                      int has_center, int mode, T cval, int dil)
 {
 #pragma clang fp contract(off)
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -1370,9 +1375,9 @@ __global__ __launch_bounds__(256) void wt_taps_kernel(const T *in, const T *var,
         T acc = has_center ? kc * I : (T)0, norm = has_center ? kc : (T)0;
         const T iv = var ? var[(int64_t)row * P + x] : (T)1;
         for (int t = 0; t < ntaps; ++t) {
-            const int zz = wt_pad_index(z + offs[3 * t], Z, mode);
-            const int yy = wt_pad_index(y + offs[3 * t + 1], Y, mode);
-            const int xx = wt_pad_index(x + offs[3 * t + 2], W, mode);
+            const int zz = wt_pad_index(z + offs[3 * t], Z, mode, dil);
+            const int yy = wt_pad_index(y + offs[3 * t + 1], Y, mode, dil);
+            const int xx = wt_pad_index(x + offs[3 * t + 2], W, mode, dil);
             const T v = (zz < 0 || yy < 0 || xx < 0) ? cval : in[((int64_t)zz * Y + yy) * P + xx];
             if (var) {
                 const T dlt = I - v;

@@ -402,14 +402,31 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
     the tuned kernels.  Everything else the reference accepts - any ``kernel`` array of the image's
     dimensionality (non-separable, even-sized, large), signals and cubes, and the np.pad modes
     'symmetric', 'reflect', 'edge', 'wrap' and 'constant' - runs tap by tap on the generic
-    operator (wt_taps_conv), in the reference's tap order."""
-    if mode not in _PAD_MODES:
-        raise NotImplementedError(f"np.pad mode '{mode}' is not implemented in the HIP engine "
-                                  f"({', '.join(_PAD_MODES)} are)")
+    operator (wt_taps_conv), in the reference's tap order; the remaining np.pad modes are padded by
+    np.pad itself, as in the reference, and filtered by the same operator."""
     kernel = np.asarray(kernel)
     nd = np.ndim(image)
     if nd not in (1, 2, 3) or kernel.ndim != nd:
         raise ValueError("Unsupported number of dimensions")
+    if mode not in _PAD_MODES:
+        # The other np.pad modes ('linear_ramp', 'maximum', 'mean', 'median', 'minimum', 'empty', or a
+        # callable): the reference hands `mode` straight to np.pad (ref:77) - so does this path, with the
+        # reference's own pad widths; the padded array then goes through the generic operator (whose
+        # taps never leave it for the samples that are kept) and the interior is cropped on the way
+        # back.  Border synthesis on the host, the arithmetic on the GPU.  np.pad raises for unknown modes.
+        img = np.asarray(image)
+        widths = [(n // 2 * 2 ** s,) * 2 for n in kernel.shape]                     # ref:76-77
+        padded = np.pad(img, widths, mode=mode)
+        var = None
+        if bilateral_variance is not None:                   # (used at the centre sample only, ref:97)
+            var = np.pad(np.broadcast_to(np.asarray(bilateral_variance, dtype=np.float64), img.shape), widths,
+                         mode="constant", constant_values=1.0)
+        res = atrous_convolution(padded, kernel, var, s, mode="constant")
+        res = res[tuple(slice(w[0], w[0] + n) for w, n in zip(widths, img.shape))]
+        if output is None:
+            return np.ascontiguousarray(res)
+        output[...] = res
+        return output
     f64 = _is_f64(image)                                  # float64 engine (ref:319-320)
     fam = None
     flags = 0
@@ -885,27 +902,90 @@ class AtrousTransform:
         return coefficients
 
     def _call_generic(self, arr, level, recursive):
-        """Standard algorithm (ref:408-444) for a user-defined scaling function with an even number
-        of taps or more than 15: every conv_s tap by tap through the generic operator, the detail
-        planes by subtraction; float32 or float64 planes as the input's type asks."""
-        if recursive or self.bilateral is not None:
-            raise NotImplementedError("scaling functions with an even number of taps or more than 15 "
-                                      "are served by the standard algorithm without bilateral filtering")
+        """The transform for a user-defined scaling function with an even number of taps or more than
+        15, tap by tap through the generic operator - float32 or float64 planes as the input's type
+        asks; signals, images and cubes.
+
+        * standard algorithm (ref:408-444): conv_s = convolution()'s zero-stuffed kernel, centre n // 2
+          (_filter_taps); with bilateral filtering (ref:433-440) the variance of sdev_loc from
+          conv_s(I) and conv_s(I^2) (ref:24-32), then the reference's own tap loop, range-weighted
+          (_reference_taps, ref:74-105), under the symmetric pad.
+        * recursive algorithm (ref:330-406): the array is padded once by (n // 2) * 2**(level-1) per
+          axis (ref:394-395); at scale s every polyphase sub-array of stride d = 2**s is filtered on
+          its own by the BASE operator (ref:354-390) - i.e. the base tap list with offsets times d
+          under the polyphase border rule (an out-of-range index is extended inside its own residue
+          class: wt_taps_conv_ex pad modes 5 / 6) - and the planes are cropped (ref:405-406).  For an
+          even tap count this is NOT the standard algorithm shifted: the base kernel's anchor n // 2
+          scales with d, the zero-stuffed kernel's centre does not."""
         f64 = _is_f64(arr)
         a = np.ascontiguousarray(arr, dtype=np.float64 if f64 else np.float32)
         nd = a.ndim
         scaling_function = self.scaling_function_class(nd)
-        plan = _generic_plan(a.shape, f64, level)
-        plan.upload(PLANE_INPUT, a.reshape(plan.shape))
+        kernel = np.asarray(scaling_function.kernel, dtype=np.float64)
+        sb = None if self.bilateral is None else self._sigma_bilateral(level)
+        if recursive:
+            if level < 1:
+                raise ValueError("recursive=True needs level >= 1")
+            pads = [(n // 2) * 2 ** (level - 1) for n in kernel.shape]                # ref:394
+            work = np.pad(a, [(w, w) for w in pads], mode="symmetric")               # ref:395
+        else:
+            pads, work = None, a
+        plan = _generic_plan(work.shape, f64, level)
+        depth = work.shape[0] if nd == 3 else 0
+        plan.upload(PLANE_INPUT, work.reshape(plan.shape))
+        if recursive:
+            # the base operators' tap lists (scale 0); offsets are multiplied by d below
+            f_offs, f_wts = _filter_taps(kernel, 0, convolve=nd == 1)                # convolution() on a sub-array
+            r_kc, r_offs, r_wts = _reference_taps(kernel, 0)                         # atrous_convolution on a sub-array
+            conv_pad = _lib.PAD_POLY_MIRROR if nd == 1 else _lib.PAD_POLY_SYMMETRIC  # ref:65-69 / :39-63 per sub-array
+        sq, mean, var = PLANE_SCRATCH(6), PLANE_SCRATCH(7), _TMP_PLANE     # (scratch 0/1: the smooth planes; 5: noise maps)
         cur = PLANE_INPUT
         for s in range(level):
             nxt = level if s == level - 1 else PLANE_SCRATCH(s & 1)
-            _generic_smooth(plan, scaling_function, nd, a.shape, cur, nxt, s)      # ref:432
-            plan.binary("sub", cur, nxt, s)                                        # ref:442
+            d = 2 ** s
+
+            def smooth(src, dst):
+                if recursive:
+                    plan.taps_conv(src, PLANE_NONE, dst, f_offs * d, f_wts, None, depth=depth, pad_mode=conv_pad, dilation=d)
+                else:
+                    _generic_smooth(plan, scaling_function, nd, work.shape, src, dst, s)       # ref:432
+            if sb is None:
+                smooth(cur, nxt)
+            else:
+                # ref:434-436 / 375-377: variance = sdev_loc(c, sf, s, variance=True) * sigma_b[s]**2 (* (s+1))
+                plan.binary("mul", cur, cur, sq)
+                smooth(sq, var)
+                smooth(cur, mean)
+                plan.variance_from_moments(mean, var, var, float(sb[s]) ** 2,
+                                           float(s + 1) if self.bilateral_scaling else 1.0)
+                if recursive:                                                       # ref:378, on every sub-array
+                    plan.taps_conv(cur, var, nxt, r_offs * d, r_wts, r_kc, depth=depth,
+                                   pad_mode=_lib.PAD_POLY_SYMMETRIC, dilation=d)
+                else:                                                               # ref:439-440
+                    kc, offs, wts = _reference_taps(kernel, s)
+                    plan.taps_conv(cur, var, nxt, offs, wts, kc, depth=depth, pad_mode=_PAD_MODES["symmetric"])
+            plan.binary("sub", cur, nxt, s)                                        # ref:442 / 402-403
             cur = nxt
         if level == 0:
             plan.decompose(PLANE_INPUT, 0)
-        return Coefficients(plan, scaling_function, None, _shape=a.shape if nd == 3 else None,
+        if not recursive:
+            return Coefficients(plan, scaling_function, self.bilateral, _shape=a.shape if nd == 3 else None,
+                                _dtype=_result_dtype(arr))
+        out = _generic_plan(a.shape, f64, level)                                     # ref:405-406: remove the pads
+        try:
+            for s in range(level + 1):
+                if nd == 3:
+                    Z, Y, X = a.shape
+                    Yp = work.shape[1]
+                    for z in range(Z):
+                        out.copy_window_from(plan, s, s, (z + pads[0]) * Yp + pads[1], pads[2], z * Y, 0, Y, X)
+                elif nd == 2:
+                    out.copy_window_from(plan, s, s, pads[0], pads[1], 0, 0, a.shape[0], a.shape[1])
+                else:
+                    out.copy_window_from(plan, s, s, 0, pads[0], 0, 0, 1, a.shape[0])
+        finally:
+            release_plan(plan)
+        return Coefficients(out, scaling_function, self.bilateral, _shape=a.shape if nd == 3 else None,
                             _dtype=_result_dtype(arr))
 
     def _call_f64(self, arr, level, with_sum=False):
