@@ -356,6 +356,16 @@ int wt_taps_conv_ex(wt_plan *plan, int src, int var, int dst, const int32_t *off
  * conv(I^2) themselves (scaling functions the tuned wt_local_variance does not take) */
 int wt_variance_from_moments(wt_plan *plan, int mean, int meansq, int dst, float f1, float f2,
                              int take_sqrt);
+/* Circular products of richardson_lucy(fft=True) (watroo/utils.py:245-254, 284) through a
+ * hand-written FFT, for whole-image plans whose height and width are powers of two (2 .. 8192):
+ *   wt_fft_spectrum(plan, src)        kernel spectrum of the plan <- rfft2-equivalent of plane src
+ *                                     (the PSF as the caller placed it periodically, :246-250)
+ *   wt_fft_apply(plan, src, dst, conj) dst = irfft2(rfft2(src) * K)  (conj: * conj(K), :254 / :284)
+ * wt_fft_supported: host logic, *ok = 1 when an H x W image qualifies.  Other sizes (and small PSFs,
+ * where it is faster) keep the direct periodic form of wt_filter2d_ex. */
+int wt_fft_supported(int64_t H, int64_t W, int *ok);
+int wt_fft_spectrum(wt_plan *plan, int src);
+int wt_fft_apply(wt_plan *plan, int src, int dst, int conj);
 /* multiresolution-support update of a residual plane (watroo/utils.py:263-276):
  * sig = significance(plane, tau); hard: mrs = persistent ? max(mrs,sig) : sig, plane *= mrs;
  * soft: mrs = persistent ? mrs*sig : sig, plane *= mrs**inv_pow */
@@ -458,6 +468,9 @@ int wt64_filter2d(wt_plan64 *plan, int src, int dst, const double *kernel, int k
                   int ax, int border);
 int wt64_mrs_update(wt_plan64 *plan, int plane, int mrs_plane, double tau, int soft,
                     int noise_plane, int persistent, double inv_pow);
+/* wt_fft_spectrum / wt_fft_apply in float64 */
+int wt64_fft_spectrum(wt_plan64 *plan, int src);
+int wt64_fft_apply(wt_plan64 *plan, int src, int dst, int conj);
 /* generalized_anscombe (watroo/wavelets.py:14-21) */
 int wt64_anscombe(wt_plan64 *plan, int src, int dst, double alpha, double g, double sigma,
                   int inverse);

@@ -832,6 +832,37 @@ def g22_remaining_refusals():
     save("g22_refusals", "atrous_convolution pad modes: hard; transforms: 1-D hard, 2-D/3-D semantic(cv2 stand-in)", **out)
 
 
+def g23_richardson_lucy_fft_large_psf():
+    """Round 4: richardson_lucy(fft=True) with a LARGE PSF (25 x 23 and 24 x 32 taps) on power-of-two
+    images - the shapes the HIP engine now serves through its own FFT (numpy rfft2 / irfft2 in the
+    reference's loop, utils.py:245-254, 284; the a-trous transform inside through the cv2 stand-in)."""
+    rng = np.random.default_rng(2300)
+    yy, xx = np.mgrid[0:64, 0:128]
+    truth = (np.exp(-((yy - 20.) ** 2 + (xx - 40.) ** 2) / 30.) * 40 + np.exp(-((yy - 45.) ** 2 + (xx - 90.) ** 2) / 80.) * 25
+             + 2.0).astype(np.float32)
+    ky, kx = np.mgrid[0:25, 0:23]
+    psf = np.exp(-((ky - 12.) ** 2 / 40. + (kx - 11.) ** 2 / 25. + 0.02 * (ky - 12.) * (kx - 11.))).astype(np.float32)
+    psf /= psf.sum()
+    even = rng.uniform(0.2, 1.0, (24, 32)).astype(np.float32) * np.hanning(24)[:, None].astype(np.float32) \
+        * np.hanning(32)[None, :].astype(np.float32)
+    even /= even.sum()
+    data = (truth + rng.standard_normal(truth.shape).astype(np.float32) * 0.5).astype(np.float32)
+    out = {"data": data, "psf": psf, "psf_even": even}
+    out["rl_fft_soft"] = richardson_lucy(data.copy(), psf, iterations=4, fft=True)
+    out["rl_fft_hard"] = richardson_lucy(data.copy(), psf, iterations=3, threshold_type='hard', fft=True, persistent_mrs=False)
+    out["rl_fft_even"] = richardson_lucy(data.copy(), even, iterations=3, fft=True, denoise_coefficients=(4, 2))
+    out["rl_fft_f64"] = richardson_lucy(data.astype(np.float64) * 10 + 100, psf.astype(np.float64), iterations=3, fft=True)
+    for name, k in (("psf", psf), ("psf_even", even)):
+        pad = np.zeros_like(data)
+        H, W = data.shape
+        kh, kw = k.shape
+        pad[H // 2 - kh // 2:H // 2 - kh // 2 + kh, W // 2 - kw // 2:W // 2 - kw // 2 + kw] = k
+        f = np.fft.rfft2(np.roll(pad, (H // 2, W // 2), axis=(0, 1)))
+        out[f"circ_conv_{name}"] = np.fft.irfft2(np.fft.rfft2(data) * f)
+        out[f"circ_corr_{name}"] = np.fft.irfft2(np.fft.rfft2(data) * f.conj())
+    save("g23_rl_fft_large", "hard(numpy fft; transform via cv2 stand-in)", **out)
+
+
 if __name__ == "__main__":
     if "--only" in sys.argv:                      # e.g. --only g13_richardson_lucy_fft
         globals()[sys.argv[sys.argv.index("--only") + 1]]()
@@ -859,3 +890,4 @@ if __name__ == "__main__":
         g20_float64()
         g21_general_operator()
         g22_remaining_refusals()
+        g23_richardson_lucy_fft_large_psf()

@@ -372,3 +372,106 @@ def test_bilateral_and_recursive_transforms_with_even_or_long_taps_vs_reference_
     assert np.isfinite(c.get_noise())
     c.denoise([5, 3])
     assert np.sum(c, axis=0).shape == a.shape
+
+
+# --------------------------------------------------------------------------- circular products through the FFT
+@pytest.mark.parametrize("shape,dtype", [((64, 128), np.float32), ((512, 256), np.float32), ((2, 8), np.float32),
+                                         ((2048, 2048), np.float32), ((256, 512), np.float64), ((8192, 64), np.float32)])
+def test_fft_circular_products_vs_numpy(L, shape, dtype):
+    """wt_fft_spectrum / wt_fft_apply (row FFTs in LDS, transposes, the spectrum product fused into the
+    first inverse pass) against numpy's irfft2(rfft2(x) * rfft2(k)) and the conjugate product, float32
+    and float64, square and very oblong power-of-two shapes."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(dtype)
+    k = np.zeros(shape, dtype)
+    kh, kw = min(shape[0], 9), min(shape[1], 7)
+    k[:kh, :kw] = rng.random((kh, kw))
+    k /= k.sum()
+    k = np.roll(k, (-(kh // 2), -(kw // 2)), axis=(0, 1))
+    f = np.fft.rfft2(k.astype(np.float64))
+    conv = np.fft.irfft2(np.fft.rfft2(x.astype(np.float64)) * f, s=shape)
+    corr = np.fft.irfft2(np.fft.rfft2(x.astype(np.float64)) * f.conj(), s=shape)
+    if dtype == np.float32:
+        p = L.Plan(L.default_context(), shape[0], shape[1], L.B3SPLINE, 0)
+    else:
+        p = L.Plan64(L.default_context(), shape[0], shape[1], B3_TAPS, 0)
+    S = L.PLANE_SCRATCH(6)
+    p.upload(S, k)
+    p.upload(L.PLANE_INPUT, x)
+    p.fft_spectrum(S)
+    tol = (4e-6 if dtype == np.float32 else 1e-13) * float(np.abs(x).max())
+    p.fft_apply(L.PLANE_INPUT, L.PLANE_OUT, False)
+    assert float(np.abs(p.download(L.PLANE_OUT) - conv).max()) <= tol
+    p.fft_apply(L.PLANE_INPUT, L.PLANE_OUT, True)
+    assert float(np.abs(p.download(L.PLANE_OUT) - corr).max()) <= tol
+    p.close()
+    assert L.fft_supported(*shape) and not L.fft_supported(48, 40) and not L.fft_supported(16384, 64)
+
+
+def test_richardson_lucy_fft_large_psf_vs_reference_golden(L):
+    """g23: richardson_lucy(fft=True) with PSFs of 575 and 768 taps on a 64 x 128 image - the FFT path of
+    the engine - against the unmodified reference (numpy rfft2 in its loop), soft / hard thresholds, an
+    even-sized PSF, float64; and against the direct periodic form of the same products."""
+    from conftest import load_golden
+    import wavelets_amd as WA
+    from wavelets_amd import utils as WU
+    g = load_golden("g23_rl_fft_large")
+    d = g["data"]
+    cases = (("rl_fft_soft", "psf", dict(iterations=4)),
+             ("rl_fft_hard", "psf", dict(iterations=3, threshold_type="hard", persistent_mrs=False)),
+             ("rl_fft_even", "psf_even", dict(iterations=3, denoise_coefficients=(4, 2))))
+    assert g["psf"].size >= WU._FFT_MIN_TAPS and g["psf_even"].size >= WU._FFT_MIN_TAPS
+    direct = {}
+    for name, psf, kw in cases:
+        got = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, g[name], atol=2e-4 * np.abs(g[name]).max(), rtol=2e-4)
+        keep, WU._FFT_MIN_TAPS = WU._FFT_MIN_TAPS, 1 << 30          # the direct periodic correlations
+        try:
+            direct[name] = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+        finally:
+            WU._FFT_MIN_TAPS = keep
+        if "hard" not in name:      # (a hard threshold may flip on a last-bit difference)
+            np.testing.assert_allclose(got, direct[name], atol=5e-5 * np.abs(got).max(), rtol=0)
+    got = WA.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
+    assert got.dtype == np.float64
+    np.testing.assert_allclose(got, g["rl_fft_f64"], atol=1e-9 * np.abs(g["rl_fft_f64"]).max(), rtol=0)
+
+
+def test_fft_products_beat_the_banded_direct_form_for_a_129x129_psf(L):
+    """a 129 x 129 PSF at 2048^2 - the FFT form of one circular product must be at
+    least 5 x faster than the banded direct form (16 641 taps per pixel), with the same result."""
+    H = W = 2048
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((H, W)).astype(np.float32)
+    ky, kx = np.mgrid[0:129, 0:129]
+    psf = np.exp(-((ky - 64.) ** 2 + (kx - 64.) ** 2) / 600.).astype(np.float32)
+    psf /= psf.sum()
+    ctx = L.default_context()
+    p = L.Plan(ctx, H, W, L.B3SPLINE, 0)
+    p.upload(L.PLANE_INPUT, x)
+    pad = np.zeros((H, W), np.float32)
+    pad[H // 2 - 64:H // 2 + 65, W // 2 - 64:W // 2 + 65] = psf
+    S, A, B = L.PLANE_SCRATCH(6), L.PLANE_SCRATCH(7), L.PLANE_SCRATCH(8)
+    p.upload(S, np.roll(pad, (H // 2, W // 2), axis=(0, 1)))
+    p.fft_spectrum(S)
+
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+    t_fft = timed(lambda: p.fft_apply(L.PLANE_INPUT, A, False), 10)
+    flipped = np.ascontiguousarray(psf[::-1, ::-1])
+    t_dir = timed(lambda: p.filter2d(L.PLANE_INPUT, B, flipped, anchor=(64, 64), periodic=True), 2)
+    a, b = p.download(A), p.download(B)
+    p.close()
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "fft_vs_direct.txt"), "a") as f:
+            f.write(f"2048^2, 129x129 PSF: fft {t_fft:.3f} ms, banded direct {t_dir:.3f} ms, ratio {t_dir / t_fft:.1f}\n")
+    except OSError:
+        pass
+    assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(x).max())
+    assert t_dir >= 5 * t_fft, (t_fft, t_dir)

@@ -533,3 +533,24 @@ def test_g22_remaining_pad_modes_bilateral_and_recursive_with_even_or_long_taps(
     a64 = a.astype(np.float64) + 1e4
     close(O.atrous_recursive_taps_nd(a64, 3, t), g["even4_rec2_f64_L3"], 1e-11 * 1e4)
     close(O.atrous_standard_bilateral_taps_nd(a64, 2, t, 1), g["even4_bil2_f64_L2"], 1e-10 * 1e4)
+
+
+def test_g23_large_psf_fft_products_and_richardson_lucy():
+    """g23 (round 4): richardson_lucy(fft=True) with 25 x 23 and 24 x 32 PSFs on a 64 x 128 image - the
+    oracle's direct periodic correlations against the reference's rfft2 products (numpy only) and the
+    whole iteration (float32 and float64)."""
+    g = load_golden("g23_rl_fft_large")
+    d = g["data"]
+    tol = 2e-5 * float(np.abs(d).max())
+    for name in ("psf", "psf_even"):
+        k = g[name]
+        kh, kw = k.shape
+        close(O.filter2d_periodic(d, k[::-1, ::-1], (kh - 1 - kh // 2, kw - 1 - kw // 2)), g[f"circ_conv_{name}"], tol)
+        close(O.filter2d_periodic(d, k, (kh // 2, kw // 2)), g[f"circ_corr_{name}"], tol)
+    for name, psf, kw in (("rl_fft_soft", "psf", dict(iterations=4)),
+                          ("rl_fft_hard", "psf", dict(iterations=3, threshold_type="hard", persistent_mrs=False)),
+                          ("rl_fft_even", "psf_even", dict(iterations=3, denoise_coefficients=(4, 2)))):
+        got = O.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+        close(got, g[name], atol=2e-4 * np.abs(g[name]).max(), rtol=2e-4)
+    got = O.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
+    close(got, g["rl_fft_f64"], atol=1e-9 * np.abs(g["rl_fft_f64"]).max(), rtol=0)

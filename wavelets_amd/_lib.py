@@ -159,6 +159,11 @@ SIGNATURES = {
     "wt64_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
                                     _c.c_double, _c.c_double]),
     "wt64_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_double]),
+    "wt_fft_supported": (_c.c_int, [_i64, _i64, _c.POINTER(_c.c_int)]),
+    "wt_fft_spectrum": (_c.c_int, [_vp, _c.c_int]),
+    "wt_fft_apply": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_fft_spectrum": (_c.c_int, [_vp, _c.c_int]),
+    "wt64_fft_apply": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_decompose_ex": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_plan_fused_ok": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_int)]),
     "wt64_decompose_pass": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -199,6 +204,13 @@ def load():
 def check(rc):
     if rc != 0:
         raise WatrooHipError(load().wt_last_error().decode("utf-8", "replace"))
+
+
+def fft_supported(H, W):
+    """True when an H x W image can take the FFT path of the circular products (powers of two, 2 .. 8192)."""
+    ok = _c.c_int(0)
+    check(load().wt_fft_supported(H, W, _c.byref(ok)))
+    return bool(ok.value)
 
 
 def set_option(name, value):
@@ -671,6 +683,14 @@ class Plan:
         check(load().wt_mrs_update(self._h, plane, mrs_plane, float(tau), int(soft), noise_plane,
                                    int(persistent), float(inv_pow)))
 
+    def fft_spectrum(self, src):
+        """kernel spectrum of the plan <- FFT2 of plane src (wt_fft_spectrum)"""
+        check(load().wt_fft_spectrum(self._h, src))
+
+    def fft_apply(self, src, dst, conj=False):
+        """dst = irfft2(rfft2(src) * K) or, conj, * conj(K) (wt_fft_apply)"""
+        check(load().wt_fft_apply(self._h, src, dst, int(conj)))
+
     def anscombe(self, src, dst, alpha=1.0, g=0.0, sigma=0.0, inverse=False):
         check(load().wt_anscombe(self._h, src, dst, alpha, g, sigma, int(inverse)))
 
@@ -864,6 +884,12 @@ class Plan64:
 
     def copy(self, src, dst):
         self.copy_window_from(self, src, dst, 0, 0, 0, 0, self.H, self.W)
+
+    def fft_spectrum(self, src):
+        check(load().wt64_fft_spectrum(self._h, src))
+
+    def fft_apply(self, src, dst, conj=False):
+        check(load().wt64_fft_apply(self._h, src, dst, int(conj)))
 
     def filter2d(self, src, dst, kernel, flags=0, anchor=None, periodic=False):
         k = np.ascontiguousarray(kernel, dtype=np.float64)

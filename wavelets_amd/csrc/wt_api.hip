@@ -9,6 +9,7 @@
 #include "wt_internal.h"
 #include "wt_kernels.h"
 #include "wt_fused_decl.h"
+#include "wt_fft.h"
 
 // =============================================================================================
 // errors
@@ -2244,6 +2245,45 @@ extern "C" int wt_filter2d_ex(wt_plan *p, int src, int dst, const float *kernel,
     }
     WT_HIP(hipGetLastError());
     return 0;
+}
+
+// ---- circular products through the FFT (wt_fft.h; watroo/utils.py:245-254, 284)
+extern "C" int wt_fft_supported(int64_t H, int64_t W, int *ok)
+{
+    if (!ok) WT_FAIL("wt_fft_supported: null pointer");
+    *ok = (H <= WT_FFT_MAX_N && W <= WT_FFT_MAX_N && wt_fft_size_ok((int)H, (int)W)) ? 1 : 0;
+    return 0;
+}
+
+static int fft_plan_check(const wt_plan *p, const char *who)
+{
+    if (p->nranks != 1 || p->g.row0 != 0 || p->g.nrows != p->g.H) WT_FAIL("%s: whole-image plans only", who);
+    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("%s: image %d x %d is not a power of two per side (2 .. %d)", who, p->g.H, p->g.W, WT_FFT_MAX_N);
+    return 0;
+}
+
+extern "C" int wt_fft_spectrum(wt_plan *p, int src)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_fft_spectrum: null plan");
+    WT_TRY(fft_plan_check(p, "wt_fft_spectrum"));
+    float *s = nullptr;
+    WT_TRY(plane_base(p, src, &s));
+    const size_t before = p->raw_allocs.size();
+    WT_TRY(wt_fft_prepare<float>(p->ctx, p->fft, p->g.H, p->g.W, p->raw_allocs));
+    if (p->raw_allocs.size() != before) p->raw_bytes += (size_t)3 * p->g.H * p->g.W * sizeof(float2) + (size_t)(p->g.H + p->g.W) / 2 * sizeof(float2);
+    return wt_fft_set_spectrum<float>(p->ctx, p->fft, s, p->g.P);
+}
+
+extern "C" int wt_fft_apply(wt_plan *p, int src, int dst, int conj)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_fft_apply: null plan");
+    WT_TRY(fft_plan_check(p, "wt_fft_apply"));
+    float *s = nullptr, *d = nullptr;
+    WT_TRY(plane_base(p, src, &s));
+    WT_TRY(plane_base(p, dst, &d));
+    return wt_fft_apply_t<float>(p->ctx, p->fft, s, d, p->g.P, conj);
 }
 
 extern "C" int wt_filter2d(wt_plan *p, int src, int dst, const float *kernel, int kh, int kw, int flags)

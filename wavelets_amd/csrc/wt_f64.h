@@ -1558,6 +1558,29 @@ extern "C" int wt64_filter2d(wt_plan64 *p, int src, int dst, const double *kerne
     return 0;
 }
 
+/* wt_fft_spectrum / wt_fft_apply in float64 */
+extern "C" int wt64_fft_spectrum(wt_plan64 *p, int src)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_fft_spectrum: null plan");
+    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("wt64_fft_spectrum: image %d x %d is not a power of two per side (2 .. %d)", p->g.H, p->g.W, WT_FFT_MAX_N);
+    double *s = nullptr;
+    WT_TRY(plan64_base(p, src, &s));
+    WT_TRY(wt_fft_prepare<double>(p->ctx, p->fft, p->g.H, p->g.W, p->allocs));
+    return wt_fft_set_spectrum<double>(p->ctx, p->fft, s, p->g.P);
+}
+
+extern "C" int wt64_fft_apply(wt_plan64 *p, int src, int dst, int conj)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_fft_apply: null plan");
+    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("wt64_fft_apply: image %d x %d is not a power of two per side (2 .. %d)", p->g.H, p->g.W, WT_FFT_MAX_N);
+    double *s = nullptr, *d = nullptr;
+    WT_TRY(plan64_base(p, src, &s));
+    WT_TRY(plan64_base(p, dst, &d));
+    return wt_fft_apply_t<double>(p->ctx, p->fft, s, d, p->g.P, conj);
+}
+
 /* multiresolution-support update (watroo/utils.py:263-276), as wt_mrs_update */
 extern "C" int wt64_mrs_update(wt_plan64 *p, int plane, int mrs_plane, double tau, int soft, int noise_plane, int persistent, double inv_pow)
 {

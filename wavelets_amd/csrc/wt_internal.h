@@ -119,6 +119,16 @@ struct wt_ctx {
 
 #define WT_MAX_CUSTOM_TAPS 15
 
+// Device state of the FFT path of one plan: twiddle tables of both lengths, two work arrays and the
+// kernel spectrum (stored TRANSPOSED, W x H, the layout the forward transform ends in).
+struct WtFftState {
+    int H = 0, W = 0;
+    void *tw_w = nullptr, *tw_h = nullptr, *a = nullptr, *b = nullptr, *spec = nullptr;
+    bool have_spec = false;
+};
+
+
+
 struct wt_plan {
     wt_ctx *ctx = nullptr;
     Geo g{};
@@ -154,6 +164,7 @@ struct wt_plan {
     // user-defined scaling function (wt_plan_set_taps): odd number of 1-D taps, 0 = built-in family
     int ntaps = 0;
     float taps[WT_MAX_CUSTOM_TAPS] = {0};
+    WtFftState fft;                         // circular products of richardson_lucy(fft=True), wt_fft.h (buffers in raw_allocs)
 };
 
 // float64 engine (wt_f64.h): double planes; the fused double passes (wt_fused_tu.hip) launch on it too
@@ -173,6 +184,7 @@ struct wt_plan64 {
     double *psf = nullptr;                          // PSF taps of wt64_filter2d
     size_t psf_cap = 0;
     std::vector<void *> allocs;
+    WtFftState fft;                                 // as wt_plan::fft (buffers in allocs)
 };
 
 // Profiling bracket: records events around a kernel launch when ctx->profiling.

@@ -302,6 +302,10 @@ def _periodic_operand(kernel, ay, ax):
     return np.ascontiguousarray(kernel), dict(anchor=(ay, ax), periodic=True)
 
 
+# PSFs of at least this many taps take the FFT form of the circular products (power-of-two images)
+_FFT_MIN_TAPS = int(__import__("os").environ.get("WATROO_HIP_FFT_MIN_TAPS", "512"))
+
+
 def richardson_lucy(data, psf,
                     iterations=10, denoise_coefficients=(5, 2, 1),
                     threshold_type='soft', uniform_init=False, persistent_mrs=True, fft=False):
@@ -310,8 +314,9 @@ def richardson_lucy(data, psf,
     (ref:261), the multiresolution-support update per scale (ref:263-276), the plane sum
     (ref:278) and the second PSF correlation (ref:286) - nothing returns to the host until
     the final estimate.  ``fft=True`` selects the reference's circular (periodic-border)
-    products (ref:245-254, 284); they are evaluated as direct periodic correlations of the PSF
-    (equal to the rFFT products up to rounding) so the loop stays on the device."""
+    products (ref:245-254, 284): through the engine's own FFT for PSFs of 512 taps or more on
+    power-of-two images (wt_fft_apply), else as direct periodic correlations of the PSF (equal to the
+    rFFT products up to rounding) - either way the loop stays on the device."""
     # float64 / promoted data: the float64 engine (ref wavelets.py:319-320) - except with
     # uniform_init, where the reference itself keeps the estimate in float32 (ref:233)
     f64 = _result_dtype(data) == np.float64 and not uniform_init and np.ndim(data) == 2
@@ -355,12 +360,30 @@ def richardson_lucy(data, psf,
         raise ValueError("richardson_lucy(fft=True) needs an even image width (numpy.fft.irfft2 "
                          "returns W - 1 columns in the reference)")
     e = img.shape[0] % 2
-    fwd_k, fwd = _periodic_operand(psf_flipped, kh - 1 - kh // 2 - e, kw - 1 - kw // 2) if fft \
-        else (psf_flipped, {})
-    bwd_k, bwd = _periodic_operand(psf, kh // 2 + e, kw // 2) if fft else (psf, {})
+    # Large PSFs on power-of-two images: the products run through the engine's own FFT (wt_fft_apply:
+    # row FFTs in LDS, transposes, the spectrum product fused into the first inverse pass) instead of
+    # the direct periodic form, which costs kh * kw taps per pixel.  The periodic kernel image is built
+    # as the reference builds it (ref:246-250) and transformed once.
+    use_fft = bool(fft) and kh * kw >= _FFT_MIN_TAPS and kh <= img.shape[0] and kw <= img.shape[1] \
+        and _lib.fft_supported(img.shape[0], img.shape[1])
+    if use_fft:
+        H, W = img.shape
+        padded_psf = np.zeros((H, W), dtype=ft)
+        padded_psf[H // 2 - kh // 2:H // 2 - kh // 2 + kh, W // 2 - kw // 2:W // 2 - kw // 2 + kw] = psf     # ref:247-249
+        plan.upload(CONV, np.roll(padded_psf, (H // 2, W // 2), axis=(0, 1)))                                    # ref:250
+        plan.fft_spectrum(CONV)
+        fwd_k = bwd_k = None
+        fwd = bwd = {}
+    else:
+        fwd_k, fwd = _periodic_operand(psf_flipped, kh - 1 - kh // 2 - e, kw - 1 - kw // 2) if fft \
+            else (psf_flipped, {})
+        bwd_k, bwd = _periodic_operand(psf, kh // 2 + e, kw // 2) if fft else (psf, {})
     data_noise = coefficients.noise       # None with uniform_init: every iteration then estimates
     for iteration in range(iterations):                                  # ref:252
-        plan.filter2d(PSI, PHI, fwd_k, **fwd)                            # ref:255-257
+        if use_fft:
+            plan.fft_apply(PSI, PHI, False)                              # ref:254
+        else:
+            plan.filter2d(PSI, PHI, fwd_k, **fwd)                        # ref:255-257
         plan.binary("sub", DATA, PHI, RES)                               # ref:259
         plan.decompose(RES, level)                                       # ref:261
         # ref:262: a fresh Coefficients per iteration inherits the data's noise; when that is None
@@ -374,7 +397,10 @@ def richardson_lucy(data, psf,
                             1.0 / (iteration + 1))
         plan.plane_sum(0, level + 1, RES)                                # ref:278
         plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
-        plan.filter2d(RES, CONV, bwd_k, **bwd)                           # ref:284-286
+        if use_fft:
+            plan.fft_apply(RES, CONV, True)                              # ref:284
+        else:
+            plan.filter2d(RES, CONV, bwd_k, **bwd)                       # ref:284-286
         plan.binary("mul", PSI, CONV, PSI)                               # ref:288
     # psi is float32 by construction with uniform_init (ref:233), else np.sum of the data's planes
     return plan.download(PSI).astype(np.float32 if uniform_init else _result_dtype(data), copy=False)
