@@ -228,6 +228,18 @@ int wt_decompose_sum(wt_plan *plan, int src, int level, int dst, int flags);
  * Reference flow: watroo/utils.py:83-102 (numpy in, numpy out). */
 int wt_decompose_sum_host(wt_plan *plan, const float *host_in, int64_t in_stride, int level,
                           int dst, float *host_out, int64_t out_stride, int block_rows);
+/* utils.denoise(data, weights, noise=<given>) host to host (watroo/utils.py:83-102): as
+ * wt_decompose_sum_host with Coefficients.denoise placed between the passes - the first k_passes
+ * passes of the fused schedule (wt_schedule) run plain, wt_denoise_sum over their n_den planes
+ * (thresholds tau[k], weights wgt[k]; tau <= 0: weight only) starts the plane sum on the rows they
+ * have finished, the remaining passes carry it, finished rows of dst go down while later blocks of
+ * the image are still coming up.  The planes are left unthresholded (denoise() does not return
+ * them).  Bit-identical to the serial sequence.  Requires 0 < k_passes < number of passes, n_den =
+ * the scales of those passes, an all-fused schedule and an image worth pipelining (else an error:
+ * run the serial sequence). */
+int wt_denoise_sum_host(wt_plan *plan, const float *host_in, int64_t in_stride, int level,
+                        int k_passes, int n_den, const double *tau, const double *wgt, int soft,
+                        int dst, float *host_out, int64_t out_stride, int block_rows);
 /* *ok = 1 when wt_decompose_sum(plan, ., level, ., bit0) runs as accumulate passes (else it is the
  * two-call form).  The host uses it to interleave Coefficients.denoise with the passes:
  * wt_decompose_pass for the passes that produce the thresholded planes, wt_abs_median,

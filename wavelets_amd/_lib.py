@@ -86,6 +86,8 @@ SIGNATURES = {
     "wt_decompose_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_decompose_pass_sum": (_c.c_int, [_vp] + [_c.c_int] * 8),
     "wt_decompose_sum_host": (_c.c_int, [_vp, _fp, _i64, _c.c_int, _c.c_int, _fp, _i64, _c.c_int]),
+    "wt_denoise_sum_host": (_c.c_int, [_vp, _fp, _i64, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double),
+                                       _c.POINTER(_c.c_double), _c.c_int, _c.c_int, _fp, _i64, _c.c_int]),
     "wt_plan_fused_ok": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_int)]),
     "wt_atrous_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt_smooth": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -443,6 +445,19 @@ def _as_f32(a):
     return a
 
 
+def _as_f32_rows(a):
+    """float32 2-D array whose rows are contiguous (unit column stride, row stride a multiple of 4 bytes
+    and >= the width): a row-strided view is handed to the library as it is (its row stride goes down
+    as the host stride), anything else is copied"""
+    a = np.asarray(a)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D image")
+    if a.dtype == np.float32 and a.shape[1] > 0 and a.strides[1] == 4 and a.strides[0] % 4 == 0 \
+            and a.strides[0] >= 4 * a.shape[1]:
+        return a
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 class Plan:
     """Device planes of one image (or one row strip of it).  wt_plan."""
 
@@ -559,14 +574,30 @@ class Plan:
         """upload + decompose_sum + download(dst) with the PCIe legs pipelined behind the passes
         (wt_decompose_sum_host): returns the reconstruction as an ndarray; the device state is
         that of the three calls."""
-        host = _as_f32(host)
+        host = _as_f32_rows(host)                 # (a row-strided view goes down as it is: hipMemcpy2D)
         if host.shape != self.shape:
             raise ValueError(f"image shape {host.shape} != plan strip shape {self.shape}")
         if out is None:
             out = host_empty(self.shape, self.ctx)
         assert out.dtype == np.float32 and out.shape == self.shape and out.strides[1] == 4
-        check(load().wt_decompose_sum_host(self._h, host.ctypes.data_as(_fp), host.shape[1], level, dst,
+        check(load().wt_decompose_sum_host(self._h, host.ctypes.data_as(_fp), host.strides[0] // 4, level, dst,
                                            out.ctypes.data_as(_fp), out.strides[0] // 4, block_rows))
+        return out
+
+    def denoise_sum_host(self, host, level, k_passes, taus, wgts, soft, dst=PLANE_OUT, out=None, block_rows=0):
+        """upload + first k_passes passes + denoise_sum over their planes + remaining passes +
+        download(dst), pipelined over blocks of rows (wt_denoise_sum_host): the denoised image."""
+        host = _as_f32_rows(host)
+        if host.shape != self.shape:
+            raise ValueError(f"image shape {host.shape} != plan strip shape {self.shape}")
+        if out is None:
+            out = host_empty(self.shape, self.ctx)
+        assert out.dtype == np.float32 and out.shape == self.shape and out.strides[1] == 4
+        n = len(taus)
+        t = (_c.c_double * n)(*[float(v) for v in taus])
+        w = (_c.c_double * n)(*[float(v) for v in wgts])
+        check(load().wt_denoise_sum_host(self._h, host.ctypes.data_as(_fp), host.strides[0] // 4, level, k_passes, n, t, w,
+                                         int(soft), dst, out.ctypes.data_as(_fp), out.strides[0] // 4, block_rows))
         return out
 
     def decompose_pass_sum(self, cur, nxt, s0, ns, flags, sum_plane, first, last):

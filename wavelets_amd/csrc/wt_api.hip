@@ -1657,10 +1657,18 @@ extern "C" int wt_decompose_sum(wt_plan *p, int src, int level, int dst, int fla
 // be the target of a 2-D memcpy: blocks bounce through the plan's contiguous stage plane (a copy
 // kernel per block, hidden behind the transfers); the stage rows of a block are reused for the
 // reconstruction rows once the block has been copied on (stream order).
-extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t in_stride, int level, int dst, float *host_out,
-                                     int64_t out_stride, int block_rows)
+// Threshold step of the pipelined host call (wt_denoise_sum_host): Coefficients.denoise over the first
+// n_den planes - the planes of the first k_passes passes of the schedule - fused with the start of the
+// plane sum, between those passes and the ones that carry the sum on.
+struct HostDenoise {
+    int k_passes, n_den, soft;
+    const double *tau, *wgt;
+};
+static int denoise_sum_rows(wt_plan *p, int count, int dst, int n_den, const double *tau, const double *wgt, int soft, int r0, int r1);
+
+static int host_pipeline(wt_plan *p, const float *host_in, int64_t in_stride, int level, int dst, float *host_out, int64_t out_stride,
+                         int block_rows, const HostDenoise *den)
 {
-    WtGuard guard_(ctx_of(p));
     if (!p || !host_in || !host_out) WT_FAIL("wt_decompose_sum_host: null pointer");
     if (in_stride < p->g.W || out_stride < p->g.W) WT_FAIL("wt_decompose_sum_host: host stride below the width %d", p->g.W);
     if (level < 0 || level > p->max_level) WT_FAIL("wt_decompose_sum_host: level %d exceeds plan max_level %d", level, p->max_level);
@@ -1679,6 +1687,15 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
     if (block_rows <= 0) block_rows = std::max(256, (H + 15) / 16);  // sixteen blocks: measured best at 8192^2 (tail = one block of each leg)
     block_rows = (block_rows + 63) / 64 * 64;
     if (pipe && (H < 2 * block_rows || (int64_t)H * W < (1 << 22))) pipe = false;      // small images: nothing to overlap
+    if (den) {
+        // the threshold step sits between two passes of an all-fused schedule and covers exactly the
+        // planes of the passes before it; anything else is the caller's job (serial sequence)
+        int covered = 0;
+        for (int i = 0; i < np && i < den->k_passes; ++i) covered += tr[3 * i + 1];
+        if (!pipe || den->k_passes < 1 || den->k_passes >= np || covered != den->n_den)
+            WT_FAIL("wt_denoise_sum_host: the threshold step must follow the first k passes (0 < k < passes) of a fused schedule and cover "
+                    "their planes (got k = %d, n_den = %d, %d passes%s)", den->k_passes, den->n_den, np, pipe ? "" : ", no pipeline for this plan / size");
+    }
     if (!pipe) {
         WT_TRY(wt_upload(p, WT_PLANE_INPUT, host_in, in_stride));
         WT_TRY(wt_decompose_sum(p, WT_PLANE_INPUT, level, dst, 1));
@@ -1708,7 +1725,8 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
         return rc;
     };
     std::vector<int> done(np, 0);
-    int out_done = 0, rc = 0;
+    int out_done = 0, rc = 0, den_done = 0;
+    const int kd = den ? den->k_passes : 0;              // passes [0, kd) are plain, the threshold step follows them
     hipError_t e = hipSuccess;
     auto run = [&]() -> int {
         // the transfer streams start behind whatever the compute stream was doing to these planes
@@ -1750,13 +1768,20 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
                 const int s0 = tr[3 * i], ns = tr[3 * i + 1], halo = tr[3 * i + 2];
                 const bool last = s0 + ns == level;
                 const int nxt = last ? level : WT_PLANE_SCRATCH(i & 1);
+                if (den && i == kd && avail > den_done) {
+                    // rows the plain passes have finished: thresholds + start of the sum (the sum-carrying
+                    // passes below read these rows of `dst` only where they store, no halo)
+                    WT_TRY(denoise_sum_rows(p, den->n_den, dst, den->n_den, den->tau, den->wgt, den->soft, den_done, avail));
+                    den_done = avail;
+                }
                 const int ready = avail == H ? H : std::max(done[i], avail - halo);
                 if (ready > done[i]) {
                     FusedRows rows;
                     rows.n = 1;
                     rows.lo[0] = done[i];
                     rows.hi[0] = ready;
-                    WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, 1 | 2, last ? 2 : 1, i == 0, dst, rows));
+                    const int acc = (den && i < kd) ? 0 : (last ? 2 : 1);
+                    WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, 1 | 2, acc, acc != 0 && i == 0, dst, rows));
                     done[i] = ready;
                 }
                 avail = done[i];
@@ -1792,6 +1817,33 @@ extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t i
     WT_HIP(e);
     if (out_done != H) WT_FAIL("wt_decompose_sum_host: internal error, %d of %d rows delivered", out_done, H);
     return 0;
+}
+
+extern "C" int wt_decompose_sum_host(wt_plan *p, const float *host_in, int64_t in_stride, int level, int dst, float *host_out,
+                                     int64_t out_stride, int block_rows)
+{
+    WtGuard guard_(ctx_of(p));
+    return host_pipeline(p, host_in, in_stride, level, dst, host_out, out_stride, block_rows, nullptr);
+}
+
+// utils.denoise with the noise level GIVEN (watroo/utils.py:83-102 with noise=...: every threshold is
+// known before the first pixel arrives), host to host: the image goes up in blocks of rows, the first
+// k_passes passes of the fused schedule run on a block as its rows arrive, Coefficients.denoise over
+// their n_den planes starts the plane sum (wt_denoise_sum on the finished rows; the planes are left
+// as they are: denoise() does not return them), the remaining passes carry the sum, and finished
+// rows of the result go down while later blocks are still coming up - about one PCIe leg instead of
+// two.  Same kernels on row sub-ranges: the result equals upload + passes + wt_denoise_sum + passes +
+// download bit for bit.  Needs 0 < k_passes < passes of an all-fused schedule and a size worth
+// pipelining; otherwise an error (the caller runs the serial sequence).
+extern "C" int wt_denoise_sum_host(wt_plan *p, const float *host_in, int64_t in_stride, int level, int k_passes, int n_den,
+                                   const double *tau, const double *wgt, int soft, int dst, float *host_out, int64_t out_stride,
+                                   int block_rows)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!tau || !wgt) WT_FAIL("wt_denoise_sum_host: null tau / wgt");
+    if (n_den < 1 || n_den > WT_MAX_SUM_PLANES) WT_FAIL("wt_denoise_sum_host: n_den %d out of range", n_den);
+    HostDenoise den{k_passes, n_den, soft, tau, wgt};
+    return host_pipeline(p, host_in, in_stride, level, dst, host_out, out_stride, block_rows, &den);
 }
 
 extern "C" int wt_plan_fused_ok(wt_plan *p, int level, int *ok)
@@ -1912,6 +1964,30 @@ extern "C" int wt_denoise_sum(wt_plan *p, int first, int count, int dst, int n_d
     const int64_t n4 = plan_n4(p);
     ProfScope ps(p->ctx, "wt_denoise_sum_kernel");
     hipLaunchKernelGGL(wt_denoise_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, p->ctx->stream, a, nz, o, n4);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+// wt_denoise_sum over the strip-local rows [r0, r1) of planes 0 .. count-1 (planes are contiguous with
+// pitch P: a row range is a flat range); planes are not written back
+static int denoise_sum_rows(wt_plan *p, int count, int dst, int n_den, const double *tau, const double *wgt, int soft, int r0, int r1)
+{
+    if (r1 <= r0) return 0;
+    DenoiseSumArgs a{};
+    a.n = count; a.n_den = n_den; a.soft = soft; a.write_back = 0;
+    const size_t off = (size_t)r0 * p->g.P;
+    for (int i = 0; i < count; ++i) {
+        float *b = nullptr;
+        WT_TRY(plane_base(p, i, &b));
+        a.p[i] = b + off;
+        a.tau[i] = i < n_den ? tau[i] : 0.0;
+        a.wgt[i] = i < n_den ? (float)wgt[i] : 1.f;
+    }
+    float *o = nullptr;
+    WT_TRY(plane_base(p, dst, &o));
+    const int64_t n4 = (int64_t)(r1 - r0) * p->g.P / 4;
+    ProfScope ps(p->ctx, "wt_denoise_sum_kernel");
+    hipLaunchKernelGGL(wt_denoise_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, p->ctx->stream, a, (const float *)nullptr, o + off, n4);
     WT_HIP(hipGetLastError());
     return 0;
 }

@@ -11,7 +11,7 @@ import warnings
 import numpy as np
 
 from . import _lib
-from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, acquire_plan64, default_context
+from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, acquire_plan64, default_context, release_plan
 from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of, _needs_generic,
                        _result_dtype, _taps_f64, _to_f32_image,
                        generalized_anscombe,
@@ -70,6 +70,40 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     return out
 
 
+def _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe):
+    """denoise() with the noise level GIVEN as a scalar: every threshold is known before the first pixel
+    arrives, so the whole call is one pipelined host-to-host pass (wt_denoise_sum_host: upload, passes,
+    thresholds, passes, download over blocks of rows - about one PCIe leg instead of two).  Returns the
+    result, or None when the case is not the pipeline's (the caller runs the serial sequence)."""
+    if noise is None or np.ndim(noise) != 0 or bilateral is not None or anscombe or plan.custom or level < 2:
+        return None
+    if img.size < (1 << 22) or not plan.fused_ok(level):
+        return None
+    entries = list(zip(range(level + 1), weights, (1,) * len(weights)))
+    n_den = max([scl + 1 for scl, sig, _ in entries if sig != 0], default=0)
+    sched = _lib.schedule(plan.family, level, True)
+    k, covered = 0, 0
+    while k < len(sched) and (covered < n_den or k == 0):
+        covered += sched[k][1]
+        k += 1
+    if k == 0 or k >= len(sched) or n_den == 0:
+        return None
+    sigma_e = sf.sigma_e()
+    taus = []
+    for scl in range(covered):
+        sig = weights[scl] if scl < len(weights) else 0
+        tau = float(sig * noise * sigma_e[scl]) if sig != 0 and noise != 0 else 0.0     # ref wavelets.py:133-141
+        if tau < 0:                      # erf(|w / tau|) = erf(|w| / |tau|); |w| > tau always true (hard)
+            tau = -tau if soft_threshold else 0.0
+        taus.append(tau)
+    try:
+        return plan.denoise_sum_host(img, level, k, taus, [1.0] * covered, soft_threshold)
+    except _lib.WatrooHipError as e:
+        if "wt_denoise_sum_host: the threshold step" in str(e):     # no pipeline for this plan / size / option
+            return None
+        raise
+
+
 def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None,
             soft_threshold=True, anscombe=False):
     """Denoise ``data``: transform over ``len(weights)`` scales, threshold each scale at
@@ -112,6 +146,10 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     transform = AtrousTransform(scaling_function, bilateral=bilateral)
     sf = scaling_function(2)
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
+    piped = _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe)
+    if piped is not None:
+        release_plan(plan)
+        return piped.astype(_result_dtype(data), copy=False)
     plan.upload(PLANE_INPUT, img)
     if anscombe:
         plan.anscombe(PLANE_INPUT, PLANE_INPUT)                           # ref:93-94
