@@ -516,3 +516,48 @@ def test_denoise_with_given_noise_is_pipelined_over_pcie_and_bitwise_the_serial_
     ent = ctx.profile_entries()
     ctx.profile(False)
     assert ent["wt_denoise_sum_kernel"][0] > 4, ent
+
+
+def test_windowed_riding_histogram_exact_median_and_fallback_when_the_window_misses(L):
+    """Round 4: the first fused pass bins 21-bit keys of |w_0| in a window that a 4096-pixel sample of
+    the input places around the predicted median (wt_median_window_kernel): get_noise then reads the plane
+    ONCE more instead of twice.  The median stays EXACT: (a) ordinary images, both families, windowed on
+    and off give np.median; (b) images built so that the sample mispredicts (zeros around every sample
+    point; a plane whose magnitudes spread over 80 octaves) land in bin 0 / 2047 and are redone with the
+    ordinary passes; (c) the select really took the short path where it should (one wt_hist launch)."""
+    import wavelets_amd as WA
+    ctx = L.default_context()
+    H, W = 1100, 1300
+    rng = np.random.default_rng(17)
+    base = rng.standard_normal((H, W)).astype(np.float32)
+    holes = base.copy()
+    ys = ((2 * np.arange(64) + 1) * H) >> 7
+    xs = ((2 * np.arange(64) + 1) * W) >> 7
+    for y in ys:
+        for x in xs:
+            holes[max(y - 4, 0):y + 5, max(x - 4, 0):x + 5] = 0.0          # every sample sees |w_0| = 0
+    spread = (base * np.float32(10.0) ** rng.integers(-12, 12, (H, W)).astype(np.float32)).astype(np.float32)
+    spikes = np.zeros((H, W), np.float32)
+    spikes[ys[:, None], xs[None, :]] = 1e6                                   # ... and here only the samples are non-zero
+    for name, img in (("gauss", base), ("offset", base * 1e-3 + 40), ("holes", holes), ("spread", spread), ("spikes", spikes)):
+        for cls in (WA.B3spline, WA.Triangle):
+            for window in (1, 0):
+                L.set_option("hist_window", window)
+                try:
+                    ctx.profile(True)
+                    ctx.profile_reset()
+                    c = WA.AtrousTransform(cls)(img, 3)
+                    got = c.get_noise()
+                    ent = ctx.profile_entries()
+                    ctx.profile(False)
+                finally:
+                    L.set_option("hist_window", 1)
+                want = np.median(np.abs(c.data[0])) / 0.6745 / c.sigma_e[0]
+                assert got == want, (name, cls.__name__, window, got, want)
+                nh = ent.get("wt_hist_kernel", (0, 0))[0]
+                if window and name in ("gauss", "offset"):
+                    assert nh == 1 and "wt_median_window_kernel" in ent, (name, ent)      # the short path
+                if window and name in ("holes", "spikes"):
+                    assert nh == 4, (name, ent)            # one pass in vain, then the ordinary three
+                if not window:
+                    assert nh == 2 and "wt_median_window_kernel" not in ent, (name, ent)

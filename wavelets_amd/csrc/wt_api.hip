@@ -1207,6 +1207,7 @@ static int g_opt_split_dry = 0;
 
 static void wt_set_fused64(int on);     // wt_f64.h (included at the end of this file)
 static void wt_set_select64_list(int on);
+static void wt_set_hist_window(int on);
 // wt_decompose_sum_host: pipeline the PCIe legs with the passes (0: upload, passes, download in turn)
 static int g_opt_host_pipeline = getenv("WT_NO_HOST_PIPELINE") ? 0 : 1;
 
@@ -1224,6 +1225,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "host_pipeline")) { g_opt_host_pipeline = value != 0; return 0; }
     if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
     if (!strcmp(name, "select64_list")) { wt_set_select64_list(value != 0); return 0; }
+    if (!strcmp(name, "hist_window")) { wt_set_hist_window(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "scatter_strips")) { g_opt_scatter_strips = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
@@ -1463,12 +1465,33 @@ extern "C" int wt_bilateral_conv(wt_plan *p, int src, int var, int dst, int s, i
 // flag bit4: the fused first pass of a plain decomposition also histograms |w_0| (first radix level
 // of wt_abs_median's select).  begin: clear the bins once per entry point (a pass may be several
 // launches); end: leave the marker if the histogram variant really ran.
-static int prehist_begin(wt_plan *p, int flags)
+// (src: the plane the first pass reads.  Whole images of at least 2^20 pixels with a built-in family get
+// the WINDOWED histogram: wt_median_window_kernel predicts where the median of |w_0| lies from 4096
+// pixels of `src`, and the first pass bins 21-bit keys around it - wt_abs_median then needs ONE more
+// pass over the plane instead of two.  wt_set_option("hist_window", 0) keeps the plain 11-bit bins.)
+static int g_opt_hist_window = getenv("WT_NO_HIST_WINDOW") ? 0 : 1;
+static inline uint32_t *hist_base_word(wt_ctx *c) { return c->d_hist + WT_HIST_BINS + 30; }
+static void wt_set_hist_window(int on) { g_opt_hist_window = on; }
+static int prehist_begin(wt_plan *p, int flags, int src = WT_PLANE_NONE)
 {
-    p->ctx->prehist_ran = false;
+    wt_ctx *c = p->ctx;
+    c->prehist_ran = false;
     if (flags & 16) {
-        p->ctx->prehist_plan = nullptr;                  // the bins are about to be cleared
-        WT_HIP(hipMemsetAsync(p->ctx->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), p->ctx->stream));
+        c->prehist_plan = nullptr;                       // the bins are about to be cleared
+        c->prehist_windowed = false;
+        WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+        if (g_opt_hist_window && src != WT_PLANE_NONE && p->nranks == 1 && !p->g.border && !p->ntaps &&
+            (int64_t)p->g.H * p->g.W >= ((int64_t)1 << 20) && p->g.H >= 64 && p->g.W >= 64) {
+            float *in = nullptr;
+            WT_TRY(plane_base(p, src, &in));
+            ProfScope ps(c, "wt_median_window_kernel");
+            uint32_t *keys = (uint32_t *)c->d_partials;      // 16 KB of the reduction scratch (stream-ordered use)
+            if (p->family == WT_B3SPLINE) hipLaunchKernelGGL(wt_median_sample_kernel<5>, dim3(64), dim3(64), 0, c->stream, (const float *)in, p->g, keys);
+            else hipLaunchKernelGGL(wt_median_sample_kernel<3>, dim3(64), dim3(64), 0, c->stream, (const float *)in, p->g, keys);
+            hipLaunchKernelGGL(wt_median_window_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)keys, hist_base_word(c));
+            WT_HIP(hipGetLastError());
+            c->prehist_windowed = true;
+        }
     }
     return 0;
 }
@@ -1518,7 +1541,8 @@ static int decompose_pass_impl(wt_plan *p, int cur, int nxt, int s0, int ns, int
         // plain first pass that also histograms the first radix level of |w_0| for wt_abs_median
         // (the caller cleared the bins: a pass may be several launches)
         p->ctx->prehist_ran = true;
-        return wt_fused_launch(p, in, oc, ow, s0, ns, 3, nullptr, nullptr, rows, p->ctx->d_hist);
+        return wt_fused_launch(p, in, oc, ow, s0, ns, 3, nullptr, nullptr, rows, p->ctx->d_hist,
+                               p->ctx->prehist_windowed ? hist_base_word(p->ctx) : nullptr);
     }
     return wt_fused_launch(p, in, oc, ow, s0, ns, acc, first_of_sum ? nullptr : ps, ps, rows);
 }
@@ -1527,7 +1551,7 @@ extern "C" int wt_decompose_pass(wt_plan *p, int cur, int nxt, int s0, int ns, i
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt_decompose_pass: null plan");
-    WT_TRY(prehist_begin(p, flags));
+    WT_TRY(prehist_begin(p, flags, s0 == 0 ? cur : WT_PLANE_NONE));
     WT_TRY(decompose_pass_impl(p, cur, nxt, s0, ns, flags, 0, false, WT_PLANE_NONE));
     prehist_end(p);
     return 0;
@@ -1873,7 +1897,7 @@ extern "C" int wt_decompose(wt_plan *p, int src, int level, int flags)
     int np = 0;
     if (p->ntaps) flags &= ~1;          // user-defined taps: one generic pass per scale
     WT_TRY(wt_schedule(p->family, level, (flags & 1) && wt_fused_supported(p), tr, 32, &np));
-    WT_TRY(prehist_begin(p, flags));
+    WT_TRY(prehist_begin(p, flags, src));
     WT_TRY(run_schedule(p, src, level, flags, tr, np, false, WT_PLANE_NONE));
     prehist_end(p);
     return 0;
@@ -2563,14 +2587,28 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
     WtSelectState *st = (WtSelectState *)(c->d_hist + WT_HIST_BINS + 4);
     WtSelectState *hst = (WtSelectState *)c->h_pinned;
     hst->k = (unsigned long long)klo; hst->cum_le = 0; hst->prefix = 0; hst->failed = 0;
-    WT_HIP(hipMemcpyAsync(st, hst, sizeof(WtSelectState), hipMemcpyHostToDevice, c->stream));
-    if (!pre) WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
-    WT_TRY(select_pass(p, b, st, 0u, 20, 0x7ffu, 0, pre));
-    WT_TRY(select_pass(p, b, st, 0x7ff00000u, 10, 0x3ffu, 0));
-    WT_TRY(select_pass(p, b, st, 0x7ffffc00u, 0, 0x3ffu, 1));
-    WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(WtSelectState), hipMemcpyDeviceToHost, c->stream));
-    WT_HIP(hipStreamSynchronize(c->stream));                 // the one host round trip of the select
-    const WtSelectState res_st = *(const WtSelectState *)((const char *)c->h_pinned + 64);
+    const bool windowed = pre && c->prehist_windowed;
+    c->prehist_windowed = false;
+    WtSelectState res_st{};
+    auto run = [&](bool have_hist, bool window) -> int {
+        WT_HIP(hipMemcpyAsync(st, hst, sizeof(WtSelectState), hipMemcpyHostToDevice, c->stream));
+        if (!have_hist) WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+        if (window) {
+            // the riding histogram sits in a predicted window of 21-bit keys: its step fixes 21 bits at once
+            hipLaunchKernelGGL(wt_select_window_step_kernel, dim3(1), dim3(256), 0, c->stream, c->d_hist, st, (const uint32_t *)hist_base_word(c));
+            WT_HIP(hipGetLastError());
+        } else {
+            WT_TRY(select_pass(p, b, st, 0u, 20, 0x7ffu, 0, have_hist));
+            WT_TRY(select_pass(p, b, st, 0x7ff00000u, 10, 0x3ffu, 0));
+        }
+        WT_TRY(select_pass(p, b, st, 0x7ffffc00u, 0, 0x3ffu, 1));
+        WT_HIP(hipMemcpyAsync((char *)c->h_pinned + 64, st, sizeof(WtSelectState), hipMemcpyDeviceToHost, c->stream));
+        WT_HIP(hipStreamSynchronize(c->stream));             // the one host round trip of the select
+        res_st = *(const WtSelectState *)((const char *)c->h_pinned + 64);
+        return 0;
+    };
+    WT_TRY(run(pre, windowed));
+    if (windowed && res_st.failed == 3) WT_TRY(run(false, false));    // the window missed the median: the ordinary three passes
     if (res_st.failed) WT_FAIL("wt_abs_median: rank %lld not found (NaN input?)", (long long)klo);
     const int64_t cum_le = (int64_t)res_st.cum_le;           // elements <= v_lo
     const uint32_t ulo = res_st.prefix;

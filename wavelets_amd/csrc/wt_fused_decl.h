@@ -36,6 +36,10 @@ struct FusedArgsT {
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
     T *out_w3;      // w_{s0+3} of a four-scale pass (3-tap family); LAST on purpose: the older fields keep their offsets
+    // ACC == 3, float: nullptr = bins are the top 11 magnitude bits; else the WINDOWED form (round 4) - bin
+    // = clamp((bits >> 10) - *hist_base, 0, 2047): 2046 bins of 21-bit resolution around a predicted
+    // median (wt_median_window_kernel), everything below / above in bins 0 / 2047
+    const uint32_t *hist_base;
 };
 typedef FusedArgsT<float> FusedArgs;
 
@@ -82,7 +86,7 @@ WT_FUSED_TU_DECL(3, 0) WT_FUSED_TU_DECL(3, 1) WT_FUSED_TU_DECL(3, 2) WT_FUSED_TU
 // acc: see wt_fused_dispatch_acc; p_in / p_out only for acc != 0
 static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **out_w, int s0, int ns,
                            int acc = 0, const float *p_in = nullptr, float *p_out = nullptr,
-                           const FusedRows &rows = FusedRows(), uint32_t *hist = nullptr)
+                           const FusedRows &rows = FusedRows(), uint32_t *hist = nullptr, const uint32_t *hist_base = nullptr)
 {
     FusedArgs a{};
     a.in = in;
@@ -93,6 +97,7 @@ static int wt_fused_launch(wt_plan *p, const float *in, float *out_c, float **ou
     a.p_in = p_in;
     a.p_out = p_out;
     a.hist = hist;
+    a.hist_base = hist_base;
     const bool b3 = p->family == WT_B3SPLINE;
     if (acc == 3) return b3 ? wt_fused_tu_f32_k5_acc3(p, a, s0, ns, rows) : wt_fused_tu_f32_k3_acc3(p, a, s0, ns, rows);
     if (acc == 1) return b3 ? wt_fused_tu_f32_k5_acc1(p, a, s0, ns, rows) : wt_fused_tu_f32_k3_acc1(p, a, s0, ns, rows);

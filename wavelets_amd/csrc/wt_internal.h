@@ -108,6 +108,7 @@ struct wt_ctx {
     const void *prehist_plan = nullptr;          // a wt_plan or a wt_plan64
     int prehist_plane = 0;
     bool prehist_ran = false;     // set by the launch of the histogram variant (per entry point)
+    bool prehist_windowed = false; // the riding histogram is the windowed form (wt_median_window_kernel placed it)
     // candidate list of the float64 median select (wt64_abs_median): 64-bit keys + a counter word
     unsigned long long *d_cand = nullptr;
     size_t d_cand_cap = 0;        // keys

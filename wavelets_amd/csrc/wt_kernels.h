@@ -1551,8 +1551,138 @@ __global__ __launch_bounds__(256) void wt_select_step_kernel(uint32_t *hist, WtS
             cum += h[i];
         }
     }
-    if (threadIdx.x == 255 && k >= incl) st->failed = 1;  // rank beyond the population (NaN input)
+    if (threadIdx.x == 255 && k >= incl && st->failed == 0) st->failed = 1;  // rank beyond the population (NaN input);
+                                                                              // (an earlier verdict - 3: window missed - stands)
     for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;     // ready for the next pass
+}
+
+// Round 4: where the 2048 bins of the riding histogram should sit.  With the top 11 magnitude bits as
+// the key (8 exponent + 3 mantissa bits) a detail plane populates a few dozen bins and two more passes
+// over the plane must resolve the other 20 bits.  This kernel - ONE workgroup, before the transform -
+// computes |w_0| = |I - h * I| at 4096 pixels of a regular grid straight from the input image (scale 0
+// needs a K x K neighbourhood; wt_median_sample_kernel), takes the median of that sample
+// (wt_median_window_kernel, one workgroup) and centres a window of 2046 keys of 21
+// bits (relative resolution 1.2e-4, +-12 % around the estimate) on it: *base = first key of the window.
+// The standard error of a 4096-sample median is ~2 % of sigma, so the true median lies inside the
+// window except for pathological images - which the select detects (rank in bin 0 / 2047) and redoes
+// with its ordinary three passes.  The prediction only places bins; it never enters a result.
+template <int K>
+__global__ __launch_bounds__(64) void wt_median_sample_kernel(const float *in, Geo g, uint32_t *keys)
+{
+    // one sample per thread, 64 workgroups of one wave: the K * K loads of a sample are independent and
+    // the 4096 samples spread over the chip (as ONE workgroup this step took 0.08 ms - more than the
+    // pass over the plane it saves)
+    constexpr int hw = K / 2;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int sy = i >> 6, sx = i & 63;
+    const int y = (int)(((int64_t)(2 * sy + 1) * g.H) >> 7), x = (int)(((int64_t)(2 * sx + 1) * g.W) >> 7);
+    float v[K][K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+        const float *row = in + (int64_t)(wt_refl(y + a - hw, g.H) - g.row0) * g.P;
+#pragma unroll
+        for (int b = 0; b < K; ++b) v[a][b] = row[wt_refl(x + b - hw, g.W)];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+        float r = 0.f;
+#pragma unroll
+        for (int b = 0; b < K; ++b) r = fmaf(wt_tap<K>(b), v[a][b], r);
+        acc = fmaf(wt_tap<K>(a), r, acc);
+    }
+    keys[i] = __float_as_uint(v[hw][hw] - acc) & 0x7fffffffu;
+}
+
+__global__ __launch_bounds__(1024) void wt_median_window_kernel(const uint32_t *keys, uint32_t *base)
+{
+    constexpr int NS = 4096;
+    __shared__ uint32_t key[NS];
+    __shared__ uint32_t lh[WT_HIST_BINS];
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t sh_k, sh_prefix;
+    for (int i = threadIdx.x; i < NS; i += 1024) key[i] = keys[i];
+    uint32_t k = NS / 2 - 1, prefix = 0, known = 0;
+    for (int lvl = 0; lvl < 2; ++lvl) {                  // 11 + 10 bits: the top 21 bits of the sample's lower median
+        const int shift = lvl == 0 ? 20 : 10;
+        const uint32_t mask = lvl == 0 ? 0x7ffu : 0x3ffu;
+        for (int i = threadIdx.x; i < WT_HIST_BINS; i += 1024) lh[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < NS; i += 1024)
+            if ((key[i] & known) == prefix) atomicAdd(&lh[(key[i] >> shift) & mask], 1u);
+        __syncthreads();
+        const uint32_t h0 = lh[2 * threadIdx.x], h1 = lh[2 * threadIdx.x + 1];
+        part[threadIdx.x] = h0 + h1;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t incl = part[threadIdx.x], excl = incl - h0 - h1;
+        if (k >= excl && k < incl) {
+            const bool second = k >= excl + h0;
+            sh_k = k - excl - (second ? h0 : 0);
+            sh_prefix = prefix | ((uint32_t)(2 * threadIdx.x + (second ? 1 : 0)) << shift);
+        }
+        __syncthreads();
+        k = sh_k;
+        prefix = sh_prefix;
+        known |= mask << shift;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int key21 = (int)(prefix >> 10);
+        *base = (uint32_t)max(key21 - WT_HIST_BINS / 2, 0);
+    }
+}
+
+// Step after a WINDOWED riding histogram (bins: 0 = below the window, 1 .. 2046 = the 21-bit keys base + bin,
+// 2047 = above): the bin that holds rank k fixes the top 21 bits at once; a rank in bin 0 / 2047 means the
+// prediction missed (failed = 3: the host redoes the select with its ordinary passes).  Clears the bins.
+__global__ __launch_bounds__(256) void wt_select_window_step_kernel(uint32_t *hist, WtSelectState *st, const uint32_t *base)
+{
+    __shared__ unsigned long long part[256];
+    constexpr int per = WT_HIST_BINS / 256;
+    const int b0 = threadIdx.x * per;
+    uint32_t h[per];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+        h[i] = hist[b0 + i];
+        s += h[i];
+    }
+    const unsigned long long k = st->k;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long incl = part[threadIdx.x];
+    unsigned long long cum = incl - s;
+    if (k >= cum && k < incl) {
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            if (k < cum + h[i]) {
+                const int bin = b0 + i;
+                if (bin == 0 || bin == WT_HIST_BINS - 1) {
+                    st->failed = 3;
+                } else {
+                    st->k = k - cum;
+                    st->cum_le = cum;
+                    st->prefix = (*base + (uint32_t)bin) << 10;
+                }
+                break;
+            }
+            cum += h[i];
+        }
+    }
+    if (threadIdx.x == 255 && k >= incl) st->failed = 1;
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256) hist[i] = 0;
 }
 
 #ifndef WT_HIST_UNROLL
