@@ -561,3 +561,24 @@ def test_windowed_riding_histogram_exact_median_and_fallback_when_the_window_mis
                     assert nh == 4, (name, ent)            # one pass in vain, then the ordinary three
                 if not window:
                     assert nh == 2 and "wt_median_window_kernel" not in ent, (name, ent)
+    # float64: the windowed histogram carries 22 bits; the select goes straight to its gather pass
+    for name, img in (("gauss", base), ("holes", holes), ("spikes", spikes), ("spread", spread)):
+        img64 = img.astype(np.float64)
+        for window in (1, 0):
+            L.set_option("hist_window", window)
+            try:
+                ctx.profile(True)
+                ctx.profile_reset()
+                c = WA.AtrousTransform(WA.B3spline)(img64, 3)
+                got = c.get_noise()
+                ent = ctx.profile_entries()
+                ctx.profile(False)
+            finally:
+                L.set_option("hist_window", 1)
+            assert c.data.dtype == np.float64
+            assert got == np.median(np.abs(c.data[0])) / 0.6745 / c.sigma_e[0], (name, window)
+            nh = ent.get("wt64_hist_kernel", (0, 0))[0]
+            if window and name == "gauss":
+                assert nh == 0 and ent["wt64_collect_kernel"][0] == 1 and "wt_median_window_kernel" in ent, ent
+            if not window and name == "gauss":
+                assert nh == 1 and ent["wt64_collect_kernel"][0] == 1, ent

@@ -1486,8 +1486,8 @@ static int prehist_begin(wt_plan *p, int flags, int src = WT_PLANE_NONE)
             WT_TRY(plane_base(p, src, &in));
             ProfScope ps(c, "wt_median_window_kernel");
             uint32_t *keys = (uint32_t *)c->d_partials;      // 16 KB of the reduction scratch (stream-ordered use)
-            if (p->family == WT_B3SPLINE) hipLaunchKernelGGL(wt_median_sample_kernel<5>, dim3(64), dim3(64), 0, c->stream, (const float *)in, p->g, keys);
-            else hipLaunchKernelGGL(wt_median_sample_kernel<3>, dim3(64), dim3(64), 0, c->stream, (const float *)in, p->g, keys);
+            if (p->family == WT_B3SPLINE) hipLaunchKernelGGL((wt_median_sample_kernel<5, float>), dim3(64), dim3(64), 0, c->stream, (const float *)in, p->g, keys);
+            else hipLaunchKernelGGL((wt_median_sample_kernel<3, float>), dim3(64), dim3(64), 0, c->stream, (const float *)in, p->g, keys);
             hipLaunchKernelGGL(wt_median_window_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)keys, hist_base_word(c));
             WT_HIP(hipGetLastError());
             c->prehist_windowed = true;

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void wt64_select_step_kernel(uint32_t *hist, S
             cum += h[i];
         }
     }
-    if (threadIdx.x == 255 && k >= incl) st->failed = 1;
+    if (threadIdx.x == 255 && k >= incl && st->failed == 0) st->failed = 1;
     for (int i = threadIdx.x; i < nbins; i += 256) hist[i] = 0;
 }
 
@@ -613,6 +613,53 @@ __global__ __launch_bounds__(256) void wt64_select_step_kernel(uint32_t *hist, S
 // the select on the list (below) - lower AND upper median, so the extra pass for the upper median of an
 // even count disappears too.  A bin that does not fit the list (ties: constant or quantised data) is
 // left alone: bin_count > cap, nothing is gathered, the host continues with the radix passes.
+// step after a WINDOWED riding histogram (22-bit keys base + bin in bins 1 .. 2046): as
+// wt_select_window_step_kernel; failed = 3 when the rank lies outside the window
+__global__ __launch_bounds__(256) void wt64_select_window_step_kernel(uint32_t *hist, Select64State *st, const uint32_t *base)
+{
+    __shared__ unsigned long long part[256];
+    constexpr int per = WT_HIST_BINS / 256;
+    const int b0 = threadIdx.x * per;
+    uint32_t h[per];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+        h[i] = hist[b0 + i];
+        s += h[i];
+    }
+    const unsigned long long k = st->k;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long incl = part[threadIdx.x];
+    unsigned long long cum = incl - s;
+    if (k >= cum && k < incl) {
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            if (k < cum + h[i]) {
+                const int bin = b0 + i;
+                if (bin == 0 || bin == WT_HIST_BINS - 1) {
+                    st->failed = 3;
+                } else {
+                    st->k = k - cum;
+                    st->cum_le = cum;
+                    st->prefix = (unsigned long long)(*base + (uint32_t)bin) << 41;
+                    st->bin_count = h[i];
+                }
+                break;
+            }
+            cum += h[i];
+        }
+    }
+    if (threadIdx.x == 255 && k >= incl && st->failed == 0) st->failed = 1;
+    for (int i = threadIdx.x; i < WT_HIST_BINS; i += 256) hist[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void wt64_collect_kernel(const double *p, int nrows, int P, int W, unsigned long long prefix_mask,
                                                            const Select64State *st, unsigned long long *list, unsigned long long cap)
 {
@@ -990,6 +1037,7 @@ static int fused64_pass(wt_plan64 *p, int cur, int nxt, int s0, int ns, int acc,
     if (acc == 3) {
         if (s0 != 0) WT_FAIL("float64 pass: the histogram variant exists for the first pass only");
         a.hist = p->ctx->d_hist;
+        a.hist_base = p->ctx->prehist_windowed ? hist_base_word(p->ctx) : nullptr;
         p->ctx->prehist_ran = true;
         return b3 ? wt_fused_tu_f64_k5_acc3(p, a, s0, ns, rows) : wt_fused_tu_f64_k3_acc3(p, a, s0, ns, rows);
     }
@@ -1000,12 +1048,29 @@ static int fused64_pass(wt_plan64 *p, int cur, int nxt, int s0, int ns, int acc,
 
 // flag bit4 of wt64_decompose_ex / wt64_decompose_pass: the first pass also histograms the exponent
 // field of |w_0| (first level of wt64_abs_median's select); same marker protocol as the float32 engine
-static int prehist64_begin(wt_plan64 *p, int flags)
+static int prehist64_begin(wt_plan64 *p, int flags, int src = WT_PLANE_NONE)
 {
-    p->ctx->prehist_ran = false;
+    wt_ctx *c = p->ctx;
+    c->prehist_ran = false;
     if (flags & 16) {
-        p->ctx->prehist_plan = nullptr;
-        WT_HIP(hipMemsetAsync(p->ctx->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), p->ctx->stream));
+        c->prehist_plan = nullptr;
+        c->prehist_windowed = false;
+        WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+        // the windowed form, as in float32 (prehist_begin): 22-bit keys around a median predicted from
+        // 4096 pixels of `src` - the select then goes straight to its gather pass
+        const int fam = fused64_family(p);
+        if (g_opt_hist_window && src != WT_PLANE_NONE && fam >= 0 && !p->g.border && (int64_t)p->g.H * p->g.W >= ((int64_t)1 << 20) &&
+            p->g.H >= 64 && p->g.W >= 64) {
+            double *in = nullptr;
+            WT_TRY(plan64_base(p, src, &in));
+            ProfScope ps(c, "wt_median_window_kernel");
+            uint32_t *keys = (uint32_t *)c->d_partials;
+            if (fam == WT_B3SPLINE) hipLaunchKernelGGL((wt_median_sample_kernel<5, double>), dim3(64), dim3(64), 0, c->stream, (const double *)in, p->g, keys);
+            else hipLaunchKernelGGL((wt_median_sample_kernel<3, double>), dim3(64), dim3(64), 0, c->stream, (const double *)in, p->g, keys);
+            hipLaunchKernelGGL(wt_median_window_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)keys, hist_base_word(c));
+            WT_HIP(hipGetLastError());
+            c->prehist_windowed = true;
+        }
     }
     return 0;
 }
@@ -1076,7 +1141,7 @@ extern "C" int wt64_decompose_ex(wt_plan64 *p, int src, int level, int depth, in
         int np = 0;
         bool all = false;
         if (fused64_ok(p, level, depth, tr, &np, &all)) {
-            WT_TRY(prehist64_begin(p, flags));
+            WT_TRY(prehist64_begin(p, flags, src));
             WT_TRY(fused64_run(p, src, level, tr, np, false, WT_PLANE_NONE, flags));
             prehist64_end(p);
             return 0;
@@ -1137,7 +1202,7 @@ extern "C" int wt64_decompose_pass(wt_plan64 *p, int cur, int nxt, int s0, int n
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_decompose_pass: null plan");
-    WT_TRY(prehist64_begin(p, flags));
+    WT_TRY(prehist64_begin(p, flags, s0 == 0 ? cur : WT_PLANE_NONE));
     WT_TRY(fused64_pass(p, cur, nxt, s0, ns, (flags & 16) && s0 == 0 ? 3 : 0, false, WT_PLANE_NONE));
     prehist64_end(p);
     return 0;
@@ -1283,11 +1348,8 @@ extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
     const int64_t klo = (N - 1) / 2;
     Select64State *st = (Select64State *)(c->d_hist + WT_HIST_BINS + 16);
     Select64State *hst = (Select64State *)c->h_pinned;
-    memset(hst, 0, sizeof *hst);
-    hst->k = (unsigned long long)klo;
-    hst->upper = ~0ull;
-    WT_HIP(hipMemcpyAsync(st, hst, sizeof(Select64State), hipMemcpyHostToDevice, c->stream));
-    if (!pre) WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+    const bool windowed = pre && c->prehist_windowed;
+    c->prehist_windowed = false;
     const int shifts[6] = {52, 41, 30, 19, 8, 0};
     const int bits[6] = {11, 11, 11, 11, 11, 8};
     // (work items are (row, chunk of 2048 samples) pairs: the grid is sized to the device, 8 blocks per CU)
@@ -1312,38 +1374,58 @@ extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
         *out = *(const Select64State *)((const char *)c->h_pinned + 64);
         return 0;
     };
-    WT_TRY(level(0, pre));
-    WT_TRY(level(1, false));
     Select64State res{};
-    bool listed = false;
-    if (g_opt_select64_list) {
-        const size_t cap = (size_t)1 << 20;
-        if (!c->d_cand) {
-            WT_HIP(hipMalloc(&c->d_cand, (cap + 1) * sizeof(unsigned long long)));
-            c->d_cand_cap = cap;
+    // one attempt: the first 22 bits from the riding histogram (windowed: one step; plain: its step and a
+    // second level over the plane) or from two passes, then the gathered list, else the radix passes
+    auto attempt = [&](bool have_hist, bool window) -> int {
+        memset(hst, 0, sizeof *hst);
+        hst->k = (unsigned long long)klo;
+        hst->upper = ~0ull;
+        WT_HIP(hipMemcpyAsync(st, hst, sizeof(Select64State), hipMemcpyHostToDevice, c->stream));
+        if (!have_hist) WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+        mask = 0;
+        if (window) {
+            hipLaunchKernelGGL(wt64_select_window_step_kernel, dim3(1), dim3(256), 0, c->stream, c->d_hist, st, (const uint32_t *)hist_base_word(c));
+            WT_HIP(hipGetLastError());
+            mask = 0x7ffffe0000000000ull;                    // the top 22 bits
+        } else {
+            WT_TRY(level(0, have_hist));
+            WT_TRY(level(1, false));
         }
-        WT_HIP(hipMemsetAsync(c->d_cand + c->d_cand_cap, 0, sizeof(unsigned long long), c->stream));
-        {
-            ProfScope ps(c, "wt64_collect_kernel");
-            hipLaunchKernelGGL(wt64_collect_kernel, dim3(hgrid), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, mask,
-                               (const Select64State *)st, c->d_cand, (unsigned long long)c->d_cand_cap);
+        bool listed = false;
+        if (g_opt_select64_list) {
+            const size_t cap = (size_t)1 << 20;
+            if (!c->d_cand) {
+                WT_HIP(hipMalloc(&c->d_cand, (cap + 1) * sizeof(unsigned long long)));
+                c->d_cand_cap = cap;
+            }
+            WT_HIP(hipMemsetAsync(c->d_cand + c->d_cand_cap, 0, sizeof(unsigned long long), c->stream));
+            {
+                ProfScope ps(c, "wt64_collect_kernel");
+                hipLaunchKernelGGL(wt64_collect_kernel, dim3(hgrid), dim3(256), 0, c->stream, (const double *)b, p->g.nrows, p->g.P, p->g.W, mask,
+                                   (const Select64State *)st, c->d_cand, (unsigned long long)c->d_cand_cap);
+            }
+            hipLaunchKernelGGL(wt64_list_select_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)c->d_cand,
+                               (unsigned long long)c->d_cand_cap, st, 41);
+            WT_HIP(hipGetLastError());
+            WT_TRY(read_state(&res));
+            if (res.failed == 3) return 0;                   // the window missed: the caller redoes the select
+            listed = res.failed == 0;
+            if (res.failed == 2) {                           // the bin did not fit the list: the state is untouched
+                hst->failed = 0;
+                WT_HIP(hipMemcpyAsync(&st->failed, &hst->failed, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            }
         }
-        hipLaunchKernelGGL(wt64_list_select_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)c->d_cand,
-                           (unsigned long long)c->d_cand_cap, st, 41);
-        WT_HIP(hipGetLastError());
-        WT_TRY(read_state(&res));
-        listed = res.failed == 0;
-        if (res.failed == 2) {                                   // the bin did not fit the list: the state is untouched
-            hst->failed = 0;
-            WT_HIP(hipMemcpyAsync(&st->failed, &hst->failed, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (!listed) {
+            if (res.failed == 1) WT_FAIL("wt64_abs_median: rank %lld not found (NaN input?)", (long long)klo);
+            for (int i = 2; i < 6; ++i) WT_TRY(level(i, false));
+            WT_TRY(read_state(&res));
+            res.upper = ~0ull;
         }
-    }
-    if (!listed) {
-        if (res.failed == 1) WT_FAIL("wt64_abs_median: rank %lld not found (NaN input?)", (long long)klo);
-        for (int i = 2; i < 6; ++i) WT_TRY(level(i, false));
-        WT_TRY(read_state(&res));
-        res.upper = ~0ull;
-    }
+        return 0;
+    };
+    WT_TRY(attempt(pre, windowed));
+    if (windowed && res.failed == 3) WT_TRY(attempt(false, false));
     if (res.failed) WT_FAIL("wt64_abs_median: rank %lld not found (NaN input?)", (long long)klo);
     const unsigned long long ulo = res.prefix;
     unsigned long long uhi = ulo;

@@ -352,15 +352,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     __shared__ V ring[SUM && NS > 1 ? (G1 + G2 + G3) * (NV + 1) : 1];   // + one spare slot per row for the halo lanes
 
     __shared__ uint32_t lh[HIST ? WT_HIST_BINS : 1];
-    // windowed bins (float): shift 10 and the window's first 21-bit key; plain: shift 20, base 0 - one code path
+    // windowed bins: shift 10 (float) / 41 (double) and the window's first key; plain: shift 20 / 52, base 0 - one code path
     int hist_shift = 20, hist_lo = 0;
     if constexpr (HIST) {                                // (before the early exits: all waves pass the barrier)
         for (int i = threadIdx.x; i < WT_HIST_BINS; i += NL) lh[i] = 0;
-        if constexpr (PX == 4) {
-            if (a.hist_base) {
-                hist_shift = 10;
-                hist_lo = (int)__builtin_amdgcn_readfirstlane(*a.hist_base);
-            }
+        if (a.hist_base) {
+            hist_shift = PX == 4 ? 10 : 41;
+            hist_lo = (int)__builtin_amdgcn_readfirstlane(*a.hist_base);
+        } else if (PX == 2) {
+            hist_shift = 52;                             // double, plain: the exponent field
         }
         __syncthreads();
     }
@@ -656,7 +656,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                                                      (unsigned long long)__double_as_longlong(d0.y)};
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        if (FAST || x + j < g.W) atomicAdd(&lh[(uint32_t)((b[j] & 0x7fffffffffffffffull) >> 52)], 1u);
+                        if (FAST || x + j < g.W)
+                            atomicAdd(&lh[min(max((int)((b[j] & 0x7fffffffffffffffull) >> hist_shift) - hist_lo, 0), WT_HIST_BINS - 1)], 1u);
                 }
             }
         }

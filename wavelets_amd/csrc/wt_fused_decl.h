@@ -36,9 +36,9 @@ struct FusedArgsT {
                   // 2 = loads re-read one row, 4 = no filtering (same loads/stores), 16 = with 4: do
                   // not issue the predicated-off stores
     T *out_w3;      // w_{s0+3} of a four-scale pass (3-tap family); LAST on purpose: the older fields keep their offsets
-    // ACC == 3, float: nullptr = bins are the top 11 magnitude bits; else the WINDOWED form (round 4) - bin
-    // = clamp((bits >> 10) - *hist_base, 0, 2047): 2046 bins of 21-bit resolution around a predicted
-    // median (wt_median_window_kernel), everything below / above in bins 0 / 2047
+    // ACC == 3: nullptr = bins are the top 11 magnitude bits; else the WINDOWED form (round 4) - bin =
+    // clamp((bits >> 10 [float] or 41 [double]) - *hist_base, 0, 2047): 2046 bins of 21- / 22-bit resolution
+    // around a predicted median (wt_median_window_kernel), everything below / above in bins 0 / 2047
     const uint32_t *hist_base;
 };
 typedef FusedArgsT<float> FusedArgs;

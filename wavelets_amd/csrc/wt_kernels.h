@@ -1566,8 +1566,15 @@ __global__ __launch_bounds__(256) void wt_select_step_kernel(uint32_t *hist, WtS
 // The standard error of a 4096-sample median is ~2 % of sigma, so the true median lies inside the
 // window except for pathological images - which the select detects (rank in bin 0 / 2047) and redoes
 // with its ordinary three passes.  The prediction only places bins; it never enters a result.
-template <int K>
-__global__ __launch_bounds__(64) void wt_median_sample_kernel(const float *in, Geo g, uint32_t *keys)
+// window key of a sample: the top 21 magnitude bits of a float, the top 22 of a double
+__device__ __forceinline__ uint32_t wt_window_key(float v) { return (__float_as_uint(v) & 0x7fffffffu) >> 10; }
+__device__ __forceinline__ uint32_t wt_window_key(double v)
+{
+    return (uint32_t)(((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull) >> 41);
+}
+
+template <int K, typename T>
+__global__ __launch_bounds__(64) void wt_median_sample_kernel(const T *in, Geo g, uint32_t *keys)
 {
     // one sample per thread, 64 workgroups of one wave: the K * K loads of a sample are independent and
     // the 4096 samples spread over the chip (as ONE workgroup this step took 0.08 ms - more than the
@@ -1576,24 +1583,25 @@ __global__ __launch_bounds__(64) void wt_median_sample_kernel(const float *in, G
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int sy = i >> 6, sx = i & 63;
     const int y = (int)(((int64_t)(2 * sy + 1) * g.H) >> 7), x = (int)(((int64_t)(2 * sx + 1) * g.W) >> 7);
-    float v[K][K];
+    T v[K][K];
 #pragma unroll
     for (int a = 0; a < K; ++a) {
-        const float *row = in + (int64_t)(wt_refl(y + a - hw, g.H) - g.row0) * g.P;
+        const T *row = in + (int64_t)(wt_refl(y + a - hw, g.H) - g.row0) * g.P;
 #pragma unroll
         for (int b = 0; b < K; ++b) v[a][b] = row[wt_refl(x + b - hw, g.W)];
     }
-    float acc = 0.f;
+    T acc = (T)0;
 #pragma unroll
     for (int a = 0; a < K; ++a) {
-        float r = 0.f;
+        T r = (T)0;
 #pragma unroll
-        for (int b = 0; b < K; ++b) r = fmaf(wt_tap<K>(b), v[a][b], r);
-        acc = fmaf(wt_tap<K>(a), r, acc);
+        for (int b = 0; b < K; ++b) r = fma((T)wt_tap<K>(b), v[a][b], r);
+        acc = fma((T)wt_tap<K>(a), r, acc);
     }
-    keys[i] = __float_as_uint(v[hw][hw] - acc) & 0x7fffffffu;
+    keys[i] = wt_window_key(v[hw][hw] - acc);
 }
 
+// median of the 4096 window keys (<= 22 bits: two levels of 11) -> *base = first key of the window
 __global__ __launch_bounds__(1024) void wt_median_window_kernel(const uint32_t *keys, uint32_t *base)
 {
     constexpr int NS = 4096;
@@ -1603,9 +1611,9 @@ __global__ __launch_bounds__(1024) void wt_median_window_kernel(const uint32_t *
     __shared__ uint32_t sh_k, sh_prefix;
     for (int i = threadIdx.x; i < NS; i += 1024) key[i] = keys[i];
     uint32_t k = NS / 2 - 1, prefix = 0, known = 0;
-    for (int lvl = 0; lvl < 2; ++lvl) {                  // 11 + 10 bits: the top 21 bits of the sample's lower median
-        const int shift = lvl == 0 ? 20 : 10;
-        const uint32_t mask = lvl == 0 ? 0x7ffu : 0x3ffu;
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        const int shift = lvl == 0 ? 11 : 0;
+        const uint32_t mask = 0x7ffu;
         for (int i = threadIdx.x; i < WT_HIST_BINS; i += 1024) lh[i] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < NS; i += 1024)
@@ -1632,10 +1640,7 @@ __global__ __launch_bounds__(1024) void wt_median_window_kernel(const uint32_t *
         known |= mask << shift;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const int key21 = (int)(prefix >> 10);
-        *base = (uint32_t)max(key21 - WT_HIST_BINS / 2, 0);
-    }
+    if (threadIdx.x == 0) *base = (uint32_t)max((int)prefix - WT_HIST_BINS / 2, 0);
 }
 
 // Step after a WINDOWED riding histogram (bins: 0 = below the window, 1 .. 2046 = the 21-bit keys base + bin,
