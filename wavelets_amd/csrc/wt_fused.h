@@ -646,9 +646,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                     const uint32_t b[4] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z),
                                            __float_as_uint(d0.w)};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)       // (one v_bfe_u32 for the magnitude's top bits: the march is issue-bound)
                         if (FAST || x + j < g.W)
-                            atomicAdd(&lh[min(max((int)((b[j] & 0x7fffffffu) >> hist_shift) - hist_lo, 0), WT_HIST_BINS - 1)], 1u);
+                            atomicAdd(&lh[min(max((int)__builtin_amdgcn_ubfe(b[j], (uint32_t)hist_shift, 31u - (uint32_t)hist_shift) - hist_lo, 0),
+                                              WT_HIST_BINS - 1)], 1u);
                 } else {
                     // double: the top 11 bits of the 63-bit magnitude are the exponent field (first level
                     // of wt64_abs_median's select)
