@@ -873,6 +873,8 @@ def main():
         group.barrier()
         state["main_done"] = True
         release(plan, coefficients)
+        if os.environ.get("WT_BENCH_TEST_HANG_AFTER_MAIN"):       # testing aid: a later phase that never finishes -
+            time.sleep(1e6)                                        # the watchdog must emit the stored line
         # (3) strip planes over scattered 2-MiB chunks (what single-GPU plans use) instead of
         # plain hipMalloc: measured AFTER the line above is safe, guarded by the same ramp check on the
         # mapped planes over the real transport; the faster placement becomes the reported value.

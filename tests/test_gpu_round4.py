@@ -594,3 +594,20 @@ def test_windowed_riding_histogram_exact_median_and_fallback_when_the_window_mis
                 assert nh == 0 and ent["wt64_collect_kernel"][0] == 1 and "wt_median_window_kernel" in ent, ent
             if not window and name == "gauss":
                 assert nh == 1 and ent["wt64_collect_kernel"][0] == 1, ent
+
+
+def test_bench_emits_the_stored_measurement_when_a_later_phase_hangs():
+    """The main multi-GPU measurement is stored before the optional placement A/B starts; if that later
+    phase never finishes (here: a testing aid makes every rank sleep), the watchdog inside rank 0 emits
+    the stored line - marked `time_limit_hit` - instead of losing the run, and the ranks leave with 0."""
+    import subprocess
+    env = dict(_clean_env(), WT_BENCH_TEST_HANG_AFTER_MAIN="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--size", "2048",
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--no-build", "--time-limit", "70"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert "time_limit_hit" in out and out["n_gpus"] == 2 and out["value"] > 0 and out["halo_selfcheck"]["ok"]
+    assert out["strip_planes"]["chosen"] == "hipMalloc" and "scattered_ms_per_step" not in out["strip_planes"]
+    assert r.returncode == 0, r.returncode
