@@ -113,3 +113,54 @@ def test_generic_tap_coefficients_reacquire_a_storage_plan_when_they_lost_theirs
                 assert calls == [(kind,) + hw + ((WV._lib.B3SPLINE if kind == "f32" else (1.0,)), 2)], calls
                 assert [u[0] for u in plan.uploaded] == [0, 1, 2] and plan.uploaded[0][1] == hw
                 obj._plan = None
+
+
+@pytest.mark.parametrize("taps", [[0.5, 0.5], [0.1, 0.4, 0.3, 0.2], list(np.hanning(19)[1:-1] / np.hanning(19)[1:-1].sum())])
+def test_axis_by_axis_generic_filter_reproduces_convolution_and_the_recursive_base_operator(taps):
+    """_generic_filter (round 4) applies a scaling function's outer-product kernel axis by axis through
+    the generic operator - K taps per axis instead of K**ndim.  A numpy model of wt_taps_kernel stands in
+    for the plan: (a) standard algorithm: the result is the oracle's convolution() for even / long taps
+    at every scale; (b) recursive algorithm (offsets (j - K // 2) * d under the polyphase border rule):
+    every polyphase sub-array equals the base operator applied to it on its own."""
+    from wavelets_amd import wavelets as WV
+
+    class SF:
+        coefficients_1d = np.asarray(taps)
+
+    class ModelPlan:
+        def __init__(self, a):
+            self.planes = {WV.PLANE_INPUT: a}
+            self.nd = a.ndim
+
+        def taps_conv(self, src, var, dst, offs, wts, kc, depth=0, pad_mode=0, fill_value=0.0, dilation=1):
+            a = self.planes[src]
+            if pad_mode in (WV._lib.PAD_POLY_SYMMETRIC, WV._lib.PAD_POLY_MIRROR):
+                out = np.zeros_like(a)
+                mode = "symmetric" if pad_mode == WV._lib.PAD_POLY_SYMMETRIC else "reflect"
+                for starts in np.ndindex(*(dilation,) * a.ndim):          # every residue class on its own
+                    sl = tuple(slice(st, None, dilation) for st in starts)
+                    sub = a[sl]
+                    if sub.size:
+                        out[sl] = apply_taps(sub, None, np.asarray(offs) // dilation, wts, mode)
+                self.planes[dst] = out
+            else:
+                mode = {v: k for k, v in _PAD_MODES.items()}[pad_mode]
+                self.planes[dst] = apply_taps(a, None, offs, wts, mode)
+
+    rng = np.random.default_rng(len(taps))
+    t = np.asarray(taps)
+    for a in (rng.standard_normal(70), rng.standard_normal((23, 31)), rng.standard_normal((5, 9, 12))):
+        for s in (0, 1, 2):
+            plan = ModelPlan(a)
+            WV._generic_smooth(plan, SF, a.ndim, a.shape, WV.PLANE_INPUT, WV.PLANE_OUT, s)
+            np.testing.assert_allclose(plan.planes[WV.PLANE_OUT], O.convolution_taps_nd(a, t, s), rtol=0, atol=1e-12)
+            d = 2 ** s
+            plan = ModelPlan(a)
+            WV._generic_filter(plan, SF, a.ndim, a.shape, WV.PLANE_INPUT, WV.PLANE_OUT, d, 0,
+                               WV._lib.PAD_POLY_MIRROR if a.ndim == 1 else WV._lib.PAD_POLY_SYMMETRIC, dilation=d)
+            want = np.zeros_like(a)
+            for starts in np.ndindex(*(d,) * a.ndim):
+                sl = tuple(slice(st, None, d) for st in starts)
+                if a[sl].size:
+                    want[sl] = O.convolution_taps_nd(np.ascontiguousarray(a[sl]), t, 0)
+            np.testing.assert_allclose(plan.planes[WV.PLANE_OUT], want, rtol=0, atol=1e-12)

@@ -222,12 +222,54 @@ def _generic_plan(shape, f64, level=0):
     return acquire_plan(default_context(), rows, cols, _lib.B3SPLINE, level)
 
 
+_SEP_PLANES = (PLANE_SCRATCH(8), PLANE_SCRATCH(9))      # intermediates of the axis-by-axis generic filter
+
+
+def _generic_filter(plan, scaling_function, ndim, shape, src, dst, offset_scale, centre_scale, pad_mode, dilation=1):
+    """The scaling function's kernel - an outer product of its 1-D taps (ref:170-187) - through the
+    generic tap-list operator, AXIS BY AXIS (round 4): K taps per axis instead of K**ndim per sample (17
+    taps on an image: 34 instead of 289).  Tap j of an axis reads the sample at j * offset_scale - c,
+    c = ((K - 1) * centre_scale + 1) // 2 when the operator is the zero-stuffed kernel of the standard
+    algorithm (offset_scale = centre_scale = 2**s: cv2's / scipy's centre n // 2 of the stuffed kernel),
+    or (j - K // 2) * offset_scale when it is the BASE kernel applied to a polyphase sub-array (the
+    recursive algorithm: centre_scale = 0).  Signals convolve (scipy.ndimage.convolve, ref:65-69): the
+    offsets change sign.  Rounding differs from the K**ndim-tap sum in the last bits, as any separable
+    evaluation does; two taps gain nothing from the split and keep the single launch."""
+    taps = np.asarray(scaling_function.coefficients_1d, dtype=np.float64).ravel()
+    K = taps.size
+    if centre_scale:
+        c = ((K - 1) * centre_scale + 1) // 2
+        o = np.arange(K) * offset_scale - c
+    else:
+        o = (np.arange(K) - K // 2) * offset_scale
+    if ndim == 1:
+        o = -o
+    depth = shape[0] if ndim == 3 else 0
+    if ndim == 1 or K < 3:
+        offs = np.zeros((K,) * ndim + (3,), dtype=np.int32)
+        wts = np.ones((K,) * ndim)
+        for ax in range(ndim):
+            sh = [1] * ndim
+            sh[ax] = K
+            offs[..., 3 - ndim + ax] = o.reshape(sh)
+            wts = wts * taps.reshape(sh)
+        plan.taps_conv(src, PLANE_NONE, dst, offs.reshape(-1, 3), wts.ravel(), None, depth=depth, pad_mode=pad_mode,
+                       dilation=dilation)
+        return
+    cur = src
+    for i, ax in enumerate(range(ndim - 1, -1, -1)):              # x first, then y (, then z)
+        offs = np.zeros((K, 3), dtype=np.int32)
+        offs[:, 3 - ndim + ax] = o
+        nxt = dst if i == ndim - 1 else _SEP_PLANES[i]
+        plan.taps_conv(cur, PLANE_NONE, nxt, offs, taps, None, depth=depth, pad_mode=pad_mode, dilation=dilation)
+        cur = nxt
+
+
 def _generic_smooth(plan, scaling_function, ndim, shape, src, dst, s):
-    """conv_s through the generic tap-list operator: 'mirror' border for signals (ref:65-69),
+    """conv_s (ref:35-69) through the generic tap-list operator: 'mirror' border for signals (ref:65-69),
     BORDER_REFLECT = 'symmetric' otherwise (ref:39-63)"""
-    offs, wts = _filter_taps(scaling_function.kernel, s, convolve=ndim == 1)
-    plan.taps_conv(src, PLANE_NONE, dst, offs, wts, None, depth=shape[0] if ndim == 3 else 0,
-                   pad_mode=_PAD_MODES["reflect" if ndim == 1 else "symmetric"])
+    _generic_filter(plan, scaling_function, ndim, shape, src, dst, 2 ** s, 2 ** s,
+                    _PAD_MODES["reflect" if ndim == 1 else "symmetric"])
 
 
 def _plane_shape(shape):
@@ -907,7 +949,7 @@ class AtrousTransform:
         asks; signals, images and cubes.
 
         * standard algorithm (ref:408-444): conv_s = convolution()'s zero-stuffed kernel, centre n // 2
-          (_filter_taps); with bilateral filtering (ref:433-440) the variance of sdev_loc from
+          (_generic_filter: axis by axis); with bilateral filtering (ref:433-440) the variance of sdev_loc from
           conv_s(I) and conv_s(I^2) (ref:24-32), then the reference's own tap loop, range-weighted
           (_reference_taps, ref:74-105), under the symmetric pad.
         * recursive algorithm (ref:330-406): the array is padded once by (n // 2) * 2**(level-1) per
@@ -935,7 +977,6 @@ class AtrousTransform:
         plan.upload(PLANE_INPUT, work.reshape(plan.shape))
         if recursive:
             # the base operators' tap lists (scale 0); offsets are multiplied by d below
-            f_offs, f_wts = _filter_taps(kernel, 0, convolve=nd == 1)                # convolution() on a sub-array
             r_kc, r_offs, r_wts = _reference_taps(kernel, 0)                         # atrous_convolution on a sub-array
             conv_pad = _lib.PAD_POLY_MIRROR if nd == 1 else _lib.PAD_POLY_SYMMETRIC  # ref:65-69 / :39-63 per sub-array
         sq, mean, var = PLANE_SCRATCH(6), PLANE_SCRATCH(7), _TMP_PLANE     # (scratch 0/1: the smooth planes; 5: noise maps)
@@ -945,8 +986,8 @@ class AtrousTransform:
             d = 2 ** s
 
             def smooth(src, dst):
-                if recursive:
-                    plan.taps_conv(src, PLANE_NONE, dst, f_offs * d, f_wts, None, depth=depth, pad_mode=conv_pad, dilation=d)
+                if recursive:         # the base kernel on every sub-array of stride d (ref:371-372)
+                    _generic_filter(plan, scaling_function, nd, work.shape, src, dst, d, 0, conv_pad, dilation=d)
                 else:
                     _generic_smooth(plan, scaling_function, nd, work.shape, src, dst, s)       # ref:432
             if sb is None:
