@@ -115,6 +115,32 @@ def test_spawn_reports_the_first_failing_rank_and_stops_the_others(tmp_path):
     assert "RC 7 rank 1 exited with code 7" in r.stdout, r.stdout + r.stderr
 
 
+def test_spawn_reports_a_rank_killed_by_a_signal_the_way_a_shell_does(tmp_path):
+    script = tmp_path / "segv.py"
+    script.write_text("import os, signal, time\nif os.environ['RANK'] == '0':\n    os.kill(os.getpid(), signal.SIGKILL)\ntime.sleep(600)\n")
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        from wavelets_amd import launch
+        print("RC", *launch.spawn(2, [sys.executable, {str(script)!r}], time_limit=60, grace=2.0))
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert "RC 137 rank 0 was killed by signal 9" in r.stdout, r.stdout + r.stderr
+
+
+def test_rendezvous_refuses_a_peer_of_another_user(monkeypatch):
+    """Abstract sockets have no permissions; the group checks SO_PEERCRED before it unpickles anything."""
+    import socket
+    from wavelets_amd import launch
+    a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+    launch._check_peer(a)                                   # our own uid: accepted
+    monkeypatch.setattr(os, "getuid", lambda: 54321)
+    with pytest.raises(PermissionError, match="uid"):
+        launch._check_peer(a)
+    assert a.fileno() == -1                                 # and the connection is gone
+    b.close()
+
+
 def test_watchdog_fires_inside_a_stuck_rank():
     code = textwrap.dedent(f"""
         import sys, time

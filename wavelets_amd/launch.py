@@ -54,6 +54,17 @@ def _recv(sock):
     return pickle.loads(_recv_exact(sock, n))
 
 
+def _check_peer(sock):
+    """Abstract sockets carry no file permissions: any local user could connect (or bind the name
+    first) and feed pickles to a rank.  SO_PEERCRED names the peer's uid as the kernel saw it at
+    connect() / listen() time; anything but our own uid is refused before a byte is read."""
+    cred = sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+    _pid, uid, _gid = struct.unpack("3i", cred)
+    if uid != os.getuid():
+        sock.close()
+        raise PermissionError(f"rendezvous: peer runs as uid {uid}, this job as uid {os.getuid()}")
+
+
 def default_name(env=None):
     """Name of the rendezvous socket of this job (see the module docstring)."""
     env = os.environ if env is None else env
@@ -93,6 +104,7 @@ class SocketGroup:
                         raise TimeoutError(f"rendezvous: {world - 1 - len(self._peers)} of {world - 1} ranks did "
                                            f"not connect within {connect_timeout:.0f} s") from None
                     conn.settimeout(op_timeout)
+                    _check_peer(conn)
                     r = _recv(conn)
                     if not isinstance(r, int) or not 0 < r < world or r in self._peers:
                         conn.close()
@@ -114,6 +126,7 @@ class SocketGroup:
                         raise TimeoutError(f"rendezvous: rank 0 did not listen within {connect_timeout:.0f} s") from None
                     time.sleep(0.02)
             s.settimeout(max(op_timeout, connect_timeout))
+            _check_peer(s)
             _send(s, rank)
             if _recv(s) != world:
                 raise RuntimeError("rendezvous: the ranks disagree about the world size")
@@ -210,7 +223,10 @@ def spawn(nranks, argv, time_limit=900.0, env=None, grace=5.0, tee_rank0=None):
                 continue
             live.discard(r)
             if code != 0 and rc == 0:
-                rc, reason = code, f"rank {r} exited with code {code}"
+                if code < 0:                    # killed by a signal: the shell's convention
+                    rc, reason = 128 - code, f"rank {r} was killed by signal {-code}"
+                else:
+                    rc, reason = code, f"rank {r} exited with code {code}"
         if rc != 0:
             break
         if live and time.monotonic() - t0 > time_limit:
