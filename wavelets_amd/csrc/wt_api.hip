@@ -27,15 +27,20 @@ void wt_set_error(const char *fmt, ...)
 extern "C" const char *wt_last_error(void) { return g_err; }
 
 // Per-context serialisation of the entry points (see wt_ctx::mu).  Two-plan operations lock both
-// contexts in address order.
+// contexts in address order.  The guard also makes the (first) context's device the calling thread's
+// current one: HIP's current device is per thread, so a host thread other than the one that created
+// the context - or one that has since used a context on another GPU - would otherwise launch on a
+// stream of a device that is not current.
 struct WtGuard {
     std::recursive_mutex *a = nullptr, *b = nullptr;
     explicit WtGuard(wt_ctx *c, wt_ctx *d = nullptr)
     {
+        const int dev = c ? c->device : -1;
         if (c == d) d = nullptr;
         if (c && d && d < c) std::swap(c, d);
         if (c) { a = &c->mu; a->lock(); }
         if (d) { b = &d->mu; b->lock(); }
+        if (dev >= 0) (void)hipSetDevice(dev);
     }
     ~WtGuard()
     {
