@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle.so")
+# WT_ORACLE_LIB: another build of the same source (tools/oracle_sanitize.sh: -fsanitize=address,undefined)
+_SO = os.environ.get("WT_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")
 FAMILY = {"triangle": 0, "b3spline": 1}
 _lib = None
 
