@@ -863,6 +863,30 @@ def g23_richardson_lucy_fft_large_psf():
     save("g23_rl_fft_large", "hard(numpy fft; transform via cv2 stand-in)", **out)
 
 
+def g24_richardson_lucy_fft_non_pow2():
+    """Round 4: richardson_lucy(fft=True) with a large PSF on images whose sides are NOT powers of two
+    (72 x 100, and 75 x 100: an odd height moves the row anchors, utils.py:246-250) - the HIP engine
+    serves them through a periodically extended power-of-two FFT."""
+    rng = np.random.default_rng(2400)
+    ky, kx = np.mgrid[0:25, 0:23]
+    psf = np.exp(-((ky - 12.) ** 2 / 40. + (kx - 11.) ** 2 / 25. + 0.02 * (ky - 12.) * (kx - 11.))).astype(np.float32)
+    psf /= psf.sum()
+    even = rng.uniform(0.2, 1.0, (24, 26)).astype(np.float32) * np.hanning(24)[:, None].astype(np.float32) \
+        * np.hanning(26)[None, :].astype(np.float32)
+    even /= even.sum()
+    out = {"psf": psf, "psf_even": even}
+    for tag, (H, W) in (("a", (72, 100)), ("odd", (75, 100))):
+        yy, xx = np.mgrid[0:H, 0:W]
+        truth = (np.exp(-((yy - 20.) ** 2 + (xx - 40.) ** 2) / 30.) * 40 + np.exp(-((yy - 50.) ** 2 + (xx - 70.) ** 2) / 80.) * 25
+                 + 2.0).astype(np.float32)
+        data = (truth + rng.standard_normal(truth.shape).astype(np.float32) * 0.5).astype(np.float32)
+        out[f"data_{tag}"] = data
+        out[f"rl_{tag}_soft"] = richardson_lucy(data.copy(), psf, iterations=3, fft=True)
+        out[f"rl_{tag}_even"] = richardson_lucy(data.copy(), even, iterations=3, fft=True, denoise_coefficients=(4, 2))
+        out[f"rl_{tag}_f64"] = richardson_lucy(data.astype(np.float64) * 10 + 100, psf.astype(np.float64), iterations=3, fft=True)
+    save("g24_rl_fft_nonpow2", "hard(numpy fft; transform via cv2 stand-in)", **out)
+
+
 if __name__ == "__main__":
     if "--only" in sys.argv:                      # e.g. --only g13_richardson_lucy_fft
         globals()[sys.argv[sys.argv.index("--only") + 1]]()
@@ -891,3 +915,4 @@ if __name__ == "__main__":
         g21_general_operator()
         g22_remaining_refusals()
         g23_richardson_lucy_fft_large_psf()
+        g24_richardson_lucy_fft_non_pow2()

@@ -611,3 +611,89 @@ def test_bench_emits_the_stored_measurement_when_a_later_phase_hangs():
     assert "time_limit_hit" in out and out["n_gpus"] == 2 and out["value"] > 0 and out["halo_selfcheck"]["ok"]
     assert out["strip_planes"]["chosen"] == "hipMalloc" and "scattered_ms_per_step" not in out["strip_planes"]
     assert r.returncode == 0, r.returncode
+
+
+def test_richardson_lucy_fft_on_sides_that_are_not_powers_of_two(L):
+    """g24: richardson_lucy(fft=True) on 72 x 100 and 75 x 100 images (odd height: the reference's row
+    anchors move by one) through the periodically EXTENDED power-of-two frame (utils._ExtendedFFT) -
+    against the unmodified reference, float32 and float64, odd and even PSFs, and against the direct
+    periodic form of the same products."""
+    from conftest import load_golden
+    import wavelets_amd as WA
+    from wavelets_amd import utils as WU
+    g = load_golden("g24_rl_fft_nonpow2")
+    calls = []
+    keep_apply, keep_min = WU._ExtendedFFT.apply, WU._FFT_MIN_TAPS
+
+    def counting(self, src, dst, conj):
+        calls.append((self.Mh, self.Mw, bool(conj)))
+        return keep_apply(self, src, dst, conj)
+
+    WU._ExtendedFFT.apply = counting
+    try:
+        for tag, frame in (("a", (128, 128)), ("odd", (128, 128))):
+            d = g[f"data_{tag}"]
+            for name, psf, kw in ((f"rl_{tag}_soft", "psf", dict(iterations=3)),
+                                  (f"rl_{tag}_even", "psf_even", dict(iterations=3, denoise_coefficients=(4, 2)))):
+                WU._FFT_MIN_TAPS = 1                                   # small images: force the FFT form
+                del calls[:]
+                got = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+                assert calls == [(frame[0], frame[1], False), (frame[0], frame[1], True)] * 3, calls
+                assert got.dtype == np.float32
+                np.testing.assert_allclose(got, g[name], atol=2e-4 * np.abs(g[name]).max(), rtol=2e-4)
+                WU._FFT_MIN_TAPS = 1 << 30                             # the direct periodic correlations
+                direct = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+                np.testing.assert_allclose(got, direct, atol=5e-5 * np.abs(got).max(), rtol=0)
+            WU._FFT_MIN_TAPS = 1
+            got = WA.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
+            assert got.dtype == np.float64
+            np.testing.assert_allclose(got, g[f"rl_{tag}_f64"], atol=1e-9 * np.abs(g[f"rl_{tag}_f64"]).max(), rtol=0)
+        # the default threshold: a 25 x 23 PSF on 72 x 100 stays on the direct form (the frame is 2.3x the image)
+        WU._FFT_MIN_TAPS = keep_min
+        del calls[:]
+        WA.richardson_lucy(g["data_a"].copy(), g["psf"], fft=True, iterations=1)
+        assert calls == []
+    finally:
+        WU._ExtendedFFT.apply, WU._FFT_MIN_TAPS = keep_apply, keep_min
+
+
+def test_extended_fft_beats_the_direct_form_on_a_3072_square_image(L):
+    """3072 x 3072 (not a power of two: e.g. a full-disc EUV imager frame) with a 65 x 65 PSF: one circular
+    product through the extended 4096^2 frame against the banded direct periodic form."""
+    from wavelets_amd import utils as WU
+    side, k = 3072, 65
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((side, side), dtype=np.float32)
+    psf = rng.uniform(0.1, 1.0, (k, k)).astype(np.float32)
+    psf /= psf.sum()
+    ctx = L.default_context()
+    p = L.Plan(ctx, side, side, L.B3SPLINE, 1)
+    A, B = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3)
+    try:
+        p.upload(L.PLANE_INPUT, x)
+        ext = WU._ExtendedFFT(p, False, psf)
+        assert ext.ok and (ext.Mh, ext.Mw) == (4096, 4096) and ext.worth_it(WU._FFT_MIN_TAPS)
+        ext.prepare(WU.B3spline(2))
+        kern, kw = WU._periodic_operand(np.ascontiguousarray(psf[::-1, ::-1]), k - 1 - k // 2, k - 1 - k // 2)
+
+        def timed(fn, n):
+            fn()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(n):
+                fn()
+            return ctx.timer_stop() / n
+
+        t_ext = timed(lambda: ext.apply(L.PLANE_INPUT, A, False), 5)
+        t_dir = timed(lambda: p.filter2d(L.PLANE_INPUT, B, kern, **kw), 2)
+        a, b = p.download(A), p.download(B)
+        np.testing.assert_allclose(a, b, atol=2e-5 * np.abs(b).max(), rtol=0)
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", "fft_vs_direct.txt"), "a") as f:
+                f.write(f"3072^2, 65x65 PSF: extended-frame fft {t_ext:.3f} ms, banded direct {t_dir:.3f} ms, ratio {t_dir / t_ext:.1f}\n")
+        except OSError:
+            pass
+        assert t_dir >= 2 * t_ext, (t_ext, t_dir)
+        ext.close()
+    finally:
+        p.close()

@@ -554,3 +554,17 @@ def test_g23_large_psf_fft_products_and_richardson_lucy():
         close(got, g[name], atol=2e-4 * np.abs(g[name]).max(), rtol=2e-4)
     got = O.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
     close(got, g["rl_fft_f64"], atol=1e-9 * np.abs(g["rl_fft_f64"]).max(), rtol=0)
+
+
+def test_g24_richardson_lucy_fft_on_images_that_are_not_powers_of_two():
+    """g24 (round 4): richardson_lucy(fft=True) with 25 x 23 and 24 x 26 PSFs on 72 x 100 and 75 x 100
+    images (the odd height moves the row anchors by one, utils.py:246-250), float32 and float64."""
+    g = load_golden("g24_rl_fft_nonpow2")
+    for tag in ("a", "odd"):
+        d = g[f"data_{tag}"]
+        got = O.richardson_lucy(d.copy(), g["psf"], iterations=3, fft=True)
+        close(got, g[f"rl_{tag}_soft"], atol=2e-4 * np.abs(g[f"rl_{tag}_soft"]).max(), rtol=2e-4)
+        got = O.richardson_lucy(d.copy(), g["psf_even"], iterations=3, fft=True, denoise_coefficients=(4, 2))
+        close(got, g[f"rl_{tag}_even"], atol=2e-4 * np.abs(g[f"rl_{tag}_even"]).max(), rtol=2e-4)
+        got = O.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
+        close(got, g[f"rl_{tag}_f64"], atol=1e-9 * np.abs(g[f"rl_{tag}_f64"]).max(), rtol=0)

@@ -164,3 +164,35 @@ def test_axis_by_axis_generic_filter_reproduces_convolution_and_the_recursive_ba
                 if a[sl].size:
                     want[sl] = O.convolution_taps_nd(np.ascontiguousarray(a[sl]), t, 0)
             np.testing.assert_allclose(plan.planes[WV.PLANE_OUT], want, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape,kshape", [((72, 100), (25, 23)), ((75, 100), (25, 23)), ((75, 100), (24, 26)),
+                                          ((33, 20), (33, 19)), ((48, 40), (1, 7)), ((21, 6), (2, 2))])
+def test_extended_frame_reproduces_the_circular_products_of_the_image(shape, kshape):
+    """richardson_lucy(fft=True) on sides that are not powers of two (utils._ExtendedFFT): the index
+    logic - periodic extension windows, PSF laid around the frame's origin, window copied back -
+    replayed with numpy's FFT on the frame must equal the reference's products on the image itself
+    (utils.py:246-254, 284), odd heights included."""
+    from wavelets_amd import utils as WU
+    rng = np.random.default_rng(sum(shape) + sum(kshape))
+    H, W = shape
+    x = rng.standard_normal(shape)
+    k = rng.uniform(0.1, 1.0, kshape)
+    kh, kw = kshape
+    # the reference's kernel spectrum (utils.py:246-250)
+    pad = np.zeros(shape)
+    pad[H // 2 - kh // 2:H // 2 - kh // 2 + kh, W // 2 - kw // 2:W // 2 - kw // 2 + kw] = k
+    f = np.fft.rfft2(np.roll(pad, (H // 2, W // 2), axis=(0, 1)))
+    want_conv = np.fft.irfft2(np.fft.rfft2(x) * f, s=shape)
+    want_corr = np.fft.irfft2(np.fft.rfft2(x) * f.conj(), s=shape)
+    e, hy, hx, Mh, Mw = WU._ext_geometry(H, W, kh, kw)
+    assert Mh & (Mh - 1) == 0 and Mw & (Mw - 1) == 0 and Mh >= H + 2 * hy and Mw >= W + 2 * hx
+    F = np.fft.fft2(WU._ext_kernel_frame(k, H, Mh, Mw))
+    frame = np.zeros((Mh, Mw))
+    for sy, sx, dy, dx, nr, nc in WU._ext_windows(H, W, hy, hx):
+        frame[dy:dy + nr, dx:dx + nc] = x[sy:sy + nr, sx:sx + nc]
+    X = np.fft.fft2(frame)
+    conv = np.fft.ifft2(X * F).real[hy:hy + H, hx:hx + W]
+    corr = np.fft.ifft2(X * F.conj()).real[hy:hy + H, hx:hx + W]
+    np.testing.assert_allclose(conv, want_conv, atol=1e-11)
+    np.testing.assert_allclose(corr, want_corr, atol=1e-11)

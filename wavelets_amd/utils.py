@@ -340,8 +340,85 @@ def _periodic_operand(kernel, ay, ax):
     return np.ascontiguousarray(kernel), dict(anchor=(ay, ax), periodic=True)
 
 
-# PSFs of at least this many taps take the FFT form of the circular products (power-of-two images)
+# PSFs of at least this many taps take the FFT form of the circular products (power-of-two images;
+# other sizes: times twice the area ratio of the power-of-two frame they are extended into)
 _FFT_MIN_TAPS = int(__import__("os").environ.get("WATROO_HIP_FFT_MIN_TAPS", "512"))
+
+
+def _next_pow2(n):
+    return 1 << max(1, int(n - 1).bit_length())
+
+
+def _ext_geometry(H, W, kh, kw):
+    """(e, hy, hx, Mh, Mw) of the extended frame: halo rows / columns and the power-of-two frame size"""
+    e = H % 2
+    hy, hx = kh // 2 + e, kw // 2
+    return e, hy, hx, _next_pow2(H + 2 * hy), _next_pow2(W + 2 * hx)
+
+
+def _ext_kernel_frame(psf, H, Mh, Mw):
+    """The PSF laid around the frame's origin as ref utils.py:246-250 lays it around the image's"""
+    kh, kw = psf.shape
+    frame = np.zeros((Mh, Mw), dtype=psf.dtype)
+    rows = (np.arange(kh) - kh // 2 - H % 2) % Mh
+    cols = (np.arange(kw) - kw // 2) % Mw
+    frame[np.ix_(rows, cols)] = psf
+    return frame
+
+
+def _ext_windows(H, W, hy, hx):
+    """(sy, sx, dy, dx, rows, cols) copies that extend an H x W image periodically by (hy, hx)"""
+    return [(sy, sx, dy, dx, nr, nc)
+            for sy, dy, nr in ((H - hy, 0, hy), (0, hy, H), (0, hy + H, hy))
+            for sx, dx, nc in ((W - hx, 0, hx), (0, hx, W), (0, hx + W, hx)) if nr and nc]
+
+
+class _ExtendedFFT:
+    """Circular products of an H x W image whose sides are NOT powers of two through the engine's
+    power-of-two FFT (wt_fft.h).  A product with a kernel of support [-hy, hy] x [-hx, hx] only looks
+    hy rows / hx columns beyond a pixel, so the image is extended PERIODICALLY by that much on every
+    side (nine device window copies), placed in a zeroed power-of-two frame that holds H + 2 hy rows and
+    W + 2 hx columns, the frame's own circular product is taken, and the H x W window is copied back:
+    inside it no term has wrapped around the frame, so it equals the product of period (H, W).  The
+    kernel spectrum is that of the PSF laid around the frame's origin exactly as the reference lays it
+    around the image's (ref utils.py:246-250; for an odd height the reference's two rolls by H // 2
+    leave the centre one row above the origin - `e`)."""
+
+    def __init__(self, plan, f64, psf):
+        H, W = plan.H, plan.W
+        self.e, self.hy, self.hx, self.Mh, self.Mw = _ext_geometry(H, W, *psf.shape)
+        self.plan, self.big = plan, None
+        self.ok = self.hy <= H and self.hx <= W and _lib.fft_supported(self.Mh, self.Mw)
+        self.f64, self.psf = f64, psf
+
+    def worth_it(self, min_taps):
+        kh, kw = self.psf.shape
+        return self.ok and kh * kw * self.plan.H * self.plan.W >= 2 * min_taps * self.Mh * self.Mw
+
+    def prepare(self, sf):
+        ft = np.float64 if self.f64 else np.float32
+        ctx = default_context()
+        if self.f64:
+            self.big = _lib.acquire_plan64(ctx, self.Mh, self.Mw, _taps_f64(sf, 2), 1)
+        else:
+            self.big = acquire_plan(ctx, self.Mh, self.Mw, _family_of(sf), 1)
+        frame = _ext_kernel_frame(self.psf.astype(ft, copy=False), self.plan.H, self.Mh, self.Mw)
+        self.A, self.B = PLANE_SCRATCH(0), PLANE_SCRATCH(1)
+        self.big.upload(self.A, frame)
+        self.big.fft_spectrum(self.A)
+        self.big.fill(self.A, 0.0)             # the frame outside the extended image stays zero from here on
+
+    def apply(self, src, dst, conj):
+        H, W = self.plan.H, self.plan.W
+        for sy, sx, dy, dx, nr, nc in _ext_windows(H, W, self.hy, self.hx):
+            self.big.copy_window_from(self.plan, src, self.A, sy, sx, dy, dx, nr, nc)
+        self.big.fft_apply(self.A, self.B, conj)
+        self.plan.copy_window_from(self.big, self.B, dst, self.hy, self.hx, 0, 0, H, W)
+
+    def close(self):
+        if self.big is not None:
+            _lib.release_plan(self.big)
+            self.big = None
 
 
 def richardson_lucy(data, psf,
@@ -404,7 +481,19 @@ def richardson_lucy(data, psf,
     # as the reference builds it (ref:246-250) and transformed once.
     use_fft = bool(fft) and kh * kw >= _FFT_MIN_TAPS and kh <= img.shape[0] and kw <= img.shape[1] \
         and _lib.fft_supported(img.shape[0], img.shape[1])
-    if use_fft:
+    ext = None
+    if fft and not use_fft and kh <= img.shape[0] and kw <= img.shape[1] \
+            and not _lib.fft_supported(img.shape[0], img.shape[1]):
+        # sides that are not powers of two: the same FFT on a periodically extended frame
+        ext = _ExtendedFFT(plan, f64, psf)
+        if ext.worth_it(_FFT_MIN_TAPS):
+            ext.prepare(sf)
+        else:
+            ext = None
+    if ext is not None:
+        fwd_k = bwd_k = None
+        fwd = bwd = {}
+    elif use_fft:
         H, W = img.shape
         padded_psf = np.zeros((H, W), dtype=ft)
         padded_psf[H // 2 - kh // 2:H // 2 - kh // 2 + kh, W // 2 - kw // 2:W // 2 - kw // 2 + kw] = psf     # ref:247-249
@@ -417,28 +506,36 @@ def richardson_lucy(data, psf,
             else (psf_flipped, {})
         bwd_k, bwd = _periodic_operand(psf, kh // 2 + e, kw // 2) if fft else (psf, {})
     data_noise = coefficients.noise       # None with uniform_init: every iteration then estimates
-    for iteration in range(iterations):                                  # ref:252
-        if use_fft:
-            plan.fft_apply(PSI, PHI, False)                              # ref:254
-        else:
-            plan.filter2d(PSI, PHI, fwd_k, **fwd)                        # ref:255-257
-        plan.binary("sub", DATA, PHI, RES)                               # ref:259
-        plan.decompose(RES, level)                                       # ref:261
-        # ref:262: a fresh Coefficients per iteration inherits the data's noise; when that is None
-        # its lazy MAD estimate (ref:131-132) comes from the RESIDUAL's plane 0 - the planes the
-        # plan holds right now.  One owner of the plan throughout: `coefficients`.
-        coefficients.noise = data_noise
-        for s, c in enumerate(denoise_coefficients):                     # ref:263-276
-            t = coefficients._tau(c, s, soft)
-            tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
-            plan.mrs_update(s, MRS[s], tau, soft, noise_plane, persistent_mrs,
-                            1.0 / (iteration + 1))
-        plan.plane_sum(0, level + 1, RES)                                # ref:278
-        plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
-        if use_fft:
-            plan.fft_apply(RES, CONV, True)                              # ref:284
-        else:
-            plan.filter2d(RES, CONV, bwd_k, **bwd)                       # ref:284-286
-        plan.binary("mul", PSI, CONV, PSI)                               # ref:288
+    try:
+        for iteration in range(iterations):                                  # ref:252
+            if ext is not None:
+                ext.apply(PSI, PHI, False)                                   # ref:254
+            elif use_fft:
+                plan.fft_apply(PSI, PHI, False)                              # ref:254
+            else:
+                plan.filter2d(PSI, PHI, fwd_k, **fwd)                        # ref:255-257
+            plan.binary("sub", DATA, PHI, RES)                               # ref:259
+            plan.decompose(RES, level)                                       # ref:261
+            # ref:262: a fresh Coefficients per iteration inherits the data's noise; when that is None
+            # its lazy MAD estimate (ref:131-132) comes from the RESIDUAL's plane 0 - the planes the
+            # plan holds right now.  One owner of the plan throughout: `coefficients`.
+            coefficients.noise = data_noise
+            for s, c in enumerate(denoise_coefficients):                     # ref:263-276
+                t = coefficients._tau(c, s, soft)
+                tau, noise_plane = (0.0, PLANE_NONE) if t is None else t
+                plan.mrs_update(s, MRS[s], tau, soft, noise_plane, persistent_mrs,
+                                1.0 / (iteration + 1))
+            plan.plane_sum(0, level + 1, RES)                                # ref:278
+            plan.binary("add_div", RES, PHI, RES)                            # ref:280-281
+            if ext is not None:
+                ext.apply(RES, CONV, True)                                   # ref:284
+            elif use_fft:
+                plan.fft_apply(RES, CONV, True)                              # ref:284
+            else:
+                plan.filter2d(RES, CONV, bwd_k, **bwd)                       # ref:284-286
+            plan.binary("mul", PSI, CONV, PSI)                               # ref:288
+    finally:
+        if ext is not None:
+            ext.close()
     # psi is float32 by construction with uniform_init (ref:233), else np.sum of the data's planes
     return plan.download(PSI).astype(np.float32 if uniform_init else _result_dtype(data), copy=False)
