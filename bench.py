@@ -420,7 +420,14 @@ def main():
 
     if os.environ.get("WT_BENCH_REPORT_MODULES"):     # (tests: what this rank has imported before its first GPU call)
         sys.stderr.write(f"[bench rank {rank}] torch_in_sys_modules={'torch' in sys.modules}\n")
-    ctx = _lib.Context(local_rank)
+    device = local_rank
+    ndev = _lib.device_count()
+    if world > 1 and ndev and local_rank >= ndev:
+        # fewer visible devices than local ranks: a launcher that pins every rank to its own GPU with
+        # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES shows each of them exactly one device
+        device = local_rank % ndev
+        sys.stderr.write(f"[bench rank {rank}] LOCAL_RANK {local_rank} but {ndev} visible device(s): using device {device}\n")
+    ctx = _lib.Context(device)
     rccl_ranks = 1
     if group is not None:
         from wavelets_amd.parallel import init_comm
