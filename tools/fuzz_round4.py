@@ -59,9 +59,21 @@ def case_denoise(rng, f64):
     scale = max(1.0, float(np.abs(a).max()))
     tol = (1e-11 if f64 else 2e-5) * scale
     if not soft:
-        # a hard threshold may flip on a last-bit difference of a coefficient: allow a few isolated pixels
-        bad = np.abs(got - want) > tol
-        ok = bad.mean() < 1e-4
+        # A hard threshold flips when a coefficient sits within rounding distance of it (the two sides
+        # round the transform differently in the last bits - and data on a large offset is coarsely
+        # quantised, so MANY coefficients sit there).  Exact check: pixels where some plane's |w| is
+        # within `amb` of its threshold are set aside (and must stay a minority); all others must agree.
+        c = O.Coeffs(O.atrous_standard_nd(a.copy(), level, fam), fam)
+        noise = c.get_noise()
+        amb = (1e-13 if f64 else 4e-6) * scale
+        ambiguous = np.zeros(a.shape, dtype=bool)
+        for scl, sg in enumerate(sig):
+            if sg != 0 and noise != 0:
+                ambiguous |= np.abs(np.abs(c.data[scl]) - sg * noise * c.sigma_e[scl]) <= amb
+        bad = (np.abs(got - want) > tol) & ~ambiguous
+        ok = not bad.any() and ambiguous.mean() < 0.2
+        if not ok:
+            return tag + f": {int(bad.sum())} pixels differ away from a threshold ({100 * ambiguous.mean():.2f} % ambiguous)"
     else:
         ok = bool(np.abs(got - want).max() <= tol)
     if got.dtype != dtype:
