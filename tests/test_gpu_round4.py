@@ -305,6 +305,29 @@ def test_float64_denoise_interleaved_equals_the_plain_sequence(L):
     assert float(np.abs(got - ref).max()) <= 1e-11 * float(np.abs(img).max())
 
 
+def test_float64_cfg3_at_full_size_properties(L):
+    """BASELINE configs[2] on the float64 engine at its full size (8192 x 8192, Triangle, 8 scales,
+    denoise([5, 3, 2]) soft; bench.py's `float64_cfg3` entry) through size-independent properties: the
+    interleaved flow gives the bits of transform -> Coefficients.denoise -> np.sum(axis=0), the noise
+    estimate is the exact median of the plane 0 the engine produced, and soft thresholds shrink."""
+    import wavelets_amd as WA
+    rng = np.random.default_rng(8)
+    img = rng.standard_normal((8192, 8192))
+    sig = [5, 3, 2, 0, 0, 0, 0, 0]
+    got = WA.denoise(img, list(sig), WA.Triangle)
+    assert got.dtype == np.float64 and got.shape == img.shape
+    c = WA.AtrousTransform(WA.Triangle)(img, len(sig))
+    w0 = np.abs(c.data[0])
+    noise = c.get_noise()
+    assert noise == np.median(w0) / 0.6745 / c.sigma_e[0]
+    del w0
+    c.denoise(list(sig))
+    want = np.sum(c, axis=0)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # soft thresholds shrink: the thresholded image has less energy than the input, and is not the input
+    assert float(np.abs(got).mean()) < float(np.abs(img).mean()) and not np.array_equal(got, img)
+
+
 # --------------------------------------------------------------------------- the last refusals (g22)
 def _sf(name, taps, e1, e2, e3):
     import wavelets_amd as WA

@@ -805,14 +805,19 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
     int slot0 = 0;                                       // ring slot of window row 0
 
     const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
-    for (int r = r0; r < r1; ++r) {
+    // One step of the march.  The window does NOT slide through the registers (K * K 8-byte moves per
+    // row, ~10 % of the kernel's vector instructions): the row loop is unrolled K times and in phase U
+    // window row i lives in slot (i + U) % K - the entering row replaces the row that left (K moves).
+    // Same operations in the same order in every phase: identical bits.
+    auto step = [&](const int r, auto utag) {
+        constexpr int U = decltype(utag)::value;
         load_win_row(min(r + 1, r1 - 1) + hw, nxt);      // software prefetch of the entering row
         const int64_t roff = (int64_t)(q + d * r) * g.P;
-        const float I[2] = {win[hw][hw].x, win[hw][hw].y};
+        const float I[2] = {win[(hw + U) % K][hw].x, win[(hw + U) % K][hw].y};
         float vv[2];
         if (a.inline_var) {
             float2 hn, h2n;
-            row_filters(win[K - 1], hn, h2n);            // the row that entered the window
+            row_filters(win[(K - 1 + U) % K], hn, h2n);  // the row that entered the window
             {
                 const int sn = slot0 == 0 ? K - 1 : slot0 - 1;
                 hring[sn][0][tid] = hn;
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
             for (int j = 0; j < K; ++j) {
                 if (i == hw && j == hw) continue;
                 const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
-                const float2 t2 = win[K - 1 - i][K - 1 - j];
+                const float2 t2 = win[(K - 1 - i + U) % K][K - 1 - j];
                 const wt_p2 t = {t2.x, t2.y};
                 const wt_p2 diff = Iv - t;
                 const wt_p2 ex = __builtin_elementwise_fma(diff * diff, s2, (wt_p2){lk, lk});
@@ -878,10 +883,21 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         wt_store2(a.out_c + roff, x, g.P, make_float2(o[0], o[1]));
         if (a.out_w) wt_store2(a.out_w + roff, x, g.P, make_float2(ow[0], ow[1]));
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int i = 0; i < K - 1; ++i) win[i][j] = win[i + 1][j];
-            win[K - 1][j] = nxt[j];
+        for (int j = 0; j < K; ++j) win[U][j] = nxt[j];    // slot of the row that left <- the row that entered
+    };
+    int r = r0;
+    while (true) {
+        step(r, std::integral_constant<int, 0>{});
+        if (++r >= r1) break;
+        step(r, std::integral_constant<int, 1>{});
+        if (++r >= r1) break;
+        step(r, std::integral_constant<int, 2>{});
+        if (++r >= r1) break;
+        if constexpr (K > 3) {
+            step(r, std::integral_constant<int, 3>{});
+            if (++r >= r1) break;
+            step(r, std::integral_constant<int, 4>{});
+            if (++r >= r1) break;
         }
     }
 }
