@@ -89,9 +89,10 @@ def algorithmic_bytes_per_pixel(kernel, level=LEVEL, interleaved=False, n_fold=3
         # interleaved: the sum's share is 4 per plane the kernel folds (the planes of the first pass)
         return (4.0 * n_fold if interleaved else 4.0 * (level + 2)) + 8.0 * 3   # + RMW of the three thresholded planes
     if kernel.startswith("wt_hist"):
-        # the launches of a select share the one compulsory read (two when the first level rides
-        # on the transform's first pass, three otherwise)
-        return 4.0 / (2.0 if interleaved else 3.0)
+        # the launches of a select share the one compulsory read (at the bench's sizes two passes over
+        # the plane: a windowed first one - riding on the transform's first pass or on its own - and
+        # the refinement)
+        return 4.0 / 2.0
     if kernel.startswith("wt_signif"):
         return 8.0
     if kernel.startswith("wt_bilateral"):

@@ -305,6 +305,62 @@ def test_float64_denoise_interleaved_equals_the_plain_sequence(L):
     assert float(np.abs(got - ref).max()) <= 1e-11 * float(np.abs(img).max())
 
 
+def test_standalone_select_places_its_window_from_a_sample_of_the_plane(L):
+    """Round 4 (late): a plane no fused pass has histogrammed - bilateral / recursive transforms, an edited
+    plane, wt_abs_median on any plane - gets the same 21-bit window, placed from a 4096-sample of the
+    plane itself: TWO passes over the plane instead of three.  Exact median on ordinary, quantised,
+    constant and heavy-tailed planes, even / odd counts, option on and off; a plane whose sample
+    mispredicts (non-zero only at the sample points / zero only there) falls back to the three passes;
+    small planes keep them."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(23)
+    H, W = 1031, 1100                                        # odd count: the median is one element
+    ys = ((2 * np.arange(64) + 1) * H) >> 7
+    xs = ((2 * np.arange(64) + 1) * W) >> 7
+    g = rng.standard_normal((H, W)).astype(np.float32)
+    spikes = np.zeros((H, W), np.float32)
+    spikes[ys[:, None], xs[None, :]] = 7.0
+    holes = g.copy()
+    holes[ys[:, None], xs[None, :]] = 0.0
+    cases = [("gauss", g, 2), ("offset", g * 1e-3 + 40, 2), ("quantised", np.round(g * 3) / 3, 2),
+             ("constant", np.full((H, W), 2.5, np.float32), 2), ("cauchy", rng.standard_cauchy((H, W)).astype(np.float32), 2),
+             ("spikes", spikes, 5), ("holes", holes, 5)]    # 5: the windowed pass and its refinement in vain, then three
+    p = L.Plan(ctx, H, W, L.B3SPLINE, 1)
+    try:
+        for name, a, n_hist in cases:
+            p.upload(0, a)
+            want = np.median(np.abs(a))
+            for window in (1, 0):
+                L.set_option("hist_window", window)
+                try:
+                    ctx.profile(True)
+                    ctx.profile_reset()
+                    got = p.abs_median(0)
+                    ent = ctx.profile_entries()
+                    ctx.profile(False)
+                finally:
+                    L.set_option("hist_window", 1)
+                assert got == want, (name, window, got, want)
+                nh = ent.get("wt_hist_kernel", (0, 0))[0]
+                assert nh == (n_hist if window else 3), (name, window, ent)
+    finally:
+        p.close()
+    # even count (two middle elements), and a plane below the size threshold
+    for shape, nh_want in (((1024, 1024), 2), ((512, 600), 3)):
+        a = rng.standard_normal(shape).astype(np.float32)
+        p = L.Plan(ctx, shape[0], shape[1], L.TRIANGLE, 1)
+        try:
+            p.upload(0, a)
+            ctx.profile(True)
+            ctx.profile_reset()
+            got = p.abs_median(0)
+            ent = ctx.profile_entries()
+            ctx.profile(False)
+            assert got == np.median(np.abs(a)) and ent.get("wt_hist_kernel", (0, 0))[0] == nh_want, (shape, ent)
+        finally:
+            p.close()
+
+
 def test_float64_cfg3_at_full_size_properties(L):
     """BASELINE configs[2] on the float64 engine at its full size (8192 x 8192, Triangle, 8 scales,
     denoise([5, 3, 2]) soft; bench.py's `float64_cfg3` entry) through size-independent properties: the

@@ -1174,11 +1174,13 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
     const int X = (g.W + 3) / 4;                 // float4 columns
     const int gx = gx_override ? gx_override : (X + 63) / 64;
     const int n_max = (g.nrows + d - 1) / d;     // longest chain
-    const int64_t want_items = std::max<int64_t>(1, (int64_t)524288 / std::max(1, gx * 64));
+    static const int64_t lanes_env = getenv("WT_CHAIN_LANES") ? atoll(getenv("WT_CHAIN_LANES")) : 0;   // experiments
+    static const int smax_env = getenv("WT_CHAIN_SMAX") ? atoi(getenv("WT_CHAIN_SMAX")) : 0;
+    const int64_t want_items = std::max<int64_t>(1, (lanes_env > 0 ? lanes_env : (int64_t)524288) / std::max(1, gx * 64));
     int chunks_target = (int)std::max<int64_t>(1, want_items / std::min(d, g.nrows));
     int S = (n_max + chunks_target - 1) / chunks_target;
     S = std::max(S, std::min(n_max, 8));
-    S = std::min(S, 64);
+    S = std::min(S, smax_env > 0 ? smax_env : 64);
     int chunks = (n_max + S - 1) / S;
     int64_t items = (int64_t)d * chunks;
     while ((items + 3) / 4 > 65528) {             // grid.y limit
@@ -2612,8 +2614,31 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
         res_st = *(const WtSelectState *)((const char *)c->h_pinned + 64);
         return 0;
     };
-    WT_TRY(run(pre, windowed));
-    if (windowed && res_st.failed == 3) WT_TRY(run(false, false));    // the window missed the median: the ordinary three passes
+    // No riding histogram (a plane of a bilateral / recursive / generic transform, or an edited one):
+    // the same window, placed from a 4096-sample of the plane itself, lets ONE pass bin the top 21 bits
+    // - two passes over the plane instead of three.
+    bool window = windowed;
+    if (!pre && g_opt_hist_window && p->nranks == 1 && N >= ((int64_t)1 << 20) && p->g.H >= 64 && p->g.W >= 64) {
+        WT_HIP(hipMemsetAsync(c->d_hist, 0, WT_HIST_BINS * sizeof(uint32_t), c->stream));
+        uint32_t *keys = (uint32_t *)c->d_partials;          // 16 KB of the reduction scratch (stream-ordered use)
+        {
+            ProfScope ps(c, "wt_median_window_kernel");
+            hipLaunchKernelGGL(wt_plane_sample_kernel<float>, dim3(64), dim3(64), 0, c->stream, (const float *)b, p->g.nrows, p->g.W, p->g.P, keys);
+            hipLaunchKernelGGL(wt_median_window_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)keys, hist_base_word(c));
+        }
+        {
+            ProfScope ps(c, "wt_hist_kernel");
+            const int X4 = (p->g.W + 3) / 4, nchunk = (X4 + 256 * WT_HIST_UNROLL - 1) / (256 * WT_HIST_UNROLL);
+            const int64_t nitems = (int64_t)p->g.nrows * nchunk;
+            hipLaunchKernelGGL((wt_hist_kernel<4, true>), dim3((unsigned)std::min<int64_t>(nitems, 4 * c->num_cus)), dim3(256), 0, c->stream,
+                               (const float *)b, p->g.nrows, p->g.P / 4, p->g.W, 0u, (const WtSelectState *)st, 10, 0x7ffu, c->d_hist,
+                               (const uint32_t *)hist_base_word(c));
+        }
+        WT_HIP(hipGetLastError());
+        window = true;
+    }
+    WT_TRY(run(pre || window, window));
+    if (window && res_st.failed == 3) WT_TRY(run(false, false));      // the window missed the median: the ordinary three passes
     if (res_st.failed) WT_FAIL("wt_abs_median: rank %lld not found (NaN input?)", (long long)klo);
     const int64_t cum_le = (int64_t)res_st.cum_le;           // elements <= v_lo
     const uint32_t ulo = res_st.prefix;

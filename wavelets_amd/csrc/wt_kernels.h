@@ -1617,6 +1617,17 @@ __global__ __launch_bounds__(64) void wt_median_sample_kernel(const T *in, Geo g
     keys[i] = wt_window_key(v[hw][hw] - acc);
 }
 
+// the same sample taken from a PLANE that already holds the coefficients (select without a riding
+// histogram: bilateral / recursive / generic transforms, Coefficients built from arrays)
+template <typename T>
+__global__ __launch_bounds__(64) void wt_plane_sample_kernel(const T *plane, int nrows, int W, int P, uint32_t *keys)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int sy = i >> 6, sx = i & 63;
+    const int y = (int)(((int64_t)(2 * sy + 1) * nrows) >> 7), x = (int)(((int64_t)(2 * sx + 1) * W) >> 7);
+    keys[i] = wt_window_key(plane[(int64_t)y * P + x]);
+}
+
 // median of the 4096 window keys (<= 22 bits: two levels of 11) -> *base = first key of the window
 __global__ __launch_bounds__(1024) void wt_median_window_kernel(const uint32_t *keys, uint32_t *base)
 {
@@ -1720,13 +1731,18 @@ __global__ __launch_bounds__(256) void wt_select_window_step_kernel(uint32_t *hi
 //  * work items are (row, chunk of 256 * UNROLL float4) pairs; the loads of the NEXT item are
 //    issued before the atomics of the current one (8 loads of 16 B in flight per thread instead of
 //    4 with a full drain per iteration: the read stream was latency-bound at 4.7 TB/s).
-template <int REP>
+//  * WIN (round 4, the select of a plane no fused pass has histogrammed): every element is binned into
+//    the WINDOW of 21-bit keys that starts at *wbase (bins as in the riding histogram of wt_fused_kernel:
+//    0 = below, 1 .. 2046 = key - base, 2047 = above; wt_select_window_step_kernel reads them) - the
+//    first TWO levels of the select in one pass over the plane.
+template <int REP, bool WIN = false>
 __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows, int P4, int W,
                                                       uint32_t prefix_mask, const WtSelectState *st,
                                                       int shift, uint32_t bin_mask,
-                                                      uint32_t *hist)
+                                                      uint32_t *hist, const uint32_t *wbase = nullptr)
 {
-    const uint32_t prefix_val = st->prefix & prefix_mask;      // wave-uniform scalar load
+    const uint32_t prefix_val = WIN ? 0u : st->prefix & prefix_mask;      // wave-uniform scalar load
+    const int win_lo = WIN ? (int)*wbase : 0;
     __shared__ uint32_t lh[WT_HIST_BINS * REP];
     for (int i = threadIdx.x; i < WT_HIST_BINS * REP; i += 256) lh[i] = 0;
     __syncthreads();
@@ -1756,8 +1772,12 @@ __global__ __launch_bounds__(256) void wt_hist_kernel(const float *p, int nrows,
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t w = b[k] & 0x7fffffffu;
-                if (k < nv && (w & prefix_mask) == prefix_val)
-                    atomicAdd(&lh[((w >> shift) & bin_mask) * REP + rep], 1u);
+                if constexpr (WIN) {
+                    if (k < nv) atomicAdd(&lh[min(max((int)(w >> 10) - win_lo, 0), WT_HIST_BINS - 1) * REP + rep], 1u);
+                } else {
+                    if (k < nv && (w & prefix_mask) == prefix_val)
+                        atomicAdd(&lh[((w >> shift) & bin_mask) * REP + rep], 1u);
+                }
             }
         }
     };
