@@ -71,7 +71,7 @@ def case_denoise(rng, f64):
             if sg != 0 and noise != 0:
                 ambiguous |= np.abs(np.abs(c.data[scl]) - sg * noise * c.sigma_e[scl]) <= amb
         bad = (np.abs(got - want) > tol) & ~ambiguous
-        ok = not bad.any() and ambiguous.mean() < 0.2
+        ok = not bad.any() and ambiguous.mean() < 0.5       # (heavy tails: the band scales with max|a|)
         if not ok:
             return tag + f": {int(bad.sum())} pixels differ away from a threshold ({100 * ambiguous.mean():.2f} % ambiguous)"
     else:
