@@ -388,17 +388,18 @@ def main():
     if world > 1:
         from wavelets_amd.launch import Watchdog
 
-        def on_expire():
-            sys.stderr.write(f"[bench rank {rank}] time limit of {args.time_limit:.0f} s exceeded\n")
+        def on_expire(what=None):
+            what = what or f"time limit of {args.time_limit:.0f} s exceeded"
+            sys.stderr.write(f"[bench rank {rank}] {what}\n")
             if rank == 0:
                 if state["result"] is not None:
-                    state["result"]["time_limit_hit"] = (f"{args.time_limit:.0f} s: this is the last complete "
+                    state["result"]["time_limit_hit"] = (f"{what}: this is the last complete "
                                                          "measurement; a later phase of the run did not finish")
                     state["result"].pop("_brief", None)
                     emit(json.dumps(state["result"]))
                 else:
-                    emit(json.dumps({"error": f"time limit of {args.time_limit:.0f} s exceeded before the first "
-                                              "complete measurement", "n_gpus": world, "launcher": args.launcher}))
+                    emit(json.dumps({"error": f"{what} before the first complete measurement", "n_gpus": world,
+                                     "launcher": args.launcher}))
         # (a little ahead of the launcher's own limit, so that the stored result gets out; a rank that
         #  has finished the main measurement leaves with code 0)
         dog = Watchdog(max(5.0, args.time_limit - 20.0), on_expire,
@@ -887,6 +888,12 @@ def main():
         # plain hipMalloc: measured AFTER the line above is safe, guarded by the same ramp check on the
         # mapped planes over the real transport; the faster placement becomes the reported value.
         if not args.no_scatter_ab and not args.no_exchange:
+            # (its own, short limit: mapped planes have never met a real xGMI transport - if this phase
+            #  stalls, the stored line goes out after two and a half minutes, not at the run's limit)
+            from wavelets_amd.launch import Watchdog
+            ab_limit = min(150.0, max(5.0, args.time_limit / 4))
+            dog_ab = Watchdog(ab_limit, lambda: on_expire(f"the scattered-planes A/B did not finish within {ab_limit:.0f} s"),
+                              code=lambda: 0)
             try:
                 _lib.set_option("scatter_strips", 1)
                 plan2 = make_plan()
@@ -916,6 +923,7 @@ def main():
             except Exception as e:
                 planes_ab["scattered_error"] = repr(e)
             finally:
+                dog_ab.cancel()
                 _lib.set_option("scatter_strips", 0)
         _lib.set_option("overlap", 1)
         return out
