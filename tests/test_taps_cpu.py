@@ -196,3 +196,24 @@ def test_extended_frame_reproduces_the_circular_products_of_the_image(shape, ksh
     corr = np.fft.ifft2(X * F.conj()).real[hy:hy + H, hx:hx + W]
     np.testing.assert_allclose(conv, want_conv, atol=1e-11)
     np.testing.assert_allclose(corr, want_corr, atol=1e-11)
+
+
+def test_extension_windows_tile_the_extended_image_exactly_once():
+    """utils._ext_windows: the device copies that extend an H x W image periodically by (hy, hx) must write
+    every element of the (H + 2 hy) x (W + 2 hx) rectangle exactly once, each from the pixel
+    ((y - hy) mod H, (x - hx) mod W) - for halos from 0 up to the full image size."""
+    from wavelets_amd import utils as WU
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        hy, hx = int(rng.integers(0, H + 1)), int(rng.integers(0, W + 1))
+        src = np.arange(H * W).reshape(H, W)
+        dst = np.full((H + 2 * hy, W + 2 * hx), -1)
+        hits = np.zeros_like(dst)
+        for sy, sx, dy, dx, nr, nc in WU._ext_windows(H, W, hy, hx):
+            assert nr > 0 and nc > 0 and sy >= 0 and sx >= 0 and sy + nr <= H and sx + nc <= W
+            dst[dy:dy + nr, dx:dx + nc] = src[sy:sy + nr, sx:sx + nc]
+            hits[dy:dy + nr, dx:dx + nc] += 1
+        assert (hits == 1).all()
+        yy, xx = np.mgrid[0:H + 2 * hy, 0:W + 2 * hx]
+        assert np.array_equal(dst, src[(yy - hy) % H, (xx - hx) % W])
