@@ -2098,7 +2098,9 @@ extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, 
     ChainArgs a{};
     a.in = c; a.out_c = t; a.out_w = nullptr; a.aux = nullptr;
     a.noise = nz; a.gamma = gm; a.tau = tau; a.factor = factor; a.soft = soft; a.whiten = 1;
-    WT_TRY(launch_chain_args<MODE_WOW>(p, a, s, "wt_chain_kernel<wow>"));
+    // (no per-pixel noise map, no gamma accumulator: the instantiation without conditional loads)
+    if (!nz && !gm) WT_TRY(launch_chain_args<MODE_WOW_PLAIN>(p, a, s, "wt_chain_kernel<wow>"));
+    else WT_TRY(launch_chain_args<MODE_WOW>(p, a, s, "wt_chain_kernel<wow>"));
     std::swap(p->coef[plane], p->scratch[3]);     // both are "first margin row" pointers
     return 0;
 }
