@@ -2100,6 +2100,7 @@ extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, 
     a.noise = nz; a.gamma = gm; a.tau = tau; a.factor = factor; a.soft = soft; a.whiten = 1;
     // (no per-pixel noise map, no gamma accumulator: the instantiation without conditional loads)
     if (!nz && !gm) WT_TRY(launch_chain_args<MODE_WOW_PLAIN>(p, a, s, "wt_chain_kernel<wow>"));
+    else if (!nz) WT_TRY(launch_chain_args<MODE_WOW_GAMMA>(p, a, s, "wt_chain_kernel<wow>"));
     else WT_TRY(launch_chain_args<MODE_WOW>(p, a, s, "wt_chain_kernel<wow>"));
     std::swap(p->coef[plane], p->scratch[3]);     // both are "first margin row" pointers
     return 0;

@@ -125,7 +125,10 @@ __device__ __forceinline__ float wt_wow_point(float c, float power, bool has_pow
 // the row loop make the compiler's vmcnt bookkeeping inexact, every use of a (possibly) loaded value
 // then waits for ALL outstanding memory operations - the prefetched rows and the row just stored
 // included (13 % of the lattice kernel, 3 % of the row kernel at 8192^2).
-enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3, MODE_WOW = 4, MODE_WOW_PLAIN = 5 };
+// MODE_WOW_GAMMA: scalar noise WITH the gamma accumulator (wow(h > 0)): its row is read with one
+// unconditional 16-byte load per lane (clamped column, like the input rows) instead of guarded scalars.
+enum { MODE_SMOOTH = 0, MODE_SMOOTH_SQ = 1, MODE_DECOMP = 2, MODE_VAR = 3, MODE_WOW = 4, MODE_WOW_PLAIN = 5, MODE_WOW_GAMMA = 6 };
+#define WT_IS_WOW(M) ((M) == MODE_WOW || (M) == MODE_WOW_PLAIN || (M) == MODE_WOW_GAMMA)
 
 // Raw operands of the horizontal K-tap filter of one row at the thread's 4 pixels:
 //   d >= 4: K float4 at x + (j-hw) d      d < 4: 3 float4 covering x-4 .. x+7
@@ -158,7 +161,7 @@ __device__ __forceinline__ void wt_hrow_filter(const float4 *raw, int d, float4 
             float4 v = raw[j];
             if (j == hw) cen = v;
             float4 vv = f4_mul(v, v);
-            if (MODE == MODE_SMOOTH_SQ || MODE == MODE_WOW || MODE == MODE_WOW_PLAIN) v = vv;
+            if (MODE == MODE_SMOOTH_SQ || WT_IS_WOW(MODE)) v = vv;
             h = (j == 0) ? f4_scale(wt_tap<K>(0), v) : f4_fma(wt_tap<K>(j), v, h);
             if (MODE == MODE_VAR)
                 h2 = (j == 0) ? f4_scale(wt_tap<K>(0), vv) : f4_fma(wt_tap<K>(j), vv, h2);
@@ -171,7 +174,7 @@ __device__ __forceinline__ void wt_hrow_filter(const float4 *raw, int d, float4 
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             e2[i] = e[i] * e[i];
-            if (MODE == MODE_SMOOTH_SQ || MODE == MODE_WOW || MODE == MODE_WOW_PLAIN) e[i] = e2[i];
+            if (MODE == MODE_SMOOTH_SQ || WT_IS_WOW(MODE)) e[i] = e2[i];
         }
         cen = C;
         float o[4], o2[4];
@@ -275,12 +278,17 @@ struct WtVert {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = wt_var_point(pp[k], mm[k], a.f1, a.f2, a.take_sqrt);
             wt_store4(a.out_c + off, x, g.P, make_float4(v[0], v[1], v[2], v[3]), a.nt, lane_ok);
-        } else if (MODE == MODE_WOW || MODE == MODE_WOW_PLAIN) {
+        } else if (WT_IS_WOW(MODE)) {
             // fused wow update: o = conv_s(c^2) (local power), cen[0] = c at this row; result
             // goes to a different plane (the host swaps plane pointers afterwards)
             const float cc[4] = {cen[0].x, cen[0].y, cen[0].z, cen[0].w};
             const float pw[4] = {o.x, o.y, o.z, o.w};
             float nn[4] = {1.f, 1.f, 1.f, 1.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, r4[4];
+            if constexpr (MODE == MODE_WOW_GAMMA) {
+                // (columns clamped into the row's pitch: lanes that store nothing read something harmless)
+                const float4 g4 = *reinterpret_cast<const float4 *>(a.gamma + off + min(max(x, 0), g.P - 4));
+                gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
+            }
             if constexpr (MODE == MODE_WOW) {
                 const bool full = x + 3 < g.W;
                 if (a.noise && lane_ok) {
@@ -300,6 +308,7 @@ struct WtVert {
             if constexpr (MODE == MODE_WOW) {
                 if (a.gamma) wt_store4(a.gamma + off, x, g.P, make_float4(gg[0], gg[1], gg[2], gg[3]), a.nt, lane_ok);
             }
+            if constexpr (MODE == MODE_WOW_GAMMA) wt_store4(a.gamma + off, x, g.P, make_float4(gg[0], gg[1], gg[2], gg[3]), a.nt, lane_ok);
         } else {
             wt_store4(a.out_c + off, x, g.P, o, a.nt, lane_ok);
             if (MODE == MODE_DECOMP && a.out_w)
