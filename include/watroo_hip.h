@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 5
+#define WT_ABI_VERSION 6
 
 typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
 typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */
@@ -402,6 +402,19 @@ int wt64_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int max_level, const dou
 int wt64_plan_destroy(wt_plan64 *plan);
 int wt64_plan_set_border(wt_plan64 *plan, int border);
 int wt64_upload(wt_plan64 *plan, int plane, const double *host, int64_t host_pitch);
+/* plane <- (double) of an INTEGER image, widened on the device: the reference promotes integer input to
+ * float64 on the host before anything else (watroo/wavelets.py:297, 319-320).  host: nrows rows of W
+ * native-endian integers of type `dtype`, host_pitch_bytes apart.  Exact up to 2^53, round-to-nearest-even
+ * beyond (numpy's astype). */
+#define WT_INT8 1
+#define WT_UINT8 2
+#define WT_INT16 3
+#define WT_UINT16 4
+#define WT_INT32 5
+#define WT_UINT32 6
+#define WT_INT64 7
+#define WT_UINT64 8
+int wt64_upload_int(wt_plan64 *plan, int plane, const void *host, int64_t host_pitch_bytes, int dtype);
 int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
 /* AtrousTransform.atrous_standard (watroo/wavelets.py:408-444).  Images (depth 0) under the
  * symmetric border with the taps of a built-in family run the FUSED multi-scale passes of the

@@ -776,3 +776,65 @@ def test_extended_fft_beats_the_direct_form_on_a_3072_square_image(L):
         ext.close()
     finally:
         p.close()
+
+
+@pytest.mark.parametrize("dtype", [np.bool_, np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64])
+def test_integer_images_are_widened_on_the_device_exactly(L, dtype):
+    """Round 4 (late): the reference promotes integer images to float64 on the host (ref wavelets.py:297,
+    319-320); here they cross PCIe as integers and wt64_upload_int widens them on the device.  The plane
+    must hold exactly numpy's astype(float64) - including 64-bit values beyond 2^53 (round to nearest
+    even) - for contiguous and row-strided sources; non-native byte order takes the host path."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(3)
+    H, W = 37, 1030
+    if dtype is np.bool_:
+        a = rng.random((H, W)) < 0.5
+    else:
+        info = np.iinfo(dtype)
+        a = rng.integers(info.min, info.max, (H, W), dtype=dtype, endpoint=True)
+        a[0, :4] = [info.min, info.max, info.max - 1 if info.max > 1 else 0, 0]
+    wide = np.zeros((H, W + 7), dtype=a.dtype)
+    wide[:, :W] = a
+    p = L.Plan64(ctx, H, W, (0.25, 0.5, 0.25), 1)
+    try:
+        for src in (a, wide[:, :W]):                         # contiguous rows, and rows 7 elements apart
+            p.fill(L.PLANE_INPUT, -1.0)
+            p.upload(L.PLANE_INPUT, src)
+            got = p.download(L.PLANE_INPUT)
+            assert np.array_equal(got, a.astype(np.float64)), dtype
+        if a.dtype.itemsize > 1:
+            swapped = a.astype(a.dtype.newbyteorder())       # big-endian data: host promotion, same values
+            p.upload(L.PLANE_INPUT, swapped)
+            assert np.array_equal(p.download(L.PLANE_INPUT), a.astype(np.float64))
+    finally:
+        p.close()
+
+
+def test_integer_image_through_the_api_equals_its_float64_promotion(L):
+    """AtrousTransform / denoise / wow on an int16 image (a FITS frame) = the same on image.astype(float64),
+    bit for bit, float64 results - and the integer really travelled as an integer."""
+    import wavelets_amd as WA
+    rng = np.random.default_rng(4)
+    img = (1000 + 80 * rng.standard_normal((600, 700))).astype(np.int16)
+    seen = []
+    keep = L.Plan64.upload
+
+    def spy(self, plane, host):
+        seen.append(np.asarray(host).dtype)
+        return keep(self, plane, host)
+
+    L.Plan64.upload = spy
+    try:
+        c = WA.AtrousTransform(WA.B3spline)(img, 4)
+        d = WA.denoise(img, [5, 3, 2], WA.Triangle)
+        w, _ = WA.wow(img)
+    finally:
+        L.Plan64.upload = keep
+    assert seen and all(t == np.int16 for t in seen), seen
+    f = img.astype(np.float64)
+    c64 = WA.AtrousTransform(WA.B3spline)(f, 4)
+    assert c.data.dtype == np.float64 and np.array_equal(np.asarray(c.data), np.asarray(c64.data))
+    d64 = WA.denoise(f, [5, 3, 2], WA.Triangle)
+    assert d.dtype == np.float64 and np.array_equal(d, d64)
+    w64, _ = WA.wow(f)
+    assert w.dtype == np.float64 and np.array_equal(w, w64)

@@ -132,6 +132,7 @@ SIGNATURES = {
     "wt64_plan_destroy": (_c.c_int, [_vp]),
     "wt64_plan_set_border": (_c.c_int, [_vp, _c.c_int]),
     "wt64_upload": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double), _i64]),
+    "wt64_upload_int": (_c.c_int, [_vp, _c.c_int, _vp, _i64, _c.c_int]),
     "wt64_download": (_c.c_int, [_vp, _c.c_int, _c.POINTER(_c.c_double), _i64]),
     "wt64_decompose": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_decompose_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
@@ -197,7 +198,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = res, args
-            if L.wt_abi_version() != 5:
+            if L.wt_abi_version() != 6:
                 raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
             _lib = L
     return _lib
@@ -785,7 +786,18 @@ class Plan64:
     def shape(self):
         return (self.H, self.W)
 
+    # numpy integer kinds the device widens itself (wt64_upload_int); bool travels as uint8
+    _INT_CODES = {"b1": 2, "i1": 1, "u1": 2, "i2": 3, "u2": 4, "i4": 5, "u4": 6, "i8": 7, "u8": 8}
+
     def upload(self, plane, host):
+        """plane <- host image as float64.  Integer images (what the reference promotes to float64 first,
+        ref wavelets.py:297, 319-320) cross PCIe as they are and are widened on the device."""
+        h = np.asarray(host)
+        code = self._INT_CODES.get(h.dtype.str[1:]) if h.dtype.kind in "iub" and h.dtype.isnative else None
+        if (code is not None and h.ndim == 2 and h.shape == self.shape and h.size
+                and h.strides[1] == h.itemsize and h.strides[0] >= h.shape[1] * h.itemsize):
+            check(load().wt64_upload_int(self._h, plane, _vp(h.ctypes.data), h.strides[0], code))
+            return
         host = np.ascontiguousarray(host, dtype=np.float64)
         if host.shape != self.shape:
             raise ValueError(f"image shape {host.shape} != plan shape {self.shape}")

@@ -184,6 +184,8 @@ struct wt_plan64 {
     double *tmp[3] = {nullptr, nullptr, nullptr};   // private temporaries of the filters (no plane id)
     double *psf = nullptr;                          // PSF taps of wt64_filter2d
     size_t psf_cap = 0;
+    void *istage = nullptr;                         // integer image on its way into a plane (wt64_upload_int)
+    size_t istage_cap = 0;
     std::vector<void *> allocs;
     WtFftState fft;                                 // as wt_plan::fft (buffers in allocs)
 };

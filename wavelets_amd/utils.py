@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, acquire_plan64, default_context, release_plan
-from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _family_of, _needs_generic,
+from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _f64_source, _family_of, _needs_generic,
                        _result_dtype, _taps_f64, _to_f32_image,
                        generalized_anscombe,
                        PLANE_INPUT)
@@ -115,7 +115,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
         # float64 images: the same interleaving as float32 below on the float64 engine - fused passes,
         # the first one histogramming |w_0|, thresholds + start of the sum in one kernel
         # (wt64_denoise_sum), the later passes carrying the sum
-        img = np.ascontiguousarray(data, dtype=np.float64)
+        img = _f64_source(data)           # (integer images are widened on the device)
         level = len(weights)
         transform = AtrousTransform(scaling_function)
         sf = scaling_function(2)
@@ -436,7 +436,7 @@ def richardson_lucy(data, psf,
     # uniform_init, where the reference itself keeps the estimate in float32 (ref:233)
     f64 = _result_dtype(data) == np.float64 and not uniform_init and np.ndim(data) == 2
     ft = np.float64 if f64 else np.float32
-    img = np.ascontiguousarray(data, dtype=np.float64) if f64 else _to_f32_image(data, "data")
+    img = _f64_source(data) if f64 else _to_f32_image(data, "data")
     psf = np.ascontiguousarray(psf, dtype=ft)
     if psf.ndim != 2:
         raise ValueError("psf must be 2-D")

@@ -143,6 +143,16 @@ _BUILTIN_TAPS = {_lib.TRIANGLE: np.array([1 / 4, 1 / 2, 1 / 4]),
                  _lib.B3SPLINE: np.array([1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16])}
 
 
+def _f64_source(arr):
+    """The array a float64 plan uploads: native integer images stay as they are (Plan64.upload widens
+    them on the device, a quarter or less of the bytes over PCIe and no host astype - the reference's
+    promotion, ref:297, 319-320, happens there); everything else becomes contiguous float64."""
+    a = np.asarray(arr)
+    if a.dtype.kind in "iub" and a.dtype.isnative and a.ndim == 2:
+        return np.ascontiguousarray(a)
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
 def _family_of(scaling_function, ndim=2):
     """Engine family of a scaling-function class or instance: the built-in enum, or - for a
     user-defined AbstractScalingFunction subclass (ref:152-229) - the tuple of its 1-D taps,
@@ -370,7 +380,7 @@ def convolution(arr, scaling_function, s=0, output=None):
         output[...] = res
         return output
     if _is_f64(arr) and np.ndim(arr) in (1, 2, 3):
-        a = np.ascontiguousarray(arr, dtype=np.float64)
+        a = _f64_source(arr)
         plan = acquire_plan64(default_context(), *_plane_shape(a.shape),
                               _taps_f64(scaling_function, a.ndim), 0)
         try:
@@ -416,7 +426,7 @@ def convolution(arr, scaling_function, s=0, output=None):
 def sdev_loc(image, scaling_function, s=0, variance=False):
     """Local standard deviation (or variance) at scale ``s`` (ref:24-32)."""
     if _is_f64(image) and np.ndim(image) == 2:
-        a = np.ascontiguousarray(image, dtype=np.float64)
+        a = _f64_source(image)
         plan = acquire_plan64(default_context(), a.shape[0], a.shape[1], _taps_f64(scaling_function, 2), 0)
         try:
             plan.upload(PLANE_INPUT, a)
@@ -513,7 +523,7 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
             return res
         output[...] = res
         return output
-    img = np.ascontiguousarray(image, dtype=np.float64) if f64 else _to_f32_image(image, "image")
+    img = _f64_source(image) if f64 else _to_f32_image(image, "image")
     if f64:
         if not isinstance(fam, tuple):                   # built-in family: its (symmetric) taps
             fam = _taps_f64(Triangle if fam == _lib.TRIANGLE else B3spline, 2)
@@ -525,7 +535,7 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
         if bilateral_variance is None:
             plan.smooth(PLANE_INPUT, PLANE_OUT, s)
         else:
-            var = np.broadcast_to(np.asarray(bilateral_variance, img.dtype), img.shape)
+            var = np.broadcast_to(np.asarray(bilateral_variance, np.float64 if f64 else np.float32), img.shape)
             plan.upload(_TMP_PLANE, var)
             plan.bilateral_conv(PLANE_INPUT, _TMP_PLANE, PLANE_OUT, s, flags)
         res = plan.download(PLANE_OUT)
@@ -1036,7 +1046,7 @@ class AtrousTransform:
         them); otherwise one generic pass per scale: signals as 1 x N images under the 'mirror'
         border of the 1-D branch (ref:65-69), cubes as (Z*Y) x X images (ref:46-63); with
         bilateral filtering the per-scale sequence of ref:433-442."""
-        a = np.ascontiguousarray(arr, dtype=np.float64)
+        a = _f64_source(arr)
         nd = a.ndim
         scaling_function = self.scaling_function_class(nd)
         plan = acquire_plan64(default_context(), *_plane_shape(a.shape), _taps_f64(scaling_function, nd), level)
