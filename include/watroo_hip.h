@@ -402,10 +402,11 @@ int wt64_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int max_level, const dou
 int wt64_plan_destroy(wt_plan64 *plan);
 int wt64_plan_set_border(wt_plan64 *plan, int border);
 int wt64_upload(wt_plan64 *plan, int plane, const double *host, int64_t host_pitch);
-/* plane <- (double) of an INTEGER image, widened on the device: the reference promotes integer input to
- * float64 on the host before anything else (watroo/wavelets.py:297, 319-320).  host: nrows rows of W
- * native-endian integers of type `dtype`, host_pitch_bytes apart.  Exact up to 2^53, round-to-nearest-even
- * beyond (numpy's astype). */
+/* plane <- (double) of an image of another element type, widened on the device: the reference recasts
+ * integer and big-endian input to float64 on the host before anything else (watroo/wavelets.py:297,
+ * 319-320: int16 .. int64, '>f4', '>f8' - what a FITS file holds).  host: nrows rows of W elements of type
+ * `dtype`, host_pitch_bytes apart; dtype | WT_BYTESWAPPED: the elements are in the other byte order.
+ * Integers are exact up to 2^53 and round to nearest even beyond (numpy's astype). */
 #define WT_INT8 1
 #define WT_UINT8 2
 #define WT_INT16 3
@@ -414,6 +415,9 @@ int wt64_upload(wt_plan64 *plan, int plane, const double *host, int64_t host_pit
 #define WT_UINT32 6
 #define WT_INT64 7
 #define WT_UINT64 8
+#define WT_FLOAT32 9
+#define WT_FLOAT64 10
+#define WT_BYTESWAPPED 16
 int wt64_upload_int(wt_plan64 *plan, int plane, const void *host, int64_t host_pitch_bytes, int dtype);
 int wt64_download(wt_plan64 *plan, int plane, double *host, int64_t host_pitch);
 /* AtrousTransform.atrous_standard (watroo/wavelets.py:408-444).  Images (depth 0) under the

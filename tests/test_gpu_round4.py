@@ -778,34 +778,37 @@ def test_extended_fft_beats_the_direct_form_on_a_3072_square_image(L):
         p.close()
 
 
-@pytest.mark.parametrize("dtype", [np.bool_, np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64])
-def test_integer_images_are_widened_on_the_device_exactly(L, dtype):
-    """Round 4 (late): the reference promotes integer images to float64 on the host (ref wavelets.py:297,
-    319-320); here they cross PCIe as integers and wt64_upload_int widens them on the device.  The plane
-    must hold exactly numpy's astype(float64) - including 64-bit values beyond 2^53 (round to nearest
-    even) - for contiguous and row-strided sources; non-native byte order takes the host path."""
+@pytest.mark.parametrize("dtype", ["?", "i1", "u1", "<i2", "<u2", "<i4", "<u4", "<i8", "<u8",
+                                   ">i2", ">u2", ">i4", ">u4", ">i8", ">u8", ">f4", ">f8", "<f4"])
+def test_integer_and_big_endian_images_are_widened_on_the_device_exactly(L, dtype):
+    """Round 4 (late): the reference recasts integer and big-endian images to float64 on the host (ref
+    wavelets.py:297, 319-320); here they cross PCIe as they are and wt64_upload_int widens (and byte-swaps)
+    them on the device.  The plane must hold exactly numpy's astype(float64) - including 64-bit integers
+    beyond 2^53 (round to nearest even) and float specials - for contiguous and row-strided sources."""
     ctx = L.default_context()
     rng = np.random.default_rng(3)
     H, W = 37, 1030
-    if dtype is np.bool_:
+    dt = np.dtype(dtype)
+    if dt.kind == "b":
         a = rng.random((H, W)) < 0.5
+    elif dt.kind == "f":
+        a = (rng.standard_normal((H, W)) * 10.0 ** rng.integers(-20, 20, (H, W))).astype(dt)
+        a[0, :5] = [0.0, -0.0, np.inf, -np.inf, np.nan]
     else:
-        info = np.iinfo(dtype)
-        a = rng.integers(info.min, info.max, (H, W), dtype=dtype, endpoint=True)
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, (H, W), dtype=dt.newbyteorder("="), endpoint=True).astype(dt)
         a[0, :4] = [info.min, info.max, info.max - 1 if info.max > 1 else 0, 0]
-    wide = np.zeros((H, W + 7), dtype=a.dtype)
+    assert a.dtype == dt and L.Plan64.device_widens(dt) == (dt.str != "<f4")
+    wide = np.zeros((H, W + 7), dtype=dt)
     wide[:, :W] = a
+    want = a.astype(np.float64)
     p = L.Plan64(ctx, H, W, (0.25, 0.5, 0.25), 1)
     try:
         for src in (a, wide[:, :W]):                         # contiguous rows, and rows 7 elements apart
             p.fill(L.PLANE_INPUT, -1.0)
             p.upload(L.PLANE_INPUT, src)
             got = p.download(L.PLANE_INPUT)
-            assert np.array_equal(got, a.astype(np.float64)), dtype
-        if a.dtype.itemsize > 1:
-            swapped = a.astype(a.dtype.newbyteorder())       # big-endian data: host promotion, same values
-            p.upload(L.PLANE_INPUT, swapped)
-            assert np.array_equal(p.download(L.PLANE_INPUT), a.astype(np.float64))
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), dtype
     finally:
         p.close()
 
@@ -838,3 +841,13 @@ def test_integer_image_through_the_api_equals_its_float64_promotion(L):
     assert d.dtype == np.float64 and np.array_equal(d, d64)
     w64, _ = WA.wow(f)
     assert w.dtype == np.float64 and np.array_equal(w, w64)
+    # a big-endian float32 frame (FITS): recast to float64 by the reference ('>f4' in its list, ref:297)
+    be = (f * 0.37).astype(">f4")
+    seen.clear()
+    L.Plan64.upload = spy
+    try:
+        cb = WA.AtrousTransform(WA.Triangle)(be, 3)
+    finally:
+        L.Plan64.upload = keep
+    assert seen == [np.dtype(">f4")] and cb.data.dtype == np.float64
+    assert np.array_equal(np.asarray(cb.data), np.asarray(WA.AtrousTransform(WA.Triangle)(be.astype(np.float64), 3).data))

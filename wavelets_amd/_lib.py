@@ -786,14 +786,25 @@ class Plan64:
     def shape(self):
         return (self.H, self.W)
 
-    # numpy integer kinds the device widens itself (wt64_upload_int); bool travels as uint8
-    _INT_CODES = {"b1": 2, "i1": 1, "u1": 2, "i2": 3, "u2": 4, "i4": 5, "u4": 6, "i8": 7, "u8": 8}
+    # element types the device widens itself (wt64_upload_int): integers, bool (as uint8), and - in the
+    # other byte order only - float32 / float64 (FITS data is big-endian)
+    _INT_CODES = {"b1": 2, "i1": 1, "u1": 2, "i2": 3, "u2": 4, "i4": 5, "u4": 6, "i8": 7, "u8": 8, "f4": 9, "f8": 10}
+
+    @classmethod
+    def device_widens(cls, dtype):
+        """True for element types Plan64.upload sends as they are (see _f64_source in wavelets.py)."""
+        dtype = np.dtype(dtype)
+        if dtype.str[1:] not in cls._INT_CODES:
+            return False
+        return dtype.kind in "iub" or (dtype.kind == "f" and not dtype.isnative)
 
     def upload(self, plane, host):
-        """plane <- host image as float64.  Integer images (what the reference promotes to float64 first,
-        ref wavelets.py:297, 319-320) cross PCIe as they are and are widened on the device."""
+        """plane <- host image as float64.  Integer and big-endian images (what the reference recasts to
+        float64 first, ref wavelets.py:297, 319-320) cross PCIe as they are and are widened on the device."""
         h = np.asarray(host)
-        code = self._INT_CODES.get(h.dtype.str[1:]) if h.dtype.kind in "iub" and h.dtype.isnative else None
+        code = self._INT_CODES.get(h.dtype.str[1:]) if self.device_widens(h.dtype) else None
+        if code is not None and not h.dtype.isnative and h.itemsize > 1:
+            code |= 16                                       # WT_BYTESWAPPED
         if (code is not None and h.ndim == 2 and h.shape == self.shape and h.size
                 and h.strides[1] == h.itemsize and h.strides[0] >= h.shape[1] * h.itemsize):
             check(load().wt64_upload_int(self._h, plane, _vp(h.ctypes.data), h.strides[0], code))

@@ -903,21 +903,48 @@ extern "C" int wt64_upload(wt_plan64 *p, int plane, const double *host, int64_t 
 // numpy astype of 30 ms for a 4096^2 int16 frame, and four times the bytes over PCIe).  Here the integers
 // cross as they are and one kernel widens them into the plane; int -> double is exact up to 2^53 and
 // rounds to nearest even beyond, as numpy's astype does.
-template <typename I>
+// SWAP: the elements are in the other byte order (FITS data is big-endian: astropy hands out '>i2', '>i4',
+// '>f4', '>f8' arrays, all of which the reference recasts to float64, ref:297) - swapped here, per element.
+template <int N> struct WtUintOf;
+template <> struct WtUintOf<1> { typedef uint8_t T; };
+template <> struct WtUintOf<2> { typedef uint16_t T; };
+template <> struct WtUintOf<4> { typedef uint32_t T; };
+template <> struct WtUintOf<8> { typedef uint64_t T; };
+__device__ __forceinline__ uint8_t wt_bswap(uint8_t v) { return v; }
+__device__ __forceinline__ uint16_t wt_bswap(uint16_t v) { return __builtin_bswap16(v); }
+__device__ __forceinline__ uint32_t wt_bswap(uint32_t v) { return __builtin_bswap32(v); }
+__device__ __forceinline__ uint64_t wt_bswap(uint64_t v) { return __builtin_bswap64(v); }
+
+template <typename I, bool SWAP>
 __global__ __launch_bounds__(256) void wt64_from_int_kernel(const I *src, double *dst, int W, int P, int nrows)
 {
+    typedef typename WtUintOf<sizeof(I)>::T U;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
-    for (int y = blockIdx.y; y < nrows; y += gridDim.y) dst[(int64_t)y * P + x] = (double)src[(int64_t)y * W + x];
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        U raw = reinterpret_cast<const U *>(src)[(int64_t)y * W + x];
+        if (SWAP) raw = wt_bswap(raw);
+        dst[(int64_t)y * P + x] = (double)__builtin_bit_cast(I, raw);
+    }
+}
+
+template <typename I>
+static void wt64_from_int_launch(wt_plan64 *p, double *b, bool swap)
+{
+    const dim3 grid = grid64(p), block(256);
+    if (swap) hipLaunchKernelGGL((wt64_from_int_kernel<I, true>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
+    else hipLaunchKernelGGL((wt64_from_int_kernel<I, false>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
 }
 
 extern "C" int wt64_upload_int(wt_plan64 *p, int plane, const void *host, int64_t host_pitch_bytes, int dtype)
 {
     WtGuard guard_(ctx_of(p));
     if (!p || !host) WT_FAIL("wt64_upload_int: null pointer");
-    static const int isz[9] = {0, 1, 1, 2, 2, 4, 4, 8, 8};
-    if (dtype < WT_INT8 || dtype > WT_UINT64) WT_FAIL("wt64_upload_int: unknown integer type %d", dtype);
-    const size_t row = (size_t)p->g.W * isz[dtype];
+    static const int isz[11] = {0, 1, 1, 2, 2, 4, 4, 8, 8, 4, 8};
+    const bool swap = (dtype & WT_BYTESWAPPED) != 0;
+    const int base = dtype & ~WT_BYTESWAPPED;
+    if (base < WT_INT8 || base > WT_FLOAT64) WT_FAIL("wt64_upload_int: unknown element type %d", dtype);
+    const size_t row = (size_t)p->g.W * isz[base];
     if (host_pitch_bytes < (int64_t)row) WT_FAIL("wt64_upload_int: row pitch %lld below the %zu bytes of a row", (long long)host_pitch_bytes, row);
     double *b = nullptr;
     WT_TRY(plan64_base(p, plane, &b));
@@ -936,21 +963,20 @@ extern "C" int wt64_upload_int(wt_plan64 *p, int plane, const void *host, int64_
         p->istage_cap = need;
     }
     WT_HIP(hipMemcpy2DAsync(p->istage, row, host, (size_t)host_pitch_bytes, row, p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream));
-    const dim3 grid = grid64(p), block(256);
-    const int W = p->g.W, P = p->g.P, n = p->g.nrows;
-    hipStream_t st = p->ctx->stream;
-    switch (dtype) {
-        case WT_INT8: hipLaunchKernelGGL(wt64_from_int_kernel<int8_t>, grid, block, 0, st, (const int8_t *)p->istage, b, W, P, n); break;
-        case WT_UINT8: hipLaunchKernelGGL(wt64_from_int_kernel<uint8_t>, grid, block, 0, st, (const uint8_t *)p->istage, b, W, P, n); break;
-        case WT_INT16: hipLaunchKernelGGL(wt64_from_int_kernel<int16_t>, grid, block, 0, st, (const int16_t *)p->istage, b, W, P, n); break;
-        case WT_UINT16: hipLaunchKernelGGL(wt64_from_int_kernel<uint16_t>, grid, block, 0, st, (const uint16_t *)p->istage, b, W, P, n); break;
-        case WT_INT32: hipLaunchKernelGGL(wt64_from_int_kernel<int32_t>, grid, block, 0, st, (const int32_t *)p->istage, b, W, P, n); break;
-        case WT_UINT32: hipLaunchKernelGGL(wt64_from_int_kernel<uint32_t>, grid, block, 0, st, (const uint32_t *)p->istage, b, W, P, n); break;
-        case WT_INT64: hipLaunchKernelGGL(wt64_from_int_kernel<int64_t>, grid, block, 0, st, (const int64_t *)p->istage, b, W, P, n); break;
-        default: hipLaunchKernelGGL(wt64_from_int_kernel<uint64_t>, grid, block, 0, st, (const uint64_t *)p->istage, b, W, P, n); break;
+    switch (base) {
+        case WT_INT8: wt64_from_int_launch<int8_t>(p, b, false); break;
+        case WT_UINT8: wt64_from_int_launch<uint8_t>(p, b, false); break;
+        case WT_INT16: wt64_from_int_launch<int16_t>(p, b, swap); break;
+        case WT_UINT16: wt64_from_int_launch<uint16_t>(p, b, swap); break;
+        case WT_INT32: wt64_from_int_launch<int32_t>(p, b, swap); break;
+        case WT_UINT32: wt64_from_int_launch<uint32_t>(p, b, swap); break;
+        case WT_INT64: wt64_from_int_launch<int64_t>(p, b, swap); break;
+        case WT_UINT64: wt64_from_int_launch<uint64_t>(p, b, swap); break;
+        case WT_FLOAT32: wt64_from_int_launch<float>(p, b, swap); break;
+        default: wt64_from_int_launch<double>(p, b, swap); break;
     }
     WT_HIP(hipGetLastError());
-    WT_HIP(hipStreamSynchronize(st));          // the caller's buffer is free again when this returns (as wt64_upload)
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));          // the caller's buffer is free again when this returns (as wt64_upload)
     return 0;
 }
 

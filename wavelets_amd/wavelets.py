@@ -144,11 +144,12 @@ _BUILTIN_TAPS = {_lib.TRIANGLE: np.array([1 / 4, 1 / 2, 1 / 4]),
 
 
 def _f64_source(arr):
-    """The array a float64 plan uploads: native integer images stay as they are (Plan64.upload widens
-    them on the device, a quarter or less of the bytes over PCIe and no host astype - the reference's
-    promotion, ref:297, 319-320, happens there); everything else becomes contiguous float64."""
+    """The array a float64 plan uploads: integer images and big-endian ones (what a FITS file holds)
+    stay as they are (Plan64.upload widens / byte-swaps them on the device: a quarter or less of the
+    bytes over PCIe and no host astype - the reference's recast, ref:297, 319-320, happens there);
+    everything else becomes contiguous float64."""
     a = np.asarray(arr)
-    if a.dtype.kind in "iub" and a.dtype.isnative and a.ndim == 2:
+    if a.ndim == 2 and Plan64.device_widens(a.dtype):       # integers; big-endian floats (FITS)
         return np.ascontiguousarray(a)
     return np.ascontiguousarray(a, dtype=np.float64)
 
