@@ -180,6 +180,11 @@ int wt_host_alloc(wt_ctx *ctx, size_t bytes, void **host_ptr);
 int wt_host_free(void *host_ptr);
 /* host image = this strip's rows, `host_stride` floats between rows (>= W). */
 int wt_upload(wt_plan *plan, int plane, const float *host, int64_t host_stride);
+/* plane <- (float) of an image of another element type, widened (byte-swapped) on the device: what the
+ * reference does not recast to float64 (watroo/wavelets.py:297) - uint8 pictures, raw big-endian FITS
+ * integers - is served in float32 here, without a host astype.  Type codes: WT_INT8 .. WT_FLOAT64,
+ * | WT_BYTESWAPPED (defined with wt64_upload_int below). */
+int wt_upload_int(wt_plan *plan, int plane, const void *host, int64_t host_pitch_bytes, int dtype);
 int wt_download(wt_plan *plan, int plane, float *host, int64_t host_stride);
 int wt_copy_plane(wt_plan *plan, int src, int dst);
 int wt_fill_plane(wt_plan *plan, int plane, float value);

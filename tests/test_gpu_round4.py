@@ -851,3 +851,72 @@ def test_integer_image_through_the_api_equals_its_float64_promotion(L):
         L.Plan64.upload = keep
     assert seen == [np.dtype(">f4")] and cb.data.dtype == np.float64
     assert np.array_equal(np.asarray(cb.data), np.asarray(WA.AtrousTransform(WA.Triangle)(be.astype(np.float64), 3).data))
+
+
+@pytest.mark.parametrize("dtype", ["?", "i1", "u1", "<i2", "<u2", "<i4", "<u4", "<i8", "<u8", ">i2", ">u2", ">i4", ">u4",
+                                   ">i8", ">u8", ">f4", ">f8"])
+def test_float32_plans_widen_other_element_types_on_the_device(L, dtype):
+    """wt_upload_int: what the reference does not recast to float64 (uint8 pictures, raw big-endian FITS
+    integers, ...) is served in float32 - widened and byte-swapped on the device, bit for bit numpy's
+    astype(float32) (round to nearest even where float32 cannot hold the integer); contiguous and strided rows."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(5)
+    H, W = 41, 1028
+    dt = np.dtype(dtype)
+    if dt.kind == "b":
+        a = rng.random((H, W)) < 0.5
+    elif dt.kind == "f":
+        a = (rng.standard_normal((H, W)) * 10.0 ** rng.integers(-10, 10, (H, W))).astype(dt)
+        a[0, :5] = [0.0, -0.0, np.inf, -np.inf, np.nan]
+    else:
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, (H, W), dtype=dt.newbyteorder("="), endpoint=True).astype(dt)
+        a[0, :4] = [info.min, info.max, info.max - 1 if info.max > 1 else 0, 0]
+    assert L.device_widens(dt)
+    wide = np.zeros((H, W + 5), dtype=dt)
+    wide[:, :W] = a
+    with np.errstate(over="ignore"):
+        want = a.astype(np.float32)
+    p = L.Plan(ctx, H, W, L.B3SPLINE, 1)
+    try:
+        for src in (a, wide[:, :W]):
+            p.fill(L.PLANE_INPUT, -1.0)
+            p.upload(L.PLANE_INPUT, src)
+            got = p.download(L.PLANE_INPUT)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), dtype
+    finally:
+        p.close()
+
+
+def test_uint8_and_big_endian_integer_images_through_the_float32_api(L):
+    """A uint8 picture and a raw big-endian int16 FITS frame (neither is in the reference's recast list: served
+    in float32) through AtrousTransform / denoise / wow: identical to the same calls on image.astype(float32),
+    and the integers travelled as integers."""
+    import wavelets_amd as WA
+    rng = np.random.default_rng(6)
+    u8 = np.clip(120 + 40 * rng.standard_normal((520, 640)), 0, 255).astype(np.uint8)
+    be = (1000 + 80 * rng.standard_normal((520, 640))).astype(">i2")
+    seen = []
+    keep = L.Plan.upload
+
+    def spy(self, plane, host):
+        seen.append(np.asarray(host).dtype)
+        return keep(self, plane, host)
+
+    for img in (u8, be):
+        del seen[:]
+        L.Plan.upload = spy
+        try:
+            c = WA.AtrousTransform(WA.B3spline)(img, 4)
+            d = WA.denoise(img, [5, 3, 2], WA.Triangle)
+            w, _ = WA.wow(img)
+            s = np.sum(WA.AtrousTransform(WA.B3spline)(img, 3, with_sum=True), axis=0)
+        finally:
+            L.Plan.upload = keep
+        assert seen and all(t == img.dtype for t in seen), seen
+        f = img.astype(np.float32)
+        assert c.data.dtype == np.float32
+        assert np.array_equal(np.asarray(c.data), np.asarray(WA.AtrousTransform(WA.B3spline)(f, 4).data))
+        assert d.dtype == np.float32 and np.array_equal(d, WA.denoise(f, [5, 3, 2], WA.Triangle))
+        assert np.array_equal(w, WA.wow(f)[0])
+        assert np.array_equal(s, np.sum(WA.AtrousTransform(WA.B3spline)(f, 3, with_sum=True), axis=0))

@@ -31,11 +31,24 @@ def timed(fn, n=5):
     return (time.perf_counter() - t) / n * 1e3
 
 
-codes = L.Plan64._INT_CODES
-for name, fn in (("denoise(img, [5, 3, 2], Triangle)", lambda: W.denoise(img, [5, 3, 2], W.Triangle)), ("wow(img)", lambda: W.wow(img))):
-    L.Plan64._INT_CODES = codes
-    t_dev = timed(fn)
-    L.Plan64._INT_CODES = {}
-    t_host = timed(fn)
-    L.Plan64._INT_CODES = codes
-    print(f"{side}^2 int16  {name}: {t_dev:.2f} ms widened on the device, {t_host:.2f} ms promoted on the host")
+import wavelets_amd._lib as LIB     # noqa: E402
+
+
+def host_promotion(on):
+    """switch the device widening off (the host astype of earlier rounds) / on"""
+    L.Plan64._INT_CODES = {} if on else LIB._ELEM_CODES
+    LIB.device_widens = (lambda dt: False) if on else keep_widens
+    W.wavelets._lib.device_widens = LIB.device_widens
+
+
+keep_widens = LIB.device_widens
+images = (("int16 (float64 engine)", img), ("uint8 (float32 engine)", np.clip(img // 8, 0, 255).astype(np.uint8)),
+          ("'>i2' raw FITS (float32 engine)", img.astype(">i2")))
+for label, im in images:
+    for name, fn in (("denoise(img, [5, 3, 2], Triangle)", lambda: W.denoise(im, [5, 3, 2], W.Triangle)), ("wow(img)", lambda: W.wow(im))):
+        host_promotion(False)
+        t_dev = timed(fn)
+        host_promotion(True)
+        t_host = timed(fn)
+        host_promotion(False)
+        print(f"{side}^2 {label}  {name}: {t_dev:.2f} ms widened on the device, {t_host:.2f} ms converted on the host")

@@ -76,6 +76,7 @@ SIGNATURES = {
     "wt_host_alloc": (_c.c_int, [_vp, _c.c_size_t, _c.POINTER(_vp)]),
     "wt_host_free": (_c.c_int, [_vp]),
     "wt_upload": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
+    "wt_upload_int": (_c.c_int, [_vp, _c.c_int, _vp, _i64, _c.c_int]),
     "wt_download": (_c.c_int, [_vp, _c.c_int, _fp, _i64]),
     "wt_copy_plane": (_c.c_int, [_vp, _c.c_int, _c.c_int]),
     "wt_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_float]),
@@ -439,6 +440,32 @@ def host_empty(shape, ctx=None, dtype=np.float32):
     return _host_pool.empty(ctx if ctx is not None else default_context(), shape, dtype)
 
 
+# element types the device widens itself (wt_upload_int / wt64_upload_int): integers, bool (as uint8) and -
+# in the other byte order only - float32 / float64 (FITS data is big-endian)
+_ELEM_CODES = {"b1": 2, "i1": 1, "u1": 2, "i2": 3, "u2": 4, "i4": 5, "u4": 6, "i8": 7, "u8": 8, "f4": 9, "f8": 10}
+
+
+def device_widens(dtype):
+    """True for element types Plan.upload / Plan64.upload send over PCIe as they are."""
+    dtype = np.dtype(dtype)
+    if dtype.str[1:] not in _ELEM_CODES:
+        return False
+    return dtype.kind in "iub" or (dtype.kind == "f" and not dtype.isnative)
+
+
+def _elem_source(host, shape):
+    """(address, row pitch in bytes, type code) of a host image the device can widen, else None"""
+    h = host
+    if not device_widens(h.dtype) or h.ndim != 2 or h.shape != tuple(shape) or not h.size:
+        return None
+    if h.strides[1] != h.itemsize or h.strides[0] < h.shape[1] * h.itemsize:
+        return None
+    code = _ELEM_CODES[h.dtype.str[1:]]
+    if not h.dtype.isnative and h.itemsize > 1:
+        code |= 16                                       # WT_BYTESWAPPED
+    return h.ctypes.data, h.strides[0], code
+
+
 def _as_f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     if a.ndim != 2:
@@ -519,6 +546,12 @@ class Plan:
 
     # ---- transfers
     def upload(self, plane, host):
+        """plane <- host image as float32; integer and byte-swapped images cross PCIe as they are and
+        are widened on the device (wt_upload_int) instead of by a host astype."""
+        src = _elem_source(np.asarray(host), self.shape)
+        if src is not None:
+            check(load().wt_upload_int(self._h, plane, _vp(src[0]), src[1], src[2]))
+            return
         host = _as_f32(host)
         if host.shape != self.shape:
             raise ValueError(f"image shape {host.shape} != plan strip shape {self.shape}")
@@ -786,28 +819,15 @@ class Plan64:
     def shape(self):
         return (self.H, self.W)
 
-    # element types the device widens itself (wt64_upload_int): integers, bool (as uint8), and - in the
-    # other byte order only - float32 / float64 (FITS data is big-endian)
-    _INT_CODES = {"b1": 2, "i1": 1, "u1": 2, "i2": 3, "u2": 4, "i4": 5, "u4": 6, "i8": 7, "u8": 8, "f4": 9, "f8": 10}
-
-    @classmethod
-    def device_widens(cls, dtype):
-        """True for element types Plan64.upload sends as they are (see _f64_source in wavelets.py)."""
-        dtype = np.dtype(dtype)
-        if dtype.str[1:] not in cls._INT_CODES:
-            return False
-        return dtype.kind in "iub" or (dtype.kind == "f" and not dtype.isnative)
+    _INT_CODES = _ELEM_CODES          # (emptied by tools/bench_int_input.py to time the host promotion)
+    device_widens = staticmethod(device_widens)
 
     def upload(self, plane, host):
         """plane <- host image as float64.  Integer and big-endian images (what the reference recasts to
         float64 first, ref wavelets.py:297, 319-320) cross PCIe as they are and are widened on the device."""
-        h = np.asarray(host)
-        code = self._INT_CODES.get(h.dtype.str[1:]) if self.device_widens(h.dtype) else None
-        if code is not None and not h.dtype.isnative and h.itemsize > 1:
-            code |= 16                                       # WT_BYTESWAPPED
-        if (code is not None and h.ndim == 2 and h.shape == self.shape and h.size
-                and h.strides[1] == h.itemsize and h.strides[0] >= h.shape[1] * h.itemsize):
-            check(load().wt64_upload_int(self._h, plane, _vp(h.ctypes.data), h.strides[0], code))
+        src = _elem_source(np.asarray(host), self.shape) if self._INT_CODES else None
+        if src is not None:
+            check(load().wt64_upload_int(self._h, plane, _vp(src[0]), src[1], src[2]))
             return
         host = np.ascontiguousarray(host, dtype=np.float64)
         if host.shape != self.shape:

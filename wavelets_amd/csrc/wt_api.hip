@@ -1002,6 +1002,67 @@ extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_
     return 0;
 }
 
+// plane <- (float) of an image of another element type (uint8 pictures, raw big-endian FITS integers ...:
+// everything the reference does NOT recast to float64 and this engine serves in float32), widened on the
+// device instead of by a host astype.  Same type codes as wt64_upload_int.
+template <typename I>
+static void from_elems_launch(wt_plan *p, float *b, bool swap)
+{
+    const dim3 grid((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)), block(256);
+    if (swap) hipLaunchKernelGGL((wt_from_elems_kernel<I, float, true>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
+    else hipLaunchKernelGGL((wt_from_elems_kernel<I, float, false>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
+}
+
+extern "C" int wt_upload_int(wt_plan *p, int plane, const void *host, int64_t host_pitch_bytes, int dtype)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !host) WT_FAIL("wt_upload_int: null pointer");
+    static const int isz[11] = {0, 1, 1, 2, 2, 4, 4, 8, 8, 4, 8};
+    const bool swap = (dtype & WT_BYTESWAPPED) != 0;
+    const int base = dtype & ~WT_BYTESWAPPED;
+    if (base < WT_INT8 || base > WT_FLOAT64) WT_FAIL("wt_upload_int: unknown element type %d", dtype);
+    const size_t row = (size_t)p->g.W * isz[base];
+    if (host_pitch_bytes < (int64_t)row) WT_FAIL("wt_upload_int: row pitch %lld below the %zu bytes of a row", (long long)host_pitch_bytes, row);
+    float *b = nullptr;
+    WT_TRY(plane_base(p, plane, &b));
+    const size_t need = row * p->g.nrows;
+    if (p->istage_cap < need) {
+        WT_HIP(hipSetDevice(p->ctx->device));
+        WT_HIP(hipStreamSynchronize(p->ctx->stream));
+        if (p->istage) {
+            (void)hipFree(p->istage);
+            p->raw_allocs.erase(std::remove(p->raw_allocs.begin(), p->raw_allocs.end(), p->istage), p->raw_allocs.end());
+            p->raw_bytes -= p->istage_cap;
+            p->istage = nullptr;
+            p->istage_cap = 0;
+        }
+        WT_HIP(hipMalloc(&p->istage, need));
+        p->raw_allocs.push_back(p->istage);
+        p->raw_bytes += need;
+        p->istage_cap = need;
+    }
+    const bool pinned = try_pin(host, (size_t)(p->g.nrows - 1) * (size_t)host_pitch_bytes + row);
+    hipError_t e = hipMemcpy2DAsync(p->istage, row, host, (size_t)host_pitch_bytes, row, p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);          // (the host rows are free again)
+    if (pinned) (void)hipHostUnregister(const_cast<void *>(host));
+    WT_HIP(e);
+    switch (base) {
+        case WT_INT8: from_elems_launch<int8_t>(p, b, false); break;
+        case WT_UINT8: from_elems_launch<uint8_t>(p, b, false); break;
+        case WT_INT16: from_elems_launch<int16_t>(p, b, swap); break;
+        case WT_UINT16: from_elems_launch<uint16_t>(p, b, swap); break;
+        case WT_INT32: from_elems_launch<int32_t>(p, b, swap); break;
+        case WT_UINT32: from_elems_launch<uint32_t>(p, b, swap); break;
+        case WT_INT64: from_elems_launch<int64_t>(p, b, swap); break;
+        case WT_UINT64: from_elems_launch<uint64_t>(p, b, swap); break;
+        case WT_FLOAT32: from_elems_launch<float>(p, b, swap); break;
+        default: from_elems_launch<double>(p, b, swap); break;
+    }
+    WT_HIP(hipGetLastError());
+    WT_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+}
+
 extern "C" int wt_download(wt_plan *p, int plane, float *host, int64_t host_stride)
 {
     WtGuard guard_(ctx_of(p));

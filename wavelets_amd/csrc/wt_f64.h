@@ -903,37 +903,12 @@ extern "C" int wt64_upload(wt_plan64 *p, int plane, const double *host, int64_t 
 // numpy astype of 30 ms for a 4096^2 int16 frame, and four times the bytes over PCIe).  Here the integers
 // cross as they are and one kernel widens them into the plane; int -> double is exact up to 2^53 and
 // rounds to nearest even beyond, as numpy's astype does.
-// SWAP: the elements are in the other byte order (FITS data is big-endian: astropy hands out '>i2', '>i4',
-// '>f4', '>f8' arrays, all of which the reference recasts to float64, ref:297) - swapped here, per element.
-template <int N> struct WtUintOf;
-template <> struct WtUintOf<1> { typedef uint8_t T; };
-template <> struct WtUintOf<2> { typedef uint16_t T; };
-template <> struct WtUintOf<4> { typedef uint32_t T; };
-template <> struct WtUintOf<8> { typedef uint64_t T; };
-__device__ __forceinline__ uint8_t wt_bswap(uint8_t v) { return v; }
-__device__ __forceinline__ uint16_t wt_bswap(uint16_t v) { return __builtin_bswap16(v); }
-__device__ __forceinline__ uint32_t wt_bswap(uint32_t v) { return __builtin_bswap32(v); }
-__device__ __forceinline__ uint64_t wt_bswap(uint64_t v) { return __builtin_bswap64(v); }
-
-template <typename I, bool SWAP>
-__global__ __launch_bounds__(256) void wt64_from_int_kernel(const I *src, double *dst, int W, int P, int nrows)
-{
-    typedef typename WtUintOf<sizeof(I)>::T U;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
-        U raw = reinterpret_cast<const U *>(src)[(int64_t)y * W + x];
-        if (SWAP) raw = wt_bswap(raw);
-        dst[(int64_t)y * P + x] = (double)__builtin_bit_cast(I, raw);
-    }
-}
-
 template <typename I>
 static void wt64_from_int_launch(wt_plan64 *p, double *b, bool swap)
 {
     const dim3 grid = grid64(p), block(256);
-    if (swap) hipLaunchKernelGGL((wt64_from_int_kernel<I, true>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
-    else hipLaunchKernelGGL((wt64_from_int_kernel<I, false>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
+    if (swap) hipLaunchKernelGGL((wt_from_elems_kernel<I, double, true>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
+    else hipLaunchKernelGGL((wt_from_elems_kernel<I, double, false>), grid, block, 0, p->ctx->stream, (const I *)p->istage, b, p->g.W, p->g.P, p->g.nrows);
 }
 
 extern "C" int wt64_upload_int(wt_plan64 *p, int plane, const void *host, int64_t host_pitch_bytes, int dtype)
@@ -962,7 +937,11 @@ extern "C" int wt64_upload_int(wt_plan64 *p, int plane, const void *host, int64_
         p->allocs.push_back(p->istage);
         p->istage_cap = need;
     }
-    WT_HIP(hipMemcpy2DAsync(p->istage, row, host, (size_t)host_pitch_bytes, row, p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream));
+    const bool pinned = try_pin(host, (size_t)(p->g.nrows - 1) * (size_t)host_pitch_bytes + row);
+    hipError_t e = hipMemcpy2DAsync(p->istage, row, host, (size_t)host_pitch_bytes, row, p->g.nrows, hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);      // (the host rows are free again)
+    if (pinned) (void)hipHostUnregister(const_cast<void *>(host));
+    WT_HIP(e);
     switch (base) {
         case WT_INT8: wt64_from_int_launch<int8_t>(p, b, false); break;
         case WT_UINT8: wt64_from_int_launch<uint8_t>(p, b, false); break;

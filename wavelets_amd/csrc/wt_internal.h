@@ -162,6 +162,8 @@ struct wt_plan {
     uint64_t vmm_seed = 0x9e3779b97f4a7c15ull;   // shuffle stream (advances: every refill deals differently)
     size_t raw_bytes = 0;                   // bytes behind raw_allocs (hipMalloc'ed planes, stage, arena)
     float *vmm_stage = nullptr;             // hipMalloc'ed bounce plane: hipMemcpy2D does not cross mapped chunks
+    void *istage = nullptr;                 // integer / byte-swapped image on its way into a plane (wt_upload_int)
+    size_t istage_cap = 0;
     // user-defined scaling function (wt_plan_set_taps): odd number of 1-D taps, 0 = built-in family
     int ntaps = 0;
     float taps[WT_MAX_CUSTOM_TAPS] = {0};

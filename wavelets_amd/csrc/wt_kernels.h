@@ -921,6 +921,34 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// images of another element type, widened (and byte-swapped) on their way into a plane: wt_upload_int /
+// wt64_upload_int.  One element per thread from a tightly packed staging copy of the host rows.
+// SWAP: the elements are in the other byte order (FITS data is big-endian: astropy hands out '>i2', '>i4',
+// '>f4', '>f8' arrays, all of which the reference recasts to float64, ref:297) - swapped here, per element.
+template <int N> struct WtUintOf;
+template <> struct WtUintOf<1> { typedef uint8_t T; };
+template <> struct WtUintOf<2> { typedef uint16_t T; };
+template <> struct WtUintOf<4> { typedef uint32_t T; };
+template <> struct WtUintOf<8> { typedef uint64_t T; };
+__device__ __forceinline__ uint8_t wt_bswap(uint8_t v) { return v; }
+__device__ __forceinline__ uint16_t wt_bswap(uint16_t v) { return __builtin_bswap16(v); }
+__device__ __forceinline__ uint32_t wt_bswap(uint32_t v) { return __builtin_bswap32(v); }
+__device__ __forceinline__ uint64_t wt_bswap(uint64_t v) { return __builtin_bswap64(v); }
+
+template <typename I, typename O, bool SWAP>
+__global__ __launch_bounds__(256) void wt_from_elems_kernel(const I *src, O *dst, int W, int P, int nrows)
+{
+    typedef typename WtUintOf<sizeof(I)>::T U;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        U raw = reinterpret_cast<const U *>(src)[(int64_t)y * W + x];
+        if (SWAP) raw = wt_bswap(raw);
+        dst[(int64_t)y * P + x] = (O)__builtin_bit_cast(I, raw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pointwise kernels over the strip's owned rows: rows are contiguous (pitch P), so they are a
 // flat float4 range of nrows*P/4 elements.  Grid-stride, 16 B per lane.
 // ---------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import PLANE_NONE, PLANE_OUT, PLANE_SCRATCH, acquire_plan, acquire_plan64, default_context, release_plan
-from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _f64_source, _family_of, _needs_generic,
+from .wavelets import (AtrousTransform, B3spline, Coefficients, _decompose_denoise_sum, _f32_source, _f64_source, _family_of, _needs_generic,
                        _result_dtype, _taps_f64, _to_f32_image,
                        generalized_anscombe,
                        PLANE_INPUT)
@@ -141,12 +141,14 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
         if anscombe:
             plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)
         return coefficients._from_plane(plan.download(PLANE_OUT)).astype(_result_dtype(data), copy=False)
-    img = _to_f32_image(data, "data")
+    img = _f32_source(data, "data")       # (integer / byte-swapped images are widened on the device)
     level = len(weights)
     transform = AtrousTransform(scaling_function, bilateral=bilateral)
     sf = scaling_function(2)
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
-    piped = _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe)
+    piped = None
+    if img.dtype == np.float32:           # the pipelined host call takes float32 rows
+        piped = _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe)
     if piped is not None:
         release_plan(plan)
         return piped.astype(_result_dtype(data), copy=False)

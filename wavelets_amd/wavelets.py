@@ -317,6 +317,16 @@ def _to_f32_image(arr, what="arr"):
     return np.ascontiguousarray(arr, dtype=np.float32)
 
 
+def _f32_source(arr, what="arr"):
+    """The array a float32 plan uploads: integer and byte-swapped images (uint8 pictures, raw big-endian
+    FITS integers - what the reference does not recast to float64) stay as they are and are widened on
+    the device (Plan.upload); everything else becomes contiguous float32 (_to_f32_image)."""
+    a = np.asarray(arr)
+    if a.ndim == 2 and _lib.device_widens(a.dtype):
+        return np.ascontiguousarray(a)
+    return _to_f32_image(arr, what)
+
+
 _RECAST = [np.dtype(t) for t in (np.int32, np.int64, '>f4', '>f8', 'int16', 'uint16', 'int32', 'uint32')]
 
 
@@ -934,13 +944,14 @@ class AtrousTransform:
             return self._call_1d(arr, level, recursive)
         if np.ndim(arr) == 3:
             return self._call_3d(arr, level, recursive)
-        img = _to_f32_image(arr)
+        img = _to_f32_image(arr) if recursive else _f32_source(arr)
         scaling_function = self.scaling_function_class(img.ndim)
         if recursive:
             return self._recursive(img, level, scaling_function, _result_dtype(arr))
         plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                             _family_of(scaling_function), level)
-        summed = bool(with_sum) and self.bilateral is None and not plan.custom
+        # (the pipelined host call takes float32 rows; an image widened on the device is uploaded whole)
+        summed = bool(with_sum) and self.bilateral is None and not plan.custom and img.dtype == np.float32
         host_sum = None
         if summed:
             # ref:432,442 + utils.py:98; the upload, the passes and the download of the synthesis are
