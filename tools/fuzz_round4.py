@@ -16,6 +16,8 @@ Every case draws from its own generator (seed, case), so any case can be replaye
   kind 3  atrous_convolution with every np.pad mode, 1-D / 2-D / 3-D, any kernel shape, dilation 2^s
   kind 4  scaling functions with an even number of taps or more than 15: standard / recursive transforms,
           1-D / 2-D, against the oracle's tap-list restatement
+  kind 5  integer / big-endian images through denoise(): the device widening against the oracle on the
+          promoted array (float64 for the reference's recast list, float32 otherwise)
 """
 import os
 import sys
@@ -171,6 +173,34 @@ def case_generic(rng):
     return None if err <= tol else tag + f": max err {err:.3e} tol {tol:.1e}"
 
 
+def case_elem_types(rng):
+    """integer / byte-swapped inputs through denoise(): the device widening (wt_upload_int / wt64_upload_int)
+    against the oracle on the array promoted the way the reference (or, for types it does not recast,
+    this engine) promotes it"""
+    H, Wd = int(rng.integers(8, 700)), int(rng.integers(8, 900))
+    dts = ["u1", "i1", "<i2", "<u2", "<i4", "<u4", "<i8", ">i2", ">u2", ">i4", ">f4", ">f8"]
+    dt = np.dtype(dts[int(rng.integers(0, len(dts)))])
+    if dt.kind == "f":
+        a = (rng.standard_normal((H, Wd)) * 30 + 100).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        lo, hi = max(info.min, -30000), min(info.max, 30000)
+        a = np.clip(rng.standard_normal((H, Wd)) * (hi - lo) / 12 + (hi + lo) / 2, lo, hi).astype(dt)
+    cls, fam = ((W.B3spline, "b3spline"), (W.Triangle, "triangle"))[int(rng.integers(0, 2))]
+    level = int(rng.integers(1, 6))
+    sig = [float(rng.choice([0, 1, 2, 3])) for _ in range(level)]
+    tag = f"denoise {dt.str} {H}x{Wd} {fam} sigma={sig}"
+    got = W.denoise(a, sig, scaling_function=cls)
+    recast = dt in [np.dtype(t) for t in (np.int32, np.int64, '>f4', '>f8', 'int16', 'uint16', 'int32', 'uint32')]
+    promoted = a.astype(np.float64 if recast else np.float32)
+    want = O.denoise(promoted.copy(), sig, family=fam)
+    if got.dtype != promoted.dtype:
+        return tag + f": dtype {got.dtype}, expected {promoted.dtype}"
+    tol = (1e-11 if recast else 2e-5) * max(1.0, float(np.abs(promoted).max()))
+    err = float(np.abs(got - want).max())
+    return None if err <= tol else tag + f": max err {err:.3e} tol {tol:.1e}"
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -182,10 +212,10 @@ def main():
         if case % 10 == 0:
             print(f"... case {case} of {n_cases}, {fails} failures so far", flush=True)
         rng = np.random.default_rng([seed, case])
-        kind = case % 5
+        kind = case % 6
         try:
             msg = (lambda: case_denoise(rng, False), lambda: case_denoise(rng, True), lambda: case_rl(rng),
-                   lambda: case_pad(rng), lambda: case_generic(rng))[kind]()
+                   lambda: case_pad(rng), lambda: case_generic(rng), lambda: case_elem_types(rng))[kind]()
         except Exception as ex:            # noqa: BLE001
             msg = f"kind {kind}: raised {type(ex).__name__}: {ex}"
         if msg:
