@@ -920,3 +920,10 @@ def test_uint8_and_big_endian_integer_images_through_the_float32_api(L):
         assert d.dtype == np.float32 and np.array_equal(d, WA.denoise(f, [5, 3, 2], WA.Triangle))
         assert np.array_equal(w, WA.wow(f)[0])
         assert np.array_equal(s, np.sum(WA.AtrousTransform(WA.B3spline)(f, 3, with_sum=True), axis=0))
+        sf = WA.B3spline(2)
+        assert np.array_equal(WA.sdev_loc(img, sf, 1), WA.sdev_loc(f, sf, 1))
+        assert np.array_equal(WA.convolution(img, sf, 2), WA.convolution(f, sf, 2))
+        assert np.array_equal(WA.atrous_convolution(img, sf.kernel, s=1), WA.atrous_convolution(f, sf.kernel, s=1))
+        psf = np.outer(np.hanning(7), np.hanning(7)).astype(np.float32)
+        psf /= psf.sum()
+        assert np.array_equal(WA.richardson_lucy(img, psf, iterations=2), WA.richardson_lucy(f, psf, iterations=2))

@@ -438,7 +438,7 @@ def richardson_lucy(data, psf,
     # uniform_init, where the reference itself keeps the estimate in float32 (ref:233)
     f64 = _result_dtype(data) == np.float64 and not uniform_init and np.ndim(data) == 2
     ft = np.float64 if f64 else np.float32
-    img = _f64_source(data) if f64 else _to_f32_image(data, "data")
+    img = _f64_source(data) if f64 else _f32_source(data, "data")
     psf = np.ascontiguousarray(psf, dtype=ft)
     if psf.ndim != 2:
         raise ValueError("psf must be 2-D")

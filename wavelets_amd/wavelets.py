@@ -413,7 +413,7 @@ def convolution(arr, scaling_function, s=0, output=None):
         cube = np.ascontiguousarray(arr, dtype=np.float32)
         img = cube.reshape(cube.shape[0] * cube.shape[1], cube.shape[2])
     else:
-        img = _to_f32_row(arr) if one_d else _to_f32_image(arr)
+        img = _to_f32_row(arr) if one_d else _f32_source(arr)
     fam = _family_of(scaling_function, 1 if one_d else 2)
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], fam, 0)
     try:
@@ -445,7 +445,7 @@ def sdev_loc(image, scaling_function, s=0, variance=False):
             return plan.download(PLANE_OUT)
         finally:
             release_plan(plan)
-    img = _to_f32_image(image, "image")
+    img = _f32_source(image, "image")
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1],
                         _family_of(scaling_function), 0)
     try:
@@ -534,7 +534,7 @@ def atrous_convolution(image, kernel, bilateral_variance=None, s=0, mode="symmet
             return res
         output[...] = res
         return output
-    img = _f64_source(image) if f64 else _to_f32_image(image, "image")
+    img = _f64_source(image) if f64 else _f32_source(image, "image")
     if f64:
         if not isinstance(fam, tuple):                   # built-in family: its (symmetric) taps
             fam = _taps_f64(Triangle if fam == _lib.TRIANGLE else B3spline, 2)
