@@ -492,6 +492,11 @@ int wt64_binary(wt_plan64 *plan, int op, int a, int b, int dst);
  * per-scale update (as wt_wow_update), gamma blend, fill, {sum, sumsq, min, max} */
 int wt64_wow_update(wt_plan64 *plan, int plane, int power_plane, double tau, int soft,
                     int noise_plane, double factor, int gamma_plane);
+/* one scale of the wow loop on a float64 image (watroo/utils.py:193-203): local power conv_s(c^2) and the
+ * update in a row pass + a column pass with the update as its epilogue, in place (no power plane);
+ * identical bits to wt64_smooth(square) + wt64_wow_update. */
+int wt64_wow_scale(wt_plan64 *plan, int plane, int s, double tau, int soft, int noise_plane, double factor,
+                   int gamma_plane);
 int wt64_gamma_blend(wt_plan64 *plan, int recon, int gamma_plane, double gmin, double gmax,
                      double inv_gamma, double h);
 int wt64_fill_plane(wt_plan64 *plan, int plane, double value);

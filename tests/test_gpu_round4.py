@@ -927,3 +927,36 @@ def test_uint8_and_big_endian_integer_images_through_the_float32_api(L):
         psf = np.outer(np.hanning(7), np.hanning(7)).astype(np.float32)
         psf /= psf.sum()
         assert np.array_equal(WA.richardson_lucy(img, psf, iterations=2), WA.richardson_lucy(f, psf, iterations=2))
+
+
+def test_float64_wow_scale_equals_smooth_plus_update_bitwise(L):
+    """wt64_wow_scale (row pass of the squares + column pass with the wow update as its epilogue, in place)
+    against wt64_smooth(square) + wt64_wow_update on a second plan: identical bits for the coefficient
+    plane and the gamma accumulator - with and without threshold, noise map, gamma, both families - and
+    wow() of a float64 image still matches the float64 golden cases (test_float64_engine_vs_golden)."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(12)
+    H, W = 300, 517
+    c0 = rng.standard_normal((H, W)) * 3
+    nz0 = rng.uniform(0.5, 2.0, (H, W))
+    for taps in ((1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16), (0.25, 0.5, 0.25)):
+        for s in (0, 2, 5):
+            for tau, soft, use_noise, use_gamma in ((0.0, True, False, False), (1.3, True, False, True),
+                                                    (0.8, False, True, False), (2.0, True, True, True)):
+                a, b = L.Plan64(ctx, H, W, taps, 1), L.Plan64(ctx, H, W, taps, 1)
+                try:
+                    NZ, GM, PW = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3), L.PLANE_SCRATCH(4)
+                    for p in (a, b):
+                        p.upload(0, c0)
+                        p.upload(NZ, nz0)
+                        p.fill(GM, 0.25)
+                    npl = NZ if use_noise else L.PLANE_NONE
+                    gpl = GM if use_gamma else L.PLANE_NONE
+                    a.wow_scale(0, s, tau, soft, npl, 0.7, gpl)
+                    b.smooth(0, PW, s, True)
+                    b.wow_update(0, PW, tau, soft, npl, 0.7, gpl)
+                    assert np.array_equal(a.download(0).view(np.uint64), b.download(0).view(np.uint64)), (taps, s, tau)
+                    assert np.array_equal(a.download(GM).view(np.uint64), b.download(GM).view(np.uint64)), (taps, s, tau)
+                finally:
+                    a.close()
+                    b.close()

@@ -160,6 +160,7 @@ SIGNATURES = {
                                  _c.c_int]),
     "wt64_wow_update": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int,
                                    _c.c_double, _c.c_int]),
+    "wt64_wow_scale": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int, _c.c_double, _c.c_int]),
     "wt64_gamma_blend": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
                                     _c.c_double, _c.c_double]),
     "wt64_fill_plane": (_c.c_int, [_vp, _c.c_int, _c.c_double]),
@@ -915,6 +916,10 @@ class Plan64:
     def wow_update(self, plane, power_plane, tau, soft, noise_plane, factor, gamma_plane):
         check(load().wt64_wow_update(self._h, plane, power_plane, float(tau), int(soft),
                                      noise_plane, float(factor), gamma_plane))
+
+    def wow_scale(self, plane, s, tau, soft, noise_plane, factor, gamma_plane, flags=0):
+        """local power conv_s(c^2) + the wow update of one scale, in place (wt64_wow_scale)"""
+        check(load().wt64_wow_scale(self._h, plane, s, float(tau), int(soft), noise_plane, float(factor), gamma_plane))
 
     def gamma_blend(self, recon, gamma_plane, gmin, gmax, inv_gamma, h):
         check(load().wt64_gamma_blend(self._h, recon, gamma_plane, gmin, gmax, inv_gamma, h))

@@ -294,6 +294,24 @@ __global__ __launch_bounds__(256) void wt64_denoise_sum_kernel(DenoiseSum64Args 
 
 // wow per-scale update (watroo/utils.py:193-203): c <- c * significance; gamma += c;
 // c <- c * factor / sqrt(clip(power, 1e-15)).  power / noise / gamma may be null.
+// one coefficient of the update; `pw`: its local power (has_power) - shared by the pointwise kernel and the
+// column pass that forms the power itself (wt64_wow_axis_kernel): identical bits
+__device__ __forceinline__ double wt64_wow_point(double t, bool has_power, double pw, const double *noise, double *gamma, int64_t o,
+                                                 double tau, int soft, double factor)
+{
+    if (tau > 0.0) {
+        const double tt = noise ? tau * noise[o] : tau;
+        t = t * wt_sig64(t, tt, soft);
+    }
+    if (gamma) gamma[o] = gamma[o] + t;
+    double q = factor;
+    if (has_power) {
+        const double lp = pw <= 0.0 ? 1e-15 : pw;
+        q = factor / sqrt(lp);
+    }
+    return t * q;
+}
+
 __global__ __launch_bounds__(256) void wt64_wow_kernel(double *c, const double *power, const double *noise, double *gamma, int W, int P,
                                                        int nrows, double tau, int soft, double factor)
 {
@@ -301,18 +319,28 @@ __global__ __launch_bounds__(256) void wt64_wow_kernel(double *c, const double *
     if (x >= W) return;
     for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
         const int64_t o = (int64_t)y * P + x;
-        double t = c[o];
-        if (tau > 0.0) {
-            const double tt = noise ? tau * noise[o] : tau;
-            t = t * wt_sig64(t, tt, soft);
+        c[o] = wt64_wow_point(c[o], power != nullptr, power ? power[o] : 0.0, noise, gamma, o, tau, soft, factor);
+    }
+}
+
+// The column pass of conv_s(c^2) with the update as its epilogue (wt64_wow_scale): `rows` holds the row-
+// filtered squares (wt64_rows_kernel, square = 1); the local power of a pixel is formed in registers and
+// the coefficient is updated IN PLACE (this pass reads neighbours from `rows` only) - no power plane, one
+// pass over the coefficients less than smooth + wt64_wow_update.
+__global__ __launch_bounds__(256) void wt64_wow_axis_kernel(const double *rows, double *c, const double *noise, double *gamma, int W, int P,
+                                                            int nrows, int d, int border, Taps64 t, double tau, int soft, double factor)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        double acc = 0.0;
+        for (int j = 0; j < t.n; ++j) {
+            const double v = rows[(int64_t)wt_refl_b(y + (j - hw) * d, nrows, d, border) * P + x];
+            acc = j == 0 ? t.k[0] * v : fma(t.k[j], v, acc);
         }
-        if (gamma) gamma[o] = gamma[o] + t;
-        double q = factor;
-        if (power) {
-            const double lp = power[o] <= 0.0 ? 1e-15 : power[o];
-            q = factor / sqrt(lp);
-        }
-        c[o] = t * q;
+        const int64_t o = (int64_t)y * P + x;
+        c[o] = wt64_wow_point(c[o], true, acc, noise, gamma, o, tau, soft, factor);
     }
 }
 
@@ -1531,6 +1559,31 @@ extern "C" int wt64_wow_update(wt_plan64 *p, int plane, int power_plane, double 
     if (pw == c || gm == c || nz == c) WT_FAIL("wt64_wow_update: the plane aliases one of its operands");
     hipLaunchKernelGGL(wt64_wow_kernel, grid64(p), dim3(256), 0, p->ctx->stream, c, (const double *)pw, (const double *)nz, gm, p->g.W, p->g.P,
                        p->g.nrows, tau, soft, factor);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* One scale of the wow loop on an image (watroo/utils.py:193-203): local power conv_s(c^2) and the update of
+ * wt64_wow_update in two kernels - the row pass of the squares into a private temporary, then the column
+ * pass with the update as its epilogue, in place.  Same operations in the same order as wt64_smooth(square)
+ * + wt64_wow_update: identical bits. */
+extern "C" int wt64_wow_scale(wt_plan64 *p, int plane, int s, double tau, int soft, int noise_plane, double factor, int gamma_plane)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_wow_scale: null plan");
+    if (s < 0 || s > 24) WT_FAIL("wt64_wow_scale: scale %d out of range", s);
+    if (p->g.border != 0) WT_FAIL("wt64_wow_scale: images under the symmetric border only");
+    double *c = nullptr, *nz = nullptr, *gm = nullptr, *t1 = nullptr;
+    WT_TRY(plan64_base(p, plane, &c));
+    if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
+    if (gamma_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, gamma_plane, &gm));
+    if (gm == c || nz == c) WT_FAIL("wt64_wow_scale: the plane aliases one of its operands");
+    WT_TRY(plan64_tmp(p, 0, &t1));
+    const Taps64 t = taps64(p);
+    const int d = 1 << s;
+    hipLaunchKernelGGL(wt64_rows_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)c, t1, p->g, d, t, 1);
+    hipLaunchKernelGGL(wt64_wow_axis_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)t1, c, (const double *)nz, gm, p->g.W,
+                       p->g.P, p->g.nrows, d, p->g.border, t, tau, soft, factor);
     WT_HIP(hipGetLastError());
     return 0;
 }

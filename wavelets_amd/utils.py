@@ -319,6 +319,10 @@ def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sd
                 plan.binary("mul", s, s, _SQ_PLANE)
                 plan.smooth3d(_SQ_PLANE, _POW_PLANE, s, coefficients._shape[0])
                 plan.wow_update(s, _POW_PLANE, tau, soft_threshold, noise_plane, factor, gplane)
+            elif (whitening and h < 1 and isinstance(plan, _lib.Plan64) and coefficients._ndim == 2
+                  and not _needs_generic(coefficients.scaling_function)):
+                # float64 images: row pass of the squares, column pass with the update as its epilogue
+                plan.wow_scale(s, s, tau, soft_threshold, noise_plane, factor, gplane)
             elif whitening and h < 1 and plan.custom:                     # user-defined taps
                 plan.smooth(s, _POW_PLANE, s, True)                       # conv_s(c^2), ref:194
                 plan.wow_update(s, _POW_PLANE, tau, soft_threshold, noise_plane, factor, gplane)
