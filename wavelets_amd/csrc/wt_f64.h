@@ -1014,7 +1014,15 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
     // only); any other one-row image or one-slice cube still sees every axis' taps (they reflect
     // onto the same sample and contribute sum(k) - which is 1 only for normalised taps)
     const bool cols = !(Y == 1 && depth == 0 && (g.border == 2 || g.border == 3)), deep = depth > 0;
-    if (cols && !deep && !square) {
+    // One marching kernel or the two plain passes (identical bits)?  Measured per scale (ms, B3, chain | two
+    // passes): 2048^2 0.076 | 0.059 at every d; 4096^2 0.24 | 0.24 up to d = 64, 0.31 | 0.29 at 256, 0.64 | 0.28
+    // at 1024; 8192^2 0.90 | 1.03 up to d = 128, 1.03 | 1.18 at 256, 1.23 | 1.12 at 512, 1.66 | 1.19 at 1024.
+    // The chain saves a plane round trip - which only costs when the planes do not sit in the Infinity
+    // Cache - and loses when the chains get short (2 * hw warm-up rows per chunk, K scalar loads per row).
+    static const int chain_env = getenv("WT64_CHAIN") ? atoi(getenv("WT64_CHAIN")) : -1;       // 0 / 1 force (experiments)
+    const bool big_planes = (size_t)g.nrows * g.P * sizeof(double) >= ((size_t)256 << 20);
+    const bool use_chain = chain_env >= 0 ? chain_env != 0 : (big_planes && (g.H + d - 1) / d >= 24);
+    if (cols && !deep && !square && use_chain) {
         // images: one kernel per scale (register window down every polyphase row chain)
         const int n_max = (g.H + d - 1) / d;             // longest chain
         // enough work items to fill the chip, chunks of at least 32 chain steps (2 * hw warm-up rows each)
