@@ -960,3 +960,44 @@ def test_float64_wow_scale_equals_smooth_plus_update_bitwise(L):
                 finally:
                     a.close()
                     b.close()
+
+
+def test_float64_two_pixel_kernels_equal_the_one_pixel_ones_bitwise(L):
+    """wt64_rows2 / wt64_cols2 / wt64_wow_axis2 (two pixels per thread, 16-byte accesses; even widths, even
+    dilations for the row filter) against the one-pixel kernels (option f64_pairs = 0): smooth with and
+    without squared input, the detail plane of a generic-path scale, wt64_wow_scale - several dilations,
+    an odd width (falls back), images narrower than the taps' reach (reflected pairs)."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(21)
+    taps5 = (1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16)
+    for (H, W) in ((130, 518), (64, 10), (33, 257)):
+        a = rng.standard_normal((H, W)) * 2 + 5
+        nz = rng.uniform(0.5, 2.0, (H, W))
+        res = {}
+        for pairs in (1, 0):
+            L.set_option("f64_pairs", pairs)
+            try:
+                p = L.Plan64(ctx, H, W, taps5, 1)
+                out = []
+                try:
+                    A, B, NZ, GM = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3), L.PLANE_SCRATCH(4), L.PLANE_SCRATCH(5)
+                    p.upload(A, a)
+                    p.upload(NZ, nz)
+                    for s in (0, 1, 3, 6):
+                        p.smooth(A, B, s)
+                        out.append(p.download(B))
+                        p.smooth(A, B, s, True)
+                        out.append(p.download(B))
+                        p.copy(A, 0)
+                        p.fill(GM, 0.5)
+                        p.wow_scale(0, s, 1.1, True, NZ, 0.9, GM)
+                        out.append(p.download(0))
+                        out.append(p.download(GM))
+                finally:
+                    p.close()
+                res[pairs] = out
+            finally:
+                L.set_option("f64_pairs", 1)
+        assert len(res[0]) == len(res[1]) == 16
+        for k, (u, v) in enumerate(zip(res[1], res[0])):
+            assert np.array_equal(u.view(np.uint64), v.view(np.uint64)), ((H, W), k)

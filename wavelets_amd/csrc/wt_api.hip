@@ -1275,6 +1275,7 @@ static int g_opt_split_dry = 0;
 
 static void wt_set_fused64(int on);     // wt_f64.h (included at the end of this file)
 static void wt_set_select64_list(int on);
+static void wt_set_f64_pairs(int on);
 static void wt_set_hist_window(int on);
 // wt_decompose_sum_host: pipeline the PCIe legs with the passes (0: upload, passes, download in turn)
 static int g_opt_host_pipeline = getenv("WT_NO_HOST_PIPELINE") ? 0 : 1;
@@ -1293,6 +1294,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "host_pipeline")) { g_opt_host_pipeline = value != 0; return 0; }
     if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
     if (!strcmp(name, "select64_list")) { wt_set_select64_list(value != 0); return 0; }
+    if (!strcmp(name, "f64_pairs")) { wt_set_f64_pairs(value != 0); return 0; }
     if (!strcmp(name, "hist_window")) { wt_set_hist_window(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "scatter_strips")) { g_opt_scatter_strips = value != 0; return 0; }

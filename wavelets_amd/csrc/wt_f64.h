@@ -37,6 +37,55 @@ __global__ __launch_bounds__(256) void wt64_rows_kernel(const double *in, double
     }
 }
 
+// The same row filter with TWO pixels per thread (round 4, late): for an even dilation and an even width
+// the taps of the pixel pair (x, x + 1), x even, are the aligned pairs (x + (j - hw) d, + 1) - one 16-byte
+// load each instead of two 8-byte ones through separate reflections.  The one-pixel kernels run 1.9 TB/s
+// (vector-memory issue, not HBM); same FMA chains per pixel: identical bits.
+__global__ __launch_bounds__(256) void wt64_rows2_kernel(const double *in, double *tmp, Geo g, int d, Taps64 t, int square)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (x >= g.W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < g.nrows; y += gridDim.y) {
+        const double *row = in + (int64_t)y * g.P;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int j = 0; j < t.n; ++j) {
+            const int xo = x + (j - hw) * d;
+            double2 v;
+            if (xo >= 0 && xo + 1 < g.W) v = *reinterpret_cast<const double2 *>(row + xo);
+            else v = make_double2(row[wt_refl_b(xo, g.W, d, g.border)], row[wt_refl_b(xo + 1, g.W, d, g.border)]);
+            if (square) v = make_double2(v.x * v.x, v.y * v.y);
+            acc = j == 0 ? make_double2(t.k[0] * v.x, t.k[0] * v.y) : make_double2(fma(t.k[j], v.x, acc.x), fma(t.k[j], v.y, acc.y));
+        }
+        *reinterpret_cast<double2 *>(tmp + (int64_t)y * g.P + x) = acc;
+    }
+}
+
+// ... and the column filter of an image (axis 1 of a one-slice cube), two pixels per thread
+__global__ __launch_bounds__(256) void wt64_cols2_kernel(const double *in, double *out, const double *cen, double *out_w, int W, int P,
+                                                         int nrows, int d, int border, Taps64 t)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (x >= W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int j = 0; j < t.n; ++j) {
+            const double2 v = *reinterpret_cast<const double2 *>(in + (int64_t)wt_refl_b(y + (j - hw) * d, nrows, d, border) * P + x);
+            acc = j == 0 ? make_double2(t.k[0] * v.x, t.k[0] * v.y) : make_double2(fma(t.k[j], v.x, acc.x), fma(t.k[j], v.y, acc.y));
+        }
+        const int64_t o = (int64_t)y * P + x;
+        if (out_w) {
+            const double2 c = *reinterpret_cast<const double2 *>(cen + o);
+            *reinterpret_cast<double2 *>(out_w + o) = make_double2(c.x - acc.x, c.y - acc.y);
+        }
+        *reinterpret_cast<double2 *>(out + o) = acc;
+    }
+}
+
+static int g_opt_f64_pairs = getenv("WT_NO_F64_PAIRS") ? 0 : 1;      // wt_set_option("f64_pairs", 0/1): two pixels per thread
+static void wt_set_f64_pairs(int on) { g_opt_f64_pairs = on; }
+
 // dilated filter along axis 1 (inside every slice: axis == 1) or axis 0 (across slices) of a
 // (Z, Y, X) cube stored as a (Z*Y) x X image; an image is the cube with Z = 1
 // (watroo/wavelets.py:35-63).  out_w != nullptr: also the detail plane cen - result (:442).
@@ -858,6 +907,7 @@ static int plan64_tmp(wt_plan64 *p, int i, double **base)
 
 static inline wt_ctx *ctx_of(wt_plan64 *p) { return p ? p->ctx : nullptr; }
 static inline dim3 grid64(const wt_plan64 *p) { return dim3((p->g.W + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)); }
+static inline dim3 grid64_pairs(const wt_plan64 *p) { return dim3((p->g.W / 2 + 255) / 256, (unsigned)std::min(p->g.nrows, 32768)); }
 // flat pointwise kernels: planes are contiguous (pitch even, 16-byte aligned rows): double2 groups of a plane
 static inline int64_t plan64_n2(const wt_plan64 *p) { return (int64_t)p->g.nrows * p->g.P / 2; }
 static inline int flat_grid64(const wt_plan64 *p) { return (int)std::min<int64_t>((plan64_n2(p) + 255) / 256, 256 * 16); }
@@ -1039,9 +1089,14 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
     if (cols || deep) WT_TRY(plan64_tmp(p, 0, &t1));
     if (cols && deep) WT_TRY(plan64_tmp(p, 1, &t2));
     double *r_out = (cols || deep) ? t1 : out;
-    hipLaunchKernelGGL(wt64_rows_kernel, grid, block, 0, p->ctx->stream, in, r_out, g, d, t, square);
+    const bool pairs = g_opt_f64_pairs && g.W % 2 == 0;              // two pixels per thread (16-byte accesses)
+    if (pairs && d % 2 == 0) hipLaunchKernelGGL(wt64_rows2_kernel, grid64_pairs(p), block, 0, p->ctx->stream, in, r_out, g, d, t, square);
+    else hipLaunchKernelGGL(wt64_rows_kernel, grid, block, 0, p->ctx->stream, in, r_out, g, d, t, square);
     if (!cols && !deep) {
         if (out_w) hipLaunchKernelGGL(wt64_binary_kernel, grid, block, 0, p->ctx->stream, in, (const double *)out, out_w, g.W, g.P, g.nrows, 1);
+    } else if (cols && !deep && pairs) {
+        hipLaunchKernelGGL(wt64_cols2_kernel, grid64_pairs(p), block, 0, p->ctx->stream, (const double *)t1, out, in, out_w, g.W, g.P, g.nrows, d,
+                           g.border, t);
     } else if (cols) {
         double *c_out = deep ? t2 : out;
         hipLaunchKernelGGL(wt64_axis_kernel, grid, block, 0, p->ctx->stream, (const double *)t1, c_out, in, deep ? (double *)nullptr : out_w,
@@ -1571,6 +1626,28 @@ extern "C" int wt64_wow_update(wt_plan64 *p, int plane, int power_plane, double 
     return 0;
 }
 
+// wt64_wow_axis_kernel with two pixels per thread (even widths): 16-byte accesses throughout
+__global__ __launch_bounds__(256) void wt64_wow_axis2_kernel(const double *rows, double *c, const double *noise, double *gamma, int W, int P,
+                                                             int nrows, int d, int border, Taps64 t, double tau, int soft, double factor)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (x >= W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int j = 0; j < t.n; ++j) {
+            const double2 v = *reinterpret_cast<const double2 *>(rows + (int64_t)wt_refl_b(y + (j - hw) * d, nrows, d, border) * P + x);
+            acc = j == 0 ? make_double2(t.k[0] * v.x, t.k[0] * v.y) : make_double2(fma(t.k[j], v.x, acc.x), fma(t.k[j], v.y, acc.y));
+        }
+        const int64_t o = (int64_t)y * P + x;
+        const double2 cc = *reinterpret_cast<const double2 *>(c + o);
+        double2 r;
+        r.x = wt64_wow_point(cc.x, true, acc.x, noise, gamma, o, tau, soft, factor);
+        r.y = wt64_wow_point(cc.y, true, acc.y, noise, gamma, o + 1, tau, soft, factor);
+        *reinterpret_cast<double2 *>(c + o) = r;
+    }
+}
+
 /* One scale of the wow loop on an image (watroo/utils.py:193-203): local power conv_s(c^2) and the update of
  * wt64_wow_update in two kernels - the row pass of the squares into a private temporary, then the column
  * pass with the update as its epilogue, in place.  Same operations in the same order as wt64_smooth(square)
@@ -1589,9 +1666,17 @@ extern "C" int wt64_wow_scale(wt_plan64 *p, int plane, int s, double tau, int so
     WT_TRY(plan64_tmp(p, 0, &t1));
     const Taps64 t = taps64(p);
     const int d = 1 << s;
-    hipLaunchKernelGGL(wt64_rows_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)c, t1, p->g, d, t, 1);
-    hipLaunchKernelGGL(wt64_wow_axis_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)t1, c, (const double *)nz, gm, p->g.W,
-                       p->g.P, p->g.nrows, d, p->g.border, t, tau, soft, factor);
+    const bool even_w = g_opt_f64_pairs && p->g.W % 2 == 0;
+    if (even_w && d % 2 == 0)
+        hipLaunchKernelGGL(wt64_rows2_kernel, grid64_pairs(p), dim3(256), 0, p->ctx->stream, (const double *)c, t1, p->g, d, t, 1);
+    else
+        hipLaunchKernelGGL(wt64_rows_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)c, t1, p->g, d, t, 1);
+    if (even_w)
+        hipLaunchKernelGGL(wt64_wow_axis2_kernel, grid64_pairs(p), dim3(256), 0, p->ctx->stream, (const double *)t1, c, (const double *)nz, gm,
+                           p->g.W, p->g.P, p->g.nrows, d, p->g.border, t, tau, soft, factor);
+    else
+        hipLaunchKernelGGL(wt64_wow_axis_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)t1, c, (const double *)nz, gm, p->g.W,
+                           p->g.P, p->g.nrows, d, p->g.border, t, tau, soft, factor);
     WT_HIP(hipGetLastError());
     return 0;
 }
