@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 6
+#define WT_ABI_VERSION 7
 
 typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
 typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */
@@ -457,6 +457,12 @@ int wt64_local_variance(wt_plan64 *plan, int src, int dst, int s, double f1, dou
  * taps_reversed as flag bit3 of wt_bilateral_conv */
 int wt64_bilateral_conv(wt_plan64 *plan, int src, int var, int dst, int s, int depth,
                         int taps_reversed);
+/* AtrousTransform(bilateral=...)(image, level) in float64 (watroo/wavelets.py:408-444, bilateral branch
+ * :433-440): as wt_decompose_bilateral - planes 0..level from plane src (not 0..level, not scratch 0 / 1),
+ * variance = sdev_loc(c_s) * sigma_b[s]**2 (* (s + 1) under bilateral_scaling).  Built-in taps: one marching
+ * kernel per scale (variance formed in its register window, both output planes written). */
+int wt64_decompose_bilateral(wt_plan64 *plan, int src, int level, const double *sigma_b,
+                             int bilateral_scaling);
 /* wt_taps_conv / wt_taps_conv_ex / wt_variance_from_moments in float64 */
 int wt64_taps_conv(wt_plan64 *plan, int src, int var, int dst, const int32_t *offsets,
                    const double *weights, int ntaps, double center_weight, int has_center,

@@ -939,7 +939,7 @@ def test_float64_wow_scale_equals_smooth_plus_update_bitwise(L):
     H, W = 300, 517
     c0 = rng.standard_normal((H, W)) * 3
     nz0 = rng.uniform(0.5, 2.0, (H, W))
-    for taps in ((1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16), (0.25, 0.5, 0.25)):
+    for taps in ((1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16), (0.25, 0.5, 0.25), (0.2, 0.6, 0.2)):   # (the last: user taps, generic kernels)
         for s in (0, 2, 5):
             for tau, soft, use_noise, use_gamma in ((0.0, True, False, False), (1.3, True, False, True),
                                                     (0.8, False, True, False), (2.0, True, True, True)):
@@ -976,6 +976,7 @@ def test_float64_two_pixel_kernels_equal_the_one_pixel_ones_bitwise(L):
         res = {}
         for pairs in (1, 0):
             L.set_option("f64_pairs", pairs)
+            L.set_option("stencil64", 0)          # (round 5: built-in taps take wt_stencil.h otherwise; these are the generic kernels)
             try:
                 p = L.Plan64(ctx, H, W, taps5, 1)
                 out = []
@@ -998,6 +999,7 @@ def test_float64_two_pixel_kernels_equal_the_one_pixel_ones_bitwise(L):
                 res[pairs] = out
             finally:
                 L.set_option("f64_pairs", 1)
+                L.set_option("stencil64", 1)
         assert len(res[0]) == len(res[1]) == 16
         for k, (u, v) in enumerate(zip(res[1], res[0])):
             assert np.array_equal(u.view(np.uint64), v.view(np.uint64)), ((H, W), k)

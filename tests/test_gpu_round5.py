@@ -1,0 +1,270 @@
+"""Round-5 GPU tests (run with -m gpu on an MI355X): the float64 per-scale kernels (wt_stencil.h for double,
+the float64 bilateral march) against the generic float64 engine and the numpy oracle, cfg5 in float64
+against the oracle, and the side stream (wow updates beside the bilateral transform) against the serial
+order."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import measured
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B3_TAPS = (1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16)
+TRI_TAPS = (0.25, 0.5, 0.25)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as entry
+    entry.build()
+    from wavelets_amd import _lib
+    return _lib
+
+
+def _bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+@pytest.mark.parametrize("shape", [(130, 518), (64, 10), (33, 257), (300, 1100), (9, 2050)])
+@pytest.mark.parametrize("taps", [B3_TAPS, TRI_TAPS])
+def test_float64_stencil_kernels_equal_the_generic_engine_bitwise(L, shape, taps):
+    """wt_stencil.h instantiated for double (row kernel for d <= 32 / 64, lattice kernel from d = 64 on
+    widths that are a multiple of two and at least 2 d, the chain kernel otherwise; d = 1 through the
+    sub-group path) against the generic one-sample-per-thread float64 kernels (option stencil64 = 0): the
+    smoothed plane, the smoothed squares, the detail plane of a per-scale decomposition, the local variance
+    (times two factors, with and without the square root) and the fused wow update in its three forms
+    (plain / gamma accumulator / noise map) - every dilation up to 512, odd widths, images narrower than
+    the taps' reach (several bounces).  Both compute rows first, then columns, FMA chains in tap order,
+    and share the per-sample expressions: identical bits."""
+    ctx = L.default_context()
+    H, W = shape
+    rng = np.random.default_rng(H * 7 + W)
+    a = rng.standard_normal((H, W)) * 2 + 5
+    nz = rng.uniform(0.5, 2.0, (H, W))
+    res = {}
+    for on in (1, 0):
+        L.set_option("stencil64", on)
+        try:
+            p = L.Plan64(ctx, H, W, taps, 1)
+            out = []
+            try:
+                A, B, NZ, GM = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3), L.PLANE_SCRATCH(4), L.PLANE_SCRATCH(5)
+                p.upload(A, a)
+                p.upload(NZ, nz)
+                for s in (0, 1, 2, 3, 5, 6, 7, 9):
+                    p.smooth(A, B, s)
+                    out.append(p.download(B))
+                    p.smooth(A, B, s, True)
+                    out.append(p.download(B))
+                    p.local_variance(A, B, s, 1.7, 3.0)
+                    out.append(p.download(B))
+                    p.local_variance(A, B, s, 1.0, 1.0, True)
+                    out.append(p.download(B))
+                    for tau, soft, npl, gpl in ((0.0, True, L.PLANE_NONE, L.PLANE_NONE), (1.1, True, L.PLANE_NONE, L.PLANE_NONE),
+                                                (0.9, False, L.PLANE_NONE, GM), (1.3, True, NZ, GM), (0.7, True, NZ, L.PLANE_NONE)):
+                        p.copy(A, 0)
+                        p.fill(GM, 0.5)
+                        p.wow_scale(0, s, tau, soft, npl, 0.9, gpl)
+                        out.append(p.download(0))
+                        out.append(p.download(GM))
+            finally:
+                p.close()
+            res[on] = out
+        finally:
+            L.set_option("stencil64", 1)
+    assert len(res[0]) == len(res[1]) == 8 * 14
+    for k, (u, v) in enumerate(zip(res[1], res[0])):
+        assert np.array_equal(_bits(u), _bits(v)), (shape, k // 14, k % 14)
+
+
+def test_float64_per_scale_decomposition_on_the_stencil_kernels_equals_the_generic_one_bitwise(L):
+    """wt64_decompose with the fused passes switched off runs one MODE_DECOMP stencil launch per scale
+    (c_{s+1} and w_s = c_s - c_{s+1} from one kernel): against the generic engine, both families, 9 scales."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(5)
+    for (H, W), taps in (((260, 1030), B3_TAPS), ((257, 513), TRI_TAPS)):
+        a = rng.standard_normal((H, W)) * 10 + 100
+        res = {}
+        L.set_option("fused64", 0)
+        try:
+            for on in (1, 0):
+                L.set_option("stencil64", on)
+                p = L.Plan64(ctx, H, W, taps, 9)
+                try:
+                    p.upload(L.PLANE_INPUT, a)
+                    p.decompose(L.PLANE_INPUT, 9)
+                    res[on] = [p.download(s) for s in range(10)]
+                finally:
+                    p.close()
+        finally:
+            L.set_option("fused64", 1)
+            L.set_option("stencil64", 1)
+        for s in range(10):
+            assert np.array_equal(_bits(res[1][s]), _bits(res[0][s])), ((H, W), s)
+        assert float(np.abs(np.sum(res[1], axis=0) - a).max()) <= 1e-13 * float(np.abs(a).max())
+
+
+@pytest.mark.parametrize("family,shape,level,sigma,scaling", [
+    ("b3spline", (200, 333), 5, 1, False), ("triangle", (257, 130), 6, [1.5, 1, 0.7], True),
+    ("b3spline", (64, 48), 3, 2, True), ("b3spline", (37, 53), 4, [0.5, 3], False)])
+def test_float64_bilateral_march_vs_oracle_and_generic_engine(L, family, shape, level, sigma, scaling):
+    """AtrousTransform(bilateral=...)(float64 image) - one wt64_bilateral_march_kernel per scale with the
+    variance of ref:434-436 formed in its register window, the weights through wt_exp2_64_from_u - against
+    (a) the numpy oracle in float64 (the reference's operation order: exp of a quotient, IEEE divisions)
+    and (b) the generic float64 engine (three kernels per scale, libm exp): 1e-12 * max|input| on every
+    plane.  The weights differ by a few 1e-15 relative (polynomial 4e-16, exponent quantised to 7e-15)."""
+    import wavelets_amd as WA
+    from oracle import atrous_numpy as O
+    cls = WA.B3spline if family == "b3spline" else WA.Triangle
+    rng = np.random.default_rng(shape[0] + level)
+    img = rng.standard_normal(shape) * 3 + 3 * np.sin(np.arange(shape[1]) / 7.0)[None, :] + 50.0
+    got = WA.AtrousTransform(cls, bilateral=sigma, bilateral_scaling=scaling)(img, level)
+    assert got.data.dtype == np.float64
+    ref = O.atrous_standard(img, level, family, bilateral=sigma, bilateral_scaling=scaling)
+    amax = float(np.abs(img).max())
+    measured(f"float64 bilateral march {family} {shape} L={level}", got.data, ref, 1e-12 * amax)
+    L.set_option("stencil64", 0)
+    try:
+        old = WA.AtrousTransform(cls, bilateral=sigma, bilateral_scaling=scaling)(img, level).data
+    finally:
+        L.set_option("stencil64", 1)
+    assert float(np.abs(got.data - old).max()) <= 1e-12 * amax
+    assert float(np.abs(np.sum(got.data, axis=0) - img).max()) <= 1e-13 * amax      # ref:442: the planes telescope
+
+
+def test_float64_bilateral_march_with_a_given_variance_plane_and_every_dilation(L):
+    """wt64_bilateral_conv (atrous_convolution(image, kernel, bilateral_variance, s), ref:74-105) through the
+    march with the variance read from a plane, dilations 1 .. 256 on an image narrower than the widest
+    reach, against the generic float64 kernel."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(3)
+    H, W = 300, 200
+    a = rng.standard_normal((H, W)) * 2 + 20
+    var = rng.uniform(0.05, 4.0, (H, W))
+    for taps in (B3_TAPS, TRI_TAPS):
+        res = {}
+        for on in (1, 0):
+            L.set_option("stencil64", on)
+            try:
+                p = L.Plan64(ctx, H, W, taps, 1)
+                try:
+                    A, V, B = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3), L.PLANE_SCRATCH(4)
+                    p.upload(A, a)
+                    p.upload(V, var)
+                    out = []
+                    for s in range(9):
+                        p.bilateral_conv(A, V, B, s)
+                        out.append(p.download(B))
+                    res[on] = out
+                finally:
+                    p.close()
+            finally:
+                L.set_option("stencil64", 1)
+        for s in range(9):
+            err = float(np.abs(res[1][s] - res[0][s]).max())
+            assert err <= 1e-12 * float(np.abs(a).max()), (len(taps), s, err)
+
+
+def test_float64_wow_bilateral_vs_oracle(L):
+    """wow(float64 image, bilateral=1, denoise_coefficients=[5, 2]) - BASELINE configs[4] in the reference's
+    default dtype, at a size the oracle finishes in seconds (256 x 320: 6 scales) - image and whitened
+    planes against the numpy oracle in float64; the same call with the side stream off gives identical bits."""
+    import wavelets_amd as WA
+    from oracle import atrous_numpy as O
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((256, 320)) + 3 * np.sin(np.arange(320) / 50.0)[None, :] + 10.0
+    rec, co = WA.wow(img.copy(), bilateral=1, denoise_coefficients=[5, 2])
+    rref, cref = O.wow(img.copy(), "b3spline", bilateral=1, denoise_coefficients=[5, 2])
+    assert rec.dtype == np.float64 and co.data.shape == cref.data.shape
+    measured("float64 wow(bilateral=1, [5,2]) 256x320 image", rec, rref, 1e-11 * float(np.abs(rref).max()))
+    measured("float64 wow(bilateral=1, [5,2]) 256x320 planes", co.data, cref.data, 1e-11 * float(np.abs(cref.data).max()))
+    L.set_option("wow_overlap", 0)
+    try:
+        rec2, co2 = WA.wow(img.copy(), bilateral=1, denoise_coefficients=[5, 2])
+    finally:
+        L.set_option("wow_overlap", 1)
+    assert np.array_equal(_bits(rec), _bits(rec2)) and np.array_equal(_bits(co.data), _bits(co2.data))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wow_updates_on_the_side_stream_equal_the_serial_order_bitwise(L, dtype):
+    """cfg5's flow (bilateral transform, MAD noise on w_0, per-scale wow updates, plane sum) with the updates
+    and the median queued on the side stream behind the per-scale events of the transform (option
+    wow_overlap, the default) against the serial order: identical planes and image, three steps in a row on
+    the same plan (the next transform must wait for the previous step's side work), 2048^2 so that every
+    kernel family (row / lattice) takes part."""
+    import wavelets_amd as WA
+    from wavelets_amd import utils as WU
+    ctx = L.default_context()
+    side = 2048
+    level = int(np.round(np.log2(side) - np.log2(5)))
+    rng = np.random.default_rng(2)
+    img = (rng.standard_normal((side, side)) + 3 * np.sin(np.arange(side) / 50.0)[None, :]).astype(dtype)
+    res = {}
+    for on in (1, 0):
+        L.set_option("wow_overlap", on)
+        try:
+            sb = [1] * (level + 1)
+            tr = WA.AtrousTransform(WA.B3spline, bilateral=sb)
+            if dtype == np.float64:
+                plan = L.Plan64(ctx, side, side, B3_TAPS, level)
+            else:
+                plan = L.Plan(ctx, side, side, L.B3SPLINE, level)
+            try:
+                plan.upload(L.PLANE_INPUT, img)
+                co = WA.Coefficients(plan, WA.B3spline(2), sb)
+                for _ in range(3):
+                    tr._run(plan, level)
+                    co.noise = None
+                    WU._wow_device(co, level, [], True, [5, 2], True, False, 3.2, None, None, 0)
+                res[on] = [plan.download(s) for s in range(level + 1)] + [plan.download(L.PLANE_OUT)]
+                co._plan = None
+            finally:
+                plan.close()
+        finally:
+            L.set_option("wow_overlap", 1)
+    for k, (u, v) in enumerate(zip(res[1], res[0])):
+        assert np.array_equal(_bits(u), _bits(v)), k
+
+
+def test_float64_cfg5_at_full_size_properties(L):
+    """cfg5 in float64 at BASELINE size (8192^2, 11 scales; 12 planes of 512 MiB): size-independent
+    properties on the device-resident flow - the bilateral planes telescope to the input (ref:442) at
+    1e-13, every plane is finite, the smooth plane's mean is the image's mean (weights normalised,
+    ref:101-103), and the whitened reconstruction has the moments wow() promises: the last plane divided by
+    its std has unit variance (ref:185-191)."""
+    import wavelets_amd as WA
+    from wavelets_amd import utils as WU
+    ctx = L.default_context()
+    side, level = 8192, 11
+    img = (np.random.default_rng(0).standard_normal((side, side), dtype=np.float32)
+           + 3 * np.sin(np.arange(side, dtype=np.float32) / 50.)[None, :]).astype(np.float64)
+    sb = [1] * (level + 1)
+    plan = L.Plan64(ctx, side, side, B3_TAPS, level)
+    try:
+        plan.upload(L.PLANE_INPUT, img)
+        tr = WA.AtrousTransform(WA.B3spline, bilateral=sb)
+        tr._run(plan, level)
+        plan.plane_sum(0, level + 1, L.PLANE_OUT)
+        back = plan.download(L.PLANE_OUT)
+        assert float(np.abs(back - img).max()) <= 1e-13 * float(np.abs(img).max())
+        del back
+        tot, tot2, lo, hi = plan.reduce(level)
+        assert np.isfinite([tot, tot2, lo, hi]).all()
+        assert abs(tot / side / side - float(img.mean())) <= 1e-3       # the bilateral filter is not mean-preserving to rounding, only nearly
+        co = WA.Coefficients(plan, WA.B3spline(2), sb)
+        co.noise = None
+        WU._wow_device(co, level, [], True, [5, 2], True, False, 3.2, None, None, 0)
+        tot, tot2, _, _ = plan.reduce(level)
+        n = float(side) * side
+        var = tot2 / n - (tot / n) ** 2
+        assert abs(var - 1.0) <= 1e-9, var
+        for s in (0, 5, level):
+            t, t2, lo, hi = plan.reduce(s)
+            assert np.isfinite([t, t2, lo, hi]).all(), s
+        co._plan = None
+    finally:
+        plan.close()

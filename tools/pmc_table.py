@@ -16,7 +16,7 @@ acc = defaultdict(lambda: defaultdict(float))       # (kernel, counter) -> dispa
 for f in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "wt_" not in k:
+        if "wt_" not in k and "wt64_" not in k:
             continue
         acc[(k, r["Counter_Name"])][(f, r["Dispatch_Id"])] += float(r["Counter_Value"])
 print("kernel,counter,dispatches,avg_per_dispatch")

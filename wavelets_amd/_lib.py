@@ -142,6 +142,7 @@ SIGNATURES = {
                                        _c.c_double, _c.c_int, _c.c_int]),
     "wt64_bilateral_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_int]),
+    "wt64_decompose_bilateral": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_int]),
     "wt64_copy_window": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64, _i64, _i64, _i64,
                                     _i64]),
     "wt64_taps_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32),
@@ -200,7 +201,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = res, args
-            if L.wt_abi_version() != 6:
+            if L.wt_abi_version() != 7:
                 raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
             _lib = L
     return _lib
@@ -894,6 +895,10 @@ class Plan64:
 
     def bilateral3d_conv(self, src, var, dst, s, depth):
         check(load().wt64_bilateral_conv(self._h, src, var, dst, s, depth, 0))
+
+    def decompose_bilateral(self, src, level, sigma_b, bilateral_scaling=False, flags=0):
+        arr = (_c.c_double * max(level, 1))(*[float(v) for v in sigma_b[:level]])
+        check(load().wt64_decompose_bilateral(self._h, src, level, arr, int(bilateral_scaling)))
 
     def copy_window_from(self, src_plan, src_plane, dst_plane, sy, sx, dy, dx, rows, cols):
         check(load().wt64_copy_window(src_plan._h, src_plane, self._h, dst_plane, sy, sx, dy, dx,

@@ -8,6 +8,7 @@
 
 #include "wt_internal.h"
 #include "wt_kernels.h"
+#include "wt_stencil_launch.h"
 #include "wt_fused_decl.h"
 #include "wt_fft.h"
 
@@ -105,6 +106,7 @@ static int prof_resolve(wt_ctx *c)
     if (c->pending.empty()) return 0;
     WT_HIP(hipStreamSynchronize(c->stream));
     if (c->comm_stream) WT_HIP(hipStreamSynchronize(c->comm_stream));
+    if (c->side_stream) WT_HIP(hipStreamSynchronize(c->side_stream));
     for (auto &p : c->pending) {
         float ms = 0.f;
         WT_HIP(hipEventElapsedTime(&ms, p.a, p.b));
@@ -235,6 +237,55 @@ extern "C" int wt_ctx_comm_info(wt_ctx *ctx, int *rank, int *nranks)
 }
 
 // =============================================================================================
+// side stream
+// =============================================================================================
+static int g_opt_wow_overlap = getenv("WT_NO_WOW_OVERLAP") ? 0 : 1;   // wt_set_option("wow_overlap", 0/1)
+bool wt_wow_overlap_enabled() { return g_opt_wow_overlap != 0; }
+
+int wt_side_join(wt_ctx *c)
+{
+    if (!c->side_pending || c->in_side) return 0;
+    WT_HIP(hipEventRecord(c->ev_side_done, c->side_stream));
+    WT_HIP(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
+    c->side_pending = false;
+    return 0;
+}
+
+int wt_side_begin(wt_ctx *c, hipEvent_t after)
+{
+    if (c->in_side) WT_FAIL("side stream: nested use");
+    if (!c->side_stream) {
+        int lo = 0, hi = 0;
+        WT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        // high priority: its workgroups go first whenever the main stream's kernel frees a slot
+        static const int prio_env = getenv("WT_SIDE_PRIORITY") ? atoi(getenv("WT_SIDE_PRIORITY")) : 1;   // experiments: 0 default, -1 low
+        WT_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_env > 0 ? hi : (prio_env < 0 ? lo : (lo + hi) / 2)));
+        WT_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
+    }
+    WT_HIP(hipStreamWaitEvent(c->side_stream, after, 0));
+    std::swap(c->stream, c->side_stream);
+    c->in_side = 1;
+    c->side_pending = true;
+    return 0;
+}
+
+void wt_side_end(wt_ctx *c)
+{
+    std::swap(c->stream, c->side_stream);
+    c->in_side = 0;
+}
+
+int wt_scale_events(wt_ctx *c, std::vector<hipEvent_t> &ev, int n)
+{
+    while ((int)ev.size() < n) {
+        hipEvent_t e = nullptr;
+        WT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev.push_back(e);
+    }
+    return 0;
+}
+
+// =============================================================================================
 // context
 // =============================================================================================
 static const int kPartialBlocks = 2048;     // 8 blocks of wt_reduce_kernel per CU
@@ -282,6 +333,11 @@ extern "C" int wt_ctx_destroy(wt_ctx *c)
         (void)hipStreamDestroy(c->xfer_in);
         (void)hipStreamDestroy(c->xfer_out);
     }
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+        (void)hipEventDestroy(c->ev_side_done);
+    }
     for (auto &p : c->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -316,6 +372,7 @@ extern "C" int wt_ctx_sync(wt_ctx *c)
 {
     WtGuard guard_(ctx_of(c));
     if (!c) WT_FAIL("wt_ctx_sync: null context");
+    WT_TRY(wt_side_join(c));
     WT_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -332,6 +389,7 @@ extern "C" int wt_timer_stop(wt_ctx *c, float *ms)
 {
     WtGuard guard_(ctx_of(c));
     if (!c || !ms) WT_FAIL("wt_timer_stop: null pointer");
+    WT_TRY(wt_side_join(c));
     WT_HIP(hipEventRecord(c->t1, c->stream));
     WT_HIP(hipEventSynchronize(c->t1));
     WT_HIP(hipEventElapsedTime(ms, c->t0, c->t1));
@@ -619,6 +677,10 @@ static int plane_base(wt_plan *p, int id, float **base)
     else if (id <= WT_PLANE_SCRATCH(0) && id > WT_PLANE_SCRATCH(WT_NUM_SCRATCH)) slot = &p->scratch[-3 - id];
     else WT_FAIL("invalid plane id %d (max_level %d)", id, p->max_level);
     if (p->ctx->prehist_plan == p && p->ctx->prehist_plane == id) p->ctx->prehist_plan = nullptr;   // plane touched
+    if (!p->ctx->in_side) {            // a main-stream access: behind everything the side stream has queued
+        WT_TRY(wt_side_join(p->ctx));
+        p->overlap_ok = false;
+    }
     WT_TRY(plan_alloc(p, slot));
     *base = *slot + (size_t)p->g.halo * p->g.P;
     return 0;
@@ -689,13 +751,21 @@ extern "C" int wt_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int family, int
     return wt_plan_create_strip(ctx, H, W, family, max_level, 0, H, 0, 0, 1, out);
 }
 
+static void destroy_events(std::vector<hipEvent_t> &ev)
+{
+    for (auto e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+}
+
 extern "C" int wt_plan_destroy(wt_plan *p)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) return 0;
     if (p->ctx->prehist_plan == p) p->ctx->prehist_plan = nullptr;
     (void)hipSetDevice(p->ctx->device);
+    (void)wt_side_join(p->ctx);
     (void)hipStreamSynchronize(p->ctx->stream);
+    destroy_events(p->scale_ev);
     int bad = 0;
     std::string why;
     for (void *q : p->raw_allocs) {
@@ -1226,43 +1296,22 @@ static int check_scale(const wt_plan *p, int s, const char *who)
     return 0;
 }
 
-// chunking of the polyphase chains: enough (phase, chunk) items to fill the chip, chunks long
-// enough that the K-1 warm-up rows stay a small fraction
+static inline StencilCtx stencil_ctx(const wt_plan *p, hipStream_t st = nullptr)
+{
+    return StencilCtx{p->ctx, st ? st : p->ctx->stream, p->g, p->family};
+}
+
+// chunking of the polyphase chains (wt_stencil_launch.h)
 static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim3 &block, int gx_override = 0)
 {
-    const Geo &g = p->g;
-    const int d = 1 << s;
-    const int X = (g.W + 3) / 4;                 // float4 columns
-    const int gx = gx_override ? gx_override : (X + 63) / 64;
-    const int n_max = (g.nrows + d - 1) / d;     // longest chain
-    static const int64_t lanes_env = getenv("WT_CHAIN_LANES") ? atoll(getenv("WT_CHAIN_LANES")) : 0;   // experiments
-    static const int smax_env = getenv("WT_CHAIN_SMAX") ? atoi(getenv("WT_CHAIN_SMAX")) : 0;
-    const int64_t want_items = std::max<int64_t>(1, (lanes_env > 0 ? lanes_env : (int64_t)524288) / std::max(1, gx * 64));
-    int chunks_target = (int)std::max<int64_t>(1, want_items / std::min(d, g.nrows));
-    int S = (n_max + chunks_target - 1) / chunks_target;
-    S = std::max(S, std::min(n_max, 8));
-    S = std::min(S, smax_env > 0 ? smax_env : 64);
-    int chunks = (n_max + S - 1) / S;
-    int64_t items = (int64_t)d * chunks;
-    while ((items + 3) / 4 > 65528) {             // grid.y limit
-        S *= 2;
-        chunks = (n_max + S - 1) / S;
-        items = (int64_t)d * chunks;
-    }
-    a.g = g;
-    a.d = d;
-    a.S = S;
-    a.chunks = chunks;
-    grid = dim3(gx, (unsigned)(((items + 3) / 4 + 7) / 8 * 8));   // multiple of 8: wt_xcd_remap
-    block = dim3(64, 4);
-    return 0;
+    return wt_chain_geometry<float>(p->g, s, a, grid, block, gx_override);
 }
 
 // tuning / A-B switches (wt_set_option)
 // 0 forces the generic addressing of the fused passes (read by the launch code of every wt_fused_tu.hip unit)
 int g_opt_fused_fast = getenv("WT_FUSED_NO_FAST") ? 0 : 1;
-static int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;
-static int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
+int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;      // (read by wt_stencil_launch.h in both units)
+int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
 static int g_opt_bilateral2 = getenv("WT_NO_BILATERAL2") ? 0 : 1;   // 2-pixel bilateral kernel
 // multi-GPU: run the halo exchange of pass i+1 beside the interior rows of pass i (0 = every
 // exchange on the compute stream, between the passes)
@@ -1276,6 +1325,7 @@ static int g_opt_split_dry = 0;
 static void wt_set_fused64(int on);     // wt_f64.h (included at the end of this file)
 static void wt_set_select64_list(int on);
 static void wt_set_f64_pairs(int on);
+static void wt_set_stencil64(int on);
 static void wt_set_hist_window(int on);
 // wt_decompose_sum_host: pipeline the PCIe legs with the passes (0: upload, passes, download in turn)
 static int g_opt_host_pipeline = getenv("WT_NO_HOST_PIPELINE") ? 0 : 1;
@@ -1287,6 +1337,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "lattice_kernel")) { g_opt_lattice = value != 0; return 0; }
     if (!strcmp(name, "bilateral2")) { g_opt_bilateral2 = value != 0; return 0; }
     if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
+    if (!strcmp(name, "wow_overlap")) { g_opt_wow_overlap = value != 0; return 0; }
     if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
@@ -1295,66 +1346,11 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "fused64")) { wt_set_fused64(value != 0); return 0; }
     if (!strcmp(name, "select64_list")) { wt_set_select64_list(value != 0); return 0; }
     if (!strcmp(name, "f64_pairs")) { wt_set_f64_pairs(value != 0); return 0; }
+    if (!strcmp(name, "stencil64")) { wt_set_stencil64(value != 0); return 0; }
     if (!strcmp(name, "hist_window")) { wt_set_hist_window(value != 0); return 0; }
     if (!strcmp(name, "scatter")) { g_opt_scatter = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     if (!strcmp(name, "scatter_strips")) { g_opt_scatter_strips = value != 0; return 0; }
     WT_FAIL("wt_set_option: unknown option '%s'", name);
-}
-
-// Row kernel (taps from an LDS copy of the row) where the horizontal halo fits the workgroup.
-template <int K, int MODE, int NW>
-static int launch_row_t(wt_plan *p, ChainArgs a, int HX, const char *name)
-{
-    constexpr int NL = NW * 64;
-    const Geo &g = p->g;
-    const int d = a.d;
-    const int VXMAX = (NL * 4 - 2 * HX) / 32 * 32;
-    const int W4 = (g.W + 3) / 4 * 4;
-    const int nx = (W4 + VXMAX - 1) / VXMAX;
-    RowArgs ra{};
-    ra.HX = HX;
-    ra.Vx = std::min(VXMAX, ((W4 + nx - 1) / nx + 31) / 32 * 32);
-    const int phases = std::min(d, g.nrows);
-    const int n_max = (g.nrows + d - 1) / d;
-    // one to two rounds of resident workgroups (16 waves per CU at <= 128 VGPRs)
-    const int slots = p->ctx->num_cus * (16 / NW) * 2;
-    int chunks = std::max(1, slots / std::max(1, nx * phases));
-    int S = (n_max + chunks - 1) / chunks;
-    S = std::max(S, std::min(n_max, 16));
-    chunks = (n_max + S - 1) / S;
-    a.S = S;
-    a.chunks = chunks;
-    ra.c = a;
-    const int64_t gy = (int64_t)d * chunks;
-    if (gy > 65535) WT_FAIL("row kernel: grid too large");
-    dim3 grid(nx, (unsigned)gy), block(NL);
-    ProfScope ps(p->ctx, name);
-    if (d < 4) hipLaunchKernelGGL((wt_row_kernel<K, MODE, true, NW>), grid, block, 0, p->ctx->stream, ra);
-    else hipLaunchKernelGGL((wt_row_kernel<K, MODE, false, NW>), grid, block, 0, p->ctx->stream, ra);
-    WT_HIP(hipGetLastError());
-    return 0;
-}
-
-static const char *row_name(int mode)
-{
-    switch (mode) {
-        case MODE_SMOOTH: return "wt_row_kernel<smooth>";
-        case MODE_SMOOTH_SQ: return "wt_row_kernel<smooth_sq>";
-        case MODE_DECOMP: return "wt_row_kernel<decomp>";
-        case MODE_VAR: return "wt_row_kernel<variance>";
-        default: return "wt_row_kernel<wow>";
-    }
-}
-
-static const char *lattice_name(int mode)
-{
-    switch (mode) {
-        case MODE_SMOOTH: return "wt_lattice_kernel<smooth>";
-        case MODE_SMOOTH_SQ: return "wt_lattice_kernel<smooth_sq>";
-        case MODE_DECOMP: return "wt_lattice_kernel<decomp>";
-        case MODE_VAR: return "wt_lattice_kernel<var>";
-        default: return "wt_lattice_kernel<wow>";
-    }
 }
 
 template <int MODE>
@@ -1366,46 +1362,7 @@ static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
         if (MODE == MODE_VAR) return launch_custom_variance(p, a.in, a.out_c, s, a.f1, a.f2, a.take_sqrt, name);
         WT_FAIL("%s: not available with user-defined taps", name);
     }
-    const bool no_row = !g_opt_row_kernel;
-    const int hw = family_taps(p->family) / 2;
-    const int d = 1 << s;
-    const int HX = std::max(32, (hw * d + 31) / 32 * 32);
-    const bool b3 = p->family == WT_B3SPLINE;
-    a.g = p->g;
-    a.d = d;
-    a.nt = (int64_t)p->g.nrows * p->g.P * 4 >= ((int64_t)32 << 20);   // planes >> L2: streaming stores
-    dim3 grid, block;
-    // d >= 64: lattice kernel (C lattice columns per thread share their taps); measured faster
-    // than the 8-wave row kernel from d = 64 up and 2.6x faster than the chain kernel at d >= 256
-    static const int lat_min_d = getenv("WT_LATTICE_MIN_D") ? std::max(4, atoi(getenv("WT_LATTICE_MIN_D"))) : 64;
-    const int lat_c = (g_opt_lattice && d >= lat_min_d && p->g.border == 0 && p->g.W % 4 == 0) ? (p->g.W >= 4 * d ? 4 : (p->g.W >= 2 * d ? 2 : 0)) : 0;
-    if (lat_c) {
-        const int J = (p->g.W + d - 1) / d;                       // lattice columns per phase
-        const int tx = ((J + lat_c - 1) / lat_c) * (d / 4);       // threads along x
-        WT_TRY(chain_geometry(p, s, a, grid, block, (tx + 63) / 64));
-        ProfScope ps(p->ctx, lattice_name(MODE));
-        if (b3 && lat_c == 4) hipLaunchKernelGGL((wt_lattice_kernel<5, MODE, 4>), grid, block, 0, p->ctx->stream, a);
-        else if (b3) hipLaunchKernelGGL((wt_lattice_kernel<5, MODE, 2>), grid, block, 0, p->ctx->stream, a);
-        else if (lat_c == 4) hipLaunchKernelGGL((wt_lattice_kernel<3, MODE, 4>), grid, block, 0, p->ctx->stream, a);
-        else hipLaunchKernelGGL((wt_lattice_kernel<3, MODE, 2>), grid, block, 0, p->ctx->stream, a);
-        WT_HIP(hipGetLastError());
-        return 0;
-    }
-    if (!no_row && 2 * HX <= 256) {
-        return b3 ? launch_row_t<5, MODE, 4>(p, a, HX, row_name(MODE)) : launch_row_t<3, MODE, 4>(p, a, HX, row_name(MODE));
-    }
-    if (!no_row && 2 * HX <= 512) {
-        return b3 ? launch_row_t<5, MODE, 8>(p, a, HX, row_name(MODE)) : launch_row_t<3, MODE, 8>(p, a, HX, row_name(MODE));
-    }
-    WT_TRY(chain_geometry(p, s, a, grid, block));
-    ProfScope ps(p->ctx, name);
-    const bool small = a.d < 4;
-    if (b3 && small) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, true>), grid, block, 0, p->ctx->stream, a);
-    else if (b3) hipLaunchKernelGGL((wt_chain_kernel<5, MODE, false>), grid, block, 0, p->ctx->stream, a);
-    else if (small) hipLaunchKernelGGL((wt_chain_kernel<3, MODE, true>), grid, block, 0, p->ctx->stream, a);
-    else hipLaunchKernelGGL((wt_chain_kernel<3, MODE, false>), grid, block, 0, p->ctx->stream, a);
-    WT_HIP(hipGetLastError());
-    return 0;
+    return wt_launch_stencil<float, MODE>(stencil_ctx(p), a, s, name);
 }
 
 template <int MODE>
@@ -1496,8 +1453,9 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     if (g_opt_bilateral2) {                              // two pixels per thread: 4 waves per SIMD
         WT_TRY(chain_geometry(p, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64));
         ProfScope ps(p->ctx, "wt_bilateral2_kernel");
-        if (b3) hipLaunchKernelGGL((wt_bilateral2_kernel<5>), grid, block, 0, p->ctx->stream, a);
-        else hipLaunchKernelGGL((wt_bilateral2_kernel<3>), grid, block, 0, p->ctx->stream, a);
+        static const int lds_pad = getenv("WT_BIL_LDS_PAD") ? atoi(getenv("WT_BIL_LDS_PAD")) : 0;   // experiments: dynamic LDS to cap the workgroups per CU
+        if (b3) hipLaunchKernelGGL((wt_bilateral2_kernel<5>), grid, block, lds_pad, p->ctx->stream, a);
+        else hipLaunchKernelGGL((wt_bilateral2_kernel<3>), grid, block, lds_pad, p->ctx->stream, a);
         WT_HIP(hipGetLastError());
         return 0;
     }
@@ -1981,6 +1939,8 @@ extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const doub
     if (src >= 0 && src <= level) WT_FAIL("wt_decompose_bilateral: src plane %d is one of the output planes", src);
     if (src <= WT_PLANE_SCRATCH(0) && src >= WT_PLANE_SCRATCH(2)) WT_FAIL("wt_decompose_bilateral: scratch planes 0..2 are used internally");
     if (level == 0) return wt_copy_plane(p, src, 0);
+    const bool overlap = g_opt_wow_overlap && p->nranks == 1;
+    if (overlap) WT_TRY(wt_scale_events(p->ctx, p->scale_ev, level));
     int cur = src;
     for (int s = 0; s < level; ++s) {
         WT_TRY(check_scale(p, s, "wt_decompose_bilateral"));
@@ -2000,8 +1960,12 @@ extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const doub
         } else {
             WT_TRY(launch_bilateral(p, in, nullptr, oc, ow, s, f1, f2, (flags & 8) != 0));
         }
+        if (overlap) WT_HIP(hipEventRecord(p->scale_ev[s], p->ctx->stream));     // w_s is written
         cur = nxt;
     }
+    // the per-scale work on w_s that follows (wt_wow_scale, wt_abs_median) may run beside the scales still queued
+    p->overlap_scales = overlap ? level : 0;
+    p->overlap_ok = overlap;
     return 0;
 }
 
@@ -2152,6 +2116,12 @@ extern "C" int wt_wow_scale(wt_plan *p, int plane, int s, double tau, int soft, 
     if (plane < 0 || plane > p->max_level) WT_FAIL("wt_wow_scale: plane %d is not a coefficient plane", plane);
     WT_TRY(check_scale(p, s, "wt_wow_scale"));
     const int spare = WT_PLANE_SCRATCH(3);
+    // Right behind a bilateral transform the update of w_s only needs scale s of it (its event): it runs on the
+    // side stream, beside the bilateral kernels of the later scales (plain mode: no maps to order against)
+    const bool side = g_opt_wow_overlap && p->overlap_ok && plane < p->overlap_scales && noise_plane == WT_PLANE_NONE &&
+                      gamma_plane == WT_PLANE_NONE && p->nranks == 1 && !p->ntaps;
+    WtSideScope side_scope(p->ctx, side ? p->scale_ev[plane] : nullptr, side);
+    if (!side_scope.ok()) return 2;
     float *c = nullptr, *t = nullptr, *nz = nullptr, *gm = nullptr;
     WT_TRY(plane_base(p, plane, &c));
     WT_TRY(plane_base(p, spare, &t));
@@ -2648,6 +2618,10 @@ extern "C" int wt_abs_median(wt_plan *p, int plane, float *median)
     WtGuard guard_(ctx_of(p));
     if (!p || !median) WT_FAIL("wt_abs_median: null pointer");
     wt_ctx *c = p->ctx;
+    // MAD of a detail plane right behind a bilateral transform: beside the scales still queued (side stream)
+    const bool side = g_opt_wow_overlap && p->overlap_ok && plane >= 0 && plane < p->overlap_scales && p->nranks == 1;
+    WtSideScope side_scope(c, side ? p->scale_ev[plane] : nullptr, side);
+    if (!side_scope.ok()) return 2;
     // a fused pass has histogrammed the first level of this plane (flag bit4 of wt_decompose /
     // wt_decompose_pass) and nothing has touched the plane or the bins since: one pass less over it
     const bool pre = c->prehist_plan == p && c->prehist_plane == plane;

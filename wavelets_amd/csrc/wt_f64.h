@@ -233,59 +233,7 @@ __global__ __launch_bounds__(256) void wt64_binary_kernel(const double *a, const
     }
 }
 
-// erf(y) for y >= 0 in double precision, branch-free (round 4).  The library erf evaluates one of
-// several ranges per lane - a wave pays for all of them, ~200 double-precision operations per sample,
-// which bounded the float64 threshold kernels at 0.40 of the HBM rate.  Here
-//     erf(y) = -expm1(a),   a = -y * (r(t) + y) = log(erfc(y)),   t = y / 3 - 1,   y clamped to 6
-// (erfc(6) = 2e-17), r ONE degree-26 polynomial (tools/make_erf64.py: weighted Chebyshev fit against
-// 50-digit mpmath values), and expm1 written out: a = n ln2 + x, |x| <= ln2 / 2,
-// expm1(a) = 2^n (1 + x q(x)) - 1 with q of degree 12, so that -expm1(a) = (1 - 2^n) - 2^n x q(x) in one
-// FMA - exact for n = 0, i.e. small arguments keep their relative accuracy.  ~50 FMAs per sample, no
-// division, no branch.  Measured against mpmath on [1e-300, 6.5]: absolute error <= 2.3e-16, relative
-// <= 2.7e-14 (the float64 parity bound of the tests is 1e-12).  erf(0) = 0 exactly; NaN stays NaN.
-// The coefficients live in constant memory, NOT in the instruction stream: a 64-bit literal cannot be
-// an operand of v_fma_f64, so with constexpr tables every Horner step was a v_mov_b64 + v_fmac_f64
-// pair (150 moves per two samples); scalar loads put them in SGPR pairs, which v_fma_f64 reads directly.
-__constant__ double WT_ERF64_Q[27] = {0x1.259bcee7098c9p-1, -0x1.142c68ccd863dp-2, 0x1.2293b824c872dp-3, -0x1.33ec0d4b613eap-4,
-                                      0x1.3c837774a376ap-5, -0x1.32f7d405cccfap-6, 0x1.0ee44d87ebd23p-7, -0x1.93aca6b315f22p-9,
-                                      0x1.84922d81926a0p-11, 0x1.3fd374d9a6dcdp-13, -0x1.8d18e3e4439d9p-12, 0x1.63d73d5b4b8bap-12,
-                                      -0x1.e1bf08c08a3fap-13, 0x1.22e8a9c630114p-13, -0x1.19446361f8e4fp-14, -0x1.49050d2260ba0p-22,
-                                      0x1.86930026aa01cp-20, 0x1.287c357a01b50p-15, 0x1.14679d6bb6ed4p-16, -0x1.d2963129dd6bep-15,
-                                      -0x1.4bd1e396300c0p-16, 0x1.2e935cbc2a44fp-15, 0x1.8e87fa9480c7fp-16, -0x1.122db495799f0p-16,
-                                      -0x1.813c9c90f35cap-17, 0x1.c52e5511ca2c2p-19, 0x1.147aa0cdd9e8cp-19};
-// 1 / k!, k = 1 .. 13
-__constant__ double WT_ERF64_F[13] = {1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
-                                      1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
-__device__ __forceinline__ double wt_erf64(double y)
-{
-    const double *Q = WT_ERF64_Q, *F = WT_ERF64_F;
-    y = y > 6.0 ? 6.0 : y;
-    const double t = fma(y, 1.0 / 3.0, -1.0);
-    double r = Q[26];
-#pragma unroll
-    for (int k = 25; k >= 0; --k) r = fma(r, t, Q[k]);
-    const double a = -(y * (r + y));                         // log(erfc(y)), in [-38.5, 0]
-    const double n = __builtin_rint(a * 0x1.71547652b82fep+0);
-    double x = fma(n, -0x1.62e42fefa39efp-1, a);
-    x = fma(n, -0x1.abc9e3b39803fp-56, x);
-    double q = F[12];
-#pragma unroll
-    for (int k = 11; k >= 0; --k) q = fma(q, x, F[k]);
-    const double s = ldexp(1.0, (int)n);
-    return fma(-s, x * q, 1.0 - s);
-}
-
-// significance of one sample (watroo/wavelets.py:137-141): erf(|v / tt|) or |v| > tt
-__device__ __forceinline__ double wt_sig64(double v, double tt, int soft)
-{
-    return soft ? wt_erf64(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
-}
-// the same with the reciprocal of a scalar threshold (the kernels form 1 / tau once per thread: the
-// argument of erf then differs from the quotient by at most one rounding, 1e-16 relative)
-__device__ __forceinline__ double wt_sig64_inv(double v, double tt, double inv_tt, int soft)
-{
-    return soft ? wt_erf64(fabs(v) * inv_tt) : (fabs(v) > tt ? 1.0 : 0.0);
-}
+// (wt_erf64, wt_sig64, wt_sig64_inv: wt_math64.h)
 
 // Coefficients.significance / denoise (watroo/wavelets.py:129-149): mode 0: dst = significance;
 // mode 1: dst = c * (wgt * significance).  tau <= 0: significance one.  noise: optional per-pixel map
@@ -356,7 +304,7 @@ __device__ __forceinline__ double wt64_wow_point(double t, bool has_power, doubl
     double q = factor;
     if (has_power) {
         const double lp = pw <= 0.0 ? 1e-15 : pw;
-        q = factor / sqrt(lp);
+        q = factor * wt_rsq64(lp);       // (as wt_wow_point<double> of wt_stencil.h: the fused update gives identical bits)
     }
     return t * q;
 }
@@ -554,6 +502,8 @@ __global__ __launch_bounds__(256) void wt64_anscombe_kernel(const double *src, d
 __global__ __launch_bounds__(256) void wt64_var_kernel(const double *mean, const double *meansq, double *dst, int W, int P, int nrows,
                                                        double f1, double f2, int take_sqrt)
 {
+#pragma clang fp contract(off)
+    // (the reference multiplies, then subtracts, ref:27; and wt_var_point of wt_stencil.h must give the same bits)
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
     for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
@@ -881,6 +831,10 @@ static int plan64_base(wt_plan64 *p, int id, double **base)
     else if (id <= WT_PLANE_SCRATCH(0) && id > WT_PLANE_SCRATCH(WT64_NUM_SCRATCH)) slot = &p->scratch[-3 - id];
     else WT_FAIL("float64 plan: invalid plane id %d (max_level %d)", id, p->max_level);
     if (p->ctx->prehist_plan == p && p->ctx->prehist_plane == id) p->ctx->prehist_plan = nullptr;   // plane touched
+    if (!p->ctx->in_side) {            // a main-stream access: behind everything the side stream has queued
+        WT_TRY(wt_side_join(p->ctx));
+        p->overlap_ok = false;
+    }
     if (!*slot) {
         void *q = nullptr;
         WT_HIP(hipSetDevice(p->ctx->device));
@@ -950,7 +904,9 @@ extern "C" int wt64_plan_destroy(wt_plan64 *p)
     if (!p) return 0;
     if (p->ctx->prehist_plan == p) p->ctx->prehist_plan = nullptr;
     (void)hipSetDevice(p->ctx->device);
+    (void)wt_side_join(p->ctx);
     (void)hipStreamSynchronize(p->ctx->stream);
+    destroy_events(p->scale_ev);
     for (void *q : p->allocs) (void)hipFree(q);
     delete p;
     return 0;
@@ -1048,6 +1004,20 @@ extern "C" int wt64_download(wt_plan64 *p, int plane, double *host, int64_t host
     return 0;
 }
 
+// Images whose taps are one of the built-in families run the per-scale kernels of wt_stencil.h instantiated
+// for double (round 5: lattice / row / chain kernels, the fused wow update, the bilateral march) instead of
+// the generic one-sample-per-thread kernels of this file; wt_set_option("stencil64", 0) restores those (A/B,
+// tests: both orders of operations are rows first, then columns, FMA chains in tap order - identical bits
+// for the filters).
+static int fused64_family(const wt_plan64 *p);
+static int g_opt_stencil64 = getenv("WT_NO_STENCIL64") ? 0 : 1;
+static void wt_set_stencil64(int on) { g_opt_stencil64 = on; }
+static inline bool stencil64_ok(const wt_plan64 *p) { return g_opt_stencil64 && fused64_family(p) >= 0 && p->g.H >= 2; }
+static inline StencilCtx stencil64_ctx(const wt_plan64 *p, hipStream_t st = nullptr)
+{
+    return StencilCtx{p->ctx, st ? st : p->ctx->stream, p->g, fused64_family(p)};
+}
+
 // conv_s of a plane: rows -> a private temporary, axis 1 (-> a second one when an axis-0 pass follows), axis 0.
 // depth = 0: an image (or a 1 x N signal: no column pass); depth = Z > 0: a (Z, Y, X) cube.
 static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, int s, int square, int depth)
@@ -1072,6 +1042,13 @@ static int smooth64(wt_plan64 *p, const double *in, double *out, double *out_w, 
     static const int chain_env = getenv("WT64_CHAIN") ? atoi(getenv("WT64_CHAIN")) : -1;       // 0 / 1 force (experiments)
     const bool big_planes = (size_t)g.nrows * g.P * sizeof(double) >= ((size_t)256 << 20);
     const bool use_chain = chain_env >= 0 ? chain_env != 0 : (big_planes && (g.H + d - 1) / d >= 24);
+    if (cols && !deep && stencil64_ok(p)) {
+        // images, built-in taps: one tiled kernel per scale (wt_stencil.h)
+        ChainArgsT<double> a{};
+        a.in = in; a.out_c = out; a.out_w = out_w;
+        a.f1 = 1.0; a.f2 = 1.0;
+        return wt64_stencil_launch(stencil64_ctx(p), square ? MODE_SMOOTH_SQ : (out_w ? MODE_DECOMP : MODE_SMOOTH), a, s);
+    }
     if (cols && !deep && !square && use_chain) {
         // images: one kernel per scale (register window down every polyphase row chain)
         const int n_max = (g.H + d - 1) / d;             // longest chain
@@ -1377,6 +1354,13 @@ extern "C" int wt64_local_variance(wt_plan64 *p, int src, int dst, int s, double
     double *in = nullptr, *o = nullptr, *mean = nullptr;
     WT_TRY(plan64_base(p, src, &in));
     WT_TRY(plan64_base(p, dst, &o));
+    if (depth == 0 && stencil64_ok(p) && !(p->g.H == 1 && (p->g.border == 2 || p->g.border == 3))) {
+        // images, built-in taps: both moments in one marching kernel (wt_stencil.h, MODE_VAR)
+        ChainArgsT<double> a{};
+        a.in = in; a.out_c = o;
+        a.f1 = f1; a.f2 = f2; a.take_sqrt = take_sqrt;
+        return wt64_stencil_launch(stencil64_ctx(p), MODE_VAR, a, s);
+    }
     WT_TRY(plan64_tmp(p, 2, &mean));
     WT_TRY(smooth64(p, in, mean, nullptr, s, 0, depth));
     WT_TRY(smooth64(p, in, o, nullptr, s, 1, depth));
@@ -1491,6 +1475,9 @@ extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
     WtGuard guard_(ctx_of(p));
     if (!p || !median) WT_FAIL("wt64_abs_median: null pointer");
     wt_ctx *c = p->ctx;
+    const bool side = wt_wow_overlap_enabled() && p->overlap_ok && plane >= 0 && plane < p->overlap_scales;   // as wt_abs_median
+    WtSideScope side_scope(c, side ? p->scale_ev[plane] : nullptr, side);
+    if (!side_scope.ok()) return 2;
     const bool pre = c->prehist_plan == p && c->prehist_plane == plane;
     c->prehist_plan = nullptr;                                   // the bins are shared with the float32 select
     double *b = nullptr;
@@ -1658,11 +1645,29 @@ extern "C" int wt64_wow_scale(wt_plan64 *p, int plane, int s, double tau, int so
     if (!p) WT_FAIL("wt64_wow_scale: null plan");
     if (s < 0 || s > 24) WT_FAIL("wt64_wow_scale: scale %d out of range", s);
     if (p->g.border != 0) WT_FAIL("wt64_wow_scale: images under the symmetric border only");
+    // (as wt_wow_scale: behind a bilateral transform the update of w_s runs beside the later scales)
+    const bool side = wt_wow_overlap_enabled() && p->overlap_ok && plane >= 0 && plane < p->overlap_scales &&
+                      noise_plane == WT_PLANE_NONE && gamma_plane == WT_PLANE_NONE && stencil64_ok(p);
+    WtSideScope side_scope(p->ctx, side ? p->scale_ev[plane] : nullptr, side);
+    if (!side_scope.ok()) return 2;
     double *c = nullptr, *nz = nullptr, *gm = nullptr, *t1 = nullptr;
     WT_TRY(plan64_base(p, plane, &c));
     if (noise_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, noise_plane, &nz));
     if (gamma_plane != WT_PLANE_NONE) WT_TRY(plan64_base(p, gamma_plane, &gm));
     if (gm == c || nz == c) WT_FAIL("wt64_wow_scale: the plane aliases one of its operands");
+    if (stencil64_ok(p) && plane >= 0 && plane <= p->max_level) {
+        // built-in taps: local power, significance, gamma sum and whitening in ONE kernel (the fused wow update
+        // of wt_stencil.h) writing a spare plane whose pointer is then swapped with the coefficient plane - as
+        // wt_wow_scale does in float32
+        double *spare = nullptr;
+        WT_TRY(plan64_tmp(p, 0, &spare));
+        ChainArgsT<double> a{};
+        a.in = c; a.out_c = spare;
+        a.noise = nz; a.gamma = gm; a.tau = tau; a.factor = factor; a.soft = soft; a.whiten = 1;
+        WT_TRY(wt64_stencil_launch(stencil64_ctx(p), !nz && !gm ? MODE_WOW_PLAIN : (!nz ? MODE_WOW_GAMMA : MODE_WOW), a, s));
+        std::swap(p->coef[plane], p->tmp[0]);
+        return 0;
+    }
     WT_TRY(plan64_tmp(p, 0, &t1));
     const Taps64 t = taps64(p);
     const int d = 1 << s;
@@ -1742,9 +1747,70 @@ extern "C" int wt64_bilateral_conv(wt_plan64 *p, int src, int var, int dst, int 
     WT_TRY(plan64_base(p, src, &in));
     WT_TRY(plan64_base(p, var, &v));
     WT_TRY(plan64_base(p, dst, &o));
+    if (depth == 0 && stencil64_ok(p))     // images, built-in (symmetric) taps: the marching kernel of wt_bilateral64.h
+        return wt64_bilateral_launch(stencil64_ctx(p), in, v, o, nullptr, s, 1.0, 1.0);
     hipLaunchKernelGGL(wt64_bilateral_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, (const double *)v, o, p->g,
                        depth > 0 ? p->g.H / depth : p->g.H, depth, 1 << s, taps64(p), taps_reversed);
     WT_HIP(hipGetLastError());
+    return 0;
+}
+
+/* AtrousTransform(bilateral=...)(image, level) in float64 (watroo/wavelets.py:408-444 with :433-440): per scale
+ * the variance of sdev_loc times sigma_b[s]**2 (times s + 1 under bilateral_scaling), the range-weighted filter
+ * and the detail plane c_s - c_{s+1}; planes 0 .. level.  As wt_decompose_bilateral in float32: with built-in
+ * taps one marching kernel per scale forms the variance in its register window and writes both planes; other
+ * taps take the three generic kernels per scale. */
+extern "C" int wt64_decompose_bilateral(wt_plan64 *p, int src, int level, const double *sigma_b, int bilateral_scaling)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !sigma_b) WT_FAIL("wt64_decompose_bilateral: null pointer");
+    if (level < 0 || level > p->max_level) WT_FAIL("wt64_decompose_bilateral: level %d exceeds plan max_level %d", level, p->max_level);
+    if (src >= 0 && src <= level) WT_FAIL("wt64_decompose_bilateral: src plane %d is one of the output planes", src);
+    if (src <= WT_PLANE_SCRATCH(0) && src >= WT_PLANE_SCRATCH(1)) WT_FAIL("wt64_decompose_bilateral: scratch planes 0 and 1 are used internally");
+    if (p->g.border != 0) WT_FAIL("wt64_decompose_bilateral: images under the symmetric border only");
+    double *in = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    if (level == 0) {
+        double *o = nullptr;
+        WT_TRY(plan64_base(p, 0, &o));
+        WT_HIP(hipMemcpyAsync(o, in, (size_t)p->g.nrows * p->g.P * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
+        return 0;
+    }
+    const bool tiled = stencil64_ok(p);
+    const bool overlap = wt_wow_overlap_enabled();
+    if (overlap) WT_TRY(wt_scale_events(p->ctx, p->scale_ev, level));
+    int cur = src;
+    for (int s = 0; s < level; ++s) {
+        if (s > 24) WT_FAIL("wt64_decompose_bilateral: scale %d out of range", s);
+        const int nxt = (s == level - 1) ? level : WT_PLANE_SCRATCH(s & 1);
+        double *oc = nullptr, *ow = nullptr;
+        WT_TRY(plan64_base(p, cur, &in));
+        WT_TRY(plan64_base(p, nxt, &oc));
+        WT_TRY(plan64_base(p, s, &ow));
+        const double f1 = sigma_b[s] * sigma_b[s];                       // watroo/wavelets.py:434-436
+        const double f2 = bilateral_scaling ? (double)(s + 1) : 1.0;
+        if (tiled) {
+            WT_TRY(wt64_bilateral_launch(stencil64_ctx(p), in, nullptr, oc, ow, s, f1, f2));
+        } else {
+            double *var = nullptr, *mean = nullptr;
+            WT_TRY(plan64_tmp(p, 1, &var));
+            WT_TRY(plan64_tmp(p, 2, &mean));
+            WT_TRY(smooth64(p, in, mean, nullptr, s, 0, 0));
+            WT_TRY(smooth64(p, in, var, nullptr, s, 1, 0));
+            hipLaunchKernelGGL(wt64_var_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)mean, (const double *)var, var, p->g.W,
+                               p->g.P, p->g.nrows, f1, f2, 0);
+            hipLaunchKernelGGL(wt64_bilateral_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, (const double *)var, oc, p->g,
+                               p->g.H, 0, 1 << s, taps64(p), 0);
+            hipLaunchKernelGGL(wt64_binary_kernel, grid64(p), dim3(256), 0, p->ctx->stream, (const double *)in, (const double *)oc, ow, p->g.W, p->g.P,
+                               p->g.nrows, 1);
+            WT_HIP(hipGetLastError());
+        }
+        if (overlap) WT_HIP(hipEventRecord(p->scale_ev[s], p->ctx->stream));     // w_s is written
+        cur = nxt;
+    }
+    // the per-scale work on w_s that follows (wt64_wow_scale, wt64_abs_median) may run beside the scales still queued
+    p->overlap_scales = overlap ? level : 0;
+    p->overlap_ok = overlap;
     return 0;
 }
 

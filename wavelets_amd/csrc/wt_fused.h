@@ -44,36 +44,7 @@
 #include "wt_fused_decl.h"
 
 
-// Element type of a pass (round 3): float - a lane owns 4 adjacent pixels - or double - 2 pixels.
-// Either way a lane moves 16 bytes per access and the register window costs the same VGPRs, so the
-// float64 passes are the float32 design at twice the bytes per pixel (the reference computes
-// float64 / integer inputs in float64, watroo/wavelets.py:297,319-320).
-template <typename T> struct WtVec;
-template <> struct WtVec<float> {
-    typedef float4 V;
-    static constexpr int PX = 4;
-};
-template <> struct WtVec<double> {
-    typedef double2 V;
-    static constexpr int PX = 2;
-};
-__device__ __forceinline__ double2 f4_scale(double k, double2 a) { return make_double2(k * a.x, k * a.y); }
-__device__ __forceinline__ double2 f4_fma(double k, double2 a, double2 c) { return make_double2(fma(k, a.x, c.x), fma(k, a.y, c.y)); }
-__device__ __forceinline__ double2 f4_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 f4_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-// the taps are dyadic rationals: exact in either precision
-template <int K, typename T>
-__device__ __forceinline__ constexpr T wt_tap_s(int i) { return (T)wt_tap<K>(i); }
-template <typename V> __device__ __forceinline__ V wt_vzero();
-template <> __device__ __forceinline__ float4 wt_vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-template <> __device__ __forceinline__ double2 wt_vzero<double2>() { return make_double2(0.0, 0.0); }
-// the group read backwards (reflection of an aligned group that lies outside the image)
-__device__ __forceinline__ float4 wt_vrev(float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
-__device__ __forceinline__ double2 wt_vrev(double2 v) { return make_double2(v.y, v.x); }
-// scheduling fence on the components of a row (see the FAST path of the kernel)
-__device__ __forceinline__ void wt_vfence(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
-__device__ __forceinline__ void wt_vfence(double2 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
-
+// (WtVec<T>, the double2 forms of the float4 helpers, wt_tap_s, wt_vzero / wt_vrev / wt_vfence: wt_device.h)
 
 template <typename T, int K, int SHIFT_PX, int NLANES>
 __device__ __forceinline__ typename WtVec<T>::V wt_hfilter_lds(const typename WtVec<T>::V *vrow, int gl, typename WtVec<T>::V own)

@@ -88,6 +88,16 @@ struct wt_ctx {
     // order it against `stream` (created with the communicator)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_to_comm = nullptr, ev_from_comm = nullptr;
+    // Side stream (round 5): per-scale work that only depends on planes the main stream has ALREADY produced
+    // runs here, beside the kernels the main stream still has queued - the wow update of scale s and the MAD
+    // estimate on w_0 beside the bilateral filter of the later scales (memory-bound beside VALU-bound).
+    // side_pending: work has been queued here since the last join (every main-stream access to a plane joins
+    // first: plane_base); in_side: an entry point is issuing its launches on the side stream right now
+    // (`stream` IS the side stream for its duration, WtSideScope).  Created on first use.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_side_done = nullptr;
+    bool side_pending = false;
+    int in_side = 0;
     // transfer streams of the pipelined host-to-host call (wt_decompose_sum_host), created on first use
     hipStream_t xfer_in = nullptr, xfer_out = nullptr;
     // small device/host scratch for selects & reductions
@@ -168,6 +178,11 @@ struct wt_plan {
     int ntaps = 0;
     float taps[WT_MAX_CUSTOM_TAPS] = {0};
     WtFftState fft;                         // circular products of richardson_lucy(fft=True), wt_fft.h (buffers in raw_allocs)
+    // events recorded on the main stream behind scale s of the last wt_decompose_bilateral ("w_s is written");
+    // overlap_scales of them are current as long as nothing else has touched the plan (overlap_ok)
+    std::vector<hipEvent_t> scale_ev;
+    int overlap_scales = 0;
+    bool overlap_ok = false;
 };
 
 // float64 engine (wt_f64.h): double planes; the fused double passes (wt_fused_tu.hip) launch on it too
@@ -190,7 +205,27 @@ struct wt_plan64 {
     size_t istage_cap = 0;
     std::vector<void *> allocs;
     WtFftState fft;                                 // as wt_plan::fft (buffers in allocs)
+    std::vector<hipEvent_t> scale_ev;               // as wt_plan::scale_ev
+    int overlap_scales = 0;
+    bool overlap_ok = false;
 };
+
+// ------------------------------------------------------------------ side stream (wt_api.hip)
+int wt_side_join(wt_ctx *c);                        // main stream waits for everything queued on the side stream
+int wt_side_begin(wt_ctx *c, hipEvent_t after);     // route the context's launches to the side stream, behind `after`
+void wt_side_end(wt_ctx *c);
+struct WtSideScope {                                // RAII form (on = false: nothing); ok() is false when the streams could not be set up
+    wt_ctx *c;
+    bool on;
+    int rc;
+    WtSideScope(wt_ctx *ctx, hipEvent_t after, bool enable) : c(ctx), on(enable), rc(enable ? wt_side_begin(ctx, after) : 0) {}
+    ~WtSideScope() { if (on && !rc) wt_side_end(c); }
+    WtSideScope(const WtSideScope &) = delete;
+    WtSideScope &operator=(const WtSideScope &) = delete;
+    bool ok() const { return rc == 0; }
+};
+bool wt_wow_overlap_enabled();
+int wt_scale_events(wt_ctx *c, std::vector<hipEvent_t> &ev, int n);   // at least n events in ev
 
 // Profiling bracket: records events around a kernel launch when ctx->profiling.
 struct ProfScope {

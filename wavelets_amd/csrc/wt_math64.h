@@ -1,0 +1,159 @@
+// Double-precision building blocks of the float64 kernels (gfx950 has no double-precision erf / exp /
+// fast rsqrt): wt_erf64, wt_exp2_64, wt_rsq64, wt_div64 and the significance forms built on them.
+//
+// The polynomial tables live in __constant__ memory WITH EXTERNAL LINKAGE on purpose: a 64-bit literal
+// cannot be an operand of v_fma_f64, and for a table the compiler can see through (constexpr, or a static
+// __constant__ nobody writes) it folds the coefficients back into the instruction stream - a v_mov_b64 +
+// v_fmac_f64 pair per Horner step; from an external table they arrive by scalar loads in SGPR pairs,
+// which v_fma_f64 reads directly.  Every translation unit that includes this header defines its own
+// tables (no relocatable device code: a code object per unit), so the host-side names must differ per
+// unit: the build passes -DWT_TU_NAME=<unit>.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef WT_TU_NAME
+#define WT_TU_NAME api
+#endif
+#define WT_PASTE2(a, b) a##_##b
+#define WT_PASTE(a, b) WT_PASTE2(a, b)
+#define WT_ERF64_Q WT_PASTE(WT_ERF64_Q, WT_TU_NAME)
+#define WT_ERF64_F WT_PASTE(WT_ERF64_F, WT_TU_NAME)
+#define WT_EXP2_64_C WT_PASTE(WT_EXP2_64_C, WT_TU_NAME)
+
+// erf(y) for y >= 0 in double precision, branch-free (round 4).  The library erf evaluates one of
+// several ranges per lane - a wave pays for all of them, ~200 double-precision operations per sample,
+// which bounded the float64 threshold kernels at 0.40 of the HBM rate.  Here
+//     erf(y) = -expm1(a),   a = -y * (r(t) + y) = log(erfc(y)),   t = y / 3 - 1,   y clamped to 6
+// (erfc(6) = 2e-17), r ONE degree-26 polynomial (tools/make_erf64.py: weighted Chebyshev fit against
+// 50-digit mpmath values), and expm1 written out: a = n ln2 + x, |x| <= ln2 / 2,
+// expm1(a) = 2^n (1 + x q(x)) - 1 with q of degree 12, so that -expm1(a) = (1 - 2^n) - 2^n x q(x) in one
+// FMA - exact for n = 0, i.e. small arguments keep their relative accuracy.  ~50 FMAs per sample, no
+// division, no branch.  Measured against mpmath on [1e-300, 6.5]: absolute error <= 2.3e-16, relative
+// <= 2.7e-14 (the float64 parity bound of the tests is 1e-12).  erf(0) = 0 exactly; NaN stays NaN.
+// The coefficients live in constant memory, NOT in the instruction stream: a 64-bit literal cannot be
+// an operand of v_fma_f64, so with constexpr tables every Horner step was a v_mov_b64 + v_fmac_f64
+// pair (150 moves per two samples); scalar loads put them in SGPR pairs, which v_fma_f64 reads directly.
+__constant__ double WT_ERF64_Q[27] = {0x1.259bcee7098c9p-1, -0x1.142c68ccd863dp-2, 0x1.2293b824c872dp-3, -0x1.33ec0d4b613eap-4,
+                                      0x1.3c837774a376ap-5, -0x1.32f7d405cccfap-6, 0x1.0ee44d87ebd23p-7, -0x1.93aca6b315f22p-9,
+                                      0x1.84922d81926a0p-11, 0x1.3fd374d9a6dcdp-13, -0x1.8d18e3e4439d9p-12, 0x1.63d73d5b4b8bap-12,
+                                      -0x1.e1bf08c08a3fap-13, 0x1.22e8a9c630114p-13, -0x1.19446361f8e4fp-14, -0x1.49050d2260ba0p-22,
+                                      0x1.86930026aa01cp-20, 0x1.287c357a01b50p-15, 0x1.14679d6bb6ed4p-16, -0x1.d2963129dd6bep-15,
+                                      -0x1.4bd1e396300c0p-16, 0x1.2e935cbc2a44fp-15, 0x1.8e87fa9480c7fp-16, -0x1.122db495799f0p-16,
+                                      -0x1.813c9c90f35cap-17, 0x1.c52e5511ca2c2p-19, 0x1.147aa0cdd9e8cp-19};
+// 1 / k!, k = 1 .. 13
+__constant__ double WT_ERF64_F[13] = {1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                      1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+__device__ __forceinline__ double wt_erf64(double y)
+{
+    const double *Q = WT_ERF64_Q, *F = WT_ERF64_F;
+    y = y > 6.0 ? 6.0 : y;
+    const double t = fma(y, 1.0 / 3.0, -1.0);
+    double r = Q[26];
+#pragma unroll
+    for (int k = 25; k >= 0; --k) r = fma(r, t, Q[k]);
+    const double a = -(y * (r + y));                         // log(erfc(y)), in [-38.5, 0]
+    const double n = __builtin_rint(a * 0x1.71547652b82fep+0);
+    double x = fma(n, -0x1.62e42fefa39efp-1, a);
+    x = fma(n, -0x1.abc9e3b39803fp-56, x);
+    double q = F[12];
+#pragma unroll
+    for (int k = 11; k >= 0; --k) q = fma(q, x, F[k]);
+    const double s = ldexp(1.0, (int)n);
+    return fma(-s, x * q, 1.0 - s);
+}
+
+// significance of one sample (watroo/wavelets.py:137-141): erf(|v / tt|) or |v| > tt
+__device__ __forceinline__ double wt_sig64(double v, double tt, int soft)
+{
+    return soft ? wt_erf64(fabs(v / tt)) : (fabs(v) > tt ? 1.0 : 0.0);
+}
+// the same with the reciprocal of a scalar threshold (the kernels form 1 / tau once per thread: the
+// argument of erf then differs from the quotient by at most one rounding, 1e-16 relative)
+__device__ __forceinline__ double wt_sig64_inv(double v, double tt, double inv_tt, int soft)
+{
+    return soft ? wt_erf64(fabs(v) * inv_tt) : (fabs(v) > tt ? 1.0 : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// double-precision building blocks of the float64 per-scale kernels (wt_stencil.h, round 5)
+// ---------------------------------------------------------------------------------------------
+// 1 / sqrt(x), x > 0 and far from the ends of the exponent range (the clipped local power of wow,
+// watroo/utils.py:195-196): v_rsq_f64 (about 2^-26) and two Newton steps, ~1 ulp - instead of the IEEE
+// sqrt and division sequences (~60 double-precision instructions per pixel).
+__device__ __forceinline__ double wt_rsq64(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
+// a / b for the divisions of the float64 bilateral kernel (b = the weight sum in [k_c, 1], or a variance
+// >= 1e-20): v_rcp_f64, two Newton steps on the reciprocal, one residual correction of the quotient.
+__device__ __forceinline__ double wt_div64(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// 2^t for t <= 0 (the range weights of the bilateral filter, watroo/wavelets.py:97, in base 2): there is
+// no double-precision exponential instruction.  t = n + f, n = round(t) taken from the low mantissa bits
+// of t + 1.5 * 2^52, |f| <= 1/2, 2^f by a degree-10 polynomial (tools/make_exp2_64.py: Chebyshev
+// interpolant of 2^f at 50 digits, 4.4e-16 relative in double Horner form), 2^n added into the exponent
+// field.  t is clamped at -1020 (2^-1020 = 9e-308: nothing in a weight sum of at least k_c sees it), so
+// the result never leaves the normal range; NaN arguments give 2^-1020.  15 double-precision operations
+// and one integer add.  The coefficients live in constant memory for the reason given at wt_erf64.
+__constant__ double WT_EXP2_64_C[11] = {0x1.0000000000000p+0, 0x1.62e42fefa3a19p-1, 0x1.ebfbdff82c598p-3, 0x1.c6b08d703ce49p-5,
+                                               0x1.3b2ab6fba1ddap-7, 0x1.5d87fe9d7a584p-10, 0x1.430913096fd9fp-13, 0x1.ffcb54062e698p-17,
+                                               0x1.62bfd47773353p-20, 0x1.b675bca4eeebbp-24, 0x1.e6063f7217bc6p-28};
+// The form of the bilateral kernel (wt_bilateral64.h), whose exponent is an FMA: with
+//   u = fma(delta^2, s / 64, 1 + log2(k) / 64)   clamped to [0, 1] by the FMA's own output modifier
+// (t = 64 (u - 1) floored at -64: weights below 2^-64 = 5e-20 of the centre tap count as 2^-64; no v_max_f64),
+// m = u + 1.5 * 2^46 carries round(64 u) = round(t) + 64 in its low mantissa bits, g = u - (m - 1.5 * 2^46) =
+// (t - round(t)) / 64, and 2^(64 g - 64) is the SAME polynomial with its coefficients scaled by 2^(6 k - 64) -
+// powers of two: every Horner step is the unscaled step times a power of two, bit for bit.  The exponent
+// field then takes round(t) + 64 as it stands.  wt_exp2u_split: the range reduction; wt_exp2u_join: the
+// exponent.  16 double-precision operations and one integer add per weight, the exponent FMA included; t is
+// quantised to 64 ulp(1) = 7e-15 (relative error of the result 5e-15).
+#define WT_EXP2U_C WT_PASTE(WT_EXP2U_C, WT_TU_NAME)
+__constant__ double WT_EXP2U_C[11] = {0x1.0000000000000p-64, 0x1.62e42fefa3a19p-59, 0x1.ebfbdff82c598p-55, 0x1.c6b08d703ce49p-51,
+                                      0x1.3b2ab6fba1ddap-47, 0x1.5d87fe9d7a584p-44, 0x1.430913096fd9fp-41, 0x1.ffcb54062e698p-39,
+                                      0x1.62bfd47773353p-36, 0x1.b675bca4eeebbp-34, 0x1.e6063f7217bc6p-32};
+__device__ __forceinline__ void wt_exp2u_split(double u, double &g, int &e)
+{
+    const double m = u + 0x1.8p46;
+    e = __double2loint(m);                                   // round(t) + 64
+    g = u - (m - 0x1.8p46);
+}
+__device__ __forceinline__ double wt_exp2u_join(double p, int e)
+{
+    return __hiloint2double(__double2hiint(p) + (e << 20), __double2loint(p));
+}
+// (scalar form: the kernels evaluate several weights in lockstep, see wt64_bilateral_march_kernel)
+__device__ __forceinline__ double wt_exp2_64_from_u(double u)
+{
+    const double *C = WT_EXP2U_C;
+    double g;
+    int e;
+    wt_exp2u_split(u, g, e);
+    double p = C[10];
+#pragma unroll
+    for (int k = 9; k >= 0; --k) p = fma(p, g, C[k]);
+    return wt_exp2u_join(p, e);
+}
+__device__ __forceinline__ double wt_exp2_64(double t)
+{
+    const double *C = WT_EXP2_64_C;
+    t = fmax(t, -1020.0);
+    const double m = t + 0x1.8p52;
+    const double f = t - (m - 0x1.8p52);
+    double p = C[10];
+#pragma unroll
+    for (int k = 9; k >= 0; --k) p = fma(p, f, C[k]);
+    const int n = __double2loint(m);                         // round(t) in two's complement
+    return __hiloint2double(__double2hiint(p) + (n << 20), __double2loint(p));
+}

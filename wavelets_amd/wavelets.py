@@ -1079,6 +1079,10 @@ class AtrousTransform:
                              _shape=a.shape if nd == 3 else None, _dtype=np.float64)
             c._sum_valid = summed
             return c
+        elif nd == 2 and level > 0:
+            # images: the per-scale sequence of ref:433-442 in one call (built-in taps: one marching
+            # kernel per scale, wt64_decompose_bilateral)
+            plan.decompose_bilateral(PLANE_INPUT, level, self._sigma_bilateral(level), self.bilateral_scaling)
         else:
             sb = self._sigma_bilateral(level)
             cur = PLANE_INPUT
