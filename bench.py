@@ -55,6 +55,7 @@ LEVEL = 6
 FAMILY = "b3spline"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy
 VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak (MI355X_MICROARCH.md chip table)
+XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (7 links per GPU; the task's figure)
 
 CONFIGS = {
     # name: (side, family, level, workload text)
@@ -435,6 +436,12 @@ def main():
         from wavelets_amd.parallel import init_comm
         init_comm(ctx, rank, world, group.bcast)
         rccl_ranks = ctx.comm_info()[1]          # what ncclCommCount says, not what we asked for
+        # who ran where: every rank's GPU (HIP ordinal, PCI bus id) and the RCCL the engine loaded - a run on a
+        # shared or mis-bound node (two ranks on one card, a stale library) explains itself in the line
+        me = dict(ctx.device_info(), rank=rank, local_rank=local_rank, pid=os.getpid(),
+                  visible=os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+        rank_table = group.gather(me)
+        rccl_version = _lib.comm_version()
         if args.force_dist:
             assert ctx.comm_selftest(1 << 20), "RCCL self-test failed"
 
@@ -764,6 +771,10 @@ def main():
                                    "started_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
                                    else ("bench.py (wavelets_amd.launch.spawn)" if "WT_RDZV" in os.environ else "other")}
                 out["strip_passes"] = strip_passes
+                out["ranks"] = rank_table
+                out["distinct_gpus"] = len({(r_.get("pci"), r_.get("device")) for r_ in rank_table or []})
+                out["rccl_version"] = rccl_version
+                out["nccl_env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}
             out["_brief"] = f"{out['value']:.0f} Mpix/s  {ms_per_step:.4f} ms  " + "  ".join(
                 f"{k}={v['avg_ms']}" for k, v in kernels.items())
             return out
@@ -876,10 +887,60 @@ def main():
         check = halo_check(plan)
         planes_ab = {"chosen": "hipMalloc", "hipMalloc_ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
                      "overlap_during_this_test": overlap["chosen"]}
+        # (2b) what this line SHOULD read: every rank times its own strip as a stand-alone image (same rows,
+        # same kernels, no exchange, no split launches) on the GPU and in the run it was measured on; the halo
+        # rows a step moves to each neighbour are priced at one xGMI link.  predicted = the slower of the two
+        # under the overlapped order, their sum under the serial one; measured / predicted says at first
+        # contact with a node whether compute, the exchange or the launch split lost the rest.
+        model, solo_ms = None, None
+        try:                                      # (every rank reaches the gather below, whatever happens here)
+            solo = _lib.Plan(ctx, nrows, W, fam, level)
+            try:
+                solo.upload(PLANE_INPUT, img0)
+                for _ in range(3):
+                    solo.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags & ~_lib.FLAG_NO_EXCHANGE)
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(ab_steps):
+                    solo.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags & ~_lib.FLAG_NO_EXCHANGE)
+                solo_ms = round(ctx.timer_stop() / ab_steps, 4)
+            finally:
+                solo.close()
+        except Exception as e:
+            solo_ms = {"error": repr(e)}
+        solo_all = group.gather(solo_ms)
+        try:
+            if rank == 0 and any(not isinstance(v, float) for v in solo_all):
+                model = {"error": "a rank could not time its strip", "strip_compute_ms_per_rank": solo_all}
+            elif rank == 0:
+                link_gbs = XGMI_LINK_GBS
+                neigh_bytes = sum(h for _, _, h in sched) * W * 4            # to EACH neighbour, per step
+                exch_ms = neigh_bytes / (link_gbs * 1e9) * 1e3 + 0.02 * len(sched)     # + ~20 us of launch / handshake per pass
+                comp_ms = max(solo_all)
+                measured_ms = m["elapsed"] / steps * 1e3
+                pred = {"overlapped": max(comp_ms, exch_ms), "serial": comp_ms + exch_ms}
+                order = "overlapped" if overlap["chosen"] == "on" else "serial"
+                model = {"strip_compute_ms_per_rank": solo_all, "strip_compute_ms": round(comp_ms, 4),
+                         "strip_compute_is": f"this rank's {nrows} x {W} strip as a stand-alone image (no exchange, whole launches), "
+                                             f"{ab_steps} steps, timed in this run",
+                         "exchange_bytes_per_neighbour_per_step": neigh_bytes,
+                         "link_GBs": link_gbs, "exchange_ms": round(exch_ms, 4),
+                         "exchange_is": "halo bytes to one neighbour / one xGMI link (up and down use different links) + 20 us per pass",
+                         "predicted_ms_per_step": {k: round(v, 4) for k, v in pred.items()},
+                         "order": order,
+                         "predicted_value_mpix_s": round(H * W / (pred[order] * 1e-3) / 1e6, 1),
+                         "measured_ms_per_step": round(measured_ms, 4),
+                         "measured_over_predicted_time": round(measured_ms / pred[order], 3),
+                         "n1_equivalent": "value / n_gpus against the N = 1 line of the same driver run is the scaling efficiency; "
+                                          "strip_compute_ms x n_gpus / that line's ms_per_step x (8192^2 x n_gpus / image pixels) "
+                                          "says how much of it the strip shape alone costs"}
+        except Exception as e:
+            model = {"error": repr(e)}
         if out is not None:
             out["overlap"] = overlap
             out["halo_selfcheck"] = check
             out["strip_planes"] = planes_ab
+            out["scaling_model"] = model
             state["result"] = out                     # from here on the time limit reports THIS line
         group.barrier()
         state["main_done"] = True
@@ -1025,6 +1086,55 @@ def main():
                                    "kernels_ms_per_step": k64}
         except Exception as e:
             out["float64_cfg3"] = {"error": repr(e)}
+        # ... and BASELINE configs[4] in float64 (round 5): wow(bilateral=1, denoise_coefficients=[5,2]) at 8192^2,
+        # 11 scales, on the float64 engine - what an int16 / FITS frame becomes (ref wavelets.py:297,319-320):
+        # the float64 bilateral march (wt_bilateral64.h, VALU-bound: 24 polynomial exponentials per pixel per
+        # scale), the fused float64 wow updates (wt_stencil.h for double) on the side stream, the plane sum.
+        try:
+            import wavelets_amd as WA
+            from wavelets_amd import utils as WU
+            lv5 = int(np.round(np.log2(8192) - np.log2(5)))
+            sb5 = [1] * (lv5 + 1)
+            p64 = _lib.Plan64(ctx, 8192, 8192, tuple(float(t) for t in WA.B3spline.coefficients_1d), lv5)
+            p64.upload(PLANE_INPUT, (make_strip(8192, 8192, seed=0)
+                                     + 3 * np.sin(np.arange(8192, dtype=np.float32) / 50.)[None, :]).astype(np.float64))
+            c64 = WA.Coefficients(p64, WA.B3spline(2), sb5)
+            tr64 = WA.AtrousTransform(WA.B3spline, bilateral=sb5)
+
+            def step64w():
+                tr64._run(p64, lv5)
+                c64.noise = None
+                WU._wow_device(c64, lv5, [], True, [5, 2], True, False, 3.2, None, None, 0)
+            for _ in range(2):
+                step64w()
+            ctx.sync()
+            n64 = 5
+            t64 = time.perf_counter()
+            for _ in range(n64):
+                step64w()
+            ctx.sync()
+            ms64 = (time.perf_counter() - t64) / n64 * 1e3
+            ctx.profile(True)
+            ctx.profile_reset()
+            for _ in range(2):
+                step64w()
+            k64 = {k: round(ms / 2, 4) for k, (calls, ms) in ctx.profile_entries().items()}
+            ctx.profile(False)
+            c64._plan = None
+            p64.close()
+            bpp = 2.0 * whole_path_bytes_per_pixel("cfg5", lv5)
+            f32_ms = (extra.get("cfg5") or {}).get("ms_per_step")
+            out["float64_cfg5"] = {"workload": "8192x8192 float64 (N(0,1) + 3 sin(x/50)), b3spline, wow(bilateral=1, denoise_coefficients=[5,2]), "
+                                               "11 scales (BASELINE configs[4] on the float64 engine); device-resident",
+                                   "value": round(8192 * 8192 / ms64 / 1e3, 1), "unit": "Mpix/s",
+                                   "ms_per_step": round(ms64, 4), "steps": n64, "bytes_per_pixel": bpp,
+                                   "frac_of_hbm_peak": round(bpp * 8192 * 8192 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "vs_float32_cfg5": round(ms64 / f32_ms, 3) if f32_ms else None,
+                                   "bound": "VALU (float64 bilateral march: ~483 double-precision operations per pixel per scale, "
+                                            "0.92 of the issue rate at the 1.9 GHz the chip holds under it - profiles/r05_*_cfg5_clocks.csv)",
+                                   "kernels_ms_per_step (overlapped kernels both count)": k64}
+        except Exception as e:
+            out["float64_cfg5"] = {"error": repr(e)}
     if out is not None:
         brief = out.pop("_brief")
         emit(brief if args.brief else json.dumps(out))

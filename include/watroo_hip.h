@@ -91,6 +91,11 @@ int wt_ctx_comm_init(wt_ctx *ctx, int rank, int nranks, const void *id128);
 /* rank / size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount);
  * 0 / 1 without a communicator.  bench.py prints the size as "rccl_ranks". */
 int wt_ctx_comm_info(wt_ctx *ctx, int *rank, int *nranks);
+/* ncclGetVersion of the loaded RCCL (0: unknown), and one line describing the context's GPU ("device=<hip
+ * ordinal> pci=<bus id> cus=<n> name=<...>", NUL-terminated, truncated to cap): what bench.py lists per rank
+ * in the multi-GPU line (the reference has no counterpart: it runs on one host, watroo/utils.py:83-219). */
+int wt_comm_version(int *version);
+int wt_ctx_device_info(wt_ctx *ctx, char *buf, int cap);
 /* test hook: nranks==1 periodic self exchange through RCCL send/recv (plumbing check). */
 int wt_comm_selftest(wt_ctx *ctx, int64_t nfloats, int *ok);
 

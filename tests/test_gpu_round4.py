@@ -43,6 +43,18 @@ def _one_json_line(r):
 
 def _check_multi_gpu_fields(out, nranks, size):
     assert out["n_gpus"] == nranks and out["rccl_ranks"] == nranks
+    # round 5: who ran where, the RCCL that was loaded, and what the line should read
+    assert [r["rank"] for r in out["ranks"]] == list(range(nranks))
+    assert all(r["pci"] not in ("", "?") and r["name"] and r["cus"] >= 64 for r in out["ranks"]), out["ranks"]
+    assert out["distinct_gpus"] == 1                  # (the test box has one card: every rank shares it, and the line says so)
+    assert out["rccl_version"] >= 20000, out["rccl_version"]
+    sm = out["scaling_model"]
+    assert "error" not in sm, sm
+    assert len(sm["strip_compute_ms_per_rank"]) == nranks and all(v > 0 for v in sm["strip_compute_ms_per_rank"])
+    assert sm["exchange_bytes_per_neighbour_per_step"] == sum(h for _, _, h in out["config"]["schedule"]) * size * 4
+    assert sm["order"] in ("overlapped", "serial") and sm["predicted_ms_per_step"][sm["order"]] > 0
+    assert abs(sm["measured_over_predicted_time"] - sm["measured_ms_per_step"] / sm["predicted_ms_per_step"][sm["order"]]) < 2e-3
+    assert sm["predicted_value_mpix_s"] > 0
     assert out["config"]["image"] == [size, size] and out["config"]["parallelism"] == f"strips{nranks}"
     assert out["halo_selfcheck"]["ok"], out["halo_selfcheck"]
     # per pass: the exchange on the communication stream, the interior launch beside it, the edge rows

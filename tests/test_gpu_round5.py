@@ -268,3 +268,60 @@ def test_float64_cfg5_at_full_size_properties(L):
         co._plan = None
     finally:
         plan.close()
+
+
+def test_failed_halo_exchange_leaves_no_rccl_group_open(tmp_path):
+    """wt_halo_exchange over a stand-in RCCL (tests/stubs/rccl_stub.c through WATROO_HIP_RCCL_LIB) whose second
+    ncclSend fails: the call reports RCCL's error with the operation that failed, the ncclGroupStart /
+    ncclGroupEnd counts stay balanced (the bug: the group stayed open and the NEXT call hung or failed
+    confusingly), the operation behind the failure is not queued, and the next exchange on the same
+    communicator goes through.  Also wt_comm_selftest on the failing path (its two device buffers are
+    released) and the version / device-info entry points of the multi-GPU line."""
+    import subprocess
+    import sys
+    import textwrap
+    so = tmp_path / "librccl_stub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", str(so), os.path.join(ROOT, "tests", "stubs", "rccl_stub.c")])
+    script = textwrap.dedent(f'''
+        import ctypes, os, sys
+        sys.path.insert(0, {ROOT!r})
+        from wavelets_amd import _lib as L
+        ctx = L.Context(0)
+        assert L.comm_version() == 29999                      # the stub answered: the override is in effect
+        stub = ctypes.CDLL(os.environ["WATROO_HIP_RCCL_LIB"])
+        def state():
+            a = (ctypes.c_int * 6)()
+            stub.rccl_stub_state(a)
+            return list(a)
+        ctx.comm_init(1, 3, L.Context.unique_id())            # an interior rank: two neighbours, two sends per exchange
+        assert ctx.comm_info() == (0, 3) or ctx.comm_info()[1] == 3
+        free0 = ctx.memory()[0] if hasattr(ctx, "memory") else None
+        plan = L.Plan(ctx, 192, 256, L.B3SPLINE, 2, row0=64, nrows=64, halo_rows=8, rank=1, nranks=3)
+        try:
+            plan.halo_exchange(L.PLANE_INPUT, 4)              # send #1 ok, send #2 fails (RCCL_STUB_FAIL_SEND=2)
+            raise SystemExit("the failing exchange did not raise")
+        except L.WatrooHipError as e:
+            msg = str(e)
+        assert "RCCL error 3" in msg and "ncclSend(down)" in msg and "rank 1/3" in msg, msg
+        depth, starts, ends, sends, recvs, nested = state()
+        assert (depth, starts, ends, nested) == (0, 1, 1, 0), state()
+        assert sends == 2 and recvs == 1, state()              # recv(down) was skipped
+        plan.halo_exchange(L.PLANE_INPUT, 4)                  # the next one works (send #3, #4)
+        assert state() == [0, 2, 2, 4, 3, 0], state()
+        plan.close()
+        os.environ["RCCL_STUB_FAIL_SEND"] = "5"
+        try:
+            ctx.comm_selftest(1 << 16)
+            raise SystemExit("the failing self-test did not raise")
+        except L.WatrooHipError as e:
+            assert "wt_comm_selftest" in str(e) and "ncclSend" in str(e), str(e)
+        assert state()[0] == 0 and state()[5] == 0, state()
+        os.environ["RCCL_STUB_FAIL_SEND"] = "0"
+        ctx.comm_selftest(1 << 16)                              # (the stub moves nothing: the result is False, not an error)
+        info = ctx.device_info()
+        assert info["device"] == 0 and info["cus"] >= 64 and info["pci"] not in ("", "?") and info["name"], info
+        print("OK", info)
+    ''')
+    env = dict(os.environ, WATROO_HIP_RCCL_LIB=str(so), RCCL_STUB_FAIL_SEND="2", RCCL_STUB_NRANKS="3")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -39,6 +39,8 @@ _i64 = _c.c_int64
 # name -> (restype, argtypes); every symbol declared in include/watroo_hip.h
 SIGNATURES = {
     "wt_abi_version": (_c.c_int, []),
+    "wt_comm_version": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "wt_ctx_device_info": (_c.c_int, [_vp, _c.c_char_p, _c.c_int]),
     "wt_last_error": (_c.c_char_p, []),
     "wt_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
     "wt_set_option": (_c.c_int, [_c.c_char_p, _c.c_int]),
@@ -207,6 +209,13 @@ def load():
     return _lib
 
 
+def comm_version():
+    """ncclGetVersion of the RCCL library the engine loads (0: unknown); loads the library."""
+    v = _c.c_int(0)
+    check(load().wt_comm_version(_c.byref(v)))
+    return v.value
+
+
 def check(rc):
     if rc != 0:
         raise WatrooHipError(load().wt_last_error().decode("utf-8", "replace"))
@@ -317,6 +326,15 @@ class Context:
         r, n = _c.c_int(0), _c.c_int(1)
         check(load().wt_ctx_comm_info(self._h, _c.byref(r), _c.byref(n)))
         return r.value, n.value
+
+    def device_info(self):
+        """{'device': ordinal, 'pci': bus id, 'cus': compute units, 'name': ...} of this context's GPU"""
+        buf = _c.create_string_buffer(256)
+        check(load().wt_ctx_device_info(self._h, buf, 256))
+        text = buf.value.decode("utf-8", "replace")
+        head, _, name = text.partition(" name=")
+        info = dict(kv.split("=", 1) for kv in head.split())
+        return {"device": int(info.get("device", -1)), "pci": info.get("pci", "?"), "cus": int(info.get("cus", 0)), "name": name}
 
     def comm_selftest(self, nfloats=1 << 20):
         ok = _c.c_int(0)

@@ -11,6 +11,7 @@
 #include "wt_stencil_launch.h"
 #include "wt_fused_decl.h"
 #include "wt_fft.h"
+#include "wt_rccl_group.h"
 
 // =============================================================================================
 // errors
@@ -140,6 +141,7 @@ struct RcclApi {
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
 };
 struct UniqueId128 {
     char b[128];
@@ -155,7 +157,12 @@ static int rccl_load()
     static std::mutex load_mu;
     std::lock_guard<std::mutex> lk(load_mu);
     if (g_rccl.h) return 0;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // WATROO_HIP_RCCL_LIB: another library with RCCL's entry points (tests load a stub whose ncclSend fails on
+    // demand, tests/stubs/rccl_stub.c)
+    const char *over = getenv("WATROO_HIP_RCCL_LIB");
+    void *h = over && *over ? dlopen(over, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+    if (over && *over && !h) WT_FAIL("cannot load WATROO_HIP_RCCL_LIB=%s: %s", over, dlerror());
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) WT_FAIL("cannot load librccl.so: %s", dlerror());
@@ -174,6 +181,7 @@ static int rccl_load()
     SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void **)(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");      // (optional)
     g_rccl.h = h;
     return 0;
 }
@@ -236,6 +244,36 @@ extern "C" int wt_ctx_comm_info(wt_ctx *ctx, int *rank, int *nranks)
     return 0;
 }
 
+// What the LIBRARY says its version is (ncclGetVersion: major * 10000 + minor * 100 + patch for 2.9 and later) -
+// bench.py prints it into the multi-GPU line next to `rccl_ranks`.  0: the symbol is missing.
+extern "C" int wt_comm_version(int *version)
+{
+    if (!version) WT_FAIL("wt_comm_version: null pointer");
+    *version = 0;
+    WT_TRY(rccl_load());
+    if (g_rccl.GetVersion) WT_NCCL(g_rccl.GetVersion(version));
+    return 0;
+}
+
+// "device=<hip ordinal> pci=<domain:bus:device.function> cus=<n> name=<marketing name>" of the context's GPU:
+// the multi-GPU bench line lists it per rank, so that a run on a shared or mis-bound node explains itself.
+extern "C" int wt_ctx_device_info(wt_ctx *c, char *buf, int cap)
+{
+    WtGuard guard_(ctx_of(c));
+    if (!c || !buf || cap < 16) WT_FAIL("wt_ctx_device_info: null pointer or a buffer below 16 bytes");
+    char pci[64] = "?";
+    if (hipDeviceGetPCIBusId(pci, (int)sizeof pci, c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(pci, sizeof pci, "?");
+    }
+    hipDeviceProp_t prop{};
+    const char *name = "?";
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) name = prop.name;
+    else (void)hipGetLastError();
+    snprintf(buf, (size_t)cap, "device=%d pci=%s cus=%d name=%s", c->device, pci, c->num_cus, name);
+    return 0;
+}
+
 // =============================================================================================
 // side stream
 // =============================================================================================
@@ -257,8 +295,9 @@ int wt_side_begin(wt_ctx *c, hipEvent_t after)
     if (!c->side_stream) {
         int lo = 0, hi = 0;
         WT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        // high priority: its workgroups go first whenever the main stream's kernel frees a slot
-        static const int prio_env = getenv("WT_SIDE_PRIORITY") ? atoi(getenv("WT_SIDE_PRIORITY")) : 1;   // experiments: 0 default, -1 low
+        // default priority: measured on cfg5 (8192^2, tools/ab_overlap.sh) 6.375 ms against 6.474 with the high
+        // priority and 6.506 without the side stream
+        static const int prio_env = getenv("WT_SIDE_PRIORITY") ? atoi(getenv("WT_SIDE_PRIORITY")) : 0;   // experiments: 1 high, -1 low
         WT_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_env > 0 ? hi : (prio_env < 0 ? lo : (lo + hi) / 2)));
         WT_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
     }
@@ -1226,16 +1265,20 @@ static int halo_exchange_on(wt_plan *p, int plane, int64_t rows, hipStream_t st,
     const size_t P = (size_t)p->g.P, cnt = (size_t)rows * P;
     const int up = p->rank - 1, dn = p->rank + 1;
     ProfScope ps(c, prof_name, st);
-    WT_NCCL(g_rccl.GroupStart());
+    WtRcclGroup<RcclApi> grp(g_rccl);      // always closed, also when a Send / Recv fails (wt_rccl_group.h)
     if (up >= 0) {
-        WT_NCCL(g_rccl.Send(b, cnt, NCCL_FLOAT32, up, c->comm, st));
-        WT_NCCL(g_rccl.Recv(b - cnt, cnt, NCCL_FLOAT32, up, c->comm, st));
+        grp.run("ncclSend(up)", [&] { return g_rccl.Send(b, cnt, NCCL_FLOAT32, up, c->comm, st); });
+        grp.run("ncclRecv(up)", [&] { return g_rccl.Recv(b - cnt, cnt, NCCL_FLOAT32, up, c->comm, st); });
     }
     if (dn < p->nranks) {
-        WT_NCCL(g_rccl.Send(b + (size_t)(p->g.nrows - rows) * P, cnt, NCCL_FLOAT32, dn, c->comm, st));
-        WT_NCCL(g_rccl.Recv(b + (size_t)p->g.nrows * P, cnt, NCCL_FLOAT32, dn, c->comm, st));
+        grp.run("ncclSend(down)", [&] { return g_rccl.Send(b + (size_t)(p->g.nrows - rows) * P, cnt, NCCL_FLOAT32, dn, c->comm, st); });
+        grp.run("ncclRecv(down)", [&] { return g_rccl.Recv(b + (size_t)p->g.nrows * P, cnt, NCCL_FLOAT32, dn, c->comm, st); });
     }
-    WT_NCCL(g_rccl.GroupEnd());
+    if (const int rc = grp.end()) {
+        wt_set_error("RCCL error %d (%s) in the halo exchange of plane %d (%lld rows, rank %d/%d): %s", rc,
+                     g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?", plane, (long long)rows, p->rank, p->nranks, grp.what);
+        return 3;
+    }
     return 0;
 }
 
@@ -1253,19 +1296,29 @@ extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
     if (nfloats < 1) WT_FAIL("wt_comm_selftest: nfloats must be positive");
     *ok = 0;
     WT_HIP(hipSetDevice(c->device));
-    float *a = nullptr, *b = nullptr;
-    WT_HIP(hipMalloc(&a, nfloats * 4));
-    WT_HIP(hipMalloc(&b, nfloats * 4));
+    struct DevBuf {          // freed on every return path
+        float *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } abuf, bbuf;
+    WT_HIP(hipMalloc(&abuf.p, nfloats * 4));
+    WT_HIP(hipMalloc(&bbuf.p, nfloats * 4));
+    float *a = abuf.p, *b = bbuf.p;
     std::vector<float> h(nfloats), r(nfloats, 0.f);
     for (int64_t i = 0; i < nfloats; ++i) h[i] = (float)(i % 977) * 0.5f + (float)c->rank;
     WT_HIP(hipMemcpyAsync(a, h.data(), nfloats * 4, hipMemcpyHostToDevice, c->stream));
     WT_HIP(hipMemsetAsync(b, 0, nfloats * 4, c->stream));   // ordered before the Recv into b
     // ring: send to (rank+1)%n, receive from (rank-1+n)%n  (self when n == 1)
     const int to = (c->rank + 1) % c->nranks, from = (c->rank + c->nranks - 1) % c->nranks;
-    WT_NCCL(g_rccl.GroupStart());
-    WT_NCCL(g_rccl.Send(a, nfloats, NCCL_FLOAT32, to, c->comm, c->stream));
-    WT_NCCL(g_rccl.Recv(b, nfloats, NCCL_FLOAT32, from, c->comm, c->stream));
-    WT_NCCL(g_rccl.GroupEnd());
+    {
+        WtRcclGroup<RcclApi> grp(g_rccl);
+        grp.run("ncclSend", [&] { return g_rccl.Send(a, nfloats, NCCL_FLOAT32, to, c->comm, c->stream); });
+        grp.run("ncclRecv", [&] { return g_rccl.Recv(b, nfloats, NCCL_FLOAT32, from, c->comm, c->stream); });
+        if (const int rc = grp.end()) {
+            (void)hipStreamSynchronize(c->stream);      // the buffers are released on return
+            wt_set_error("RCCL error %d (%s) in wt_comm_selftest: %s", rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?", grp.what);
+            return 3;
+        }
+    }
     // all-reduce of a tiny vector (d_hist is also where a fused first pass leaves the first level of
     // the median select: that marker does not survive this)
     c->prehist_plan = nullptr;
@@ -1276,8 +1329,6 @@ extern "C" int wt_comm_selftest(wt_ctx *c, int64_t nfloats, int *ok)
     int good = 1;
     for (int64_t i = 0; i < nfloats; ++i)
         if (r[i] != (float)(i % 977) * 0.5f + (float)from) { good = 0; break; }
-    (void)hipFree(a);
-    (void)hipFree(b);
     *ok = good;
     return 0;
 }
