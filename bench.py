@@ -980,6 +980,7 @@ def main():
                                 out2["overlap"] = dict(overlap, note="on / off compared on the hipMalloc'ed planes")
                                 out2["halo_selfcheck"] = check2
                                 out2["strip_planes"] = planes_ab
+                                out2["scaling_model"] = dict(model or {}, note="strip timed on hipMalloc'ed planes; the line on scattered ones")
                                 out = out2
                                 state["result"] = out
                     plan2.close()

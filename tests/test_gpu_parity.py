@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, measured, plane_bound, recon_bound, SMALL_PLANES, SMALL_RECON
+from conftest import measured_tol, load_golden, measured, plane_bound, recon_bound, SMALL_PLANES, SMALL_RECON
 
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +51,22 @@ def close(a, b, atol, rtol=0.0):
 
 def rnd(shape, seed=0):
     return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+# Tolerances of the small-fixture application tests (round 5: 4 x the worst error the same tests logged on
+# MI355X through conftest.measured_tol - gpurun_out/parity_errors.log of the run that set them, kept as
+# profiles/r05_parity_errors.log; until then 1e-5 / 2e-5 / 1e-4, 30 to 1000 x what the engine delivers).
+# Each is a fraction of max|input| (or of max|reference| for wow, whose tolerance also has a relative part).
+DENOISE_TOL = 5.2e-7        # (measured 1.3e-7) thresholded planes and reconstructions of g2 (erff vs scipy's erf in float64)
+ANSCOMBE_TOL = 4.2e-7       # (measured 1.0e-7)
+NOISE_RTOL = 5e-7           # the MAD estimate: an exact median, divided in double
+WOW_TOL = 5.2e-6              # wow() planes and image: atol = WOW_TOL * max|ref|, rtol = WOW_TOL
+WOW_BIL_TOL = 1.2e-5          # ... with bilateral filtering (range weights through v_exp_f32, Newton divisions)
+BIL_VAR_TOL = 7.8e-7          # sdev_loc: conv(I^2) - conv(I)^2 cancels
+BIL_CONV_TOL = 5.2e-7       # (measured 1.3e-7)
+BIL_TRANSFORM_TOL = 6.5e-7  # (measured 1.6e-7)
+CFG1_TOL = 6.3e-7           # (measured 1.6e-7)
+LARGE_D_TOL = 3.5e-7        # (measured 8.6e-8)
 
 
 # --------------------------------------------------------------------------- transform
@@ -465,20 +481,20 @@ def test_anscombe_bit_exact(W):
 def test_denoise_vs_golden(W):
     g = load_golden("g2_denoise")
     a = g["img"]
-    tol = 1e-5 * np.abs(a).max()
+    tol = DENOISE_TOL * np.abs(a).max()
     for fam in FAMS:
         cls = cls_of(W, fam)
         c = W.AtrousTransform(cls)(a, 4)
-        np.testing.assert_allclose(c.get_noise(), g[f"noise_{fam}"], rtol=1e-5)
+        measured_tol(f"MAD noise {fam}", c.get_noise(), g[f"noise_{fam}"], 0.0, NOISE_RTOL)
         c.denoise([5, 3])
-        close(c.data, g[f"coef_den_53_{fam}"], tol)
-        close(W.denoise(a, [5, 3], cls), g[f"denoise_53_{fam}"], tol)
-        close(W.denoise(a, [5, 3], cls, noise=0.9), g[f"denoise_53_noise_{fam}"], tol)
+        measured_tol(f"denoised planes {fam}", c.data, g[f"coef_den_53_{fam}"], tol)
+        measured_tol(f"denoise {fam}", W.denoise(a, [5, 3], cls), g[f"denoise_53_{fam}"], tol)
+        measured_tol(f"denoise noise= {fam}", W.denoise(a, [5, 3], cls, noise=0.9), g[f"denoise_53_noise_{fam}"], tol)
         got = W.denoise(a, [5, 3, 2], cls, soft_threshold=False)
-        assert (np.abs(got - g[f"denoise_532_hard_{fam}"]) > tol).sum() <= 2
+        measured_tol(f"denoise hard {fam}", got, g[f"denoise_532_hard_{fam}"], tol, allow=2)
     p = g["img_pos"]
-    close(W.denoise(p, [5, 3], W.Triangle, anscombe=True), g["denoise_53_anscombe"],
-          1e-5 * np.abs(p).max())
+    measured_tol("denoise anscombe", W.denoise(p, [5, 3], W.Triangle, anscombe=True), g["denoise_53_anscombe"],
+                 ANSCOMBE_TOL * np.abs(p).max())
 
 
 WOW_CASES = {
@@ -508,10 +524,12 @@ def test_wow_vs_golden(W, name):
     recon, coef = W.wow(a.copy(), **kw)
     ref_c, ref_r = g[f"coef_{name}"], g[f"recon_{name}"]
     assert coef.data.shape == ref_c.shape                # n_scales logic (utils.py:121-138)
-    close(coef.data, ref_c, atol=1e-4 * np.abs(ref_c).max(), rtol=1e-4)
-    close(recon, ref_r, atol=1e-4 * max(1.0, np.abs(ref_r).max()), rtol=1e-4)
+    bil = "bilat" in name                       # (range weights through v_exp_f32 and Newton divisions: stated tolerance)
+    t = WOW_BIL_TOL if bil else WOW_TOL
+    measured_tol(f"wow planes {name}", coef.data, ref_c, atol=t * np.abs(ref_c).max(), rtol=t)
+    measured_tol(f"wow image {name}", recon, ref_r, atol=t * max(1.0, np.abs(ref_r).max()), rtol=t)
     if not np.isnan(g[f"noise_{name}"]):
-        np.testing.assert_allclose(coef.noise, g[f"noise_{name}"], rtol=1e-4)
+        measured_tol(f"wow noise {name}", coef.noise, g[f"noise_{name}"], 0.0, NOISE_RTOL if not bil else WOW_BIL_TOL)
 
 
 def test_wow_from_coefficients(W):
@@ -520,28 +538,31 @@ def test_wow_from_coefficients(W):
     c = W.AtrousTransform()(a.copy(), 3)
     recon, c2 = W.wow(c, denoise_coefficients=[5, 2])
     assert c2 is c
-    close(c.data, g["coef_from_coeffs"], atol=1e-4 * np.abs(g["coef_from_coeffs"]).max(),
-          rtol=1e-4)
-    close(recon, g["recon_from_coeffs"], atol=1e-4 * np.abs(g["recon_from_coeffs"]).max(),
-          rtol=1e-4)
+    measured_tol("wow(Coefficients) planes", c.data, g["coef_from_coeffs"], atol=WOW_TOL * np.abs(g["coef_from_coeffs"]).max(),
+                 rtol=WOW_TOL)
+    measured_tol("wow(Coefficients) image", recon, g["recon_from_coeffs"], atol=WOW_TOL * np.abs(g["recon_from_coeffs"]).max(),
+                 rtol=WOW_TOL)
 
 
 @pytest.mark.parametrize("fixture", ["g5_bilateral", "g5_realne"])
 def test_bilateral_vs_golden(W, fixture):
     g = load_golden(fixture)
     a = g["img"]
-    tol = 2e-5 * np.abs(a).max()
+    amax = np.abs(a).max()
     for fam in FAMS:
         cls = cls_of(W, fam)
         sf = cls(2)
         k = sf.kernel.astype(np.float32)
         for s in (0, 1, 2):
-            close(W.sdev_loc(a, sf, s=s, variance=True), g[f"var_{fam}_s{s}"], tol)
-            close(W.sdev_loc(a, sf, s=s), g[f"sdev_{fam}_s{s}"], tol)
-            close(W.atrous_convolution(a, k, g[f"var_{fam}_s{s}"], s), g[f"bconv_{fam}_s{s}"], tol)
-        close(W.AtrousTransform(cls, bilateral=1)(a, 3).data, g[f"coef_b1_{fam}"], 5 * tol)
-        close(W.AtrousTransform(cls, bilateral=[2., .5], bilateral_scaling=True)(a, 3).data,
-              g[f"coef_blist_scaling_{fam}"], 5 * tol)
+            measured_tol(f"{fixture} variance {fam} s{s}", W.sdev_loc(a, sf, s=s, variance=True), g[f"var_{fam}_s{s}"], BIL_VAR_TOL * amax)
+            measured_tol(f"{fixture} sdev {fam} s{s}", W.sdev_loc(a, sf, s=s), g[f"sdev_{fam}_s{s}"], BIL_VAR_TOL * amax)
+            measured_tol(f"{fixture} bilateral conv {fam} s{s}", W.atrous_convolution(a, k, g[f"var_{fam}_s{s}"], s), g[f"bconv_{fam}_s{s}"],
+                         BIL_CONV_TOL * amax)
+        measured_tol(f"{fixture} bilateral transform {fam}", W.AtrousTransform(cls, bilateral=1)(a, 3).data, g[f"coef_b1_{fam}"],
+                     BIL_TRANSFORM_TOL * amax)
+        measured_tol(f"{fixture} bilateral transform list+scaling {fam}",
+                     W.AtrousTransform(cls, bilateral=[2., .5], bilateral_scaling=True)(a, 3).data,
+                     g[f"coef_blist_scaling_{fam}"], BIL_TRANSFORM_TOL * amax)
 
 
 # --------------------------------------------------------------------------- BASELINE configs
@@ -550,12 +571,13 @@ def test_cfg1_readme_512(W, O):
     a = rnd((512, 512), 0)
     c = W.AtrousTransform(W.B3spline)(a, 4)
     ref = O.Coeffs(O.atrous_standard(a, 4), "b3spline")
-    close(c.data, ref.data, 1e-5 * np.abs(a).max())
+    amax = np.abs(a).max()
+    measured_tol("cfg1 planes", c.data, ref.data, CFG1_TOL * amax)
     c.denoise([5, 3])
     ref.denoise([5, 3])
-    np.testing.assert_allclose(c.noise, ref.noise, rtol=1e-5)
-    close(c.data, ref.data, 1e-5 * np.abs(a).max())
-    close(np.sum(c, axis=0), ref.data.sum(axis=0), 1e-5 * np.abs(a).max())
+    measured_tol("cfg1 MAD noise", c.noise, ref.noise, 0.0, NOISE_RTOL)
+    measured_tol("cfg1 denoised planes", c.data, ref.data, CFG1_TOL * amax)
+    measured_tol("cfg1 denoised sum", np.sum(c, axis=0), ref.data.sum(axis=0), CFG1_TOL * amax)
 
 
 def test_cfg2_4096_b3_l6_vs_c_oracle(W, C):
@@ -651,7 +673,7 @@ def test_large_dilation_scales(W, C):
     a = rnd((2048, 1024), 9)
     c = W.AtrousTransform(W.B3spline)(a, 10)
     ref = C.decompose(a, 10, "b3spline")
-    close(c.data, ref, 1e-5 * np.abs(a).max())
+    measured_tol("large dilations, 11 planes", c.data, ref, LARGE_D_TOL * np.abs(a).max())
 
 
 # --------------------------------------------------------------------------- richardson_lucy (8f)

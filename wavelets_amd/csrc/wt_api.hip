@@ -268,7 +268,7 @@ extern "C" int wt_ctx_device_info(wt_ctx *c, char *buf, int cap)
     }
     hipDeviceProp_t prop{};
     const char *name = "?";
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) name = prop.name;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) name = prop.name[0] ? prop.name : prop.gcnArchName;   // (containers often lack the marketing name)
     else (void)hipGetLastError();
     snprintf(buf, (size_t)cap, "device=%d pci=%s cus=%d name=%s", c->device, pci, c->num_cus, name);
     return 0;
