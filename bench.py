@@ -854,6 +854,25 @@ def main():
                 recon = plan.download(PLANE_OUT)
                 out["pcie_inclusive_serial_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
                 del recon
+                if config == "headline":
+                    # what a one-shot user sees: the FIRST denoise(img, [5, 3]) of a fresh process, numpy to numpy,
+                    # next to its steady state (tools/first_call.py in a child process; ~3 s of wall time)
+                    try:
+                        import subprocess
+                        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), str(side)],
+                                           capture_output=True, text=True, timeout=120)
+                        got = {}
+                        for ln in r.stdout.splitlines():
+                            name, _, ms = ln.rpartition(" ms")[0].rpartition(" ")
+                            if ln.rstrip().endswith("ms") and ms:
+                                got[name.strip()] = float(ms)
+                        calls = [v for k, v in got.items() if k.startswith("denoise(img")]
+                        out["first_call"] = {"what": f"denoise(img, [5, 3]) at {side}^2 float32, numpy to numpy, fresh process",
+                                             "first_ms": calls[0], "steady_ms": min(calls[1:]),
+                                             "context_ms": got.get("context (HIP runtime init, stream, scratch)"),
+                                             "library_load_ms": got.get("load libwatroo_hip.so")}
+                    except Exception as e:
+                        out["first_call"] = {"error": repr(e)}
             if out is not None and not args.no_cpu and not args.brief:
                 out["cpu_baseline"] = cpu_baseline(config, side, family, level,
                                                    budget=15.0 if full else 5.0)

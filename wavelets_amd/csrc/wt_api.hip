@@ -1,8 +1,10 @@
 // libwatroo_hip.so - host side of the C ABI declared in include/watroo_hip.h.
 // Plan / buffer management, kernel dispatch, RCCL halo exchange.  gfx950 only.
 #include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <algorithm>
+#include <thread>
 #include <cstdarg>
 #include <cstdlib>
 
@@ -543,7 +545,9 @@ static int vmm_plane_alloc(wt_plan *p, size_t need, int scatter, void **out, std
         if (e != hipSuccess || g == 0) return fail("hipMemGetAllocationGranularity", e);
         // chunk size: 2 MiB (WT_SCATTER_CHUNK_KB for experiments: chunks below 2 MiB cost TLB reach -
         // 512 KiB: +30 %, 128 KiB: +85 % step time; 8-64 MiB: no different from 2 MiB)
-        static const size_t chunk_kb = getenv("WT_SCATTER_CHUNK_KB") ? (size_t)atoll(getenv("WT_SCATTER_CHUNK_KB")) : 2048;
+        // Round 5: 8 MiB by default - a quarter of the hipMemCreate / hipMemMap calls of a plan's first use
+        // (plan creation 14.8 -> 9 ms at 8192^2), the same step time (tools/first_call.py)
+        static const size_t chunk_kb = getenv("WT_SCATTER_CHUNK_KB") ? (size_t)atoll(getenv("WT_SCATTER_CHUNK_KB")) : 8192;
         size_t gmin = 0;
         if (hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gmin == 0) gmin = g;
         p->vmm_gran = std::max<size_t>(gmin, (chunk_kb << 10) / gmin * gmin);
@@ -1073,6 +1077,50 @@ static bool try_pin(const void *host, size_t bytes)
     return true;
 }
 
+// Page-locked host blocks (the result arrays of the numpy-to-numpy calls).  hipHostMalloc of 256 MiB takes 44 ms
+// on the MI355X boxes - by far the largest part of the ~100 ms a process's FIRST denoise(img) at 8192^2 took
+// (tools/first_call.py) - because it faults and locks 65 536 small pages one by one.  Large blocks are instead
+// (round 5) an anonymous mapping with the transparent-huge-page hint, first touched by several threads at once
+// (2.5 ms for 256 MiB: 128 huge pages) and then registered with the runtime (hipHostRegister of a faulted
+// huge-page range: 0.5 ms); the mapping is ours alone, unregistered before it is unmapped (nothing like the heap
+// ranges of the note above).  Small blocks, or any step of this failing: hipHostMalloc as before.
+struct WtHostBlock {
+    void *map;
+    size_t map_bytes;
+};
+static std::mutex g_host_mu;
+static std::map<void *, WtHostBlock> g_host_blocks;     // registered mappings by the pointer handed out
+static const size_t kHugePage = (size_t)2 << 20;
+
+static void *host_block_mmap(size_t bytes, WtHostBlock &blk)
+{
+    const size_t sz = (bytes + kHugePage - 1) / kHugePage * kHugePage;
+    void *m = mmap(nullptr, sz + kHugePage, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return nullptr;
+    char *al = (char *)(((uintptr_t)m + kHugePage - 1) & ~(uintptr_t)(kHugePage - 1));
+    (void)madvise(al, sz, MADV_HUGEPAGE);
+    // first touch in parallel: one write per small page (one fault per huge page where the hint is honoured)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)hw, sz / ((size_t)8 << 20)}));
+    const size_t slice = (sz / nthreads + kHugePage - 1) / kHugePage * kHugePage;
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; ++t) {
+        const size_t lo = t * slice, hi = std::min(sz, lo + slice);
+        if (lo >= hi) break;
+        th.emplace_back([al, lo, hi] {
+            for (size_t o = lo; o < hi; o += 4096) ((volatile char *)al)[o] = 0;
+        });
+    }
+    for (auto &t : th) t.join();
+    if (hipHostRegister(al, sz, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)munmap(m, sz + kHugePage);
+        return nullptr;
+    }
+    blk = WtHostBlock{m, sz + kHugePage};
+    return al;
+}
+
 extern "C" int wt_host_alloc(wt_ctx *c, size_t bytes, void **host_ptr)
 {
     WtGuard guard_(ctx_of(c));
@@ -1080,6 +1128,16 @@ extern "C" int wt_host_alloc(wt_ctx *c, size_t bytes, void **host_ptr)
     if (bytes == 0) WT_FAIL("wt_host_alloc: zero bytes");
     *host_ptr = nullptr;
     WT_HIP(hipSetDevice(c->device));
+    static const bool thp_blocks = !getenv("WT_NO_THP_HOST_BLOCKS");
+    if (thp_blocks && bytes >= ((size_t)16 << 20)) {
+        WtHostBlock blk{};
+        if (void *q = host_block_mmap(bytes, blk)) {
+            std::lock_guard<std::mutex> lk(g_host_mu);
+            g_host_blocks[q] = blk;
+            *host_ptr = q;
+            return 0;
+        }
+    }
     WT_HIP(hipHostMalloc(host_ptr, bytes, hipHostMallocPortable));
     return 0;
 }
@@ -1087,6 +1145,23 @@ extern "C" int wt_host_alloc(wt_ctx *c, size_t bytes, void **host_ptr)
 extern "C" int wt_host_free(void *host_ptr)
 {
     if (!host_ptr) return 0;
+    WtHostBlock blk{};
+    bool ours = false;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = g_host_blocks.find(host_ptr);
+        if (it != g_host_blocks.end()) {
+            blk = it->second;
+            g_host_blocks.erase(it);
+            ours = true;
+        }
+    }
+    if (ours) {
+        const hipError_t e = hipHostUnregister(host_ptr);
+        (void)munmap(blk.map, blk.map_bytes);
+        WT_HIP(e);
+        return 0;
+    }
     WT_HIP(hipHostFree(host_ptr));
     return 0;
 }
@@ -1100,6 +1175,9 @@ extern "C" int wt_upload(wt_plan *p, int plane, const float *host, int64_t host_
     WT_TRY(plane_base(p, plane, &b));
     const size_t span = ((size_t)(p->g.nrows - 1) * (size_t)host_stride + (size_t)p->g.W) * 4;
     float *target = b;
+    // (a plane mapped over scattered chunks takes host transfers through the hipMalloc'ed bounce plane: the 2-D
+    //  copy does not cross mapped chunks, and - tried in round 5 - neither does the flat hipMemcpyAsync of rows
+    //  that are contiguous on both sides: half the rate, and a download that silently delivered zeros)
     if (is_vmm(p, b)) WT_TRY(vmm_stage(p, &target));
     const bool pinned = try_pin(host, span);
     hipError_t e = hipMemcpy2DAsync(target, (size_t)p->g.P * 4, host, (size_t)host_stride * 4, (size_t)p->g.W * 4,
