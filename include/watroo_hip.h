@@ -373,6 +373,15 @@ int wt_taps_conv(wt_plan *plan, int src, int var, int dst, const int32_t *offset
 int wt_taps_conv_ex(wt_plan *plan, int src, int var, int dst, const int32_t *offsets,
                     const float *weights, int ntaps, float center_weight, int has_center,
                     int depth, int pad_mode, float fill_value, int dilation);
+/* One axis of the separable kernel of a scaling function (watroo/wavelets.py:170-187: kernel = outer product of
+ * coefficients_1d; conv_s = convolution() with the zero-stuffed kernel, :35-69, :191-197): dst[i] = sum_j
+ * weights[j] * src[pad(i + offsets[j])] along axis 2 (x), 1 (y, inside every slice) or 0 (z, across the depth
+ * slices of a cube); pad_mode / fill_value / dilation as wt_taps_conv_ex.  Up to 33 taps run on tiled kernels
+ * (LDS row segments along x, an LDS ring of rows down the polyphase chains along y / z); anything else on the
+ * tap-list operator, with identical bits. */
+int wt_axis_filter(wt_plan *plan, int src, int dst, int axis, const int32_t *offsets,
+                   const float *weights, int ntaps, int depth, int pad_mode, float fill_value,
+                   int dilation);
 /* sdev_loc's last step (watroo/wavelets.py:27-32) from the two smoothed moments: dst = (meansq -
  * mean^2, values <= 0 -> 1e-20, optionally sqrt) * f1 * f2 - for callers that form conv(I) and
  * conv(I^2) themselves (scaling functions the tuned wt_local_variance does not take) */
@@ -468,6 +477,10 @@ int wt64_bilateral_conv(wt_plan64 *plan, int src, int var, int dst, int s, int d
  * kernel per scale (variance formed in its register window, both output planes written). */
 int wt64_decompose_bilateral(wt_plan64 *plan, int src, int level, const double *sigma_b,
                              int bilateral_scaling);
+/* wt_axis_filter in float64 */
+int wt64_axis_filter(wt_plan64 *plan, int src, int dst, int axis, const int32_t *offsets,
+                     const double *weights, int ntaps, int depth, int pad_mode, double fill_value,
+                     int dilation);
 /* wt_taps_conv / wt_taps_conv_ex / wt_variance_from_moments in float64 */
 int wt64_taps_conv(wt_plan64 *plan, int src, int var, int dst, const int32_t *offsets,
                    const double *weights, int ntaps, double center_weight, int has_center,

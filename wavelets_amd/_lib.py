@@ -144,6 +144,10 @@ SIGNATURES = {
                                        _c.c_double, _c.c_int, _c.c_int]),
     "wt64_bilateral_conv": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_int]),
+    "wt_axis_filter": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_float), _c.c_int,
+                                  _c.c_int, _c.c_int, _c.c_float, _c.c_int]),
+    "wt64_axis_filter": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_double), _c.c_int,
+                                    _c.c_int, _c.c_int, _c.c_double, _c.c_int]),
     "wt64_decompose_bilateral": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_int]),
     "wt64_copy_window": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _i64, _i64, _i64, _i64,
                                     _i64]),
@@ -760,6 +764,14 @@ class Plan:
                                      int(center_weight is not None), depth, pad_mode, float(fill_value),
                                      int(dilation)))
 
+    def axis_filter(self, src, dst, axis, offsets, weights, depth=0, pad_mode=0, fill_value=0.0, dilation=1):
+        """K-tap filter along one axis (2 = x, 1 = y, 0 = z) on the tiled kernels (wt_axis_filter)"""
+        offs = np.ascontiguousarray(offsets, dtype=np.int32).ravel()
+        wts = np.ascontiguousarray(weights, dtype=np.float32).ravel()
+        assert len(offs) == len(wts)
+        check(load().wt_axis_filter(self._h, src, dst, axis, offs.ctypes.data_as(_c.POINTER(_c.c_int32)), wts.ctypes.data_as(_fp),
+                                    len(wts), depth, pad_mode, float(fill_value), int(dilation)))
+
     def variance_from_moments(self, mean, meansq, dst, f1=1.0, f2=1.0, take_sqrt=False):
         """sdev_loc's last step (ref wavelets.py:27-32) from conv(I) and conv(I^2)"""
         check(load().wt_variance_from_moments(self._h, mean, meansq, dst, f1, f2, int(take_sqrt)))
@@ -980,6 +992,13 @@ class Plan64:
                                        0.0 if center_weight is None else float(center_weight),
                                        int(center_weight is not None), depth, pad_mode, float(fill_value),
                                        int(dilation)))
+
+    def axis_filter(self, src, dst, axis, offsets, weights, depth=0, pad_mode=0, fill_value=0.0, dilation=1):
+        offs = np.ascontiguousarray(offsets, dtype=np.int32).ravel()
+        wts = np.ascontiguousarray(weights, dtype=np.float64).ravel()
+        assert len(offs) == len(wts)
+        check(load().wt64_axis_filter(self._h, src, dst, axis, offs.ctypes.data_as(_c.POINTER(_c.c_int32)), wts.ctypes.data_as(_dp),
+                                      len(wts), depth, pad_mode, float(fill_value), int(dilation)))
 
     def variance_from_moments(self, mean, meansq, dst, f1=1.0, f2=1.0, take_sqrt=False):
         check(load().wt64_variance_from_moments(self._h, mean, meansq, dst, f1, f2, int(take_sqrt)))

@@ -14,6 +14,7 @@
 #include "wt_fused_decl.h"
 #include "wt_fft.h"
 #include "wt_rccl_group.h"
+#include "wt_axis.h"
 
 // =============================================================================================
 // errors
@@ -279,6 +280,7 @@ extern "C" int wt_ctx_device_info(wt_ctx *c, char *buf, int cap)
 // =============================================================================================
 // side stream
 // =============================================================================================
+extern int g_opt_axis_filter;
 static int g_opt_wow_overlap = getenv("WT_NO_WOW_OVERLAP") ? 0 : 1;   // wt_set_option("wow_overlap", 0/1)
 bool wt_wow_overlap_enabled() { return g_opt_wow_overlap != 0; }
 
@@ -1467,6 +1469,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!strcmp(name, "bilateral2")) { g_opt_bilateral2 = value != 0; return 0; }
     if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
     if (!strcmp(name, "wow_overlap")) { g_opt_wow_overlap = value != 0; return 0; }
+    if (!strcmp(name, "axis_filter")) { g_opt_axis_filter = value != 0; return 0; }
     if (!strcmp(name, "overlap_reserve")) { g_opt_overlap_reserve = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }
     if (!strcmp(name, "split_dry")) { g_opt_split_dry = value != 0; return 0; }
     if (!strcmp(name, "fused_fast")) { g_opt_fused_fast = value != 0; return 0; }
@@ -2647,6 +2650,38 @@ extern "C" int wt_taps_conv_ex(wt_plan *p, int src, int var, int dst, const int3
                        fill_value, dilation);
     WT_HIP(hipGetLastError());
     return 0;
+}
+
+int g_opt_axis_filter = getenv("WT_NO_AXIS_FILTER") ? 0 : 1;
+
+/* K-tap filter along ONE axis of plane src -> dst: out[i] = sum_j weights[j] * in[pad(i + offsets[j])] along axis
+ * 2 (x), 1 (y, inside every slice of a cube) or 0 (z, across the `depth` slices); border rule pad_mode / fill /
+ * dilation as wt_taps_conv_ex.  The separable form of the scaling functions the tuned kernels do not take
+ * (watroo/wavelets.py:152-197: any coefficients_1d) on the tiled kernels of wt_axis.h; tap sets they do not
+ * take (more than 33 taps, irregular offsets along y / z, an x reach beyond 2048 pixels) run on the tap-list
+ * operator - same bits either way. */
+extern "C" int wt_axis_filter(wt_plan *p, int src, int dst, int axis, const int32_t *offsets, const float *weights, int ntaps, int depth,
+                              int pad_mode, float fill_value, int dilation)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !offsets || !weights) WT_FAIL("wt_axis_filter: null pointer");
+    if (ntaps < 1 || ntaps > 4096) WT_FAIL("wt_axis_filter: %d taps unsupported", ntaps);
+    if (axis < 0 || axis > 2) WT_FAIL("wt_axis_filter: axis %d (2 = x, 1 = y, 0 = z)", axis);
+    if (dilation < 1) WT_FAIL("wt_axis_filter: dilation %d must be positive", dilation);
+    if (p->nranks > 1) WT_FAIL("wt_axis_filter: the generic operator is single-GPU (whole images)");
+    if (src == dst) WT_FAIL("wt_axis_filter: dst must differ from src");
+    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_POLY_MIRROR) WT_FAIL("wt_axis_filter: unknown pad mode %d", pad_mode);
+    if (depth < 0 || (depth > 0 && p->g.nrows % depth)) WT_FAIL("wt_axis_filter: %d rows are not a multiple of depth %d", p->g.nrows, depth);
+    if (axis == 0 && depth == 0) WT_FAIL("wt_axis_filter: axis 0 needs a cube (depth > 0)");
+    float *in = nullptr, *o = nullptr;
+    WT_TRY(plane_base(p, src, &in));
+    WT_TRY(plane_base(p, dst, &o));
+    const int rc = wt_axis_filter_launch<float>(p->ctx, in, o, p->g.W, p->g.P, p->g.nrows, depth, axis, offsets, weights, ntaps, pad_mode,
+                                                fill_value, dilation);
+    if (rc >= 0) return rc;
+    std::vector<int32_t> o3((size_t)ntaps * 3, 0);
+    for (int j = 0; j < ntaps; ++j) o3[(size_t)3 * j + axis] = offsets[j];
+    return wt_taps_conv_ex(p, src, WT_PLANE_NONE, dst, o3.data(), weights, ntaps, 0.f, 0, depth, pad_mode, fill_value, dilation);
 }
 
 extern "C" int wt_binary(wt_plan *p, int op, int a, int b, int dst)

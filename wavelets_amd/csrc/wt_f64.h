@@ -1825,6 +1825,30 @@ extern "C" int wt64_taps_conv(wt_plan64 *p, int src, int var, int dst, const int
     return wt64_taps_conv_ex(p, src, var, dst, offsets, weights, ntaps, center_weight, has_center, depth, pad_mode, fill_value, 1);
 }
 
+/* wt_axis_filter in float64 */
+extern "C" int wt64_axis_filter(wt_plan64 *p, int src, int dst, int axis, const int32_t *offsets, const double *weights, int ntaps, int depth,
+                                int pad_mode, double fill_value, int dilation)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !offsets || !weights) WT_FAIL("wt64_axis_filter: null pointer");
+    if (ntaps < 1 || ntaps > 4096) WT_FAIL("wt64_axis_filter: %d taps unsupported", ntaps);
+    if (axis < 0 || axis > 2) WT_FAIL("wt64_axis_filter: axis %d (2 = x, 1 = y, 0 = z)", axis);
+    if (dilation < 1) WT_FAIL("wt64_axis_filter: dilation %d must be positive", dilation);
+    if (src == dst) WT_FAIL("wt64_axis_filter: dst must differ from src");
+    if (pad_mode < WT_PAD_SYMMETRIC || pad_mode > WT_PAD_POLY_MIRROR) WT_FAIL("wt64_axis_filter: unknown pad mode %d", pad_mode);
+    if (depth < 0 || (depth > 0 && p->g.H % depth)) WT_FAIL("wt64_axis_filter: %d rows are not a multiple of depth %d", p->g.H, depth);
+    if (axis == 0 && depth == 0) WT_FAIL("wt64_axis_filter: axis 0 needs a cube (depth > 0)");
+    double *in = nullptr, *o = nullptr;
+    WT_TRY(plan64_base(p, src, &in));
+    WT_TRY(plan64_base(p, dst, &o));
+    const int rc = wt_axis_filter_launch<double>(p->ctx, in, o, p->g.W, p->g.P, p->g.H, depth, axis, offsets, weights, ntaps, pad_mode,
+                                                 fill_value, dilation);
+    if (rc >= 0) return rc;
+    std::vector<int32_t> o3((size_t)ntaps * 3, 0);
+    for (int j = 0; j < ntaps; ++j) o3[(size_t)3 * j + axis] = offsets[j];
+    return wt64_taps_conv_ex(p, src, WT_PLANE_NONE, dst, o3.data(), weights, ntaps, 0.0, 0, depth, pad_mode, fill_value, dilation);
+}
+
 extern "C" int wt64_variance_from_moments(wt_plan64 *p, int mean, int meansq, int dst, double f1, double f2, int take_sqrt)
 {
     WtGuard guard_(ctx_of(p));

@@ -269,10 +269,10 @@ def _generic_filter(plan, scaling_function, ndim, shape, src, dst, offset_scale,
         return
     cur = src
     for i, ax in enumerate(range(ndim - 1, -1, -1)):              # x first, then y (, then z)
-        offs = np.zeros((K, 3), dtype=np.int32)
-        offs[:, 3 - ndim + ax] = o
         nxt = dst if i == ndim - 1 else _SEP_PLANES[i]
-        plan.taps_conv(cur, PLANE_NONE, nxt, offs, taps, None, depth=depth, pad_mode=pad_mode, dilation=dilation)
+        # (round 5: tiled kernels - LDS row segments along x, an LDS ring of rows down the polyphase chains along
+        #  y / z - instead of K global loads per sample; same arithmetic, identical bits: wt_axis_filter)
+        plan.axis_filter(cur, nxt, 3 - ndim + ax, o, taps, depth=depth, pad_mode=pad_mode, dilation=dilation)
         cur = nxt
 
 
