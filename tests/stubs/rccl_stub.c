@@ -1,4 +1,4 @@
-/* A stand-in for librccl.so with just the entry points libwatroo_hip.so binds (wt_api.hip, rccl_load), for
+/* A stand-in for librccl.so with just the entry points libwatroo_hip.so binds (wt_core.hip, rccl_load), for
  * tests of the error paths: WATROO_HIP_RCCL_LIB=<this library>.  Nothing moves: Send / Recv / AllReduce return
  * success without touching their buffers.  RCCL_STUB_FAIL_SEND=<n> makes the n-th ncclSend of the process
  * (1-based) return ncclInternalError once.  The group depth and the call counts are exported so that a test

@@ -214,6 +214,8 @@ def test_no_kernel_uses_scratch_memory_or_spills(tmp_path):
                                check=True, capture_output=True, text=True).stdout
         kernels += re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)",
                               notes, flags=re.S)
-    assert len(kernels) > 200 and len(set(k[0] for k in kernels)) == len(kernels)
+    # (the kernels of wt_kernels_common.h that are not templates are `static`: one copy per unit that includes them,
+    #  and a template instantiated in two units appears in both - a few dozen duplicates, no more)
+    assert len(kernels) > 200 and len(kernels) - len(set(k[0] for k in kernels)) <= 40
     bad = [(n, int(sc), int(sp)) for n, sc, sp in kernels if int(sc) or int(sp)]
     assert not bad, f"kernels with scratch / spills: {bad[:5]}"

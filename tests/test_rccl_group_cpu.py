@@ -76,7 +76,7 @@ def test_rccl_group_is_always_closed_and_reports_the_first_error(tmp_path):
 
 def test_halo_exchange_uses_the_group_bracket_and_no_bare_group_calls_remain():
     """every ncclGroupStart of the library goes through WtRcclGroup (a bare WT_NCCL(GroupStart) is the bug class)"""
-    text = open(os.path.join(ROOT, "wavelets_amd", "csrc", "wt_api.hip")).read()
+    text = open(os.path.join(ROOT, "wavelets_amd", "csrc", "wt_core.hip")).read()
     assert "g_rccl.GroupStart()" not in text and "g_rccl.GroupEnd()" not in text
     assert text.count("WtRcclGroup<RcclApi>") >= 2
 
@@ -91,8 +91,8 @@ def test_stub_rccl_library_builds_and_exports_what_the_engine_binds(tmp_path):
                  "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclAllReduce", "ncclGetErrorString",
                  "ncclGetVersion", "rccl_stub_state"):
         assert hasattr(lib, name), name
-    # the names wt_api.hip resolves with dlsym are exactly these
-    text = open(os.path.join(ROOT, "wavelets_amd", "csrc", "wt_api.hip")).read()
+    # the names wt_core.hip resolves with dlsym are exactly these
+    text = open(os.path.join(ROOT, "wavelets_amd", "csrc", "wt_core.hip")).read()
     import re
     for sym in re.findall(r'SYM\(\w+, "(nccl\w+)"\)', text):
         assert hasattr(lib, sym), sym

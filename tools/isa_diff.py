@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compare the gfx950 code of the library's kernels between two builds, kernel by kernel.
 
-    hipcc -O3 --offload-arch=gfx950 -std=c++17 --cuda-device-only -S -o before.s wavelets_amd/csrc/wt_api.hip
+    hipcc -O3 --offload-arch=gfx950 -std=c++17 --cuda-device-only -S -o before.s wavelets_amd/csrc/wt_transform.hip
     ... edit ...
     hipcc ... -o after.s ...
     python tools/isa_diff.py before.s after.s [name-filter]

@@ -22,13 +22,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def scope_name(kernel):
-    """rocprof kernel name -> ProfScope name of wt_api.hip / wt_fused.h"""
+    """rocprof kernel name -> ProfScope name of the host units / wt_fused.h"""
     m = re.match(r"void wt_fused_kernel<(?:float, )?(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", kernel)
     if m:
         _, ns, d, _, _, acc = map(int, m.groups())
         return f"{('wt_fused', 'wt_fused_acc', 'wt_fused_sum', 'wt_fused_hist')[acc]}<d{d}x{ns}>"
     m = re.match(r"void (wt_row_kernel|wt_lattice_kernel|wt_chain_kernel)<(\d+), (\d+)", kernel)
-    if m:       # the single-scale operators are named by their mode (wt_api.hip row_name / lattice_name)
+    if m:       # the single-scale operators are named by their mode (wt_stencil_launch.h wt_row_name / wt_lattice_name)
         mode = int(m.group(3))
         names = {"wt_row_kernel": ("smooth", "smooth_sq", "decomp", "variance", "wow"),
                  "wt_lattice_kernel": ("smooth", "smooth_sq", "decomp", "var", "wow"),

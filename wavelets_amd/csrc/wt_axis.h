@@ -21,7 +21,7 @@
 #define WT_AXIS_SEG 1024          // output pixels of one LDS segment (4 per lane)
 #define WT_AXIS_MAX_SPAN 2048     // largest (max offset - min offset) the LDS form takes
 
-// (wt_pad_index: wt_kernels.h, included before this header; wt_vpack / wt_vunpack: wt_stencil.h)
+// (wt_pad_index: wt_kernels_common.h, included before this header; wt_vpack / wt_vunpack: wt_stencil.h)
 
 template <typename T>
 struct AxisArgs {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void wt_axis_tile_kernel(AxisArgs<T> a)
 // ---------------------------------------------------------------------------------------------
 // host side (both element types)
 // ---------------------------------------------------------------------------------------------
-extern int g_opt_axis_filter;      // wt_set_option("axis_filter", 0/1); defined in wt_api.hip
+extern int g_opt_axis_filter;      // wt_set_option("axis_filter", 0/1); defined in wt_apps.hip
 
 // 0: launched; -1: this tap set / axis is not one the tiled kernels take (the caller falls back to the tap-list
 // operator); > 0: error.  axis: 2 = x, 1 = y, 0 = z (cubes).

@@ -4,7 +4,7 @@
 //
 //   out = (k_c I + sum_t k_t e_t I_t) / (k_c + sum_t k_t e_t),   e_t = exp(-((I - I_t)^2) / var / 2)   (:97)
 //
-// The march of wt_bilateral2_kernel (wt_kernels.h) with ONE pixel per thread: a thread owns a column and
+// The march of wt_bilateral2_kernel (wt_kernels_transform.h) with ONE pixel per thread: a thread owns a column and
 // one chunk of one polyphase row chain and keeps the K x K dilated neighbourhood in a register window of
 // K x K doubles (the float kernel's K x K float2), every input row is fetched once per chain through K
 // coalesced 8-byte loads at x + j d.  Full K x K tap set (not separable): VALU-bound, K*K - 1 exponentials

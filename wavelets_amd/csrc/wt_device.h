@@ -1,5 +1,5 @@
 // Device helpers shared by every translation unit of libwatroo_hip.so (the per-scale kernels of
-// wt_kernels.h and the fused passes of wt_fused.h, which are compiled one instantiation group per
+// wt_kernels_*.h and the fused passes of wt_fused.h, which are compiled one instantiation group per
 // translation unit - wt_fused_tu.hip): border reflection, the scaling functions' taps, float4
 // arithmetic.  gfx950 only.
 #pragma once
@@ -7,7 +7,7 @@
 
 #include "wt_internal.h"
 
-#define WT_HIST_BINS 2048      // bins of one radix level of the exact-median select (wt_kernels.h)
+#define WT_HIST_BINS 2048      // bins of one radix level of the exact-median select (wt_kernels_apps.h)
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers

@@ -7,7 +7,7 @@
 // sum, convolution(), sdev_loc() and the Anscombe transform - with double planes and double
 // arithmetic, on generic one-sample-per-thread kernels with run-time taps (the built-in families
 // pass theirs).  HBM-bound work at 8 B per sample; nothing here is tuned like the float32 path.
-// Included at the end of wt_api.hip (one translation unit).
+// The body of wt_f64.hip (its own translation unit since round 5).
 #pragma once
 
 struct Taps64 {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void wt64_cols2_kernel(const double *in, doubl
 }
 
 static int g_opt_f64_pairs = getenv("WT_NO_F64_PAIRS") ? 0 : 1;      // wt_set_option("f64_pairs", 0/1): two pixels per thread
-static void wt_set_f64_pairs(int on) { g_opt_f64_pairs = on; }
+void wt_set_f64_pairs(int on) { g_opt_f64_pairs = on; }
 
 // dilated filter along axis 1 (inside every slice: axis == 1) or axis 0 (across slices) of a
 // (Z, Y, X) cube stored as a (Z*Y) x X image; an image is the cube with Z = 1
@@ -1011,7 +1011,7 @@ extern "C" int wt64_download(wt_plan64 *p, int plane, double *host, int64_t host
 // for the filters).
 static int fused64_family(const wt_plan64 *p);
 static int g_opt_stencil64 = getenv("WT_NO_STENCIL64") ? 0 : 1;
-static void wt_set_stencil64(int on) { g_opt_stencil64 = on; }
+void wt_set_stencil64(int on) { g_opt_stencil64 = on; }
 static inline bool stencil64_ok(const wt_plan64 *p) { return g_opt_stencil64 && fused64_family(p) >= 0 && p->g.H >= 2; }
 static inline StencilCtx stencil64_ctx(const wt_plan64 *p, hipStream_t st = nullptr)
 {
@@ -1107,7 +1107,7 @@ extern "C" int wt64_smooth(wt_plan64 *p, int src, int dst, int s, int square_inp
 // algorithm and schedules with per-scale passes (L > 8) keep the generic per-scale kernels above.
 // ---------------------------------------------------------------------------------------------
 static int g_opt_fused64 = getenv("WT_NO_FUSED64") ? 0 : 1;      // wt_set_option("fused64", 0/1)
-static void wt_set_fused64(int on) { g_opt_fused64 = on; }
+void wt_set_fused64(int on) { g_opt_fused64 = on; }
 
 static int fused64_family(const wt_plan64 *p)
 {
@@ -1469,7 +1469,7 @@ extern "C" int wt64_anscombe(wt_plan64 *p, int src, int dst, double alpha, doubl
  * included: two or three reads of the plane instead of six or seven.  Bins that do not fit the list
  * (ties: constant or quantised data) continue with the radix passes as before. */
 static int g_opt_select64_list = getenv("WT_NO_SELECT64_LIST") ? 0 : 1;      // wt_set_option("select64_list", 0/1): A/B and tests
-static void wt_set_select64_list(int on) { g_opt_select64_list = on; }
+void wt_set_select64_list(int on) { g_opt_select64_list = on; }
 extern "C" int wt64_abs_median(wt_plan64 *p, int plane, double *median)
 {
     WtGuard guard_(ctx_of(p));

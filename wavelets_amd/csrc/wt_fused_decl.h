@@ -2,7 +2,7 @@
 // passes exist, and the entry points of the translation units the instantiations are compiled in.
 // The 200-odd instantiations of wt_fused_kernel take minutes to compile in one piece; they are built
 // as one group per (element type, taps, variant) in wt_fused_tu.hip - 16 translation units that
-// compile side by side - and wt_api.hip sees only the functions declared here.
+// compile side by side - and the host units see only the functions declared here.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,7 +52,7 @@ static inline bool wt_fused_supported_bytes(int64_t pitch_bytes) { return pitch_
 // Rows a launch stores (strip-local): n = 1 or 2 ranges.  reserve = compute units the chunk
 // search leaves free (for the RCCL kernels of an exchange running beside the launch).
 // A/B switch (wt_set_option "fused_fast"): 0 forces the generic addressing of the fused passes
-extern int g_opt_fused_fast;      // defined in wt_api.hip (env WT_FUSED_NO_FAST)
+extern int g_opt_fused_fast;      // defined in wt_transform.hip (env WT_FUSED_NO_FAST)
 
 struct FusedRows {
     int n = 0;

@@ -129,6 +129,7 @@ struct wt_ctx {
 };
 
 #define WT_MAX_CUSTOM_TAPS 15
+#define WT_MAX_SUM_PLANES 16      // planes one wt_plane_sum / wt_denoise_sum launch folds
 
 // Device state of the FFT path of one plan: twiddle tables of both lengths, two work arrays and the
 // kernel spectrum (stored TRANSPOSED, W x H, the layout the forward transform ends in).
@@ -210,7 +211,7 @@ struct wt_plan64 {
     bool overlap_ok = false;
 };
 
-// ------------------------------------------------------------------ side stream (wt_api.hip)
+// ------------------------------------------------------------------ side stream (wt_core.hip)
 int wt_side_join(wt_ctx *c);                        // main stream waits for everything queued on the side stream
 int wt_side_begin(wt_ctx *c, hipEvent_t after);     // route the context's launches to the side stream, behind `after`
 void wt_side_end(wt_ctx *c);

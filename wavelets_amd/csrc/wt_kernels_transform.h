@@ -1,0 +1,372 @@
+// Kernels of the transform unit (wt_transform.hip): the float32 bilateral march in its two forms and the column
+// pass of the run-time-tap filter.  (The chain / lattice / row kernels are wt_stencil.h, the fused passes
+// wt_fused.h.)  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "wt_internal.h"
+#include "wt_device.h"
+#include "wt_stencil.h"
+#include "wt_kernels_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// K10  bilateral (range-weighted) dilated convolution - watroo/wavelets.py:74-105
+//   out = (k_c I + sum_t k_t e_t I_t) / (k_c + sum_t k_t e_t),
+//   e_t = exp(-((I - I_t)^2) / var / 2)                        (numexpr expression, :97)
+// Full K x K tap set (not separable), so this kernel is transcendental/VALU-bound, not
+// HBM-bound: K*K-1 exponentials per pixel.  A lane owns 4 adjacent pixels (16-byte row loads,
+// like every other kernel); per tap the weight is ONE v_exp_f32:
+//   k_t * exp(-d^2/(2 var)) = 2^( d^2 * (-log2(e)/(2 var)) + log2(k_t) )
+// with the per-pixel factor -log2(e)/(2 var) formed once (one division per pixel instead of
+// one per tap).  fp32 rounding differs from the reference's exp()/divide sequence by a few
+// ulp of the weight - inside the stated bilateral tolerance (2e-5 * max|input|).
+// ---------------------------------------------------------------------------------------------
+// Work decomposition is the chain march of K1: a thread owns 4 columns and one polyphase row
+// chain, and keeps the K x K (dilated) neighbourhood rows in a register window that slides one
+// chain step per iteration - every input row is fetched once per chain (K coalesced 16-byte
+// loads at x + j*d, L2-served) instead of once per output row, which is what makes the large
+// dilations of wow() (d up to 1024, where a tile has no spatial reuse) HBM-neutral.
+template <int K, bool SMALL_D>
+__global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
+{
+    constexpr int hw = K / 2;
+    constexpr int NX = SMALL_D ? 3 : K;   // float4 per window row
+    const Geo g = a.g;
+    int bx, by;
+    wt_xcd_remap(bx, by);
+    const int x = (bx * 64 + threadIdx.x) * 4;
+    if (x >= g.W) return;
+    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
+    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
+    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
+    const int d = a.d;
+    const int q = item % d;
+    const int c = item / d;
+    if (c >= a.chunks || q >= g.nrows) return;
+    const int n_q = (g.nrows - q + d - 1) / d;
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+    const int gy0 = g.row0 + q;
+    constexpr bool small_d = SMALL_D;    // d < 4: taps are sub-float4 shifts
+
+    // win[i][j]: row (r - hw + i) of the chain; j-th float4 of that row:
+    //   d >= 4: pixels x + (j - hw) d .. +3     (K float4 per row)
+    //   d <  4: pixels x - 4 + 4 j .. +3        (3 float4 per row: e[12] of wt_hrow)
+    float4 win[K][NX];
+    auto load_win_row = [&](int r, float4 (&dst)[NX]) {
+        const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            dst[j] = wt_load4_b(row, SMALL_D ? x - 4 + 4 * j : x + (j - hw) * d, g.W, d, g.border);
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
+    float4 nxt[NX];
+
+    const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
+    for (int r = r0; r < r1; ++r) {
+        // software prefetch of the row that enters the window in the next iteration
+        load_win_row(min(r + 1, r1 - 1) + hw, nxt);
+        const int64_t off = (int64_t)(q + d * r) * g.P + x;
+        const float4 Ic4 = win[hw][SMALL_D ? 1 : hw];
+        const float I[4] = {Ic4.x, Ic4.y, Ic4.z, Ic4.w};
+        float vv[4];
+        if (a.inline_var) {
+            // variance of watroo/wavelets.py:434-436 from the neighbourhood already in
+            // registers: same arithmetic (row filters, then column filter) as the MODE_VAR chain
+            // kernel, so the result is bit-identical to the separate variance pass
+            float4 m4, p4, h, h2, cdummy;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                wt_hrow_filter<float, K, MODE_VAR, SMALL_D>(win[i], d, h, h2, cdummy);
+                m4 = (i == 0) ? f4_scale(wt_tap<K>(0), h) : f4_fma(wt_tap<K>(i), h, m4);
+                p4 = (i == 0) ? f4_scale(wt_tap<K>(0), h2) : f4_fma(wt_tap<K>(i), h2, p4);
+            }
+            vv[0] = wt_var_point(p4.x, m4.x, a.f1, a.f2, 0);
+            vv[1] = wt_var_point(p4.y, m4.y, a.f1, a.f2, 0);
+            vv[2] = wt_var_point(p4.z, m4.z, a.f1, a.f2, 0);
+            vv[3] = wt_var_point(p4.w, m4.w, a.f1, a.f2, 0);
+        } else {
+            const float4 v4 = *reinterpret_cast<const float4 *>(a.aux + off);
+            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        }
+        float norm[4], acc[4], s2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            norm[k] = kc;
+            acc[k] = kc * I[k];
+            s2[k] = wt_div_nr(-0.72134752044448170368f, vv[k]);   // -log2(e) / (2 var)
+        }
+        // taps in the reference order (watroo/wavelets.py:89-91): kernel index (i, j) pairs with
+        // the shift (K-1-i-hw, K-1-j-hw) * d
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float4 (&wr)[NX] = win[K - 1 - i];
+            float e[12] = {0.f};
+            if constexpr (small_d) {
+                e[0] = wr[0].x; e[1] = wr[0].y; e[2] = wr[0].z; e[3] = wr[0].w;
+                e[4] = wr[1].x; e[5] = wr[1].y; e[6] = wr[1].z; e[7] = wr[1].w;
+                e[8] = wr[2].x; e[9] = wr[2].y; e[10] = wr[2].z; e[11] = wr[2].w;
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (i == hw && j == hw) continue;
+                const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
+                float It[4];
+                if constexpr (small_d) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        It[k] = d == 1 ? e[4 + k + (K - 1 - j - hw)] : e[4 + k + 2 * (K - 1 - j - hw)];
+                } else {
+                    const float4 t = wr[SMALL_D ? 0 : K - 1 - j];
+                    It[0] = t.x; It[1] = t.y; It[2] = t.z; It[3] = t.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float diff = I[k] - It[k];
+                    const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, s2[k], lk));
+                    norm[k] += w;
+                    acc[k] = fmaf(It[k], w, acc[k]);
+                }
+            }
+        }
+        float o[4], ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = wt_div_nr(acc[k], norm[k]);
+            ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
+        }
+        const int64_t roff = (int64_t)(q + d * r) * g.P;
+        wt_store4(a.out_c + roff, x, g.P, make_float4(o[0], o[1], o[2], o[3]));
+        if (a.out_w) wt_store4(a.out_w + roff, x, g.P, make_float4(ow[0], ow[1], ow[2], ow[3]));
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) win[i][j] = win[i + 1][j];
+            win[K - 1][j] = nxt[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10b  the same bilateral convolution with TWO pixels per thread (any dilation).  The 4-pixel kernel
+// holds its K x K float4 neighbourhood in ~240 VGPRs: 2 waves per SIMD, and at that occupancy the
+// dependent chain of every tap (difference, square, scale, exp, accumulate) - not the instruction
+// count - sets the pace.  Half the pixels per thread halve the window (K x K float2) and allow
+// 3-4 waves per SIMD.  Per-pixel arithmetic is identical to wt_bilateral_kernel (same operations
+// in the same order, variance included), so the two kernels produce the same bits.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int wt_su2 __attribute__((ext_vector_type(2)));
+typedef float wt_sf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wt_store2(float *row, int x, int P, float2 v)
+{
+    const uint64_t ra = (uint64_t)row;
+    const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 4, 0x00020000);
+    const wt_sf2 t = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), r, (unsigned)x * 4u, 0, 0);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
+{
+    constexpr int hw = K / 2;
+    const Geo g = a.g;
+    int bx, by;
+    wt_xcd_remap(bx, by);
+    const int x = (bx * 64 + threadIdx.x) * 2;
+    if (x >= g.W) return;
+    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
+    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
+    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
+    const int d = a.d;
+    const int q = item % d;
+    const int c = item / d;
+    if (c >= a.chunks || q >= g.nrows) return;
+    const int n_q = (g.nrows - q + d - 1) / d;
+    const int r0 = c * a.S;
+    const int r1 = min(r0 + a.S, n_q);
+    if (r0 >= r1) return;
+    const int gy0 = g.row0 + q;
+
+    // operand columns do not depend on the row: pixel pair x + (j - hw) d, reflected per pixel at
+    // the image border; an in-image pair at an even pixel is one aligned 8-byte load
+    int xa[K], xb[K];
+    unsigned pair = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int xo = x + (j - hw) * d;
+        xa[j] = wt_refl_b(xo, g.W, d, g.border);
+        xb[j] = wt_refl_b(xo + 1, g.W, d, g.border);
+        if (xo >= 0 && xo + 1 < g.W && (xo & 1) == 0) pair |= 1u << j;   // d = 1: odd operands take two 4-byte loads
+    }
+    float2 win[K][K];
+    auto load_win_row = [&](int r, float2 (&dst)[K]) {
+        const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const char *rb = reinterpret_cast<const char *>(row);        // SGPR base + 32-bit lane offset
+            if ((pair >> j) & 1u) dst[j] = *reinterpret_cast<const float2 *>(rb + (unsigned)xa[j] * 4u);
+            else dst[j] = make_float2(*reinterpret_cast<const float *>(rb + (unsigned)xa[j] * 4u),
+                                      *reinterpret_cast<const float *>(rb + (unsigned)xb[j] * 4u));
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
+    float2 nxt[K];
+
+    // In-kernel variance: the row filters (h = row-filtered I, h2 = row-filtered I^2) of a window
+    // row are computed ONCE, when the row enters, and parked in a per-thread LDS ring of K slots
+    // (no other thread touches them: no barrier); every step reads the K pairs for the column
+    // filter instead of filtering all K rows again (4/5 of that arithmetic, ~20 % of the kernel's
+    // VALU work; at 4 waves per SIMD the kernel is VALU-bound).  Same operations in the same
+    // order as wt_hrow_filter<MODE_VAR> + WtVert: bit-identical to the separate variance pass.
+    __shared__ float2 hring[K][2][256];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    auto row_filters = [&](const float2 (&wr)[K], float2 &h, float2 &h2) {
+        float hh[2], hh2[2];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float v[2] = {wr[j].x, wr[j].y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float sq = v[k] * v[k];
+                hh[k] = (j == 0) ? wt_tap<K>(0) * v[k] : fmaf(wt_tap<K>(j), v[k], hh[k]);
+                hh2[k] = (j == 0) ? wt_tap<K>(0) * sq : fmaf(wt_tap<K>(j), sq, hh2[k]);
+            }
+        }
+        h = make_float2(hh[0], hh[1]);
+        h2 = make_float2(hh2[0], hh2[1]);
+    };
+    if (a.inline_var) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            float2 h, h2;
+            row_filters(win[i], h, h2);
+            hring[i][0][tid] = h;
+            hring[i][1][tid] = h2;
+        }
+    }
+    int slot0 = 0;                                       // ring slot of window row 0
+
+    const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
+    // One step of the march.  The window does NOT slide through the registers (K * K 8-byte moves per
+    // row, ~10 % of the kernel's vector instructions): the row loop is unrolled K times and in phase U
+    // window row i lives in slot (i + U) % K - the entering row replaces the row that left (K moves).
+    // Same operations in the same order in every phase: identical bits.
+    auto step = [&](const int r, auto utag) {
+        constexpr int U = decltype(utag)::value;
+        load_win_row(min(r + 1, r1 - 1) + hw, nxt);      // software prefetch of the entering row
+        const int64_t roff = (int64_t)(q + d * r) * g.P;
+        const float I[2] = {win[(hw + U) % K][hw].x, win[(hw + U) % K][hw].y};
+        float vv[2];
+        if (a.inline_var) {
+            float2 hn, h2n;
+            row_filters(win[(K - 1 + U) % K], hn, h2n);  // the row that entered the window
+            {
+                const int sn = slot0 == 0 ? K - 1 : slot0 - 1;
+                hring[sn][0][tid] = hn;
+                hring[sn][1][tid] = h2n;
+            }
+            float m[2], p[2];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float2 h, h2;
+                if (i < K - 1) {
+                    const int si = slot0 + i < K ? slot0 + i : slot0 + i - K;
+                    h = hring[si][0][tid];
+                    h2 = hring[si][1][tid];
+                } else {
+                    h = hn;
+                    h2 = h2n;
+                }
+                const float hk[2] = {h.x, h.y}, h2k[2] = {h2.x, h2.y};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    m[k] = (i == 0) ? wt_tap<K>(0) * hk[k] : fmaf(wt_tap<K>(i), hk[k], m[k]);
+                    p[k] = (i == 0) ? wt_tap<K>(0) * h2k[k] : fmaf(wt_tap<K>(i), h2k[k], p[k]);
+                }
+            }
+            slot0 = slot0 + 1 == K ? 0 : slot0 + 1;
+            vv[0] = wt_var_point(p[0], m[0], a.f1, a.f2, 0);
+            vv[1] = wt_var_point(p[1], m[1], a.f1, a.f2, 0);
+        } else {
+            vv[0] = a.aux[roff + x];
+            vv[1] = x + 1 < g.W ? a.aux[roff + x + 1] : 1.f;
+        }
+        // The two pixels of a thread are a register PAIR throughout the tap loop: difference,
+        // square, exponent (one v_pk_fma with the tap's log2 weight as the addend), and the two
+        // accumulations are packed-FP32 instructions; only the exponentials are per pixel.  Same
+        // operations in the same order as the four-pixel kernel: identical bits.
+        typedef float wt_p2 __attribute__((ext_vector_type(2)));
+        const wt_p2 Iv = {I[0], I[1]};
+        wt_p2 norm = {kc, kc};
+        wt_p2 acc = kc * Iv;
+        const wt_p2 s2 = {wt_div_nr(-0.72134752044448170368f, vv[0]), wt_div_nr(-0.72134752044448170368f, vv[1])};   // -log2(e) / (2 var)
+        // taps in the reference order (watroo/wavelets.py:89-91), as in wt_bilateral_kernel
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (i == hw && j == hw) continue;
+                const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
+                const float2 t2 = win[(K - 1 - i + U) % K][K - 1 - j];
+                const wt_p2 t = {t2.x, t2.y};
+                const wt_p2 diff = Iv - t;
+                const wt_p2 ex = __builtin_elementwise_fma(diff * diff, s2, (wt_p2){lk, lk});
+                const wt_p2 w = {__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+                norm += w;
+                acc = __builtin_elementwise_fma(t, w, acc);
+            }
+        }
+        float o[2], ow[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            o[k] = wt_div_nr(acc[k], norm[k]);
+            ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
+        }
+        wt_store2(a.out_c + roff, x, g.P, make_float2(o[0], o[1]));
+        if (a.out_w) wt_store2(a.out_w + roff, x, g.P, make_float2(ow[0], ow[1]));
+#pragma unroll
+        for (int j = 0; j < K; ++j) win[U][j] = nxt[j];    // slot of the row that left <- the row that entered
+    };
+    int r = r0;
+    while (true) {
+        step(r, std::integral_constant<int, 0>{});
+        if (++r >= r1) break;
+        step(r, std::integral_constant<int, 1>{});
+        if (++r >= r1) break;
+        step(r, std::integral_constant<int, 2>{});
+        if (++r >= r1) break;
+        if constexpr (K > 3) {
+            step(r, std::integral_constant<int, 3>{});
+            if (++r >= r1) break;
+            step(r, std::integral_constant<int, 4>{});
+            if (++r >= r1) break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wt_custom_cols_kernel(const float *tmp, const float *in, float *out_c,
+                                                             float *out_w, Geo g, int d, CustomTaps t)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.W) return;
+    const int hw = t.n / 2;
+    for (int y = blockIdx.y; y < g.nrows; y += gridDim.y) {
+        float acc = 0.f;
+        for (int i = 0; i < t.n; ++i) {
+            const int yy = wt_refl_b(g.row0 + y + (i - hw) * d, g.H, d, g.border) - g.row0;
+            const float v = tmp[(int64_t)yy * g.P + x];
+            acc = i == 0 ? t.k[0] * v : fmaf(t.k[i], v, acc);
+        }
+        const int64_t o = (int64_t)y * g.P + x;
+        if (out_w) out_w[o] = in[o] - acc;
+        out_c[o] = acc;
+    }
+}
+

@@ -1,5 +1,5 @@
 // Host side of the per-scale stencil kernels (wt_stencil.h): which kernel serves a dilation and how its
-// grid is cut, written once for both element types.  Included by wt_api.hip (T = float) and by
+// grid is cut, written once for both element types.  Included by wt_transform.hip (T = float) and by
 // wt_stencil64.hip (T = double).
 #pragma once
 #include <algorithm>
@@ -8,7 +8,7 @@
 #include "wt_internal.h"
 #include "wt_stencil.h"
 
-// tuning / A-B switches (wt_set_option; defined in wt_api.hip)
+// tuning / A-B switches (wt_set_option; defined in wt_transform.hip)
 extern int g_opt_row_kernel;
 extern int g_opt_lattice;
 
