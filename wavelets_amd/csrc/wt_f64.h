@@ -10,6 +10,8 @@
 // The body of wt_f64.hip (its own translation unit since round 5).
 #pragma once
 
+typedef double wt_ntd2 __attribute__((ext_vector_type(2)));     // streaming 16-byte accesses
+
 struct Taps64 {
     double k[WT64_MAX_TAPS];
     int n;
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(256) void wt64_denoise_sum_kernel(DenoiseSum64Args 
         if (noise) nz = reinterpret_cast<const double2 *>(noise)[i];
         double2 acc = make_double2(0.0, 0.0);
         for (int k = 0; k < a.n; ++k) {
-            double2 v = reinterpret_cast<const double2 *>(a.p[k])[i];
+            const wt_ntd2 raw = __builtin_nontemporal_load(reinterpret_cast<const wt_ntd2 *>(a.p[k]) + i);   // (read exactly once)
+            double2 v = make_double2(raw.x, raw.y);
             if (k < a.n_den) {
                 double2 sg = make_double2(1.0, 1.0);
                 if (a.tau[k] > 0.0) {
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void wt64_denoise_sum_kernel(DenoiseSum64Args 
             }
             acc = k == 0 ? v : make_double2(acc.x + v.x, acc.y + v.y);
         }
-        reinterpret_cast<double2 *>(dst)[i] = acc;
+        __builtin_nontemporal_store((wt_ntd2){acc.x, acc.y}, reinterpret_cast<wt_ntd2 *>(dst) + i);
     }
 }
 
@@ -464,15 +467,18 @@ struct Sum64Args {
     int n;
 };
 // np.sum(planes, axis=0) in plane order (watroo/utils.py:98); a lane owns two samples (16-byte accesses)
+// As wt_plane_sum_kernel (round 5): one 16-byte group per thread - a large grid of short-lived waves keeps the
+// most loads in flight for this n-reads-1-write stream - and streaming (nontemporal) accesses: planes read
+// exactly once should not displace cache lines (8192^2, 12 planes: 1.33 -> 1.1x ms).
 __global__ __launch_bounds__(256) void wt64_plane_sum_kernel(Sum64Args a, double *dst, int64_t n2)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
-        double2 acc = reinterpret_cast<const double2 *>(a.p[0])[i];
+        wt_ntd2 acc = __builtin_nontemporal_load(reinterpret_cast<const wt_ntd2 *>(a.p[0]) + i);
         for (int k = 1; k < a.n; ++k) {
-            const double2 v = reinterpret_cast<const double2 *>(a.p[k])[i];
-            acc = make_double2(acc.x + v.x, acc.y + v.y);
+            const wt_ntd2 v = __builtin_nontemporal_load(reinterpret_cast<const wt_ntd2 *>(a.p[k]) + i);
+            acc = acc + v;
         }
-        reinterpret_cast<double2 *>(dst)[i] = acc;
+        __builtin_nontemporal_store(acc, reinterpret_cast<wt_ntd2 *>(dst) + i);
     }
 }
 
@@ -1416,7 +1422,7 @@ extern "C" int wt64_plane_sum(wt_plan64 *p, int first, int count, int dst)
     double *d = nullptr;
     WT_TRY(plan64_base(p, dst, &d));
     ProfScope ps(p->ctx, "wt64_plane_sum_kernel");
-    hipLaunchKernelGGL(wt64_plane_sum_kernel, dim3(flat_grid64(p)), dim3(256), 0, p->ctx->stream, a, d, plan64_n2(p));
+    hipLaunchKernelGGL(wt64_plane_sum_kernel, dim3((unsigned)((plan64_n2(p) + 255) / 256)), dim3(256), 0, p->ctx->stream, a, d, plan64_n2(p));
     WT_HIP(hipGetLastError());
     return 0;
 }
