@@ -14,6 +14,11 @@ for c in headline cfg2 cfg3 cfg5; do
   cfgarg=$c
   python tools/pmc_summary.py $F profiles/${tag}_$c $side $cfgarg pmc_fetch_$c pmc_write_$c > /dev/null
 done
+cp $(ls $F/prof_cfg5_f64/*/*_kernel_stats.csv | head -1) profiles/${tag}_kernel_stats_cfg5_f32_f64.csv
+python tools/pmc_table.py $F/pmc_cfg5_f64 > profiles/${tag}_cfg5_f32_f64_pmc_fetch_write.csv      # KiB per dispatch; HBM read = 2 x FETCH_SIZE on gfx950
+cp $F/pmc_cfg5_sq/clocks.csv profiles/${tag}_cfg5_clocks.csv
+cp $F/pmc_cfg5_sq/summary.csv profiles/${tag}_cfg5_sq_counters.csv
+cp gpurun_out/parity_errors.log profiles/${tag}_parity_errors.log 2>/dev/null || true
 python - <<'PY'
 import json
 d = json.load(open("profiles/traffic.json"))

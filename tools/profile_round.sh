@@ -22,6 +22,14 @@ for c in headline cfg2 cfg3 cfg5; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/final/pmc_fetch_$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/final/pmc_write_$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu --no-build --brief > /dev/null 2>&1
 done
+# cfg5 in float64 (tools/bench_wow64.py times the float32 flow first, then the float64 one; serial order so that
+# the per-kernel averages are not stretched by the side stream): kernel stats and the two PMC passes
+export WT_NO_WOW_OVERLAP=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_cfg5_f64 -- python3 $R/tools/bench_wow64.py 8192 3 > $R/gpurun_out/final/rocprof_cfg5_f64.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/final/pmc_cfg5_f64/fetch -- python3 $R/tools/bench_wow64.py 8192 2 > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/final/pmc_cfg5_f64/write -- python3 $R/tools/bench_wow64.py 8192 2 > /dev/null 2>&1
+unset WT_NO_WOW_OVERLAP
+bash $R/tools/pmc_cfg5.sh gpurun_out/final/pmc_cfg5_sq > /dev/null 2>&1
 cd $R; cat gpurun_out/final/pytest_gpu.log 2>/dev/null | tail -2; cut -c1-300 gpurun_out/final/bench.json
 # keep only the small summary files of the rocprof runs (the merge back is capped at 64 MiB)
 find gpurun_out/final -name "*_kernel_trace.csv" -size +2M -delete

@@ -10,11 +10,14 @@
 // coalesced 8-byte loads at x + j d.  Full K x K tap set (not separable): VALU-bound, K*K - 1 exponentials
 // per pixel, and there is no double-precision exponential instruction - per tap
 //   k_t exp(-delta^2 / (2 var)) = 2^(delta^2 * (-log2(e) / (2 var)) + log2(k_t))
-// through wt_exp2_64_from_u (wt_math64.h: range reduction by the 1.5 * 2^52 trick, a degree-10 polynomial,
-// the exponent added as an integer) with the per-pixel factor formed once.  20 double-precision operations
-// per tap, ~520 per pixel; at one double-precision operation per lane per cycle-quad that prices a scale of
-// 8192^2 at ~0.9 ms, against 0.37 ms for the float kernel whose taps are packed-FP32
-// pairs around a hardware v_exp_f32.
+// with the per-pixel factor formed once: u = fma(delta^2, s / 64, 1 + log2 k_t / 64) clamped to [0, 1] by the FMA's
+// own output modifier, the range reduction by the 1.5 * 2^40 trick, 2^(j / 64) from a 64-entry table in LDS, a degree-4
+// polynomial, the exponent added as an integer (wt_math64.h, table form).  13 double-precision operations (6 of them
+// FMAs) + 4 integer operations + 1 LDS read per tap, ~330 double-precision operations per pixel with the variance
+// and the two divisions.  The kernel is bound by its double-precision issue at the clock the chip holds under it
+// (0.92 VALU busy at 1.9 GHz): the first version (a degree-10 polynomial, 12 FMAs per tap at the
+// SAME instruction count) took 1.20 ms per scale of 8192^2, this one 1.08 - against 0.37 ms for the float kernel whose
+// taps are packed-FP32 pairs around a hardware v_exp_f32.
 // Differences from the reference's operation order (exp of a quotient; IEEE divisions) are a few ulp of
 // the weight: the float64 parity bound of the tests is 1e-12 * max|input|.
 #pragma once
@@ -47,6 +50,11 @@ template <int K>
 __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<double> a)
 {
     constexpr int hw = K / 2;
+#if WT_BIL64_TABLE
+    __shared__ double exp2tab[WT_BIL64_TABLE];            // (before any wave leaves: every wave of the workgroup reads it)
+    if (threadIdx.y == 0 && threadIdx.x < WT_BIL64_TABLE) exp2tab[threadIdx.x] = WT_EXP2T_T[threadIdx.x];
+    __syncthreads();
+#endif
     const Geo g = a.g;
     int bx, by;
     wt_xcd_remap(bx, by);
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
     // the float64 engine: FMA chains in tap order): bit-identical to the separate variance pass.
     __shared__ double hring[K][2][256];
     const int tid = threadIdx.y * 64 + threadIdx.x;
+
     auto row_filters = [&](const double (&wr)[K], double &h, double &h2) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -154,6 +163,36 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
         // stays in tap order.
         constexpr int NT = K * K - 1, B = 4;
         static_assert(NT % B == 0, "taps come in batches of four");
+#if WT_BIL64_TABLE
+        const double *C = WT_EXP2T_C;
+#pragma unroll
+        for (int b0 = 0; b0 < NT; b0 += B) {
+            double tv[B], g[B], pw[B], tj[B];
+            int e[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int idx = b0 + k < hw * K + hw ? b0 + k : b0 + k + 1;
+                const int i = idx / K, j = idx % K;
+                const double lk = 1.0 + (wt_tap_log2_d<K>(i) + wt_tap_log2_d<K>(j)) / 64.0;
+                tv[k] = win[(K - 1 - i + U) % K][K - 1 - j];
+                const double diff = I - tv[k];
+                wt_exp2t_split(fmin(fmax(fma(diff * diff, s2, lk), 0.0), 1.0), g[k], e[k]);
+                tj[k] = exp2tab[e[k] & (WT_BIL64_TABLE - 1)];
+                pw[k] = C[WT_EXP2T_DEG];
+            }
+#pragma unroll
+            for (int c = WT_EXP2T_DEG - 1; c >= 0; --c) {
+#pragma unroll
+                for (int k = 0; k < B; ++k) pw[k] = fma(pw[k], g[k], C[c]);
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const double w = wt_exp2t_join(pw[k], tj[k], e[k]);
+                norm += w;
+                acc = fma(tv[k], w, acc);
+            }
+        }
+#else
         const double *C = WT_EXP2U_C;
 #pragma unroll
         for (int b0 = 0; b0 < NT; b0 += B) {
@@ -182,6 +221,7 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
                 acc = fma(tv[k], w, acc);
             }
         }
+#endif
         const double o = wt_div64(acc, norm);
         wt_store1d(a.out_c + roff, x, g.P, o);
         if (a.out_w) wt_store1d(a.out_w + roff, x, g.P, I - o);    // detail plane, wavelets.py:442

@@ -133,6 +133,57 @@ __device__ __forceinline__ double wt_exp2u_join(double p, int e)
 {
     return __hiloint2double(__double2hiint(p) + (e << 20), __double2loint(p));
 }
+// Table form: m = u + 1.5 * 2^(46 - b) carries round(2^b t) + 64 * 2^b = 2^b q + j (b = 5 or 6); 2^t = 2^(q - 64) *
+// 2^(j / 2^b) * 2^(64 g) with |64 g| <= 2^-(b+1): a table of 2^b doubles in LDS (32 entries: the 64 dwords are the 64
+// banks, conflict-free; 64 entries: two-way at worst) and a polynomial of degree 5 (2.2e-16) or 4 (2.4e-15; with the
+// quantisation of t 5.2e-15 relative in all) - 7 or 6 double-precision FMAs per weight instead of 12 at the same
+// instruction count, which the chip returns as clock (section 3.6 of DESIGN.md).  tools/make_exp2_64.py prints both.
+#ifndef WT_BIL64_TABLE
+#define WT_BIL64_TABLE 64
+#endif
+#define WT_EXP2T_C WT_PASTE(WT_EXP2T_C, WT_TU_NAME)
+#define WT_EXP2T_T WT_PASTE(WT_EXP2T_T, WT_TU_NAME)
+#if WT_BIL64_TABLE == 32
+#define WT_EXP2T_DEG 5
+#define WT_EXP2T_BITS 5
+__constant__ double WT_EXP2T_C[6] = {0x1.0000000000000p+0, 0x1.62e42fefa39efp+5, 0x1.ebfbdff7feebap+9, 0x1.c6b08d70380ddp+13, 0x1.3b2b301f1eb9cp+17,
+                                     0x1.5d885e6ef14a6p+20};
+__constant__ double WT_EXP2T_T[32] = {0x1.0000000000000p-64, 0x1.059b0d3158574p-64, 0x1.0b5586cf9890fp-64, 0x1.11301d0125b51p-64, 0x1.172b83c7d517bp-64, 0x1.1d4873168b9aap-64, 0x1.2387a6e756238p-64, 0x1.29e9df51fdee1p-64, 0x1.306fe0a31b715p-64, 0x1.371a7373aa9cbp-64, 0x1.3dea64c123422p-64, 0x1.44e086061892dp-64, 0x1.4bfdad5362a27p-64, 0x1.5342b569d4f82p-64, 0x1.5ab07dd485429p-64, 0x1.6247eb03a5585p-64, 0x1.6a09e667f3bcdp-64, 0x1.71f75e8ec5f74p-64, 0x1.7a11473eb0187p-64, 0x1.82589994cce13p-64, 0x1.8ace5422aa0dbp-64, 0x1.93737b0cdc5e5p-64, 0x1.9c49182a3f090p-64, 0x1.a5503b23e255dp-64, 0x1.ae89f995ad3adp-64, 0x1.b7f76f2fb5e47p-64, 0x1.c199bdd85529cp-64, 0x1.cb720dcef9069p-64, 0x1.d5818dcfba487p-64, 0x1.dfc97337b9b5fp-64, 0x1.ea4afa2a490dap-64, 0x1.f50765b6e4540p-64};
+#elif WT_BIL64_TABLE == 64
+#define WT_EXP2T_DEG 4
+#define WT_EXP2T_BITS 6
+__constant__ double WT_EXP2T_C[5] = {0x1.0000000000000p+0, 0x1.62e42fefa0352p+5, 0x1.ebfbdff82ac52p+9, 0x1.c6b0c40d8c4e9p+13, 0x1.3b2ad0385b409p+17};
+__constant__ double WT_EXP2T_T[64] = {0x1.0000000000000p-64, 0x1.02c9a3e778061p-64, 0x1.059b0d3158574p-64, 0x1.0874518759bc8p-64,
+ 0x1.0b5586cf9890fp-64, 0x1.0e3ec32d3d1a2p-64, 0x1.11301d0125b51p-64, 0x1.1429aaea92de0p-64,
+ 0x1.172b83c7d517bp-64, 0x1.1a35beb6fcb75p-64, 0x1.1d4873168b9aap-64, 0x1.2063b88628cd6p-64,
+ 0x1.2387a6e756238p-64, 0x1.26b4565e27cddp-64, 0x1.29e9df51fdee1p-64, 0x1.2d285a6e4030bp-64,
+ 0x1.306fe0a31b715p-64, 0x1.33c08b26416ffp-64, 0x1.371a7373aa9cbp-64, 0x1.3a7db34e59ff7p-64,
+ 0x1.3dea64c123422p-64, 0x1.4160a21f72e2ap-64, 0x1.44e086061892dp-64, 0x1.486a2b5c13cd0p-64,
+ 0x1.4bfdad5362a27p-64, 0x1.4f9b2769d2ca7p-64, 0x1.5342b569d4f82p-64, 0x1.56f4736b527dap-64,
+ 0x1.5ab07dd485429p-64, 0x1.5e76f15ad2148p-64, 0x1.6247eb03a5585p-64, 0x1.6623882552225p-64,
+ 0x1.6a09e667f3bcdp-64, 0x1.6dfb23c651a2fp-64, 0x1.71f75e8ec5f74p-64, 0x1.75feb564267c9p-64,
+ 0x1.7a11473eb0187p-64, 0x1.7e2f336cf4e62p-64, 0x1.82589994cce13p-64, 0x1.868d99b4492edp-64,
+ 0x1.8ace5422aa0dbp-64, 0x1.8f1ae99157736p-64, 0x1.93737b0cdc5e5p-64, 0x1.97d829fde4e50p-64,
+ 0x1.9c49182a3f090p-64, 0x1.a0c667b5de565p-64, 0x1.a5503b23e255dp-64, 0x1.a9e6b5579fdbfp-64,
+ 0x1.ae89f995ad3adp-64, 0x1.b33a2b84f15fbp-64, 0x1.b7f76f2fb5e47p-64, 0x1.bcc1e904bc1d2p-64,
+ 0x1.c199bdd85529cp-64, 0x1.c67f12e57d14bp-64, 0x1.cb720dcef9069p-64, 0x1.d072d4a07897cp-64,
+ 0x1.d5818dcfba487p-64, 0x1.da9e603db3285p-64, 0x1.dfc97337b9b5fp-64, 0x1.e502ee78b3ff6p-64,
+ 0x1.ea4afa2a490dap-64, 0x1.efa1bee615a27p-64, 0x1.f50765b6e4540p-64, 0x1.fa7c1819e90d8p-64};
+#endif
+#if WT_BIL64_TABLE
+__device__ __forceinline__ void wt_exp2t_split(double u, double &g, int &e)
+{
+    constexpr double M = WT_EXP2T_BITS == 5 ? 0x1.8p41 : 0x1.8p40;
+    const double m = u + M;
+    e = __double2loint(m);                                   // 2^b (round-ish(t) + 64) + j
+    g = u - (m - M);
+}
+__device__ __forceinline__ double wt_exp2t_join(double p, double tj, int e)
+{
+    const double w = p * tj;
+    return __hiloint2double(__double2hiint(w) + ((e & ~(WT_BIL64_TABLE - 1)) << (20 - WT_EXP2T_BITS)), __double2loint(w));
+}
+#endif
 // (scalar form: the kernels evaluate several weights in lockstep, see wt64_bilateral_march_kernel)
 __device__ __forceinline__ double wt_exp2_64_from_u(double u)
 {
