@@ -1150,8 +1150,8 @@ def main():
                                    "ms_per_step": round(ms64, 4), "steps": n64, "bytes_per_pixel": bpp,
                                    "frac_of_hbm_peak": round(bpp * 8192 * 8192 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "vs_float32_cfg5": round(ms64 / f32_ms, 3) if f32_ms else None,
-                                   "bound": "VALU (float64 bilateral march: ~483 double-precision operations per pixel per scale, "
-                                            "0.92 of the issue rate at the 1.9 GHz the chip holds under it - profiles/r05_*_cfg5_clocks.csv)",
+                                   "bound": "VALU (float64 bilateral march: ~330 double-precision operations per pixel per scale, "
+                                            "0.91 of the issue rate at the 2.0 GHz the chip holds under it - profiles/r05_b_cfg5_clocks.csv)",
                                    "kernels_ms_per_step (overlapped kernels both count)": k64}
         except Exception as e:
             out["float64_cfg5"] = {"error": repr(e)}
