@@ -63,7 +63,16 @@ int wt_device_count(int *count);
  *   mapped over shuffled 2-MiB physical chunks created in groups worth this many planes
  *   (DESIGN.md section 2); 0 = one hipMalloc per plane (see wt_plane_ptr).
  * "split_dry" (0): measurement aid - launch the passes of a strip plan split into edge and
- *   interior rows as "overlap" does, without exchanging (FLAG_NO_EXCHANGE runs). */
+ *   interior rows as "overlap" does, without exchanging (FLAG_NO_EXCHANGE runs).
+ * "stencil64" (1): float64 images with a built-in family run the tuned per-scale kernels (chain / lattice /
+ *   row kernels for double, the float64 bilateral march); 0 = the generic float64 kernels (identical bits for
+ *   the filters, 1e-12 for the bilateral operator).  "fused64", "f64_pairs", "select64_list", "hist_window",
+ *   "tri4", "host_pipeline", "scatter_strips": further A/B switches of the same kind.
+ * "wow_overlap" (1): behind wt_decompose_bilateral / wt64_decompose_bilateral the per-scale wow updates and
+ *   the MAD median run on a side stream beside the bilateral scales still queued; 0 = serial order (same bits).
+ * "axis_filter" (1): wt_axis_filter / wt64_axis_filter use the tiled kernels; 0 = the tap-list operator
+ *   (same bits).
+ * (the 2-MiB chunks of "scatter" are 8 MiB since ABI version 7; env WT_SCATTER_CHUNK_KB) */
 int wt_set_option(const char *name, int value);
 
 /* ---- context ---------------------------------------------------------------------- */
