@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         const wt_p2 s2 = {wt_div_nr(-0.72134752044448170368f, vv[0]), wt_div_nr(-0.72134752044448170368f, vv[1])};   // -log2(e) / (2 var)
         // taps in the reference order (watroo/wavelets.py:89-91), as in wt_bilateral_kernel
         // (round 5: forming 4 or 8 weights in lockstep, as the float64 march does, changed nothing here: cfg5 5.95-6.03 ms
-        //  either way on one box - the compiler already overlaps two to three taps)
+        //  either way on one box - the compiler already overlaps two to three taps; a second row in flight costs the
+        //  fourth wave per SIMD - 138 VGPRs - and 2.5 %)
 #pragma unroll
         for (int i = 0; i < K; ++i) {
 #pragma unroll
