@@ -232,8 +232,13 @@ def fft_supported(H, W):
     return bool(ok.value)
 
 
+_option_values = {"scatter": int(os.environ.get("WT_SCATTER", "4"))}     # options the pool restores after a temporary change
+
+
 def set_option(name, value):
     check(load().wt_set_option(name.encode(), int(value)))
+    if name in _option_values:
+        _option_values[name] = int(value)
 
 
 def device_count():
@@ -512,6 +517,8 @@ def _as_f32_rows(a):
 
 class Plan:
     """Device planes of one image (or one row strip of it).  wt_plan."""
+
+    cold = False             # True: created by the pool (acquire_plan), planes on plain hipMalloc
 
     def __init__(self, ctx, H, W, family, max_level, row0=0, nrows=None, halo_rows=0,
                  rank=0, nranks=1):
@@ -1041,8 +1048,18 @@ def acquire_plan64(ctx, H, W, taps, max_level):
     return Plan64(ctx, H, W, taps, max_level)
 
 
+_COLD_FIRST_USE = not os.environ.get("WATROO_HIP_NO_COLD_PLANS")
+
+
 def acquire_plan(ctx, H, W, family, max_level):
-    """A whole-image plan for (H, W, family, max_level): pooled if available, else new."""
+    """A whole-image plan for (H, W, family, max_level): pooled if available, else new.
+
+    Plans made HERE - for the numpy-to-numpy calls of the API - keep their planes on plain hipMalloc (round 5).
+    Mapping planes over scattered physical chunks makes the fused passes ~20 % faster, 0.1 ms
+    per transform at 8192^2, and costs ~16 ms when a plan is created and first used: worth it for device-resident
+    loops over a `_lib.Plan` (bench.py's metric: input already in HBM), not for calls that move the image over PCIe
+    both ways (10 ms at 8192^2) - and a one-shot `denoise(img)` would pay it in full (section 3.8: first call of a
+    process 48 -> 38 ms).  WATROO_HIP_NO_COLD_PLANS=1 restores scattered planes for pooled plans too."""
     key = (id(ctx), H, W, family, max_level)
     with _pool_lock:
         for i in range(len(_pool) - 1, -1, -1):
@@ -1050,7 +1067,16 @@ def acquire_plan(ctx, H, W, family, max_level):
                 plan = _pool.pop(i)[1]
                 plan.set_border(0)
                 return plan
-    return Plan(ctx, H, W, family, max_level)
+        if not _COLD_FIRST_USE or _option_values["scatter"] == 0:
+            return Plan(ctx, H, W, family, max_level)
+        keep = _option_values["scatter"]      # (the option is process-wide: changed and restored under the pool's lock)
+        set_option("scatter", 0)
+        try:
+            plan = Plan(ctx, H, W, family, max_level)
+        finally:
+            set_option("scatter", keep)
+    plan.cold = True
+    return plan
 
 
 def release_plan(plan):

@@ -614,7 +614,7 @@ static int plan_alloc(wt_plan *p, float **slot)
     // `scatter` planes and dealt to the planes in a shuffled order (fixed seed); each plane stays one
     // contiguous VIRTUAL range (hipMemAddressReserve / hipMemMap).  Small planes (< 8 MiB) stay on
     // hipMalloc: nothing to gain, and a map call per chunk to lose.
-    const int scatter = g_opt_scatter;   // wt_set_option("scatter", n); WT_SCATTER sets the initial value
+    const int scatter = p->scatter;      // wt_set_option("scatter", n) / WT_SCATTER at the time the plan was created
     // Strip plans keep plain hipMalloc unless WT_SCATTER_STRIPS=1: RCCL reads and writes the planes
     // of a strip, and its xGMI transport has never run on mapped memory here (the socket transport
     // of the one-GPU rank test has, green) - the one multi-GPU measurement must not hinge on it.
@@ -708,6 +708,7 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
     p->rank = rank;
     p->nranks = nranks;
     p->plane_floats = (size_t)(nrows + 2 * halo) * (size_t)P;
+    p->scatter = g_opt_scatter;
     {
         // default skew: 4 KiB + 256 B per plane index (keeps 16-byte alignment); WT_PLANE_SKEW
         // (bytes, multiple of 16) overrides it for experiments

@@ -157,6 +157,7 @@ struct wt_plan {
     std::vector<void *> raw_allocs;         // what hipFree gets
     size_t skew_floats = 0;
     int n_allocs = 0;
+    int scatter = 0;                        // the "scatter" option when the plan was created: its planes keep that placement
     void *arena = nullptr;                  // WT_ARENA experiment: planes carved from one allocation
     int arena_left = 0;
     size_t arena_stride = 0;
