@@ -76,7 +76,9 @@ def test_plan_create_destroy_cycles_return_device_memory(L):
         held = sum(pl.memory()[0] for pl in pooled)
         assert all(pl.memory()[2] == 0 for pl in pooled if isinstance(pl, L.Plan))
     after = ctx.device_memory()[0]
-    assert before - after <= held + (64 << 20), f"pool holds {held} bytes but {before - after} are gone"
+    # (round 5: pooled plans keep plain hipMalloc planes, which the allocator rounds up to its 2 MiB granularity -
+    #  up to 12 % of these 12-17 MiB planes - while wt_plan_memory counts the bytes asked for)
+    assert before - after <= held * 1.12 + (64 << 20), f"pool holds {held} bytes but {before - after} are gone"
     np.testing.assert_allclose(ref, img, atol=1e-5 * float(np.abs(img).max()))
 
 
