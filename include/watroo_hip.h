@@ -397,7 +397,8 @@ int wt_axis_filter(wt_plan *plan, int src, int dst, int axis, const int32_t *off
 int wt_variance_from_moments(wt_plan *plan, int mean, int meansq, int dst, float f1, float f2,
                              int take_sqrt);
 /* Circular products of richardson_lucy(fft=True) (watroo/utils.py:245-254, 284) through a
- * hand-written FFT, for whole-image plans whose height and width are powers of two (2 .. 8192):
+ * hand-written FFT, for whole-image plans whose height and width are products of 2s, 3s and 5s
+ * (2 .. 8192; powers of two: radix 2, other lengths: mixed radix 2 / 3 / 5):
  *   wt_fft_spectrum(plan, src)        kernel spectrum of the plan <- rfft2-equivalent of plane src
  *                                     (the PSF as the caller placed it periodically, :246-250)
  *   wt_fft_apply(plan, src, dst, conj) dst = irfft2(rfft2(src) * K)  (conj: * conj(K), :254 / :284)

@@ -509,7 +509,7 @@ def test_fft_circular_products_vs_numpy(L, shape, dtype):
     p.fft_apply(L.PLANE_INPUT, L.PLANE_OUT, True)
     assert float(np.abs(p.download(L.PLANE_OUT) - corr).max()) <= tol
     p.close()
-    assert L.fft_supported(*shape) and not L.fft_supported(48, 40) and not L.fft_supported(16384, 64)
+    assert L.fft_supported(*shape) and not L.fft_supported(56, 40) and not L.fft_supported(16384, 64)
 
 
 def test_richardson_lucy_fft_large_psf_vs_reference_golden(L):
@@ -707,88 +707,132 @@ def test_bench_emits_the_stored_measurement_when_a_later_phase_hangs():
 
 def test_richardson_lucy_fft_on_sides_that_are_not_powers_of_two(L):
     """g24: richardson_lucy(fft=True) on 72 x 100 and 75 x 100 images (odd height: the reference's row
-    anchors move by one) through the periodically EXTENDED power-of-two frame (utils._ExtendedFFT) -
-    against the unmodified reference, float32 and float64, odd and even PSFs, and against the direct
-    periodic form of the same products."""
+    anchors move by one) against the unmodified reference, float32 and float64, odd and even PSFs, and
+    against the direct periodic form of the same products - twice: through the mixed-radix FFT on the
+    image's own sides (round 5: 72 = 2^3 3^2, 75 = 3 5^2, 100 = 2^2 5^2) and through the periodically
+    EXTENDED frame (utils._ExtendedFFT), which sides with a prime factor above 5 take."""
     from conftest import load_golden
     import wavelets_amd as WA
     from wavelets_amd import utils as WU
     g = load_golden("g24_rl_fft_nonpow2")
     calls = []
-    keep_apply, keep_min = WU._ExtendedFFT.apply, WU._FFT_MIN_TAPS
+    keep_apply, keep_min, keep_own = WU._ExtendedFFT.apply, WU._FFT_MIN_TAPS, L.Plan.fft_apply
+    keep_own64 = L.Plan64.fft_apply
 
     def counting(self, src, dst, conj):
         calls.append((self.Mh, self.Mw, bool(conj)))
         return keep_apply(self, src, dst, conj)
 
-    WU._ExtendedFFT.apply = counting
+    def counting_own(self, src, dst, conj):
+        calls.append((self.H, self.W, bool(conj)))
+        return keep_own(self, src, dst, conj)
+
+    def counting_own64(self, src, dst, conj):
+        calls.append((self.H, self.W, bool(conj)))
+        return keep_own64(self, src, dst, conj)
+
     try:
-        for tag, frame in (("a", (128, 128)), ("odd", (128, 128))):
-            d = g[f"data_{tag}"]
-            for name, psf, kw in ((f"rl_{tag}_soft", "psf", dict(iterations=3)),
-                                  (f"rl_{tag}_even", "psf_even", dict(iterations=3, denoise_coefficients=(4, 2)))):
-                WU._FFT_MIN_TAPS = 1                                   # small images: force the FFT form
+        for extended in (False, True):
+            WU._FFT_FORCE_EXTENDED = extended
+            if extended:
+                WU._ExtendedFFT.apply = counting
+                L.Plan.fft_apply, L.Plan64.fft_apply = keep_own, keep_own64
+            else:
+                L.Plan.fft_apply, L.Plan64.fft_apply = counting_own, counting_own64
+            # frames: 72 + 2 * 12 = 96, 100 + 2 * 11 = 122 -> 125; 75 + 2 * 13 = 101 -> 108
+            for tag, frame, own in (("a", (96, 125), (72, 100)), ("odd", (108, 125), (75, 100))):
+                d = g[f"data_{tag}"]
+                for name, psf, kw in ((f"rl_{tag}_soft", "psf", dict(iterations=3)),
+                                      (f"rl_{tag}_even", "psf_even", dict(iterations=3, denoise_coefficients=(4, 2)))):
+                    WU._FFT_MIN_TAPS = 1                                   # small images: force the FFT form
+                    del calls[:]
+                    got = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+                    if extended:
+                        assert len(calls) == 6 and all(c[0] >= own[0] + g[psf].shape[0] - 1 and L.fft_supported(c[0], c[1])
+                                                       for c in calls), calls
+                        if psf == "psf":
+                            assert calls == [(frame[0], frame[1], False), (frame[0], frame[1], True)] * 3, calls
+                    else:
+                        assert calls == [(own[0], own[1], False), (own[0], own[1], True)] * 3, calls
+                    assert got.dtype == np.float32
+                    np.testing.assert_allclose(got, g[name], atol=2e-4 * np.abs(g[name]).max(), rtol=2e-4)
+                    WU._FFT_MIN_TAPS = 1 << 30                             # the direct periodic correlations
+                    direct = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
+                    np.testing.assert_allclose(got, direct, atol=5e-5 * np.abs(got).max(), rtol=0)
+                WU._FFT_MIN_TAPS = 1
                 del calls[:]
-                got = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
-                assert calls == [(frame[0], frame[1], False), (frame[0], frame[1], True)] * 3, calls
-                assert got.dtype == np.float32
-                np.testing.assert_allclose(got, g[name], atol=2e-4 * np.abs(g[name]).max(), rtol=2e-4)
-                WU._FFT_MIN_TAPS = 1 << 30                             # the direct periodic correlations
-                direct = WA.richardson_lucy(d.copy(), g[psf], fft=True, **kw)
-                np.testing.assert_allclose(got, direct, atol=5e-5 * np.abs(got).max(), rtol=0)
-            WU._FFT_MIN_TAPS = 1
-            got = WA.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
-            assert got.dtype == np.float64
-            np.testing.assert_allclose(got, g[f"rl_{tag}_f64"], atol=1e-9 * np.abs(g[f"rl_{tag}_f64"]).max(), rtol=0)
-        # the default threshold: a 25 x 23 PSF on 72 x 100 stays on the direct form (the frame is 2.3x the image)
+                got = WA.richardson_lucy(d.astype(np.float64) * 10 + 100, g["psf"].astype(np.float64), iterations=3, fft=True)
+                assert got.dtype == np.float64 and len(calls) == 6
+                np.testing.assert_allclose(got, g[f"rl_{tag}_f64"], atol=1e-9 * np.abs(g[f"rl_{tag}_f64"]).max(), rtol=0)
+        # the default threshold: a 25 x 23 PSF (575 taps) on 72 x 100 takes the FFT on the image's own sides, and
+        # stays on the direct form where only the extended frame (1.7x the image) is available
         WU._FFT_MIN_TAPS = keep_min
         del calls[:]
         WA.richardson_lucy(g["data_a"].copy(), g["psf"], fft=True, iterations=1)
         assert calls == []
+        WU._FFT_FORCE_EXTENDED = False
+        L.Plan.fft_apply = counting_own
+        WA.richardson_lucy(g["data_a"].copy(), g["psf"], fft=True, iterations=1)
+        assert calls == [(72, 100, False), (72, 100, True)], calls
     finally:
-        WU._ExtendedFFT.apply, WU._FFT_MIN_TAPS = keep_apply, keep_min
+        WU._ExtendedFFT.apply, WU._FFT_MIN_TAPS, WU._FFT_FORCE_EXTENDED = keep_apply, keep_min, False
+        L.Plan.fft_apply, L.Plan64.fft_apply = keep_own, keep_own64
 
 
-def test_extended_fft_beats_the_direct_form_on_a_3072_square_image(L):
-    """3072 x 3072 (not a power of two: e.g. a full-disc EUV imager frame) with a 65 x 65 PSF: one circular
-    product through the extended 4096^2 frame against the banded direct periodic form."""
+def test_fft_beats_the_direct_form_on_3072_and_3066_square_images(L):
+    """A 65 x 65 PSF on 3072 x 3072 (2^10 3: e.g. a full-disc EUV imager frame; the mixed-radix FFT on the image's
+    own sides since round 5) and on 3066 x 3066 (2 3 7 73: through the extended 3200 x 3200 frame): one circular
+    product against the banded direct periodic form."""
     from wavelets_amd import utils as WU
-    side, k = 3072, 65
+    k = 65
     rng = np.random.default_rng(31)
-    x = rng.standard_normal((side, side), dtype=np.float32)
     psf = rng.uniform(0.1, 1.0, (k, k)).astype(np.float32)
     psf /= psf.sum()
     ctx = L.default_context()
-    p = L.Plan(ctx, side, side, L.B3SPLINE, 1)
-    A, B = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3)
-    try:
-        p.upload(L.PLANE_INPUT, x)
-        ext = WU._ExtendedFFT(p, False, psf)
-        assert ext.ok and (ext.Mh, ext.Mw) == (4096, 4096) and ext.worth_it(WU._FFT_MIN_TAPS)
-        ext.prepare(WU.B3spline(2))
-        kern, kw = WU._periodic_operand(np.ascontiguousarray(psf[::-1, ::-1]), k - 1 - k // 2, k - 1 - k // 2)
 
-        def timed(fn, n):
+    def timed(fn, n):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(n):
             fn()
-            ctx.sync()
-            ctx.timer_start()
-            for _ in range(n):
-                fn()
-            return ctx.timer_stop() / n
+        return ctx.timer_stop() / n
 
-        t_ext = timed(lambda: ext.apply(L.PLANE_INPUT, A, False), 5)
-        t_dir = timed(lambda: p.filter2d(L.PLANE_INPUT, B, kern, **kw), 2)
-        a, b = p.download(A), p.download(B)
-        np.testing.assert_allclose(a, b, atol=2e-5 * np.abs(b).max(), rtol=0)
+    for side in (3072, 3066):
+        x = rng.standard_normal((side, side), dtype=np.float32)
+        p = L.Plan(ctx, side, side, L.B3SPLINE, 1)
+        A, B, K = L.PLANE_SCRATCH(2), L.PLANE_SCRATCH(3), L.PLANE_SCRATCH(4)
+        ext = None
         try:
-            with open(os.path.join(ROOT, "gpurun_out", "fft_vs_direct.txt"), "a") as f:
-                f.write(f"3072^2, 65x65 PSF: extended-frame fft {t_ext:.3f} ms, banded direct {t_dir:.3f} ms, ratio {t_dir / t_ext:.1f}\n")
-        except OSError:
-            pass
-        assert t_dir >= 1.5 * t_ext, (t_ext, t_dir)          # (3.0 x measured)
-        ext.close()
-    finally:
-        p.close()
+            p.upload(L.PLANE_INPUT, x)
+            if L.fft_supported(side, side):
+                assert side == 3072
+                padded = np.zeros((side, side), np.float32)
+                h = side // 2 - k // 2
+                padded[h:h + k, h:h + k] = psf
+                p.upload(K, np.roll(padded, (side // 2, side // 2), axis=(0, 1)))
+                p.fft_spectrum(K)
+                fn, what = (lambda: p.fft_apply(L.PLANE_INPUT, A, False)), "mixed-radix fft"
+            else:
+                ext = WU._ExtendedFFT(p, False, psf)
+                assert ext.ok and (ext.Mh, ext.Mw) == (3200, 3200) and ext.worth_it(WU._FFT_MIN_TAPS)
+                ext.prepare(WU.B3spline(2))
+                fn, what = (lambda: ext.apply(L.PLANE_INPUT, A, False)), "extended-frame fft (3200^2)"
+            kern, kw = WU._periodic_operand(np.ascontiguousarray(psf[::-1, ::-1]), k - 1 - k // 2, k - 1 - k // 2)
+            t_fft = timed(fn, 5)
+            t_dir = timed(lambda: p.filter2d(L.PLANE_INPUT, B, kern, **kw), 2)
+            a, b = p.download(A), p.download(B)
+            np.testing.assert_allclose(a, b, atol=2e-5 * np.abs(b).max(), rtol=0)
+            try:
+                with open(os.path.join(ROOT, "gpurun_out", "fft_vs_direct.txt"), "a") as f:
+                    f.write(f"{side}^2, 65x65 PSF: {what} {t_fft:.3f} ms, banded direct {t_dir:.3f} ms, ratio {t_dir / t_fft:.1f}\n")
+            except OSError:
+                pass
+            assert t_dir >= 1.5 * t_fft, (side, t_fft, t_dir)
+        finally:
+            if ext is not None:
+                ext.close()
+            p.close()
 
 
 @pytest.mark.parametrize("dtype", ["?", "i1", "u1", "<i2", "<u2", "<i4", "<u4", "<i8", "<u8",

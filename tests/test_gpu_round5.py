@@ -407,3 +407,54 @@ def test_seventeen_tap_scaling_function_runs_on_the_tiled_kernels_at_speed(L):
             open(os.path.join(ROOT, "gpurun_out", "axis_filter_times.txt"), "w").write("\n".join(lines) + "\n")
         except OSError:
             pass
+
+
+# --------------------------------------------------------------------------- mixed-radix FFT (2 / 3 / 5)
+@pytest.mark.parametrize("shape,dtype", [((6, 10), np.float32), ((96, 120), np.float32), ((243, 125), np.float32),
+                                         ((75, 100), np.float64), ((3072, 1536), np.float32), ((1000, 3000), np.float64),
+                                         ((7776, 60), np.float32), ((5, 8000), np.float32), ((3, 6), np.float64)])
+def test_mixed_radix_fft_circular_products_vs_numpy(L, shape, dtype):
+    """wt_fft_spectrum / wt_fft_apply on sides 2^a 3^b 5^c (wt_fft_rows_mixed_kernel: digit-reversed load, radix
+    2 / 3 / 5 stages in LDS) against numpy's full complex transforms - the reference's circular products
+    (watroo/utils.py:245-254, 284) - for odd heights, pure powers of 3 and 5, one side a power of two (the
+    radix-2 kernel) and the other not, float32 and float64."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(dtype)
+    k = np.zeros(shape, dtype)
+    kh, kw = min(shape[0], 9), min(shape[1], 7)
+    k[:kh, :kw] = rng.random((kh, kw))
+    k /= k.sum()
+    k = np.roll(k, (-(kh // 2), -(kw // 2)), axis=(0, 1))
+    f = np.fft.fft2(k.astype(np.float64))
+    conv = np.fft.ifft2(np.fft.fft2(x.astype(np.float64)) * f).real
+    corr = np.fft.ifft2(np.fft.fft2(x.astype(np.float64)) * f.conj()).real
+    assert L.fft_supported(*shape)
+    if dtype == np.float32:
+        p = L.Plan(L.default_context(), shape[0], shape[1], L.B3SPLINE, 0)
+    else:
+        p = L.Plan64(L.default_context(), shape[0], shape[1], B3_TAPS, 0)
+    try:
+        S = L.PLANE_SCRATCH(6)
+        p.upload(S, k)
+        p.upload(L.PLANE_INPUT, x)
+        p.fft_spectrum(S)
+        bound = (4e-6 if dtype == np.float32 else 1e-13) * float(np.abs(x).max())
+        p.fft_apply(L.PLANE_INPUT, L.PLANE_OUT, False)
+        measured(f"mixed fft conv {shape} {np.dtype(dtype).name}", p.download(L.PLANE_OUT), conv, bound)
+        p.fft_apply(L.PLANE_INPUT, L.PLANE_OUT, True)
+        measured(f"mixed fft corr {shape} {np.dtype(dtype).name}", p.download(L.PLANE_OUT), corr, bound)
+    finally:
+        p.close()
+
+
+def test_fft_rejects_sides_with_a_prime_factor_above_five(L):
+    for shape in ((56, 40), (64, 77), (8192 * 2, 64), (1, 64)):
+        assert not L.fft_supported(*shape)
+    p = L.Plan(L.default_context(), 56, 40, L.B3SPLINE, 0)
+    try:
+        with pytest.raises(L.WatrooHipError, match="prime factor above 5"):
+            p.fft_spectrum(L.PLANE_INPUT)
+    finally:
+        p.close()
+    for shape in ((48, 40), (75, 100), (3072, 3072), (6075, 8000), (8192, 8192)):
+        assert L.fft_supported(*shape)

@@ -175,7 +175,7 @@ def test_axis_by_axis_generic_filter_reproduces_convolution_and_the_recursive_ba
 @pytest.mark.parametrize("shape,kshape", [((72, 100), (25, 23)), ((75, 100), (25, 23)), ((75, 100), (24, 26)),
                                           ((33, 20), (33, 19)), ((48, 40), (1, 7)), ((21, 6), (2, 2))])
 def test_extended_frame_reproduces_the_circular_products_of_the_image(shape, kshape):
-    """richardson_lucy(fft=True) on sides that are not powers of two (utils._ExtendedFFT): the index
+    """richardson_lucy(fft=True) on sides the engine's FFT does not take (utils._ExtendedFFT): the index
     logic - periodic extension windows, PSF laid around the frame's origin, window copied back -
     replayed with numpy's FFT on the frame must equal the reference's products on the image itself
     (utils.py:246-254, 284), odd heights included."""
@@ -192,7 +192,14 @@ def test_extended_frame_reproduces_the_circular_products_of_the_image(shape, ksh
     want_conv = np.fft.irfft2(np.fft.rfft2(x) * f, s=shape)
     want_corr = np.fft.irfft2(np.fft.rfft2(x) * f.conj(), s=shape)
     e, hy, hx, Mh, Mw = WU._ext_geometry(H, W, kh, kw)
-    assert Mh & (Mh - 1) == 0 and Mw & (Mw - 1) == 0 and Mh >= H + 2 * hy and Mw >= W + 2 * hx
+    def smooth(n):
+        for r in (2, 3, 5):
+            while n % r == 0:
+                n //= r
+        return n == 1
+    # (round 5: the frame's sides are the next products of 2s, 3s and 5s - what wt_fft.h transforms)
+    assert smooth(Mh) and smooth(Mw) and H + 2 * hy <= Mh < 2 * (H + 2 * hy) and W + 2 * hx <= Mw < 2 * (W + 2 * hx)
+    assert not any(smooth(m) for m in range(H + 2 * hy, Mh)) and not any(smooth(m) for m in range(W + 2 * hx, Mw))
     F = np.fft.fft2(WU._ext_kernel_frame(k, H, Mh, Mw))
     frame = np.zeros((Mh, Mw))
     for sy, sx, dy, dx, nr, nc in WU._ext_windows(H, W, hy, hx):

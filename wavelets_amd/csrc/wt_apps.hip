@@ -446,7 +446,7 @@ extern "C" int wt_fft_supported(int64_t H, int64_t W, int *ok)
 static int fft_plan_check(const wt_plan *p, const char *who)
 {
     if (p->nranks != 1 || p->g.row0 != 0 || p->g.nrows != p->g.H) WT_FAIL("%s: whole-image plans only", who);
-    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("%s: image %d x %d is not a power of two per side (2 .. %d)", who, p->g.H, p->g.W, WT_FFT_MAX_N);
+    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("%s: a side of the %d x %d image has a prime factor above 5 (or lies outside 2 .. %d)", who, p->g.H, p->g.W, WT_FFT_MAX_N);
     return 0;
 }
 

@@ -1112,7 +1112,7 @@ extern "C" int wt64_fft_spectrum(wt_plan64 *p, int src)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_fft_spectrum: null plan");
-    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("wt64_fft_spectrum: image %d x %d is not a power of two per side (2 .. %d)", p->g.H, p->g.W, WT_FFT_MAX_N);
+    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("wt64_fft_spectrum: a side of the %d x %d image has a prime factor above 5 (or lies outside 2 .. %d)", p->g.H, p->g.W, WT_FFT_MAX_N);
     double *s = nullptr;
     WT_TRY(plan64_base(p, src, &s));
     WT_TRY(wt_fft_prepare<double>(p->ctx, p->fft, p->g.H, p->g.W, p->allocs));
@@ -1123,7 +1123,7 @@ extern "C" int wt64_fft_apply(wt_plan64 *p, int src, int dst, int conj)
 {
     WtGuard guard_(ctx_of(p));
     if (!p) WT_FAIL("wt64_fft_apply: null plan");
-    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("wt64_fft_apply: image %d x %d is not a power of two per side (2 .. %d)", p->g.H, p->g.W, WT_FFT_MAX_N);
+    if (!wt_fft_size_ok(p->g.H, p->g.W)) WT_FAIL("wt64_fft_apply: a side of the %d x %d image has a prime factor above 5 (or lies outside 2 .. %d)", p->g.H, p->g.W, WT_FFT_MAX_N);
     double *s = nullptr, *d = nullptr;
     WT_TRY(plan64_base(p, src, &s));
     WT_TRY(plan64_base(p, dst, &d));

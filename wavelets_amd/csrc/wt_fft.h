@@ -1,9 +1,9 @@
 // Circular products through a hand-written FFT (round 4): richardson_lucy(fft=True) of the reference
 // forms  irfft2(rfft2(psi) * fft_psf)  and  irfft2(rfft2(res) * conj(fft_psf))  (watroo/utils.py:245-254,
 // 284).  Rounds 2-3 evaluated them as direct periodic correlations - exact, but O(kh * kw) per pixel; a
-// 129 x 129 PSF costs 16 641 taps per pixel per product.  Here, for power-of-two images up to 8192 per
-// side:
-//   forward:  rows FFT (length W, one workgroup per row, radix 2 in LDS)  ->  transpose  ->  rows FFT (H)
+// 129 x 129 PSF costs 16 641 taps per pixel per product.  Here, for images whose sides have no prime factor
+// above 5 (round 5: mixed radix 2 / 3 / 5; powers of two keep the radix-2 kernel of round 4), up to 8192 per side:
+//   forward:  rows FFT (length W, one workgroup per row, in LDS)  ->  transpose  ->  rows FFT (H)
 //   product:  fused into the load of the first inverse pass (spectrum * kernel spectrum, or its conjugate)
 //   inverse:  rows IFFT (H)  ->  transpose  ->  rows IFFT (W), real part scaled by 1 / (H W) into the plane
 // Full complex transforms of the real planes (the Hermitian half is not exploited: six memory-bound
@@ -77,6 +77,106 @@ __global__ __launch_bounds__(512) void wt_fft_rows_kernel(const void *in, void *
     }
 }
 
+// The same for lengths n = r_0 r_1 ... r_{k-1} with r_t in {2, 3, 5} (round 5): decimation in time in place.
+// Stage t combines r_t transforms of length L_t = r_0 ... r_{t-1}, stored side by side, into one of length
+// L_t r_t:  X[k + q L_t] = sum_m w_r^(m q) (w_(L_t r_t)^(m k) Y_m[k]),  Y_m[k] at offset m L_t + k - the outputs
+// take the places of the inputs.  The input permutation that makes every stage's operands contiguous blocks is
+// the mixed-radix digit reversal: with i = m_{k-1} + r_{k-1} (m_{k-2} + r_{k-2} (...)) element i goes to
+// sum_t m_t L_t (bit reversal when every r_t is 2).  Twiddles: tw[j] = exp(-2 pi i j / n), j < n.
+struct WtFftFactors {
+    int nf;
+    int r[16];
+};
+
+template <int R, typename C, bool INV>
+__device__ __forceinline__ void wt_fft_butterfly(C *s, int base, int L, int k, int step, int n, const C *tw)
+{
+    C b[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+        const C a = s[base + m * L];
+        if (m == 0) {
+            b[m] = a;
+        } else {
+            C w = tw[m * k * step];
+            if (INV) w.y = -w.y;
+            b[m] = wt_cmul(w, a);
+        }
+    }
+    if (R == 2) {
+        s[base] = wt_cmake(b[0].x + b[1].x, b[0].y + b[1].y);
+        s[base + L] = wt_cmake(b[0].x - b[1].x, b[0].y - b[1].y);
+        return;
+    }
+    C o[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        C acc = b[0];
+#pragma unroll
+        for (int m = 1; m < R; ++m) {
+            C w = tw[((m * q) % R) * (n / R)];
+            if (INV) w.y = -w.y;
+            const C t = wt_cmul(w, b[m]);
+            acc = wt_cmake(acc.x + t.x, acc.y + t.y);
+        }
+        o[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) s[base + q * L] = o[q];
+}
+
+template <typename T, bool INV>
+__global__ __launch_bounds__(512) void wt_fft_rows_mixed_kernel(const void *in, void *out, int n, WtFftFactors fa, int in_pitch, int out_pitch,
+                                                                const typename WtCx<T>::C *tw, const typename WtCx<T>::C *mul, int flags, T scale)
+{
+    typedef typename WtCx<T>::C C;
+    extern __shared__ unsigned char wt_fft_lds[];
+    C *s = reinterpret_cast<C *>(wt_fft_lds);
+    const int row = blockIdx.x, nt = blockDim.x;
+    for (int i = threadIdx.x; i < n; i += nt) {
+        C v;
+        if (flags & WT_FFT_IN_REAL) {
+            v.x = reinterpret_cast<const T *>(in)[(int64_t)row * in_pitch + i];
+            v.y = (T)0;
+        } else {
+            v = reinterpret_cast<const C *>(in)[(int64_t)row * in_pitch + i];
+        }
+        if (flags & (WT_FFT_MUL | WT_FFT_MUL_CONJ)) {
+            C m = mul[(int64_t)row * n + i];
+            if (flags & WT_FFT_MUL_CONJ) m.y = -m.y;
+            v = wt_cmul(v, m);
+        }
+        // digit reversal: the digits of i from the last factor to the first, weighted by the block lengths L_t
+        int rem = i, p = 0, L = n;
+        for (int t = fa.nf - 1; t >= 0; --t) {
+            const int r = fa.r[t];
+            L /= r;                                      // L_t = r_0 ... r_{t-1}
+            const int m = rem % r;
+            rem /= r;
+            p += m * L;
+        }
+        s[p] = v;
+    }
+    __syncthreads();
+    int L = 1;
+    for (int t = 0; t < fa.nf; ++t) {
+        const int r = fa.r[t], Ln = L * r, step = n / Ln;
+        for (int j = threadIdx.x; j < n / r; j += nt) {
+            const int g = j / L, k = j - g * L, base = g * Ln + k;
+            if (r == 2) wt_fft_butterfly<2, C, INV>(s, base, L, k, step, n, tw);
+            else if (r == 3) wt_fft_butterfly<3, C, INV>(s, base, L, k, step, n, tw);
+            else wt_fft_butterfly<5, C, INV>(s, base, L, k, step, n, tw);
+        }
+        __syncthreads();
+        L = Ln;
+    }
+    for (int i = threadIdx.x; i < n; i += nt) {
+        const C v = s[i];
+        if (flags & WT_FFT_OUT_REAL) reinterpret_cast<T *>(out)[(int64_t)row * out_pitch + i] = v.x * scale;
+        else reinterpret_cast<C *>(out)[(int64_t)row * out_pitch + i] = wt_cmake(v.x * scale, v.y * scale);
+    }
+}
+
 // out[c][r] = in[r][c] for a rows x cols complex array (32 x 32 tiles through LDS, padded against bank conflicts)
 template <typename T>
 __global__ __launch_bounds__(256) void wt_fft_transpose_kernel(const typename WtCx<T>::C *in, typename WtCx<T>::C *out, int rows, int cols)
@@ -92,10 +192,23 @@ __global__ __launch_bounds__(256) void wt_fft_transpose_kernel(const typename Wt
         if (c0 + k < cols && r0 + tx < rows) out[(int64_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
 }
 
+// n = a product of 2s, 3s and 5s: the factors, largest first (the radix-2 stages then run on the longest blocks)
+static inline bool wt_fft_factor(int n, WtFftFactors &f)
+{
+    f.nf = 0;
+    if (n < 2 || n > WT_FFT_MAX_N) return false;
+    for (int r : {5, 3, 2})
+        while (n % r == 0) {
+            if (f.nf == 16) return false;
+            f.r[f.nf++] = r;
+            n /= r;
+        }
+    return n == 1;
+}
 static inline bool wt_fft_size_ok(int H, int W)
 {
-    auto pow2 = [](int n) { return n >= 2 && n <= WT_FFT_MAX_N && (n & (n - 1)) == 0; };
-    return pow2(H) && pow2(W);
+    WtFftFactors f;
+    return wt_fft_factor(H, f) && wt_fft_factor(W, f);
 }
 static inline int wt_ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
@@ -105,7 +218,7 @@ static int wt_fft_prepare(wt_ctx *c, WtFftState &f, int H, int W, std::vector<vo
     typedef typename WtCx<T>::C C;
     if (f.a && f.H == H && f.W == W) return 0;
     if (f.a) WT_FAIL("wt_fft: the plan's geometry changed");
-    if (!wt_fft_size_ok(H, W)) WT_FAIL("wt_fft: image %d x %d is not a power of two per side (2 .. %d)", H, W, WT_FFT_MAX_N);
+    if (!wt_fft_size_ok(H, W)) WT_FAIL("wt_fft: a side of the %d x %d image has a prime factor above 5 (or lies outside 2 .. %d)", H, W, WT_FFT_MAX_N);
     WT_HIP(hipSetDevice(c->device));
     auto alloc = [&](void **p, size_t bytes) -> int {
         WT_HIP(hipMalloc(p, bytes));
@@ -116,9 +229,9 @@ static int wt_fft_prepare(wt_ctx *c, WtFftState &f, int H, int W, std::vector<vo
     WT_TRY(alloc(&f.a, nc));
     WT_TRY(alloc(&f.b, nc));
     WT_TRY(alloc(&f.spec, nc));
-    auto table = [&](void **p, int n) -> int {          // exp(-2 pi i k / n), k < n / 2, in double on the host
-        std::vector<C> t((size_t)n / 2);
-        for (int k = 0; k < n / 2; ++k) {
+    auto table = [&](void **p, int n) -> int {          // exp(-2 pi i k / n), k < n, in double on the host
+        std::vector<C> t((size_t)n);
+        for (int k = 0; k < n; ++k) {
             const double ang = -2.0 * M_PI * (double)k / (double)n;
             t[k].x = (T)std::cos(ang);
             t[k].y = (T)std::sin(ang);
@@ -140,11 +253,20 @@ static int wt_fft_rows(wt_ctx *c, const void *in, void *out, int nrows, int n, i
 {
     typedef typename WtCx<T>::C C;
     const size_t lds = (size_t)n * sizeof(C);
-    const int threads = std::max(64, std::min(512, n / 2));
-    if (lds > 64 * 1024)
-        WT_HIP(hipFuncSetAttribute((const void *)wt_fft_rows_kernel<T, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((wt_fft_rows_kernel<T, INV>), dim3(nrows), dim3(threads), lds, c->stream, in, out, n, wt_ilog2(n), in_pitch, out_pitch,
-                       (const C *)tw, (const C *)mul, flags, scale);
+    const int threads = std::max(64, std::min(512, (n / 2 + 63) / 64 * 64));
+    if ((n & (n - 1)) == 0) {                            // powers of two: the radix-2 kernel
+        if (lds > 64 * 1024)
+            WT_HIP(hipFuncSetAttribute((const void *)wt_fft_rows_kernel<T, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((wt_fft_rows_kernel<T, INV>), dim3(nrows), dim3(threads), lds, c->stream, in, out, n, wt_ilog2(n), in_pitch, out_pitch,
+                           (const C *)tw, (const C *)mul, flags, scale);
+    } else {
+        WtFftFactors fa;
+        if (!wt_fft_factor(n, fa)) WT_FAIL("wt_fft: length %d has a prime factor above 5", n);
+        if (lds > 64 * 1024)
+            WT_HIP(hipFuncSetAttribute((const void *)wt_fft_rows_mixed_kernel<T, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((wt_fft_rows_mixed_kernel<T, INV>), dim3(nrows), dim3(threads), lds, c->stream, in, out, n, fa, in_pitch, out_pitch,
+                           (const C *)tw, (const C *)mul, flags, scale);
+    }
     WT_HIP(hipGetLastError());
     return 0;
 }

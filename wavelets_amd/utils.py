@@ -346,20 +346,31 @@ def _periodic_operand(kernel, ay, ax):
     return np.ascontiguousarray(kernel), dict(anchor=(ay, ax), periodic=True)
 
 
-# PSFs of at least this many taps take the FFT form of the circular products (power-of-two images;
-# other sizes: times twice the area ratio of the power-of-two frame they are extended into)
+# PSFs of at least this many taps take the FFT form of the circular products (images whose sides are
+# products of 2s, 3s and 5s; other sizes: times twice the area ratio of the frame they are extended into)
 _FFT_MIN_TAPS = int(__import__("os").environ.get("WATROO_HIP_FFT_MIN_TAPS", "512"))
+# tests: take the extended frame even where the image's own sides qualify for the FFT
+_FFT_FORCE_EXTENDED = False
 
 
-def _next_pow2(n):
-    return 1 << max(1, int(n - 1).bit_length())
+def _next_smooth(n):
+    """the smallest m >= max(n, 2) without a prime factor above 5 (the lengths wt_fft.h transforms)"""
+    m = max(2, int(n))
+    while True:
+        r = m
+        for f in (2, 3, 5):
+            while r % f == 0:
+                r //= f
+        if r == 1:
+            return m
+        m += 1
 
 
 def _ext_geometry(H, W, kh, kw):
-    """(e, hy, hx, Mh, Mw) of the extended frame: halo rows / columns and the power-of-two frame size"""
+    """(e, hy, hx, Mh, Mw) of the extended frame: halo rows / columns and the frame size (5-smooth sides)"""
     e = H % 2
     hy, hx = kh // 2 + e, kw // 2
-    return e, hy, hx, _next_pow2(H + 2 * hy), _next_pow2(W + 2 * hx)
+    return e, hy, hx, _next_smooth(H + 2 * hy), _next_smooth(W + 2 * hx)
 
 
 def _ext_kernel_frame(psf, H, Mh, Mw):
@@ -380,10 +391,11 @@ def _ext_windows(H, W, hy, hx):
 
 
 class _ExtendedFFT:
-    """Circular products of an H x W image whose sides are NOT powers of two through the engine's
-    power-of-two FFT (wt_fft.h).  A product with a kernel of support [-hy, hy] x [-hx, hx] only looks
+    """Circular products of an H x W image with a side the engine's FFT does not take (a prime factor
+    above 5; wt_fft.h transforms lengths 2^a 3^b 5^c) through that FFT.  A product with a kernel of
+    support [-hy, hy] x [-hx, hx] only looks
     hy rows / hx columns beyond a pixel, so the image is extended PERIODICALLY by that much on every
-    side (nine device window copies), placed in a zeroed power-of-two frame that holds H + 2 hy rows and
+    side (nine device window copies), placed in a zeroed frame - the next 5-smooth sizes that hold H + 2 hy rows and
     W + 2 hx columns, the frame's own circular product is taken, and the H x W window is copied back:
     inside it no term has wrapped around the frame, so it equals the product of period (H, W).  The
     kernel spectrum is that of the PSF laid around the frame's origin exactly as the reference lays it
@@ -435,8 +447,9 @@ def richardson_lucy(data, psf,
     (ref:261), the multiresolution-support update per scale (ref:263-276), the plane sum
     (ref:278) and the second PSF correlation (ref:286) - nothing returns to the host until
     the final estimate.  ``fft=True`` selects the reference's circular (periodic-border)
-    products (ref:245-254, 284): through the engine's own FFT for PSFs of 512 taps or more on
-    power-of-two images (wt_fft_apply), else as direct periodic correlations of the PSF (equal to the
+    products (ref:245-254, 284): through the engine's own mixed-radix FFT for PSFs of 512 taps or more
+    (wt_fft_apply; sides with a prime factor above 5: on a periodically extended frame), else as direct
+    periodic correlations of the PSF (equal to the
     rFFT products up to rounding) - either way the loop stays on the device."""
     # float64 / promoted data: the float64 engine (ref wavelets.py:319-320) - except with
     # uniform_init, where the reference itself keeps the estimate in float32 (ref:233)
@@ -481,16 +494,15 @@ def richardson_lucy(data, psf,
         raise ValueError("richardson_lucy(fft=True) needs an even image width (numpy.fft.irfft2 "
                          "returns W - 1 columns in the reference)")
     e = img.shape[0] % 2
-    # Large PSFs on power-of-two images: the products run through the engine's own FFT (wt_fft_apply:
+    # Large PSFs on images with 5-smooth sides: the products run through the engine's own FFT (wt_fft_apply:
     # row FFTs in LDS, transposes, the spectrum product fused into the first inverse pass) instead of
     # the direct periodic form, which costs kh * kw taps per pixel.  The periodic kernel image is built
     # as the reference builds it (ref:246-250) and transformed once.
-    use_fft = bool(fft) and kh * kw >= _FFT_MIN_TAPS and kh <= img.shape[0] and kw <= img.shape[1] \
-        and _lib.fft_supported(img.shape[0], img.shape[1])
+    own_sides = _lib.fft_supported(img.shape[0], img.shape[1]) and not _FFT_FORCE_EXTENDED
+    use_fft = bool(fft) and kh * kw >= _FFT_MIN_TAPS and kh <= img.shape[0] and kw <= img.shape[1] and own_sides
     ext = None
-    if fft and not use_fft and kh <= img.shape[0] and kw <= img.shape[1] \
-            and not _lib.fft_supported(img.shape[0], img.shape[1]):
-        # sides that are not powers of two: the same FFT on a periodically extended frame
+    if fft and not use_fft and kh <= img.shape[0] and kw <= img.shape[1] and not own_sides:
+        # a side with a prime factor above 5: the same FFT on a periodically extended frame
         ext = _ExtendedFFT(plan, f64, psf)
         if ext.worth_it(_FFT_MIN_TAPS):
             ext.prepare(sf)
