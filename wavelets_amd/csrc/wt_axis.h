@@ -20,6 +20,7 @@
 #define WT_AXIS_MAX_TAPS 33
 #define WT_AXIS_SEG 1024          // output pixels of one LDS segment (4 per lane)
 #define WT_AXIS_MAX_SPAN 2048     // largest (max offset - min offset) the LDS form takes
+#define WT_AXIS_R 8               // outputs a lane of the tile kernel sums side by side
 
 // (wt_pad_index: wt_kernels_common.h, included before this header; wt_vpack / wt_vunpack: wt_stencil.h)
 
@@ -45,26 +46,49 @@ __global__ __launch_bounds__(256) void wt_axis_x_kernel(AxisArgs<T> a)
 {
 #pragma clang fp contract(off)
     __shared__ T seg[WT_AXIS_SEG + WT_AXIS_MAX_SPAN];
+    constexpr int NV = (WT_AXIS_SEG + WT_AXIS_MAX_SPAN) / 256;   // segment elements a lane stages at most
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * WT_AXIS_SEG;
     const int nload = min(WT_AXIS_SEG, a.W - x0) + a.span;
-    for (int row = blockIdx.y; row < a.Z * a.Y; row += gridDim.y) {
-        const T *src = a.in + (int64_t)row * a.P;
-        for (int i = tid; i < nload; i += 256) {
-            const int xi = wt_pad_index(x0 + a.omin + i, a.W, a.mode, a.dil);
-            seg[i] = xi < 0 ? a.cval : src[xi];
-        }
-        __syncthreads();
-        T *dst = a.out + (int64_t)row * a.P;
+    const int nrows = a.Z * a.Y;
+    // the columns this lane stages are the same on every row: border rule applied once (-1: the fill value,
+    // -2: beyond the segment)
+    int xi[NV];
 #pragma unroll
-        for (int k = 0; k < WT_AXIS_SEG / 256; ++k) {
-            const int xl = tid + 256 * k;
-            if (x0 + xl < a.W) {
-                T acc = (T)0;
-                for (int j = 0; j < a.n; ++j) acc = acc + seg[xl + a.o[j] - a.omin] * a.w[j];
-                dst[x0 + xl] = acc;
-            }
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + 256 * k;
+        xi[k] = i < nload ? wt_pad_index(x0 + a.omin + i, a.W, a.mode, a.dil) : -2;
+    }
+    // a row's loads are issued together, one row ahead of the sums (the workgroup walks rows blockIdx.y,
+    // + gridDim.y, ...): their latency runs under the previous row's arithmetic
+    T nx[NV];
+    auto fetch = [&](int row) {
+        const T *src = a.in + (int64_t)row * a.P;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) nx[k] = xi[k] >= 0 ? src[xi[k]] : a.cval;
+    };
+    if ((int)blockIdx.y < nrows) fetch(blockIdx.y);
+    for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (xi[k] != -2) seg[tid + 256 * k] = nx[k];
+        __syncthreads();
+        if (row + (int)gridDim.y < nrows) fetch(row + gridDim.y);
+        T *dst = a.out + (int64_t)row * a.P;
+        // the four outputs of a lane side by side, tap by tap: four independent accumulation chains (each in tap
+        // order, as the tap-list operator sums) instead of one LDS round trip per tap per output
+        T acc[WT_AXIS_SEG / 256];
+#pragma unroll
+        for (int k = 0; k < WT_AXIS_SEG / 256; ++k) acc[k] = (T)0;
+        for (int j = 0; j < a.n; ++j) {
+            const T *sj = seg + tid + (a.o[j] - a.omin);
+            const T w = a.w[j];
+#pragma unroll
+            for (int k = 0; k < WT_AXIS_SEG / 256; ++k) acc[k] = acc[k] + sj[256 * k] * w;
         }
+#pragma unroll
+        for (int k = 0; k < WT_AXIS_SEG / 256; ++k)
+            if (x0 + tid + 256 * k < a.W) dst[x0 + tid + 256 * k] = acc[k];
         __syncthreads();
     }
 }
@@ -80,7 +104,7 @@ __global__ __launch_bounds__(256) void wt_axis_tile_kernel(AxisArgs<T> a)
 {
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char wt_axis_tile_raw[];
-    T *tile = reinterpret_cast<T *>(wt_axis_tile_raw);          // [S + K - 1][64]
+    T *tile = reinterpret_cast<T *>(wt_axis_tile_raw);          // [S + K - 1 (+ WT_AXIS_R unwritten)][64]
     const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + px;
     const int K = a.n, d = a.step;
@@ -100,19 +124,51 @@ __global__ __launch_bounds__(256) void wt_axis_tile_kernel(AxisArgs<T> a)
     const bool lane_ok = x < a.W;
     auto row_of = [&](int p) -> int64_t { return a.axis == 1 ? (int64_t)outer * a.Y + p : (int64_t)p * a.Y + outer; };
     const int n_in = (r1 - r0) + K - 1;
-    for (int e = g; e < n_in; e += 4) {
-        const int p = wt_pad_index(q + a.o0 + d * (r0 + e), n_axis, a.mode, a.dil);
-        T v = a.cval;
-        if (p >= 0 && lane_ok) v = a.in[row_of(p) * a.P + x];
-        tile[e * 64 + px] = v;
+    constexpr int U = 10;                                       // loads a lane has in flight together
+    for (int e0 = g; e0 < n_in; e0 += 4 * U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 4 * u;
+            v[u] = a.cval;
+            if (e < n_in && lane_ok) {
+                const int p = wt_pad_index(q + a.o0 + d * (r0 + e), n_axis, a.mode, a.dil);
+                if (p >= 0) v[u] = a.in[row_of(p) * a.P + x];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e0 + 4 * u < n_in) tile[(e0 + 4 * u) * 64 + px] = v[u];
     }
     __syncthreads();
     if (!lane_ok) return;
-    for (int r = r0 + g; r < r1; r += 4) {
-        T acc = (T)0;
-        const T *col = tile + (r - r0) * 64 + px;
-        for (int j = 0; j < K; ++j) acc = acc + col[j * 64] * a.w[j];
-        a.out[row_of(q + d * r) * a.P + x] = acc;
+    // A wave owns a contiguous quarter of the chunk's outputs and takes them WT_AXIS_R at a time down its LDS
+    // column: tap j of output r + i reads row r + i + j, so one new row per tap serves all WT_AXIS_R chains (a
+    // sliding register window, K + R - 1 LDS reads per R outputs instead of R K) and the chains are independent -
+    // each still sums in tap order.  Rows past the chunk's last (up to R below it: the launcher allocates them)
+    // hold whatever LDS held; they only reach accumulators that are not stored.
+    const int nout = r1 - r0, B = (nout + 3) / 4;
+    const int b1 = min((g + 1) * B, nout);
+    for (int r = g * B; r < b1; r += WT_AXIS_R) {
+        const T *col = tile + r * 64 + px;
+        T v[WT_AXIS_R], acc[WT_AXIS_R];
+#pragma unroll
+        for (int i = 0; i < WT_AXIS_R; ++i) {
+            v[i] = col[i * 64];
+            acc[i] = (T)0;
+        }
+        for (int j = 0; j < K; ++j) {
+            const T nxt = col[(j + WT_AXIS_R) * 64];
+            const T w = a.w[j];
+#pragma unroll
+            for (int i = 0; i < WT_AXIS_R; ++i) acc[i] = acc[i] + v[i] * w;
+#pragma unroll
+            for (int i = 0; i + 1 < WT_AXIS_R; ++i) v[i] = v[i + 1];
+            v[WT_AXIS_R - 1] = nxt;
+        }
+#pragma unroll
+        for (int i = 0; i < WT_AXIS_R; ++i)
+            if (r + i < b1) a.out[row_of(q + d * (r0 + r + i)) * a.P + x] = acc[i];
     }
 }
 
@@ -145,7 +201,11 @@ static int wt_axis_filter_launch(wt_ctx *c, const T *in, T *out, int W, int P, i
         a.omin = omin;
         a.span = omax - omin;
         ProfScope ps(c, sizeof(T) == 8 ? "wt64_axis_x_kernel" : "wt_axis_x_kernel");
-        hipLaunchKernelGGL(wt_axis_x_kernel<T>, dim3((W + WT_AXIS_SEG - 1) / WT_AXIS_SEG, (unsigned)std::min(nrows, 32768)), dim3(256), 0, c->stream, a);
+        // one resident round of workgroups (LDS: 12 / 24 KiB each), every one walking its rows with the next row's loads in flight
+        const int nxb = (W + WT_AXIS_SEG - 1) / WT_AXIS_SEG;
+        const int slots = c->num_cus * (sizeof(T) == 8 ? 6 : 8);
+        const int gy = std::max(1, std::min({nrows, 32768, (slots + nxb - 1) / nxb}));
+        hipLaunchKernelGGL(wt_axis_x_kernel<T>, dim3(nxb, (unsigned)gy), dim3(256), 0, c->stream, a);
         WT_HIP(hipGetLastError());
         return 0;
     }
@@ -158,18 +218,18 @@ static int wt_axis_filter_launch(wt_ctx *c, const T *in, T *out, int W, int P, i
     const int phases = std::min(step, n_axis);
     const int n_max = (n_axis + step - 1) / step;                // longest chain
     const int xblocks = (W + 63) / 64;
-    // chunks of up to 64 chain steps (the K - 1 halo rows of a chunk are loaded again by its neighbour): at least
-    // 4 K steps where the chains are long enough, fewer - down to the whole chain - where they are short
+    // chunks of 64 chain steps or more (the K - 1 halo rows of a chunk are loaded again by its neighbour): at least
+    // 3 K steps where the chains are long enough, fewer - down to the whole chain - where they are short
     (void)PX;
-    const int s_cap = (int)(((size_t)60 << 10) / (64 * sizeof(T))) - (n - 1);        // rows of a chunk that fit 60 KiB of LDS
-    int S = std::min({n_max, std::max(64, 4 * n), s_cap});
+    const int s_cap = (int)(((size_t)60 << 10) / (64 * sizeof(T))) - (n - 1) - WT_AXIS_R;   // rows of a chunk that fit 60 KiB of LDS
+    int S = std::min({n_max, (std::max(64, 3 * n) + 31) / 32 * 32, s_cap});     // (a multiple of 4 waves x WT_AXIS_R outputs)
     int chunks = (n_max + S - 1) / S;
     while ((int64_t)n_outer * phases * chunks > 65535) {
         if (chunks == 1) return -1;                              // (more lines than the grid holds: tap-list operator)
         S *= 2;
         chunks = (n_max + S - 1) / S;
     }
-    const size_t lds = (size_t)(S + n - 1) * 64 * sizeof(T);
+    const size_t lds = (size_t)(S + n - 1 + WT_AXIS_R) * 64 * sizeof(T);      // (+ R rows the sliding windows may read past the end)
     if (lds > (size_t)60 << 10) return -1;
     a.o0 = offs[0]; a.step = step; a.axis = axis; a.S = S; a.chunks = chunks;
     ProfScope ps(c, sizeof(T) == 8 ? "wt64_axis_tile_kernel" : "wt_axis_tile_kernel");
