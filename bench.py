@@ -859,18 +859,27 @@ def main():
                     # next to its steady state (tools/first_call.py in a child process; ~3 s of wall time)
                     try:
                         import subprocess
-                        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), str(side)],
-                                           capture_output=True, text=True, timeout=120)
-                        got = {}
-                        for ln in r.stdout.splitlines():
-                            name, _, ms = ln.rpartition(" ms")[0].rpartition(" ")
-                            if ln.rstrip().endswith("ms") and ms:
-                                got[name.strip()] = float(ms)
-                        calls = [v for k, v in got.items() if k.startswith("denoise(img")]
+
+                        def child(*extra):
+                            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), str(side), *extra],
+                                               capture_output=True, text=True, timeout=120)
+                            got = {}
+                            for ln in r.stdout.splitlines():
+                                name, _, ms = ln.rpartition(" ms")[0].rpartition(" ")
+                                if ln.rstrip().endswith("ms") and ms:
+                                    got[name.strip()] = float(ms)
+                            return got, [v for k, v in got.items() if k.startswith("denoise(img")]
+                        # (a) context created and synced first (the context's warm-up thread has finished: the
+                        #     runtime's copy queues exist), (b) no sync: context creation straight into the call
+                        got, calls = child()
+                        got_b, calls_b = child("nosync")
+                        ctx_key, sync_key = "context (HIP runtime init, stream, scratch)", "sync (joins the context's warm-up thread)"
                         out["first_call"] = {"what": f"denoise(img, [5, 3]) at {side}^2 float32, numpy to numpy, fresh process",
                                              "first_ms": calls[0], "steady_ms": min(calls[1:]),
-                                             "context_ms": got.get("context (HIP runtime init, stream, scratch)"),
-                                             "library_load_ms": got.get("load libwatroo_hip.so")}
+                                             "context_ms": got.get(ctx_key), "warmup_join_ms": got.get(sync_key),
+                                             "library_load_ms": got.get("load libwatroo_hip.so"),
+                                             "one_shot": {"what": "the same without a sync between context creation and the call",
+                                                          "context_ms": got_b.get(ctx_key), "first_ms": calls_b[0]}}
                     except Exception as e:
                         out["first_call"] = {"error": repr(e)}
             if out is not None and not args.no_cpu and not args.brief:

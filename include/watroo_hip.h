@@ -93,6 +93,14 @@ int wt_profile_reset(wt_ctx *ctx);
 int wt_profile_count(wt_ctx *ctx, int *n);
 int wt_profile_entry(wt_ctx *ctx, int i, char *name64, int64_t *calls, double *total_ms);
 
+/* The translation units the library's device code is built as ("core", "transform", "fused_f32_k5_acc0", ...):
+ * count and names, in the order a context's warm-up threads know them (wt_ctx_create loads the runtime's copy
+ * machinery and the host-side units in the background, a plan's creation the fused passes of its family;
+ * wt_ctx_sync waits for both; WATROO_HIP_NO_WARMUP=1 disables).  Build / test bookkeeping - the reference,
+ * interpreted Python, has nothing to load (watroo/wavelets.py:1-11). */
+int wt_unit_count(void);
+const char *wt_unit_name(int i);
+
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) --------------------------------- */
 /* 128-byte ncclUniqueId; rank 0 creates it, the launcher broadcasts it out of band. */
 int wt_comm_unique_id(void *id128);

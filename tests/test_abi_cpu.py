@@ -4,6 +4,7 @@ package fails loudly (no CPU fallback) when no device is present."""
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -219,3 +220,21 @@ def test_no_kernel_uses_scratch_memory_or_spills(tmp_path):
     assert len(kernels) > 200 and len(kernels) - len(set(k[0] for k in kernels)) <= 40
     bad = [(n, int(sc), int(sp)) for n, sc, sp in kernels if int(sc) or int(sp)]
     assert not bad, f"kernels with scratch / spills: {bad[:5]}"
+
+
+def test_warmup_unit_list_is_the_list_of_units_the_build_compiles():
+    """wt_unit_probe.h's WT_UNITS (what the warm-up threads of a context can load: wt_unit_count / wt_unit_name,
+    host logic) names exactly the translation units __graft_entry__._units() compiles, each of which defines its
+    probe kernel and loader."""
+    import __graft_entry__ as G
+    from wavelets_amd import _lib as L
+    built = sorted(name[:-2] for name, _, _ in G._units())
+    assert sorted(L.unit_names()) == built
+    for name, _, flags in G._units():
+        assert f"-DWT_TU_NAME={name[:-2]}" in flags
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "wavelets_amd", "libwatroo_hip.so")],
+                         capture_output=True, text=True).stdout + \
+        subprocess.run(["nm", "--defined-only", os.path.join(ROOT, "wavelets_amd", "libwatroo_hip.so")],
+                       capture_output=True, text=True).stdout
+    for u in built:
+        assert f"wt_unit_load_{u}" in out, u

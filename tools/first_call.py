@@ -30,8 +30,20 @@ t = lap("import wavelets_amd", t)
 L.load()
 t = lap("load libwatroo_hip.so", t)
 ctx = L.default_context()
-ctx.sync()
 t = lap("context (HIP runtime init, stream, scratch)", t)
+if "nosync" not in sys.argv:
+    ctx.sync()
+    t = lap("sync (joins the context's warm-up thread)", t)
+if "warm_dma" in sys.argv or "warm_all" in sys.argv:
+    # experiment: what a small warm-up moves out of the first call (DMA queues / staging of the runtime, code objects)
+    small = np.zeros((256, 256), np.float32)
+    wp = L.Plan(ctx, 256, 256, L.B3SPLINE, 2)
+    wp.upload(L.PLANE_INPUT, small)
+    if "warm_all" in sys.argv:
+        W.denoise(small, [5, 3])
+    wp.download(L.PLANE_INPUT)
+    wp.close()
+    t = lap("warm-up on a 256^2 image", t)
 if "pieces" in sys.argv:
     plan = L.Plan(ctx, side, side, L.B3SPLINE, 2)
     t = lap("plan create", t)

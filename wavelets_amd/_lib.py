@@ -40,6 +40,8 @@ _i64 = _c.c_int64
 SIGNATURES = {
     "wt_abi_version": (_c.c_int, []),
     "wt_comm_version": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "wt_unit_count": (_c.c_int, []),
+    "wt_unit_name": (_c.c_char_p, [_c.c_int]),
     "wt_ctx_device_info": (_c.c_int, [_vp, _c.c_char_p, _c.c_int]),
     "wt_last_error": (_c.c_char_p, []),
     "wt_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
@@ -218,6 +220,12 @@ def comm_version():
     v = _c.c_int(0)
     check(load().wt_comm_version(_c.byref(v)))
     return v.value
+
+
+def unit_names():
+    """the translation units of the library's device code, as its warm-up threads know them (host logic)"""
+    L = load()
+    return [L.wt_unit_name(i).decode() for i in range(L.wt_unit_count())]
 
 
 def check(rc):

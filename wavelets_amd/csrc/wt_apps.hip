@@ -10,6 +10,9 @@
 #include "wt_kernels_apps.h"
 #include "wt_fft.h"
 #include "wt_axis.h"
+#include "wt_unit_probe.h"
+
+WT_UNIT_PROBE_DEFINE
 
 // =============================================================================================
 // pointwise ops

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <thread>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 
@@ -14,6 +15,9 @@
 #include "wt_kernels_common.h"
 #include "wt_kernels_core.h"
 #include "wt_rccl_group.h"
+#include "wt_unit_probe.h"
+
+WT_UNIT_PROBE_DEFINE
 
 // =============================================================================================
 // errors
@@ -271,6 +275,90 @@ int wt_scale_events(wt_ctx *c, std::vector<hipEvent_t> &ev, int n)
 // =============================================================================================
 static const int kPartialBlocks = 2048;     // 8 blocks of wt_reduce_kernel per CU
 
+// ---------------------------------------------------------------------------------------------
+// Warm-up thread of a context (round 5).  tools/first_call.py: of the 40-52 ms a process's FIRST denoise(img)
+// at 8192^2 took after the context existed, 22 ms were the runtime setting up its copy machinery on the first
+// transfer in each direction (upload 16.5 ms against 4.7 in steady state, download 14.6 against 4.8 - the same
+// with a 256 KiB image, so not a matter of size) and 15 ms loading the code objects of the five units the call
+// launches from.  Neither needs the caller's data.
+// wt_ctx_create starts a thread that does one small transfer in each direction the numpy-to-numpy calls take
+// (pageable host memory to the device, the device to a page-locked block) through the calls the plans use, then
+// loads the three host-side units (wt_unit_probe.h; ~1 ms each): 18 ms.  It runs beside whatever the caller does
+// between creating the context and its first call on it (reading its image, say); the first entry point that
+// takes the context's lock joins it (WtGuard), so nothing of the library ever runs beside it - two threads inside
+// the runtime's lazy set-up only queue behind each other (measured: the caller's first upload 21 ms instead of
+// 14).  A first call that finds the thread finished takes 14 ms instead of 33.
+// WATROO_HIP_NO_WARMUP=1 switches it off; WATROO_HIP_WARMUP_TRACE=1 prints what it spent.
+// What was tried and dropped: loading all 21 units up front (60 ms, and a caller that does not wait gets its
+// own launches queued behind units it never uses: first call 66 ms instead of 42); a second thread per plan
+// loading the fused passes of its family and the per-scale unit (a caller that syncs first: 18 ms instead of 14,
+// one that does not: 40 instead of 33 - the loads contend with the caller's own upload and launches, and the
+// fused units cost 0.4-0.9 ms each on demand anyway).  What did help without any thread: the per-scale float32
+// kernels used to sit in the unit of the launch code (5 MB, 10.5 ms to load, paid by every first transform whether
+// it used them or not) - now wt_stencil32.hip, loaded by the first per-scale launch (first call 42 -> 33 ms).
+// ---------------------------------------------------------------------------------------------
+#define WT_UNIT_DECL(name) int wt_unit_load_##name();
+WT_UNITS(WT_UNIT_DECL)
+#undef WT_UNIT_DECL
+struct WtUnit {
+    const char *name;
+    int (*load)();
+};
+#define WT_UNIT_ROW(name) {#name, wt_unit_load_##name},
+static const WtUnit kUnits[] = {WT_UNITS(WT_UNIT_ROW)};
+#undef WT_UNIT_ROW
+
+extern "C" int wt_unit_count(void) { return (int)(sizeof(kUnits) / sizeof(kUnits[0])); }
+extern "C" const char *wt_unit_name(int i) { return i >= 0 && i < wt_unit_count() ? kUnits[i].name : nullptr; }
+
+static bool warm_trace() { static const bool v = getenv("WATROO_HIP_WARMUP_TRACE") && atoi(getenv("WATROO_HIP_WARMUP_TRACE")); return v; }
+static double warm_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void load_units(int device, std::vector<std::string> names)
+{
+    if (hipSetDevice(device) != hipSuccess) return;
+    for (const auto &n : names)
+        for (const auto &u : kUnits)
+            if (n == u.name) {
+                const double t0 = warm_now();
+                (void)u.load();
+                if (warm_trace()) fprintf(stderr, "[watroo_hip warm-up] unit %-20s %7.2f ms (at %.2f)\n", u.name, warm_now() - t0, t0);
+            }
+    (void)hipGetLastError();
+}
+
+static void ctx_warm(wt_ctx *c)
+{
+    // (the context's own stream and scratch buffers: no entry point runs on this context before the thread is
+    //  joined - WtGuard; a stream and buffers of its own cost the thread another 10 ms)
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    const size_t rows = 64, row_bytes = 1024;                 // 64 KiB: h_pinned, d_partials
+    std::vector<char> pageable(rows * row_bytes, 0);
+    double t0 = warm_now();
+    auto lap = [&](const char *what) {
+        const double t1 = warm_now();
+        if (warm_trace()) fprintf(stderr, "[watroo_hip warm-up] %-28s %7.2f ms\n", what, t1 - t0);
+        t0 = t1;
+    };
+    (void)hipMemcpy2DAsync(c->d_partials, row_bytes, pageable.data(), row_bytes, row_bytes, rows, hipMemcpyHostToDevice, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    lap("pageable -> device");
+    (void)hipMemcpy2DAsync(c->h_pinned, row_bytes, c->d_partials, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    lap("device -> page-locked");
+    (void)hipGetLastError();
+    load_units(c->device, {"core", "transform", "apps"});
+}
+
+// (called with the context's lock held: WtGuard, wt_ctx_destroy)
+void wt_ctx_warm_join(wt_ctx *c)
+{
+    if (!c || !c->warm) return;
+    c->warm->join();
+    delete c->warm;
+    c->warm = nullptr;
+}
+
 extern "C" int wt_ctx_create(int device, wt_ctx **out)
 {
     if (!out) WT_FAIL("wt_ctx_create: null pointer");
@@ -294,6 +382,8 @@ extern "C" int wt_ctx_create(int device, wt_ctx **out)
     WT_HIP(hipHostMalloc(&c->h_pinned, 65536, hipHostMallocDefault));
     WT_HIP(hipMalloc(&c->d_psf, 4096 * sizeof(float)));
     c->d_psf_cap = 4096;
+    static_assert((kPartialBlocks * 4 + 8) * sizeof(double) >= 65536, "ctx_warm copies 64 KiB through d_partials");
+    if (!(getenv("WATROO_HIP_NO_WARMUP") && atoi(getenv("WATROO_HIP_NO_WARMUP")))) c->warm = new std::thread(ctx_warm, c);
     *out = c;
     return 0;
 }
@@ -301,6 +391,7 @@ extern "C" int wt_ctx_create(int device, wt_ctx **out)
 extern "C" int wt_ctx_destroy(wt_ctx *c)
 {
     if (!c) return 0;
+    wt_ctx_warm_join(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);

@@ -11,3 +11,6 @@
 #include "wt_fft.h"
 #include "wt_axis.h"
 #include "wt_f64.h"
+#include "wt_unit_probe.h"
+
+WT_UNIT_PROBE_DEFINE

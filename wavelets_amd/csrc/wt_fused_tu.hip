@@ -2,6 +2,9 @@
 // by __graft_entry__.build() once per (WT_TU_F64, WT_TU_K, WT_TU_ACC):
 //     hipcc -c wt_fused_tu.hip -DWT_TU_F64=0 -DWT_TU_K=5 -DWT_TU_ACC=1 -o _build/fused_f32_k5_acc1.o
 #include "wt_fused.h"
+#include "wt_unit_probe.h"
+
+WT_UNIT_PROBE_DEFINE
 
 #if !defined(WT_TU_F64) || !defined(WT_TU_K) || !defined(WT_TU_ACC)
 #error "wt_fused_tu.hip: define WT_TU_F64 (0/1), WT_TU_K (3/5) and WT_TU_ACC (0..3)"

@@ -17,6 +17,7 @@
 // current one: HIP's current device is per thread, so a host thread other than the one that created
 // the context - or one that has since used a context on another GPU - would otherwise launch on a
 // stream of a device that is not current.
+void wt_ctx_warm_join(wt_ctx *c);      // (wt_core.hip; with the context's lock held)
 struct WtGuard {
     std::recursive_mutex *a = nullptr, *b = nullptr;
     explicit WtGuard(wt_ctx *c, wt_ctx *d = nullptr)
@@ -24,8 +25,8 @@ struct WtGuard {
         const int dev = c ? c->device : -1;
         if (c == d) d = nullptr;
         if (c && d && d < c) std::swap(c, d);
-        if (c) { a = &c->mu; a->lock(); }
-        if (d) { b = &d->mu; b->lock(); }
+        if (c) { a = &c->mu; a->lock(); if (c->warm) wt_ctx_warm_join(c); }
+        if (d) { b = &d->mu; b->lock(); if (d->warm) wt_ctx_warm_join(d); }
         if (dev >= 0) (void)hipSetDevice(dev);
     }
     ~WtGuard()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <thread>
 
 #include <cstdint>
 #include <cstdio>
@@ -73,6 +74,9 @@ struct wt_ctx {
     std::recursive_mutex mu;
     int device = 0;
     int num_cus = 256;                      // hipDeviceAttributeMultiprocessorCount (MI355X: 256)
+    // warm-up of the runtime's lazy parts (copy queues, code objects) beside the caller's first steps
+    // (wt_core.hip: ctx_warm); joined by the first entry point that takes the lock (WtGuard)
+    std::thread *warm = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // profiling

@@ -6,6 +6,9 @@
 #include "wt_internal.h"
 #include "wt_stencil_launch.h"
 #include "wt_bilateral64.h"
+#include "wt_unit_probe.h"
+
+WT_UNIT_PROBE_DEFINE
 
 int wt64_stencil_launch(const StencilCtx &sc, int mode, const ChainArgsT<double> &a, int s)
 {

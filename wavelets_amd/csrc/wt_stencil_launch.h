@@ -167,8 +167,11 @@ static int wt_launch_stencil(const StencilCtx &sc, ChainArgsT<T> a, int s, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// float64 entry points of wt_stencil64.hip (its own translation unit: ~110 kernel instantiations)
+// entry points of wt_stencil32.hip / wt_stencil64.hip (translation units of their own: ~110 kernel
+// instantiations each)
 // ---------------------------------------------------------------------------------------------
+// one scale in `mode` (MODE_*) on float planes; `name`: profiler name of the chain kernel
+int wt32_stencil_launch(const StencilCtx &sc, int mode, const ChainArgsT<float> &a, int s, const char *name);
 // one scale in `mode` (MODE_*) on double planes
 int wt64_stencil_launch(const StencilCtx &sc, int mode, const ChainArgsT<double> &a, int s);
 // the range-weighted dilated filter of one scale (watroo/wavelets.py:74-105) on double planes: the

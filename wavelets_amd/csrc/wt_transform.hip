@@ -10,6 +10,9 @@
 #include "wt_kernels_common.h"
 #include "wt_kernels_transform.h"
 #include "wt_fused_decl.h"
+#include "wt_unit_probe.h"
+
+WT_UNIT_PROBE_DEFINE
 
 // =============================================================================================
 // run-time taps (user-defined scaling functions): the generic separable kernels
@@ -124,7 +127,7 @@ static int launch_chain_args(wt_plan *p, ChainArgs a, int s, const char *name)
         if (MODE == MODE_VAR) return launch_custom_variance(p, a.in, a.out_c, s, a.f1, a.f2, a.take_sqrt, name);
         WT_FAIL("%s: not available with user-defined taps", name);
     }
-    return wt_launch_stencil<float, MODE>(stencil_ctx(p), a, s, name);
+    return wt32_stencil_launch(stencil_ctx(p), MODE, a, s, name);      // (wt_stencil32.hip)
 }
 
 template <int MODE>
