@@ -168,7 +168,9 @@ def cpu_baseline(config, side, family, level, budget=15.0):
     run(probe)
     per_pix = (time.perf_counter() - t) / probe.size
     s = side
-    while s > probe_side and per_pix * s * s > budget:
+    # the full-size image where ONE run of it stays within ~2 budgets (cfg3 / cfg5 at 8192^2: 6-8 s on 16
+    # threads - the same workload as the GPU's, not a quarter of it), else halved until a run fits
+    while s > probe_side and per_pix * s * s > 2.2 * budget:
         s //= 2
     img = np.random.default_rng(0).standard_normal((s, s), dtype=np.float32)
     reps, t_tot = 0, 0.0
