@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void wt_fft_rows_kernel(const void *in, void *
 // the mixed-radix digit reversal: with i = m_{k-1} + r_{k-1} (m_{k-2} + r_{k-2} (...)) element i goes to
 // sum_t m_t L_t (bit reversal when every r_t is 2).  Twiddles: tw[j] = exp(-2 pi i j / n), j < n.
 struct WtFftFactors {
-    int nf;
+    int nf, n2;          // factors; how many of them (the first n2) are 2
     int r[16];
 };
 
@@ -146,23 +146,27 @@ __global__ __launch_bounds__(512) void wt_fft_rows_mixed_kernel(const void *in, 
             if (flags & WT_FFT_MUL_CONJ) m.y = -m.y;
             v = wt_cmul(v, m);
         }
-        // digit reversal: the digits of i from the last factor to the first, weighted by the block lengths L_t
+        // digit reversal: the digits of i from the last factor to the first, weighted by the block lengths L_t.
+        // The factors come 2s first (wt_fft_factor): the 5s and 3s are peeled off by constant divisors, what is
+        // left (< 2^n2) is the bit reversal of the radix-2 digits.
         int rem = i, p = 0, L = n;
-        for (int t = fa.nf - 1; t >= 0; --t) {
-            const int r = fa.r[t];
-            L /= r;                                      // L_t = r_0 ... r_{t-1}
-            const int m = rem % r;
-            rem /= r;
+        for (int t = fa.nf - 1; t >= fa.n2; --t) {
+            int m;
+            if (fa.r[t] == 3) { L /= 3; m = rem % 3; rem /= 3; }
+            else { L /= 5; m = rem % 5; rem /= 5; }
             p += m * L;
         }
+        if (fa.n2) p += (int)(__brev((unsigned)rem) >> (32 - fa.n2));
         s[p] = v;
     }
     __syncthreads();
     int L = 1;
     for (int t = 0; t < fa.nf; ++t) {
         const int r = fa.r[t], Ln = L * r, step = n / Ln;
+        const bool pow2 = (L & (L - 1)) == 0;
+        const int sh = __ffs(L) - 1;
         for (int j = threadIdx.x; j < n / r; j += nt) {
-            const int g = j / L, k = j - g * L, base = g * Ln + k;
+            const int g = pow2 ? j >> sh : j / L, k = j - g * L, base = g * Ln + k;
             if (r == 2) wt_fft_butterfly<2, C, INV>(s, base, L, k, step, n, tw);
             else if (r == 3) wt_fft_butterfly<3, C, INV>(s, base, L, k, step, n, tw);
             else wt_fft_butterfly<5, C, INV>(s, base, L, k, step, n, tw);
@@ -192,15 +196,17 @@ __global__ __launch_bounds__(256) void wt_fft_transpose_kernel(const typename Wt
         if (c0 + k < cols && r0 + tx < rows) out[(int64_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
 }
 
-// n = a product of 2s, 3s and 5s: the factors, largest first (the radix-2 stages then run on the longest blocks)
+// n = a product of 2s, 3s and 5s: the factors, 2s first (their stages - and, as long as only 2s came before, the
+// next one - split the butterfly index by shifts; the input permutation of the radix-2 part is a bit reversal)
 static inline bool wt_fft_factor(int n, WtFftFactors &f)
 {
-    f.nf = 0;
+    f.nf = f.n2 = 0;
     if (n < 2 || n > WT_FFT_MAX_N) return false;
-    for (int r : {5, 3, 2})
+    for (int r : {2, 3, 5})
         while (n % r == 0) {
             if (f.nf == 16) return false;
             f.r[f.nf++] = r;
+            if (r == 2) ++f.n2;
             n /= r;
         }
     return n == 1;
