@@ -297,6 +297,14 @@ int wt_decompose_bilateral(wt_plan *plan, int src, int level, const double *sigm
                            int bilateral_scaling, int flags);
 /* np.sum(coefficients, axis=0) (watroo/utils.py:98,205): dst <- sum planes[first..first+n) */
 int wt_plane_sum(wt_plan *plan, int first, int count, int dst);
+/* The same sum in two parts, for wow() behind a bilateral transform (watroo/utils.py:174-205: the planes of the
+ * first scales are final long before the transform's last scales have run).  wt_plane_sum_early: dst <- planes
+ * [0, count), queued on the side stream behind the per-scale updates already there (*done = 1), or nothing at all
+ * when the plan is not in that overlapped state (*done = 0: sum in one piece with wt_plane_sum).
+ * wt_plane_sum_resume: dst <- dst + planes [first, first + count).  Additions in plane order: the bits of
+ * wt_plane_sum(plan, 0, first + count, dst).  dst: WT_PLANE_OUT or a scratch plane. */
+int wt_plane_sum_early(wt_plan *plan, int count, int dst, int *done);
+int wt_plane_sum_resume(wt_plan *plan, int first, int count, int dst);
 /* np.median(np.abs(data[0])) (watroo/wavelets.py:127): exact radix select, fp32 result */
 int wt_abs_median(wt_plan *plan, int plane, float *median);
 /* Coefficients.significance (watroo/wavelets.py:129-143): dst <- erf(|c|/tau) (soft) or
@@ -523,6 +531,9 @@ int wt64_significance(wt_plan64 *plan, int src, int dst, double tau, double wgt,
                       int noise_plane, int mode);
 /* np.sum(planes[first..first+count), axis=0) in plane order (watroo/utils.py:98) */
 int wt64_plane_sum(wt_plan64 *plan, int first, int count, int dst);
+/* wt_plane_sum_early / wt_plane_sum_resume on a float64 plan (watroo/utils.py:174-205 with float64 data) */
+int wt64_plane_sum_early(wt_plan64 *plan, int count, int dst, int *done);
+int wt64_plane_sum_resume(wt_plan64 *plan, int first, int count, int dst);
 /* wt_denoise_sum in float64: Coefficients.denoise over the first n_den planes (tau[k] <= 0: weight
  * only) fused with the plane sum of planes [first, first + count) -> dst (watroo/wavelets.py:145-149,
  * utils.py:98); write_back stores the thresholded planes */

@@ -193,7 +193,7 @@ def test_float64_wow_bilateral_vs_oracle(L):
 def test_wow_updates_on_the_side_stream_equal_the_serial_order_bitwise(L, dtype):
     """cfg5's flow (bilateral transform, MAD noise on w_0, per-scale wow updates, plane sum) with the updates
     and the median queued on the side stream behind the per-scale events of the transform (option
-    wow_overlap, the default) against the serial order: identical planes and image, three steps in a row on
+    wow_overlap, the default; with it the early part of the plane sum) against the serial order: identical planes and image, three steps in a row on
     the same plan (the next transform must wait for the previous step's side work), 2048^2 so that every
     kernel family (row / lattice) takes part."""
     import wavelets_amd as WA
@@ -203,9 +203,17 @@ def test_wow_updates_on_the_side_stream_equal_the_serial_order_bitwise(L, dtype)
     level = int(np.round(np.log2(side) - np.log2(5)))
     rng = np.random.default_rng(2)
     img = (rng.standard_normal((side, side)) + 3 * np.sin(np.arange(side) / 50.0)[None, :]).astype(dtype)
-    res = {}
+    res, early = {}, {1: [], 0: []}
+    cls = L.Plan64 if dtype == np.float64 else L.Plan
+    keep = cls.plane_sum_early
     for on in (1, 0):
         L.set_option("wow_overlap", on)
+
+        def spy(self, count, dst=L.PLANE_OUT, _on=on):
+            early[_on].append((count, keep(self, count, dst)))
+            return early[_on][-1][1]
+
+        cls.plane_sum_early = spy
         try:
             sb = [1] * (level + 1)
             tr = WA.AtrousTransform(WA.B3spline, bilateral=sb)
@@ -226,8 +234,13 @@ def test_wow_updates_on_the_side_stream_equal_the_serial_order_bitwise(L, dtype)
                 plan.close()
         finally:
             L.set_option("wow_overlap", 1)
+            cls.plane_sum_early = keep
     for k, (u, v) in enumerate(zip(res[1], res[0])):
         assert np.array_equal(_bits(u), _bits(v)), k
+    # the sum of the first planes went beside the transform's last scales (round 5, later): queued early on the
+    # side stream in the overlapped state, not at all in the serial order
+    tail = WU._SUM_TAIL_PLANES_F64 if dtype == np.float64 else WU._SUM_TAIL_PLANES
+    assert early[1] == [(level + 1 - tail, True)] * 3 and early[0] == [(level + 1 - tail, False)] * 3, early
 
 
 def test_float64_cfg5_at_full_size_properties(L):

@@ -164,6 +164,10 @@ SIGNATURES = {
     "wt64_significance": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int,
                                      _c.c_int, _c.c_int]),
     "wt64_plane_sum": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt64_plane_sum_early": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
+    "wt64_plane_sum_resume": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
+    "wt_plane_sum_early": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
+    "wt_plane_sum_resume": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_binary": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "wt64_anscombe": (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                                  _c.c_int]),
@@ -706,6 +710,16 @@ class Plan:
     def plane_sum(self, first, count, dst=PLANE_OUT):
         check(load().wt_plane_sum(self._h, first, count, dst))
 
+    def plane_sum_early(self, count, dst=PLANE_OUT):
+        """planes [0, count) summed into dst on the side stream, if the plan is in the overlapped state of a
+        bilateral transform (True), else nothing (False)"""
+        done = _c.c_int(0)
+        check(load().wt_plane_sum_early(self._h, count, dst, _c.byref(done)))
+        return bool(done.value)
+
+    def plane_sum_resume(self, first, count, dst=PLANE_OUT):
+        check(load().wt_plane_sum_resume(self._h, first, count, dst))
+
     def abs_median(self, plane):
         m = _c.c_float(0)
         check(load().wt_abs_median(self._h, plane, _c.byref(m)))
@@ -992,6 +1006,14 @@ class Plan64:
 
     def plane_sum(self, first, count, dst=PLANE_OUT):
         check(load().wt64_plane_sum(self._h, first, count, dst))
+
+    def plane_sum_early(self, count, dst=PLANE_OUT):
+        done = _c.c_int(0)
+        check(load().wt64_plane_sum_early(self._h, count, dst, _c.byref(done)))
+        return bool(done.value)
+
+    def plane_sum_resume(self, first, count, dst=PLANE_OUT):
+        check(load().wt64_plane_sum_resume(self._h, first, count, dst))
 
     def binary(self, op, a, b, dst):
         code = {"add": 0, "sub": 1, "mul": 2, "div": 3, "add_div": 4}[op]

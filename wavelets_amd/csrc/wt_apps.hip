@@ -41,6 +41,60 @@ extern "C" int wt_plane_sum(wt_plan *p, int first, int count, int dst)
     return 0;
 }
 
+// np.sum(coefficients, axis=0) in two parts (round 5).  In wow() behind a bilateral transform (watroo/utils.py:174-205)
+// the whitened planes of the first scales are final long before the last scales of the transform have run:
+// wt_plane_sum_early puts planes [0, count) into dst on the SIDE stream, behind the updates queued there and beside
+// the bilateral kernels still running (they are bound by instruction issue and leave two thirds of the memory
+// bandwidth idle); wt_plane_sum_resume finishes dst = dst + planes [first, first + count) on the main stream.  The
+// additions happen in plane order either way (a sequential sum interrupted and resumed): identical bits.
+// *done = 0: the plan is not in the overlapped state (nothing queued: the caller sums in one piece).
+static int plane_sum_launch(wt_plan *p, const float *acc, int first, int count, float *o)
+{
+    SumArgs a{};
+    a.n = 0;
+    if (acc) a.p[a.n++] = const_cast<float *>(acc);
+    for (int i = 0; i < count; ++i) {
+        float *b = nullptr;
+        WT_TRY(plane_base(p, first + i, &b));
+        a.p[a.n++] = b;
+    }
+    const int64_t n4 = plan_n4(p);
+    ProfScope ps(p->ctx, "wt_plane_sum_kernel");
+    hipLaunchKernelGGL(wt_plane_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, p->ctx->stream, a, o, n4);
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt_plane_sum_early(wt_plan *p, int count, int dst, int *done)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !done) WT_FAIL("wt_plane_sum_early: null pointer");
+    *done = 0;
+    if (count < 1 || count > WT_MAX_SUM_PLANES || count - 1 > p->max_level) WT_FAIL("wt_plane_sum_early: %d planes outside [1,%d]", count, p->max_level + 1);
+    if (dst >= 0) WT_FAIL("wt_plane_sum_early: dst must not be a coefficient plane");
+    const bool side = g_opt_wow_overlap && p->overlap_ok && count <= p->overlap_scales && p->nranks == 1 && p->ctx->side_pending;
+    if (!side) return 0;
+    WtSideScope side_scope(p->ctx, p->scale_ev[count - 1], true);
+    if (!side_scope.ok()) return 2;
+    float *o = nullptr;
+    WT_TRY(plane_base(p, dst, &o));
+    WT_TRY(plane_sum_launch(p, nullptr, 0, count, o));
+    *done = 1;
+    return 0;
+}
+
+extern "C" int wt_plane_sum_resume(wt_plan *p, int first, int count, int dst)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt_plane_sum_resume: null plan");
+    if (count < 1 || count + 1 > WT_MAX_SUM_PLANES || first < 0 || first + count - 1 > p->max_level)
+        WT_FAIL("wt_plane_sum_resume: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
+    if (dst >= 0) WT_FAIL("wt_plane_sum_resume: dst must not be a coefficient plane");
+    float *o = nullptr;
+    WT_TRY(plane_base(p, dst, &o));                 // (a main-stream access: joins the side stream)
+    return plane_sum_launch(p, o, first, count, o);  // in place: every thread reads its own group before writing it
+}
+
 static int noise_ptr(wt_plan *p, int noise_plane, float **np_);
 
 extern "C" int wt_denoise_sum(wt_plan *p, int first, int count, int dst, int n_den, const double *tau,

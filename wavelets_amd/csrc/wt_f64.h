@@ -614,6 +614,53 @@ extern "C" int wt64_plane_sum(wt_plan64 *p, int first, int count, int dst)
     return 0;
 }
 
+// the two-part sum of wow() behind a bilateral transform: see wt_plane_sum_early (wt_apps.hip)
+static int plane_sum64_launch(wt_plan64 *p, const double *acc, int first, int count, double *d)
+{
+    Sum64Args a{};
+    a.n = 0;
+    if (acc) a.p[a.n++] = acc;
+    for (int i = 0; i < count; ++i) {
+        double *b = nullptr;
+        WT_TRY(plan64_base(p, first + i, &b));
+        a.p[a.n++] = b;
+    }
+    ProfScope ps(p->ctx, "wt64_plane_sum_kernel");
+    hipLaunchKernelGGL(wt64_plane_sum_kernel, dim3((unsigned)((plan64_n2(p) + 255) / 256)), dim3(256), 0, p->ctx->stream, a, d, plan64_n2(p));
+    WT_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wt64_plane_sum_early(wt_plan64 *p, int count, int dst, int *done)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p || !done) WT_FAIL("wt64_plane_sum_early: null pointer");
+    *done = 0;
+    if (count < 1 || count > 32 || count - 1 > p->max_level) WT_FAIL("wt64_plane_sum_early: %d planes outside [1,%d]", count, p->max_level + 1);
+    if (dst >= 0) WT_FAIL("wt64_plane_sum_early: dst must not be a coefficient plane");
+    const bool side = wt_wow_overlap_enabled() && p->overlap_ok && count <= p->overlap_scales && p->ctx->side_pending;
+    if (!side) return 0;
+    WtSideScope side_scope(p->ctx, p->scale_ev[count - 1], true);
+    if (!side_scope.ok()) return 2;
+    double *d = nullptr;
+    WT_TRY(plan64_base(p, dst, &d));
+    WT_TRY(plane_sum64_launch(p, nullptr, 0, count, d));
+    *done = 1;
+    return 0;
+}
+
+extern "C" int wt64_plane_sum_resume(wt_plan64 *p, int first, int count, int dst)
+{
+    WtGuard guard_(ctx_of(p));
+    if (!p) WT_FAIL("wt64_plane_sum_resume: null plan");
+    if (count < 1 || count + 1 > 32 || first < 0 || first + count - 1 > p->max_level)
+        WT_FAIL("wt64_plane_sum_resume: planes [%d,%d) outside [0,%d]", first, first + count, p->max_level);
+    if (dst >= 0) WT_FAIL("wt64_plane_sum_resume: dst must not be a coefficient plane");
+    double *d = nullptr;
+    WT_TRY(plan64_base(p, dst, &d));
+    return plane_sum64_launch(p, d, first, count, d);
+}
+
 /* wt_denoise_sum in float64 (Coefficients.denoise over the first n_den planes + np.sum(planes, axis=0),
  * watroo/wavelets.py:145-149, utils.py:98): planes [first, first + count) -> dst; tau[k] <= 0: no
  * threshold on plane k (its weight still applies); write_back: store the thresholded planes */

@@ -22,6 +22,12 @@ __all__ = ['denoise', 'wow', 'richardson_lucy']     # enhance / prepare_params i
 _POWER_PLANE = PLANE_SCRATCH(3)
 _GAMMA_PLANE = PLANE_SCRATCH(4)
 _SQ_PLANE, _POW_PLANE = PLANE_SCRATCH(6), PLANE_SCRATCH(7)     # 3-D wow: c^2 and its 3-D smoothing
+# wow behind a bilateral transform: all but this many planes are summed early, beside the transform's last scales
+# (8192^2, 12 planes, tools/ab_sumtail.sh: float32 6.32 ms with the sum in one piece, 6.46 / 6.27 / 6.34 with 3 / 4 / 5
+#  planes left for the end; float64 16.39, 16.56 / 16.28 / 16.06)
+_SUM_TAIL_ENV = __import__("os").environ.get("WATROO_HIP_SUM_TAIL")
+_SUM_TAIL_PLANES = int(_SUM_TAIL_ENV) if _SUM_TAIL_ENV else 4
+_SUM_TAIL_PLANES_F64 = int(_SUM_TAIL_ENV) if _SUM_TAIL_ENV else 5
 
 
 def prepare_params(param, ndims):
@@ -267,12 +273,15 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
     if coefficients._ndim == 1:
         plan.set_border(2)        # the 1-D branch filters with scipy's 'mirror' border (ref:65-69)
     try:
-        _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
-                    preserve_variance, whitening, h, soft_threshold, gplane)
+        early = _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
+                            preserve_variance, whitening, h, soft_threshold, gplane)
     finally:
         plan.set_border(0)
 
-    plan.plane_sum(0, nplanes, PLANE_OUT)                                 # ref:205
+    if early:                                                             # ref:205, the rest of it
+        plan.plane_sum_resume(early, nplanes - early, PLANE_OUT)
+    else:
+        plan.plane_sum(0, nplanes, PLANE_OUT)                             # ref:205
 
     if use_gamma:                                                         # ref:207-217
         if gamma_min is None or gamma_max is None:
@@ -288,9 +297,16 @@ def _wow_device(coefficients, n_scales, weights, whitening, denoise_coefficients
 
 def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sdc, npix,
                 preserve_variance, whitening, h, soft_threshold, gplane):
-    """The per-scale loop of wow (ref:174-203)."""
+    """The per-scale loop of wow (ref:174-203).  Returns the number of leading planes whose sum (ref:205) is
+    already queued into PLANE_OUT (0: none) - behind a bilateral transform the planes of the first scales are
+    final while the transform's last scales still run, and their share of the sum goes beside those
+    (Plan.plane_sum_early; identical bits, the additions keep their order)."""
     ft = np.float64 if isinstance(plan, _lib.Plan64) else np.float32      # the data's compute type
+    tail = _SUM_TAIL_PLANES_F64 if ft is np.float64 else _SUM_TAIL_PLANES
+    early, early_at = 0, (nplanes - tail if nplanes >= 2 * tail else 0)
     for s, (_, w, d) in enumerate(zip(range(nplanes), recomposition_weights, sdc)):  # ref:174
+        if s and s == early_at and hasattr(plan, "plane_sum_early") and plan.plane_sum_early(s, PLANE_OUT):
+            early = s
         need_moments = preserve_variance or (s == n_scales and whitening and h < 1)
         if need_moments:
             tot, tot2, _, _ = plan.reduce(s)
@@ -331,6 +347,7 @@ def _wow_scales(plan, coefficients, n_scales, nplanes, recomposition_weights, sd
                 plan.wow_scale(s, s, tau, soft_threshold, noise_plane, factor, gplane)
             else:
                 plan.wow_update(s, PLANE_NONE, tau, soft_threshold, noise_plane, factor, gplane)
+    return early
 
 
 def _periodic_operand(kernel, ay, ax):
