@@ -32,7 +32,7 @@ print(f"// degree {DEG}: max relative error of the double Horner form {np.abs(ac
 print("{" + ",\n ".join(", ".join(float(a).hex() for a in coef[i:i + 4]) for i in range(0, len(coef), 4)) + "}")
 
 
-def table_form(bits, deg):
+def table_form(bits, deg, print_table=True):
     """the table form of wt_math64.h (WT_BIL64_TABLE = 2^bits): 2^(64 g) on |64 g| <= 2^-(bits+1) as a polynomial in g of
     degree `deg` (Chebyshev interpolant, coefficient k scaled by 64^k - exact) and the table 2^(j / 2^bits - 64)"""
     import math
@@ -60,9 +60,11 @@ def table_form(bits, deg):
     w = ((p * np.array(T)[e & (nt - 1)]).view(np.int64) + ((e >> bits) << 52)).view(np.float64)
     print(f"// table of {nt}, degree {deg}: max relative error of the emulated weight {np.abs(w / np.exp2(np.maximum(t, -64)) - 1).max():.2e}")
     print("C = {" + ", ".join(float(x).hex() for x in scaled) + "}")
-    print("T = {" + ",\n ".join(", ".join(float(x).hex() for x in T[i:i + 4]) for i in range(0, nt, 4)) + "}")
+    if print_table:
+        print("T = {" + ",\n ".join(", ".join(float(x).hex() for x in T[i:i + 4]) for i in range(0, nt, 4)) + "}")
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "table":
     table_form(5, 5)
     table_form(6, 4)
+    table_form(9, 3, print_table=False)      # (the kernel computes these 512 entries itself)

@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
     constexpr int hw = K / 2;
 #if WT_BIL64_TABLE
     __shared__ double exp2tab[WT_BIL64_TABLE];            // (before any wave leaves: every wave of the workgroup reads it)
+#ifdef WT_EXP2T_COMPUTED
+    for (int j = threadIdx.y * 64 + threadIdx.x; j < WT_BIL64_TABLE; j += 256) exp2tab[j] = wt_exp2_64((double)j * (1.0 / WT_BIL64_TABLE) - 64.0);
+#else
     if (threadIdx.y == 0 && threadIdx.x < WT_BIL64_TABLE) exp2tab[threadIdx.x] = WT_EXP2T_T[threadIdx.x];
+#endif
     __syncthreads();
 #endif
     const Geo g = a.g;

@@ -138,8 +138,10 @@ __device__ __forceinline__ double wt_exp2u_join(double p, int e)
 // banks, conflict-free; 64 entries: two-way at worst) and a polynomial of degree 5 (2.2e-16) or 4 (2.4e-15; with the
 // quantisation of t 5.2e-15 relative in all) - 7 or 6 double-precision FMAs per weight instead of 12 at the same
 // instruction count, which the chip returns as clock (section 3.6 of DESIGN.md).  tools/make_exp2_64.py prints both.
+// Round 5, later: 512 entries (4 KiB of LDS, computed by the workgroup itself with wt_exp2_64 instead of read from
+// constant memory) and degree 3 - |64 g| <= 2^-10; 4.0e-15 relative in all, one FMA per weight fewer again.
 #ifndef WT_BIL64_TABLE
-#define WT_BIL64_TABLE 64
+#define WT_BIL64_TABLE 512
 #endif
 #define WT_EXP2T_C WT_PASTE(WT_EXP2T_C, WT_TU_NAME)
 #define WT_EXP2T_T WT_PASTE(WT_EXP2T_T, WT_TU_NAME)
@@ -169,11 +171,17 @@ __constant__ double WT_EXP2T_T[64] = {0x1.0000000000000p-64, 0x1.02c9a3e778061p-
  0x1.c199bdd85529cp-64, 0x1.c67f12e57d14bp-64, 0x1.cb720dcef9069p-64, 0x1.d072d4a07897cp-64,
  0x1.d5818dcfba487p-64, 0x1.da9e603db3285p-64, 0x1.dfc97337b9b5fp-64, 0x1.e502ee78b3ff6p-64,
  0x1.ea4afa2a490dap-64, 0x1.efa1bee615a27p-64, 0x1.f50765b6e4540p-64, 0x1.fa7c1819e90d8p-64};
+#elif WT_BIL64_TABLE == 512
+#define WT_EXP2T_DEG 3
+#define WT_EXP2T_BITS 9
+#define WT_EXP2T_COMPUTED 1          // no constant table: entry j = wt_exp2_64(j / 512 - 64)
+__constant__ double WT_EXP2T_C[4] = {0x1.ffffffffffff6p-1, 0x1.62e42fefa39eep+5, 0x1.ebfbe13357103p+9, 0x1.c6b08e1f0e0b5p+13};
 #endif
 #if WT_BIL64_TABLE
 __device__ __forceinline__ void wt_exp2t_split(double u, double &g, int &e)
 {
-    constexpr double M = WT_EXP2T_BITS == 5 ? 0x1.8p41 : 0x1.8p40;
+    constexpr double M = WT_EXP2T_BITS == 5 ? 0x1.8p41 : (WT_EXP2T_BITS == 6 ? 0x1.8p40 : 0x1.8p37);
+    static_assert(WT_EXP2T_BITS == 5 || WT_EXP2T_BITS == 6 || WT_EXP2T_BITS == 9, "1.5 * 2^(46 - bits)");
     const double m = u + M;
     e = __double2loint(m);                                   // 2^b (round-ish(t) + 64) + j
     g = u - (m - M);
