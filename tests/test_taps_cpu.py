@@ -230,3 +230,22 @@ def test_extension_windows_tile_the_extended_image_exactly_once():
         assert (hits == 1).all()
         yy, xx = np.mgrid[0:H + 2 * hy, 0:W + 2 * hx]
         assert np.array_equal(dst, src[(yy - hy) % H, (xx - hx) % W])
+
+
+def test_fft_sizes_host_logic_matches_the_five_smooth_rule():
+    """wt_fft_supported (host logic of the C library, no GPU): exactly the sides 2 .. 8192 without a prime factor
+    above 5 - what utils._next_smooth rounds the extended frame up to."""
+    from wavelets_amd import _lib as L
+    from wavelets_amd import utils as WU
+
+    def smooth(n):
+        for r in (2, 3, 5):
+            while n % r == 0:
+                n //= r
+        return n == 1
+    for n in list(range(1, 700)) + [1000, 1024, 3000, 3072, 3125, 6075, 6561, 7776, 8000, 8191, 8192, 8193, 8748, 9000, 16384]:
+        want = 2 <= n <= 8192 and smooth(n)
+        assert L.fft_supported(n, 64) == want and L.fft_supported(60, n) == want, n
+    for n in (1, 2, 7, 11, 97, 121, 1025, 3066 + 64, 4097, 8000):
+        m = WU._next_smooth(n)
+        assert m >= max(n, 2) and smooth(m) and not any(smooth(k) for k in range(max(n, 2), m)), (n, m)
