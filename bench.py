@@ -344,6 +344,10 @@ def main():
     ap.add_argument("--time-limit", type=float, default=900.0,
                     help="wall-clock limit of a multi-rank run in seconds: at the limit every rank is "
                          "killed and a JSON line says so (the last complete measurement, if there is one)")
+    ap.add_argument("--keep-overlap", action="store_true",
+                    help="multi-GPU: keep the overlapped order whatever the serial one measures (tests: ranks that "
+                         "share one card always measure the serial order faster, and the sweep of overlap_reserve "
+                         "behind the overlapped order would never run there)")
     ap.add_argument("--no-scatter-ab", action="store_true",
                     help="multi-rank runs: skip the A/B of the strip planes' placement (plain hipMalloc only)")
     args = ap.parse_args()
@@ -904,7 +908,7 @@ def main():
             e_off, _ = timed(step, ab_steps)
             overlap["ms_per_step_off"] = round(e_off / ab_steps * 1e3, 4)
             overlap["steps_off"] = ab_steps
-            if e_off / ab_steps < 0.98 * m["elapsed"] / steps:      # (the same on every rank: MAX-reduced times)
+            if e_off / ab_steps < 0.98 * m["elapsed"] / steps and not args.keep_overlap:      # (the same on every rank: MAX-reduced times)
                 overlap["chosen"] = "off"
                 m = measure(step, steps, spin=False)                # the full timed region in the serial order
                 overlap["ms_per_step_off"] = round(m["elapsed"] / steps * 1e3, 4)
@@ -913,6 +917,31 @@ def main():
         finally:
             if overlap["chosen"] == "on":
                 _lib.set_option("overlap", 1)
+        # (1b) how many compute units the interior launch should leave to RCCL's kernels while an exchange runs
+        # beside it (option overlap_reserve, default 16 of 256: a guess until a node has run this).  Measured, like
+        # the order itself: a value at least 2 % faster than the default becomes the one the line is timed with.
+        if overlap["chosen"] == "on":
+            try:
+                base_s = m["elapsed"] / steps
+                sweep, best_r, best_s = {"16": round(base_s * 1e3, 4)}, 16, base_s
+                for r in (0, 8, 32, 64):
+                    _lib.set_option("overlap_reserve", r)
+                    for _ in range(3):
+                        step()
+                    e_r, _ = timed(step, ab_steps)                  # (MAX over the ranks: the same choice everywhere)
+                    sweep[str(r)] = round(e_r / ab_steps * 1e3, 4)
+                    if e_r / ab_steps < 0.98 * best_s:
+                        best_r, best_s = r, e_r / ab_steps
+                _lib.set_option("overlap_reserve", best_r)
+                overlap["reserve_sweep_ms_per_step"] = sweep
+                overlap["reserve_chosen"] = best_r
+                if best_r != 16:
+                    m = measure(step, steps, spin=False)            # the full timed region with the chosen value
+                    overlap["ms_per_step_on"] = round(m["elapsed"] / steps * 1e3, 4)
+                    out = report(m)
+            except Exception as e:                                  # (never lose the line over the sweep)
+                _lib.set_option("overlap_reserve", 16)
+                overlap["reserve_sweep_error"] = repr(e)
         # (2) the ramp check of the halo exchange on the plan that was timed
         check = halo_check(plan)
         planes_ab = {"chosen": "hipMalloc", "hipMalloc_ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
@@ -1020,6 +1049,7 @@ def main():
                 dog_ab.cancel()
                 _lib.set_option("scatter_strips", 0)
         _lib.set_option("overlap", 1)
+        _lib.set_option("overlap_reserve", 16)
         return out
 
     out = run_workload(args.config, args.steps, args.warmup, full=True)

@@ -80,6 +80,15 @@ def _check_multi_gpu_fields(out, nranks, size):
     assert ov["default"] == "on" and ov["chosen"] in ("on", "off") and ov["ms_per_step_on"] > 0 and ov["ms_per_step_off"] > 0
     if ov["chosen"] == "off":             # the reported value is the faster order's full timed region
         assert ov["ms_per_step_off"] < ov["ms_per_step_on"] and ov["steps_off"] == out["steps"]
+    else:                                 # round 5: the compute units left to RCCL beside the interior launch, swept
+        assert "reserve_sweep_error" not in ov, ov
+        assert set(ov["reserve_sweep_ms_per_step"]) == {"0", "8", "16", "32", "64"} and all(v > 0 for v in ov["reserve_sweep_ms_per_step"].values())
+        assert ov["reserve_chosen"] in (0, 8, 16, 32, 64)
+        best = min(ov["reserve_sweep_ms_per_step"].values())
+        if ov["reserve_chosen"] != 16:
+            assert ov["reserve_sweep_ms_per_step"][str(ov["reserve_chosen"])] < 0.98 * ov["reserve_sweep_ms_per_step"]["16"]
+        else:
+            assert best >= 0.98 * ov["reserve_sweep_ms_per_step"]["16"] * 0.9      # (nothing much faster was passed over)
     pl = out["strip_planes"]
     assert pl["chosen"] in ("hipMalloc", "scattered") and pl["hipMalloc_ms_per_step"] > 0
     if size * (size // nranks) * 4 >= (8 << 20):          # planes of 8 MiB and more can be scattered
@@ -104,6 +113,20 @@ def test_bench_ranks_under_torch_distributed_run_import_no_torch():
     out = _one_json_line(run_ranks(cmd, _clean_env(), "bench2_torchrun"))
     assert out["launcher"] == {"plumbing": "stdlib", "torch_imported_in_ranks": False,
                                "started_by": "torch.distributed.run"}
+    _check_multi_gpu_fields(out, 2, 4096)
+
+
+def test_bench_two_ranks_kept_on_the_overlapped_order_sweep_the_reserved_compute_units():
+    """`bench.py --gpus 2 --keep-overlap`: ranks that share one card always measure the serial order faster, so the
+    line of the other multi-rank tests never reaches what follows the overlapped order on a real node - the sweep of
+    `overlap_reserve` (0 / 8 / 16 / 32 / 64 compute units left to RCCL's kernels), its choice and the re-timed
+    region.  Here the order is kept and the sweep must run on every rank in step (it is made of collectively
+    timed regions), report all five values and leave a consistent line."""
+    from conftest import run_ranks
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--size", "4096", "--steps", "3",
+           "--warmup", "1", "--no-cpu", "--keep-overlap"]
+    out = _one_json_line(run_ranks(cmd, _clean_env(), "bench2_keep_overlap"))
+    assert out["overlap"]["chosen"] == "on"
     _check_multi_gpu_fields(out, 2, 4096)
 
 
