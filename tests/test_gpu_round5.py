@@ -471,3 +471,57 @@ def test_fft_rejects_sides_with_a_prime_factor_above_five(L):
         p.close()
     for shape in ((48, 40), (75, 100), (3072, 3072), (6075, 8000), (8192, 8192)):
         assert L.fft_supported(*shape)
+
+
+# --------------------------------------------------------------------------- context warm-up thread
+def test_context_warmup_thread_is_joined_by_first_use_and_by_destroy(L):
+    """wt_ctx_create starts a thread (the runtime's copy set-up through the context's own stream and scratch,
+    host-side code objects); the first entry point that takes the context's lock joins it, and so does
+    wt_ctx_destroy.  Contexts created and destroyed back to back, used at once, or never used: no deadlock, no
+    crash, correct results on the scratch buffers the thread borrowed (the reduction partials)."""
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal((300, 517)).astype(np.float32)
+    want = None
+    for k in range(6):
+        ctx = L.Context(0)
+        if k % 3 == 0:                      # destroyed at once: the destroy joins the thread
+            ctx.close()
+            continue
+        plan = L.Plan(ctx, 300, 517, L.B3SPLINE, 3)     # used at once: the plan creation joins it
+        try:
+            plan.upload(L.PLANE_INPUT, img)
+            plan.decompose_sum(L.PLANE_INPUT, 3, L.PLANE_OUT)
+            tot = plan.reduce(L.PLANE_OUT)              # (uses d_partials / h_pinned, which the thread copied through)
+            got = plan.download(L.PLANE_OUT)
+        finally:
+            plan.close()
+            ctx.close()
+        if want is None:
+            want = (got, tot)
+        assert np.array_equal(_bits(got), _bits(want[0])) and tot == want[1]
+    np.testing.assert_allclose(want[0], img, atol=2e-6 * float(np.abs(img).max()))
+    assert abs(want[1][0] - float(want[0].astype(np.float64).sum())) <= 1e-6 * float(np.abs(want[0]).sum())
+
+
+def test_warmup_can_be_switched_off_and_the_first_call_is_reported_both_ways():
+    """WATROO_HIP_NO_WARMUP=1: no thread (the first call then pays the runtime's copy set-up itself);
+    tools/first_call.py - what bench.py runs for its `first_call` entry - prints the first and the steady call in
+    both protocols."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    outs = {}
+    for tag, extra, e in (("warm", [], {}), ("one_shot", ["nosync"], {}), ("cold", [], {"WATROO_HIP_NO_WARMUP": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), "2048"] + extra,
+                           capture_output=True, text=True, timeout=300, env=dict(env, **e))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        calls = [float(ln.rpartition(" ms")[0].rpartition(" ")[2]) for ln in r.stdout.splitlines() if ln.startswith("denoise(img")]
+        assert len(calls) == 4 and all(c > 0 for c in calls), r.stdout
+        outs[tag] = calls
+    # behind a joined warm-up the first call is close to the steady state; without any it pays the set-up
+    assert outs["warm"][0] < outs["cold"][0], outs
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "first_call_2048.txt"), "w") as f:
+            f.write(repr(outs) + "\n")
+    except OSError:
+        pass
