@@ -15,8 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (script, cases, seed): tools/fuzz.py - fused / per-scale / chain schedules vs the C oracle, virtual strips vs the
 # unsharded result, bilateral transform and wow() with random keywords, float64 passes, the pipelined host call,
 # the generic tap-list operator; fuzz_lattice.py - lattice kernel vs row / chain kernels bitwise at dilations up to
-# 4096; fuzz_round4.py - denoise (float32 / float64), richardson_lucy, pad modes, generic taps, element types.
-FUZZERS = [("fuzz.py", 24, 5), ("fuzz_lattice.py", 40, 5), ("fuzz_round4.py", 48, 5), ("fuzz_round5.py", 40, 5)]
+# 4096; fuzz_round4.py - denoise (float32 / float64), richardson_lucy, pad modes, generic taps, element types;
+# fuzz_round5.py - float64 stencils / bilateral / wow, side stream + early plane sum, mixed-radix FFT.
+FUZZERS = [("fuzz.py", 24, 5), ("fuzz_lattice.py", 40, 5), ("fuzz_round4.py", 48, 5), ("fuzz_round5.py", 50, 5)]
 
 
 @pytest.mark.parametrize("script,cases,seed", FUZZERS)
