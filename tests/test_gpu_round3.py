@@ -181,13 +181,15 @@ def test_bench_default_line_carries_every_config():
         assert c["value"] > 0 and c["ms_per_step"] > 0 and c["bytes_per_pixel"] > 0 and c["dominant_kernel"]
     f64 = out["float64"]                                     # the reference's default dtype, beside the configs
     assert f64.get("fused_passes") is True and f64["value"] > 20000 and f64["bytes_per_pixel"] == 128.0
-    # round 5: BASELINE configs[4] on the float64 engine (tuned float64 kernels: within 3.2 x the float32 flow of the
+    # round 5: BASELINE configs[4] on the float64 engine (tuned float64 kernels: within 3.0 x the float32 flow of the
     # same run; 9.8 x on the generic kernels) and what the first call of a fresh process costs
     f5 = out["float64_cfg5"]
-    assert "error" not in f5 and f5["steps"] >= 3 and 0 < f5["vs_float32_cfg5"] < 3.2, f5
+    assert "error" not in f5 and f5["steps"] >= 3 and 0 < f5["vs_float32_cfg5"] < 3.0, f5       # (2.46-2.65 measured)
     assert any(k.startswith("wt64_bilateral") for k in f5["kernels_ms_per_step (overlapped kernels both count)"])
     fc = out["first_call"]
-    assert "error" not in fc and fc["steady_ms"] < fc["first_ms"] < 90.0, fc       # (100 ms before round 5)
+    # (100 ms before round 5; 14-15 ms behind an existing context - the review's bar is 30 -, 32-35 straight after creating it)
+    assert "error" not in fc and fc["steady_ms"] < fc["first_ms"] < 30.0, fc
+    assert fc["first_ms"] < fc["one_shot"]["first_ms"] < 70.0 and fc["warmup_join_ms"] > 0, fc
     rf = out["roofline"]
     assert rf["kernel"] == "wt_fused_kernel" and 0 < rf["frac"] < 1.2
     if rf["traffic"] is not None:
