@@ -921,6 +921,12 @@ def main():
         # beside it (option overlap_reserve, default 16 of 256: a guess until a node has run this).  Measured, like
         # the order itself: a value at least 2 % faster than the default becomes the one the line is timed with.
         if overlap["chosen"] == "on":
+            # (its own, short limit like the placement A/B below: if a rank stalls in here the stored line goes out
+            #  after two minutes, not at the run's limit)
+            from wavelets_amd.launch import Watchdog
+            sweep_limit = min(120.0, max(5.0, args.time_limit / 5))
+            dog_sweep = Watchdog(sweep_limit, lambda: on_expire(f"the overlap_reserve sweep did not finish within {sweep_limit:.0f} s"),
+                                 code=lambda: 0)
             try:
                 base_s = m["elapsed"] / steps
                 sweep, best_r, best_s = {"16": round(base_s * 1e3, 4)}, 16, base_s
@@ -942,6 +948,8 @@ def main():
             except Exception as e:                                  # (never lose the line over the sweep)
                 _lib.set_option("overlap_reserve", 16)
                 overlap["reserve_sweep_error"] = repr(e)
+            finally:
+                dog_sweep.cancel()
         # (2) the ramp check of the halo exchange on the plan that was timed
         check = halo_check(plan)
         planes_ab = {"chosen": "hipMalloc", "hipMalloc_ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
