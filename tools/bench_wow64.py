@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """cfg5 (wow(bilateral=1, denoise_coefficients=[5,2])) device-resident in float32 and float64, with the
-per-kernel breakdown of the library's own profiler.  python tools/bench_wow64.py [side] [steps] [plain]
-plain: also wow() without bilateral filtering."""
+per-kernel breakdown of the library's own profiler.  python tools/bench_wow64.py [side] [steps] [plain] [f32only]
+plain: also wow() without bilateral filtering; f32only: stop after the float32 flow."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -69,6 +69,8 @@ def run(f64, bilateral):
 
 
 m32 = run(False, True)
+if "f32only" in sys.argv:
+    sys.exit(0)
 m64 = run(True, True)
 print(f"float64 / float32 (bilateral) = {m64 / m32:.2f}")
 if plain:

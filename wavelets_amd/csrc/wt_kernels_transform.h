@@ -156,33 +156,65 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
 // holds its K x K float4 neighbourhood in ~240 VGPRs: 2 waves per SIMD, and at that occupancy the
 // dependent chain of every tap (difference, square, scale, exp, accumulate) - not the instruction
 // count - sets the pace.  Half the pixels per thread halve the window (K x K float2) and allow
-// 3-4 waves per SIMD.  Per-pixel arithmetic is identical to wt_bilateral_kernel (same operations
+// 4 waves per SIMD.  Per-pixel arithmetic is identical to wt_bilateral_kernel (same operations
 // in the same order, variance included), so the two kernels produce the same bits.
+//
+// Round 6: the row that enters the window is fetched with raw BUFFER loads (SGPR descriptor of the row +
+// one 32-bit lane offset per operand, 2 K four-byte loads per row) instead of per-lane branches between one
+// 8-byte and two 4-byte flat loads.  The branches cost nothing by themselves, but loads inside divergent
+// regions make the number of loads in flight path-dependent, so the compiler's wait-count pass fell back to
+// `s_waitcnt vmcnt(0)` at the join - in front of the tap loop: the "prefetched" row was waited for BEFORE the
+// 24 taps it was meant to hide behind, and the VALU idled whenever the four waves of a SIMD sat in that wait
+// together (0.78 issue-busy).  With straight-line loads the wait is counted exactly and lands where the row is
+// first used, one whole step later.  For the same reason the variance source is a template parameter (the
+// plane form loads through the same descriptors), the LDS ring slots follow the unroll phase (immediate
+// offsets), and only the border rules the launch code admits (0, 1) are compiled in.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned int wt_su2 __attribute__((ext_vector_type(2)));
 typedef float wt_sf2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void wt_store2(float *row, int x, int P, float2 v)
+// descriptor of one row (P floats) behind a wave-uniform pointer: range check = the row's pitch
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_row_rsrc(const float *row, int P)
 {
     const uint64_t ra = (uint64_t)row;
     const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 4, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 4, 0x00020000);
+}
+__device__ __forceinline__ void wt_store2(float *row, int x, int P, float2 v)
+{
     const wt_sf2 t = {v.x, v.y};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), r, (unsigned)x * 4u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), wt_row_rsrc(row, P), (unsigned)x * 4u, 0, 0);
+}
+// symmetric reflection of the bilateral kernels' two border rules (Geo::border 0 / 1; wt_refl_b without the
+// 'mirror' rules the launch code refuses)
+__device__ __forceinline__ int wt_refl_01(int i, int n, int d, int border)
+{
+    if ((unsigned)i < (unsigned)n) return i;
+    if (border == 0) return wt_refl(i, n);
+    int o = i % d;
+    if (o < 0) o += d;
+    return o + d * wt_refl((i - o) / d, (n - o + d - 1) / d);
 }
 
-template <int K>
+template <int K, bool INLINE_VAR, bool PAIRED>
 __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
 {
     constexpr int hw = K / 2;
     const Geo g = a.g;
     int bx, by;
     wt_xcd_remap(bx, by);
+#ifdef WT_BILX_OLDGEO
     const int x = (bx * 64 + threadIdx.x) * 2;
     if (x >= g.W) return;
-    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
-    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
     const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
+#else
+    // the waves of a workgroup sit SIDE BY SIDE on the same chain (round 6): a workgroup reads and writes
+    // blockDim.y * 512 contiguous bytes of one row per step.  (Until round 5 each wave had a chain of its own and the
+    // chip kept ~5 000 rows open with 512-byte accesses: HBM pages, not the VALU, set the kernel's pace.)
+    const int x = ((bx * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x) * 2;
+    if (x >= g.W) return;
+    const int item = __builtin_amdgcn_readfirstlane(by);
+#endif
     const int d = a.d;
     const int q = item % d;
     const int c = item / d;
@@ -193,30 +225,60 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
     if (r0 >= r1) return;
     const int gy0 = g.row0 + q;
 
-    // operand columns do not depend on the row: pixel pair x + (j - hw) d, reflected per pixel at
-    // the image border; an in-image pair at an even pixel is one aligned 8-byte load
-    int xa[K], xb[K];
-    unsigned pair = 0;
+    // Operand columns do not depend on the row: pixel pair x + (j - hw) d, reflected per pixel at the image border.
+    // PAIRED (the symmetric border of the whole image, Geo::border 0): two neighbouring indices reflect to the same
+    // or to neighbouring pixels whatever the number of bounces, so the pair is ONE 8-byte load at the lower of the
+    // two (unaligned for odd operands of d = 1: buffer loads need 4-byte alignment only) and at most a swap -
+    // (v0, v1), (v1, v0), (v0, v0) or (v1, v1) by two selects, which only waves that touch the left or right image
+    // border execute.  Otherwise (reflection inside polyphase components) 2 K four-byte loads.
+    unsigned xa[K], xb[K];
+    bool sa[K], sb[K];
+    bool odd = false;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int xo = x + (j - hw) * d;
-        xa[j] = wt_refl_b(xo, g.W, d, g.border);
-        xb[j] = wt_refl_b(xo + 1, g.W, d, g.border);
-        if (xo >= 0 && xo + 1 < g.W && (xo & 1) == 0) pair |= 1u << j;   // d = 1: odd operands take two 4-byte loads
+        const int ia = wt_refl_01(xo, g.W, d, g.border), ib = wt_refl_01(xo + 1, g.W, d, g.border);
+        if constexpr (PAIRED) {
+            const int lo = max(min(min(ia, ib), g.P - 2), 0);
+            xa[j] = 4u * (unsigned)lo;
+            sa[j] = ia != lo;
+            sb[j] = ib != lo;
+            odd = odd || sa[j] || !sb[j];
+        } else {
+            xa[j] = 4u * (unsigned)ia;
+            xb[j] = 4u * (unsigned)ib;
+        }
     }
+    const bool plain = !PAIRED || __builtin_amdgcn_ballot_w64(odd) == 0;     // wave-uniform: no operand of this wave is reflected
     float2 win[K][K];
     auto load_win_row = [&](int r, float2 (&dst)[K]) {
-        const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
+        const int ry = wt_refl_01(gy0 + d * r, g.H, d, g.border);
+        const __amdgpu_buffer_rsrc_t rs = wt_row_rsrc(a.in + (int64_t)(ry - g.row0) * g.P, g.P);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const char *rb = reinterpret_cast<const char *>(row);        // SGPR base + 32-bit lane offset
-            if ((pair >> j) & 1u) dst[j] = *reinterpret_cast<const float2 *>(rb + (unsigned)xa[j] * 4u);
-            else dst[j] = make_float2(*reinterpret_cast<const float *>(rb + (unsigned)xa[j] * 4u),
-                                      *reinterpret_cast<const float *>(rb + (unsigned)xb[j] * 4u));
+            if constexpr (PAIRED) {
+                const wt_sf2 v = __builtin_bit_cast(wt_sf2, __builtin_amdgcn_raw_buffer_load_b64(rs, xa[j], 0, 0));
+                dst[j] = make_float2(v.x, v.y);
+            } else {
+                dst[j] = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, xa[j], 0, 0)),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, xb[j], 0, 0)));
+            }
+        }
+    };
+    // the swap of a loaded row's reflected operands (behind a wave-uniform branch that holds no memory operation:
+    // the compiler's wait counts stay exact)
+    auto fix_row = [&](float2 (&row)[K]) {
+        if constexpr (PAIRED) {
+            if (!plain) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) row[j] = make_float2(sa[j] ? row[j].y : row[j].x, sb[j] ? row[j].y : row[j].x);
+            }
         }
     };
 #pragma unroll
     for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) fix_row(win[i]);
     float2 nxt[K];
 
     // In-kernel variance: the row filters (h = row-filtered I, h2 = row-filtered I^2) of a window
@@ -225,7 +287,7 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
     // filter instead of filtering all K rows again (4/5 of that arithmetic, ~20 % of the kernel's
     // VALU work; at 4 waves per SIMD the kernel is VALU-bound).  Same operations in the same
     // order as wt_hrow_filter<MODE_VAR> + WtVert: bit-identical to the separate variance pass.
-    __shared__ float2 hring[K][2][256];
+    __shared__ float2 hring[INLINE_VAR ? K : 1][2][256];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     auto row_filters = [&](const float2 (&wr)[K], float2 &h, float2 &h2) {
         float hh[2], hh2[2];
@@ -242,7 +304,7 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         h = make_float2(hh[0], hh[1]);
         h2 = make_float2(hh2[0], hh2[1]);
     };
-    if (a.inline_var) {
+    if constexpr (INLINE_VAR) {
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) {
             float2 h, h2;
@@ -251,35 +313,39 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
             hring[i][1][tid] = h2;
         }
     }
-    int slot0 = 0;                                       // ring slot of window row 0
 
     const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
     // One step of the march.  The window does NOT slide through the registers (K * K 8-byte moves per
     // row, ~10 % of the kernel's vector instructions): the row loop is unrolled K times and in phase U
-    // window row i lives in slot (i + U) % K - the entering row replaces the row that left (K moves).
+    // window row i lives in slot (i + U) % K - the entering row replaces the row that left (K moves) - and
+    // its row filters in ring slot (i + U) % K likewise.
     // Same operations in the same order in every phase: identical bits.
     auto step = [&](const int r, auto utag) {
         constexpr int U = decltype(utag)::value;
+#ifndef WT_BILX_NOLOAD
         load_win_row(min(r + 1, r1 - 1) + hw, nxt);      // software prefetch of the entering row
+#else
+        for (int j = 0; j < K; ++j) nxt[j] = win[U][j];
+#endif
         const int64_t roff = (int64_t)(q + d * r) * g.P;
         const float I[2] = {win[(hw + U) % K][hw].x, win[(hw + U) % K][hw].y};
         float vv[2];
-        if (a.inline_var) {
+#ifdef WT_BILX_NOVAR
+        if constexpr (false) {
+#else
+        if constexpr (INLINE_VAR) {
+#endif
             float2 hn, h2n;
             row_filters(win[(K - 1 + U) % K], hn, h2n);  // the row that entered the window
-            {
-                const int sn = slot0 == 0 ? K - 1 : slot0 - 1;
-                hring[sn][0][tid] = hn;
-                hring[sn][1][tid] = h2n;
-            }
+            hring[(K - 1 + U) % K][0][tid] = hn;
+            hring[(K - 1 + U) % K][1][tid] = h2n;
             float m[2], p[2];
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 float2 h, h2;
                 if (i < K - 1) {
-                    const int si = slot0 + i < K ? slot0 + i : slot0 + i - K;
-                    h = hring[si][0][tid];
-                    h2 = hring[si][1][tid];
+                    h = hring[(i + U) % K][0][tid];
+                    h2 = hring[(i + U) % K][1][tid];
                 } else {
                     h = hn;
                     h2 = h2n;
@@ -291,12 +357,16 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
                     p[k] = (i == 0) ? wt_tap<K>(0) * h2k[k] : fmaf(wt_tap<K>(i), h2k[k], p[k]);
                 }
             }
-            slot0 = slot0 + 1 == K ? 0 : slot0 + 1;
             vv[0] = wt_var_point(p[0], m[0], a.f1, a.f2, 0);
             vv[1] = wt_var_point(p[1], m[1], a.f1, a.f2, 0);
+        } else if constexpr (INLINE_VAR) {
+            vv[0] = I[0] * I[0] + a.f1; vv[1] = I[1] * I[1] + a.f1;       // (WT_BILX_NOVAR timing experiment)
         } else {
-            vv[0] = a.aux[roff + x];
-            vv[1] = x + 1 < g.W ? a.aux[roff + x + 1] : 1.f;
+            // variance plane: both pixels through the row's descriptor (the second column clamped into the
+            // row: a lane whose second pixel is past the image stores nothing for it)
+            const __amdgpu_buffer_rsrc_t rv = wt_row_rsrc(a.aux + roff, g.P);
+            vv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, 4u * (unsigned)x, 0, 0));
+            vv[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, 4u * (unsigned)min(x + 1, g.W - 1), 0, 0));
         }
         // The two pixels of a thread are a register PAIR throughout the tap loop: difference,
         // square, exponent (one v_pk_fma with the tap's log2 weight as the addend), and the two
@@ -308,11 +378,12 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
         wt_p2 acc = kc * Iv;
         const wt_p2 s2 = {wt_div_nr(-0.72134752044448170368f, vv[0]), wt_div_nr(-0.72134752044448170368f, vv[1])};   // -log2(e) / (2 var)
         // taps in the reference order (watroo/wavelets.py:89-91), as in wt_bilateral_kernel
-        // (round 5: forming 4 or 8 weights in lockstep, as the float64 march does, changed nothing here: cfg5 5.95-6.03 ms
-        //  either way on one box - the compiler already overlaps two to three taps; a second row in flight costs the
-        //  fourth wave per SIMD - 138 VGPRs - and 2.5 %)
 #pragma unroll
+#ifdef WT_BILX_NOTAPS
+        for (int i = 0; i < 1; ++i) {
+#else
         for (int i = 0; i < K; ++i) {
+#endif
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 if (i == hw && j == hw) continue;
@@ -332,8 +403,14 @@ __global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
             o[k] = wt_div_nr(acc[k], norm[k]);
             ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
         }
-        wt_store2(a.out_c + roff, x, g.P, make_float2(o[0], o[1]));
-        if (a.out_w) wt_store2(a.out_w + roff, x, g.P, make_float2(ow[0], ow[1]));
+#ifdef WT_BILX_NOSTORE
+        const int SP = 0;          // empty descriptor: the stores issue and are dropped by the range check
+#else
+        const int SP = g.P;
+#endif
+        wt_store2(a.out_c + roff, x, SP, make_float2(o[0], o[1]));
+        if (a.out_w) wt_store2(a.out_w + roff, x, SP, make_float2(ow[0], ow[1]));
+        fix_row(nxt);
 #pragma unroll
         for (int j = 0; j < K; ++j) win[U][j] = nxt[j];    // slot of the row that left <- the row that entered
     };

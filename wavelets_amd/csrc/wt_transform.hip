@@ -229,11 +229,37 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     dim3 grid, block;
     const bool small = (1 << s) < 4, b3 = p->family == WT_B3SPLINE;
     if (g_opt_bilateral2) {                              // two pixels per thread: 4 waves per SIMD
+#ifdef WT_BILX_OLDGEO
         WT_TRY(chain_geometry(p, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64));
-        ProfScope ps(p->ctx, "wt_bilateral2_kernel");
+#else
+        // NW waves side by side on one chain: the chain items (phase x chunk) run over grid.y alone
+        static const int NW = getenv("WT_BIL_NW") ? std::max(1, std::min(4, atoi(getenv("WT_BIL_NW")))) : 4;   // (experiments; the LDS ring holds 256 threads)
+        const int wx = ((p->g.W + 1) / 2 + 63) / 64;            // waves across a row
+        WT_TRY(chain_geometry(p, s, a, grid, block, wx));
+        {
+            int64_t items = (int64_t)a.d * a.chunks;
+            while (items > 65528) {                               // grid.y limit
+                a.S *= 2;
+                a.chunks = ((p->g.nrows + a.d - 1) / a.d + a.S - 1) / a.S;
+                items = (int64_t)a.d * a.chunks;
+            }
+            grid = dim3((wx + NW - 1) / NW, (unsigned)((items + 7) / 8 * 8));
+            block = dim3(64, NW);
+        }
+#endif
+        // WT_PROF_SCALES=1: one profiler entry per dilation (tools/bench_bil.py)
+        static const bool by_scale = getenv("WT_PROF_SCALES") != nullptr;
+        static char names[25][40];
+        if (by_scale && !names[s][0]) snprintf(names[s], sizeof names[s], "wt_bilateral2_kernel d=%d", 1 << s);
+        ProfScope ps(p->ctx, by_scale ? names[s] : "wt_bilateral2_kernel");
         static const int lds_pad = getenv("WT_BIL_LDS_PAD") ? atoi(getenv("WT_BIL_LDS_PAD")) : 0;   // experiments: dynamic LDS to cap the workgroups per CU
-        if (b3) hipLaunchKernelGGL((wt_bilateral2_kernel<5>), grid, block, lds_pad, p->ctx->stream, a);
-        else hipLaunchKernelGGL((wt_bilateral2_kernel<3>), grid, block, lds_pad, p->ctx->stream, a);
+        const bool paired = p->g.border == 0;      // one 8-byte load per operand pair (wt_kernels_transform.h)
+#define WT_BIL2(KK, IV, PR) hipLaunchKernelGGL((wt_bilateral2_kernel<KK, IV, PR>), grid, block, lds_pad, p->ctx->stream, a)
+        if (b3 && a.inline_var) { if (paired) WT_BIL2(5, true, true); else WT_BIL2(5, true, false); }
+        else if (b3) { if (paired) WT_BIL2(5, false, true); else WT_BIL2(5, false, false); }
+        else if (a.inline_var) { if (paired) WT_BIL2(3, true, true); else WT_BIL2(3, true, false); }
+        else { if (paired) WT_BIL2(3, false, true); else WT_BIL2(3, false, false); }
+#undef WT_BIL2
         WT_HIP(hipGetLastError());
         return 0;
     }
