@@ -39,15 +39,15 @@ typedef unsigned int wt_du2 __attribute__((ext_vector_type(2)));
 // 8-byte store of one pixel through a raw buffer descriptor of the row (see wt_storev)
 __device__ __forceinline__ void wt_store1d(double *row, int x, int P, double v)
 {
-    const uint64_t ra = (uint64_t)row;
-    const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
-                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
-    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 8, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_du2, v), r, (unsigned)x * 8u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_du2, v), wt_row_rsrc(row, P), (unsigned)x * 8u, 0, 0);
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<double> a)
+// Round 6 (as in wt_bilateral2_kernel): the entering row comes through raw buffer loads of the row's descriptor and the
+// variance source is a template parameter, so no memory operation sits inside a branch and the compiler's wait counts
+// are exact (the run-time `inline_var` test put an `s_waitcnt vmcnt(0)` in front of every step's taps); the ring slots
+// follow the unroll phase; the waves of a workgroup sit side by side on one chain.
+template <int K, bool INLINE_VAR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void wt64_bilateral_march_kernel(ChainArgsT<double> a)
 {
     constexpr int hw = K / 2;
 #if WT_BIL64_TABLE
@@ -62,11 +62,9 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
     const Geo g = a.g;
     int bx, by;
     wt_xcd_remap(bx, by);
-    const int x = bx * 64 + threadIdx.x;
+    const int x = (bx * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x;
     if (x >= g.W) return;
-    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
-    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
-    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
+    const int item = __builtin_amdgcn_readfirstlane(by);   // the chain item (phase, chunk) of this workgroup: scalar
     const int d = a.d;
     const int q = item % d;
     const int c = item / d;
@@ -80,12 +78,13 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
     // operand columns do not depend on the row: pixel x + (j - hw) d, reflected at the image border
     unsigned xo[K];                                       // byte offsets into a row
 #pragma unroll
-    for (int j = 0; j < K; ++j) xo[j] = (unsigned)wt_refl_b(x + (j - hw) * d, g.W, d, g.border) * 8u;
+    for (int j = 0; j < K; ++j) xo[j] = (unsigned)wt_refl_01(x + (j - hw) * d, g.W, d, g.border) * 8u;
     double win[K][K];
     auto load_win_row = [&](int r, double (&dst)[K]) {
-        const char *rb = reinterpret_cast<const char *>(wt_row_b(a.in, g, gy0 + d * r, d));   // SGPR base + 32-bit lane offset
+        const int ry = wt_refl_01(gy0 + d * r, g.H, d, g.border);
+        const __amdgpu_buffer_rsrc_t rs = wt_row_rsrc(a.in + (int64_t)(ry - g.row0) * g.P, g.P);
 #pragma unroll
-        for (int j = 0; j < K; ++j) dst[j] = *reinterpret_cast<const double *>(rb + xo[j]);
+        for (int j = 0; j < K; ++j) dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, xo[j], 0, 0));
     };
 #pragma unroll
     for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
     // touches them: no barrier); every step reads the K pairs for the column filter.  Same operations in
     // the same order as wt_hrow_filter<MODE_VAR> + WtVert (and as wt64_rows_kernel + the column pass of
     // the float64 engine: FMA chains in tap order): bit-identical to the separate variance pass.
-    __shared__ double hring[K][2][256];
+    __shared__ double hring[INLINE_VAR ? K : 1][2][256];
     const int tid = threadIdx.y * 64 + threadIdx.x;
 
     auto row_filters = [&](const double (&wr)[K], double &h, double &h2) {
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
             h2 = (j == 0) ? wt_tap_s<K, double>(0) * sq : fma(wt_tap_s<K, double>(j), sq, h2);
         }
     };
-    if (a.inline_var) {
+    if constexpr (INLINE_VAR) {
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) {
             double h, h2;
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
             hring[i][1][tid] = h2;
         }
     }
-    int slot0 = 0;                                       // ring slot of window row 0
 
     const double kc = wt_tap_s<K, double>(hw) * wt_tap_s<K, double>(hw);
     // One step of the march.  The window does NOT slide through the registers: the row loop is unrolled K
@@ -129,22 +127,18 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
         const int64_t roff = (int64_t)(q + d * r) * g.P;
         const double I = win[(hw + U) % K][hw];
         double vv;
-        if (a.inline_var) {
+        if constexpr (INLINE_VAR) {
             double hn, h2n;
             row_filters(win[(K - 1 + U) % K], hn, h2n);  // the row that entered the window
-            {
-                const int sn = slot0 == 0 ? K - 1 : slot0 - 1;
-                hring[sn][0][tid] = hn;
-                hring[sn][1][tid] = h2n;
-            }
+            hring[(K - 1 + U) % K][0][tid] = hn;
+            hring[(K - 1 + U) % K][1][tid] = h2n;
             double m, p;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 double h, h2;
                 if (i < K - 1) {
-                    const int si = slot0 + i < K ? slot0 + i : slot0 + i - K;
-                    h = hring[si][0][tid];
-                    h2 = hring[si][1][tid];
+                    h = hring[(i + U) % K][0][tid];
+                    h2 = hring[(i + U) % K][1][tid];
                 } else {
                     h = hn;
                     h2 = h2n;
@@ -152,10 +146,9 @@ __global__ __launch_bounds__(256) void wt64_bilateral_march_kernel(ChainArgsT<do
                 m = (i == 0) ? wt_tap_s<K, double>(0) * h : fma(wt_tap_s<K, double>(i), h, m);
                 p = (i == 0) ? wt_tap_s<K, double>(0) * h2 : fma(wt_tap_s<K, double>(i), h2, p);
             }
-            slot0 = slot0 + 1 == K ? 0 : slot0 + 1;
             vv = wt_var_point(p, m, a.f1, a.f2, 0);
         } else {
-            vv = a.aux[roff + x];
+            vv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wt_row_rsrc(a.aux + roff, g.P), 8u * (unsigned)x, 0, 0));
         }
         double norm = kc;
         double acc = kc * I;

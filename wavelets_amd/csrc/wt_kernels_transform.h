@@ -172,32 +172,21 @@ __global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
 // ---------------------------------------------------------------------------------------------
 typedef unsigned int wt_su2 __attribute__((ext_vector_type(2)));
 typedef float wt_sf2 __attribute__((ext_vector_type(2)));
-// descriptor of one row (P floats) behind a wave-uniform pointer: range check = the row's pitch
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_row_rsrc(const float *row, int P)
-{
-    const uint64_t ra = (uint64_t)row;
-    const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
-                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
-    return __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * 4, 0x00020000);
-}
 __device__ __forceinline__ void wt_store2(float *row, int x, int P, float2 v)
 {
     const wt_sf2 t = {v.x, v.y};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), wt_row_rsrc(row, P), (unsigned)x * 4u, 0, 0);
+#ifndef WT_BILX_STORE_AUX
+#define WT_BILX_STORE_AUX 0
+#endif
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), wt_row_rsrc(row, P), (unsigned)x * 4u, 0, WT_BILX_STORE_AUX);
 }
-// symmetric reflection of the bilateral kernels' two border rules (Geo::border 0 / 1; wt_refl_b without the
-// 'mirror' rules the launch code refuses)
-__device__ __forceinline__ int wt_refl_01(int i, int n, int d, int border)
-{
-    if ((unsigned)i < (unsigned)n) return i;
-    if (border == 0) return wt_refl(i, n);
-    int o = i % d;
-    if (o < 0) o += d;
-    return o + d * wt_refl((i - o) / d, (n - o + d - 1) / d);
-}
-
+#ifdef WT_BILX_WAVES
+#define WT_BILX_ATTR __attribute__((amdgpu_waves_per_eu(WT_BILX_WAVES, WT_BILX_WAVES)))
+#else
+#define WT_BILX_ATTR
+#endif
 template <int K, bool INLINE_VAR, bool PAIRED>
-__global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
+__global__ __launch_bounds__(256) WT_BILX_ATTR void wt_bilateral2_kernel(ChainArgs a)
 {
     constexpr int hw = K / 2;
     const Geo g = a.g;

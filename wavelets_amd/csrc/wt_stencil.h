@@ -31,6 +31,26 @@ __device__ __forceinline__ const T *wt_row_b(const T *base, const Geo &g, int gy
     const int ry = wt_refl_b(gy, g.H, d, g.border);
     return base + (int64_t)(ry - g.row0) * g.P;
 }
+// descriptor of one row (P elements of T) behind a wave-uniform pointer: range check = the row's pitch
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_row_rsrc(const T *row, int P)
+{
+    const uint64_t ra = (uint64_t)row;
+    const uint64_t ua = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) |
+                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)ua, 0, P * (int)sizeof(T), 0x00020000);
+}
+// symmetric reflection of the bilateral kernels' two border rules (Geo::border 0 / 1; wt_refl_b without the
+// 'mirror' rules the launch code refuses)
+__device__ __forceinline__ int wt_refl_01(int i, int n, int d, int border)
+{
+    if ((unsigned)i < (unsigned)n) return i;
+    if (border == 0) return wt_refl(i, n);
+    int o = i % d;
+    if (o < 0) o += d;
+    return o + d * wt_refl((i - o) / d, (n - o + d - 1) / d);
+}
+
 __device__ __forceinline__ float4 wt_load4_b(const float *row, int xo, int W, int d, int border)
 {
     if (xo >= 0 && xo + 3 < W) return *reinterpret_cast<const float4 *>(row + xo);

@@ -34,10 +34,13 @@ int wt64_bilateral_launch(const StencilCtx &sc, const double *in, const double *
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
     dim3 grid, block;
-    WT_TRY(wt_chain_geometry<double>(sc.g, s, a, grid, block, (sc.g.W + 63) / 64));     // one pixel per lane
+    WT_TRY(wt_march_geometry<double>(sc.g, s, a, grid, block, (sc.g.W + 63) / 64, 4));     // one pixel per lane, 4 waves side by side
     ProfScope ps(sc.ctx, "wt64_bilateral_kernel", sc.stream);
-    if (sc.family == WT_B3SPLINE) hipLaunchKernelGGL((wt64_bilateral_march_kernel<5>), grid, block, 0, sc.stream, a);
-    else hipLaunchKernelGGL((wt64_bilateral_march_kernel<3>), grid, block, 0, sc.stream, a);
+    const bool b3 = sc.family == WT_B3SPLINE;
+    if (b3 && a.inline_var) hipLaunchKernelGGL((wt64_bilateral_march_kernel<5, true>), grid, block, 0, sc.stream, a);
+    else if (b3) hipLaunchKernelGGL((wt64_bilateral_march_kernel<5, false>), grid, block, 0, sc.stream, a);
+    else if (a.inline_var) hipLaunchKernelGGL((wt64_bilateral_march_kernel<3, true>), grid, block, 0, sc.stream, a);
+    else hipLaunchKernelGGL((wt64_bilateral_march_kernel<3, false>), grid, block, 0, sc.stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }

@@ -55,6 +55,23 @@ static int wt_chain_geometry(const Geo &g, int s, ChainArgsT<T> &a, dim3 &grid, 
     return 0;
 }
 
+// Geometry of the bilateral marches (wt_bilateral2_kernel, wt64_bilateral_march_kernel): NW waves side by side on one
+// chain item (phase x chunk), `wx` waves across a row; the chunking is wt_chain_geometry's, the items run over grid.y.
+template <typename T>
+static int wt_march_geometry(const Geo &g, int s, ChainArgsT<T> &a, dim3 &grid, dim3 &block, int wx, int NW)
+{
+    WT_TRY(wt_chain_geometry<T>(g, s, a, grid, block, wx));
+    int64_t items = (int64_t)a.d * a.chunks;
+    while (items > 65528) {                               // grid.y limit
+        a.S *= 2;
+        a.chunks = ((g.nrows + a.d - 1) / a.d + a.S - 1) / a.S;
+        items = (int64_t)a.d * a.chunks;
+    }
+    grid = dim3((wx + NW - 1) / NW, (unsigned)((items + 7) / 8 * 8));   // multiple of 8: wt_xcd_remap
+    block = dim3(64, NW);
+    return 0;
+}
+
 // Row kernel (taps from an LDS copy of the row) where the horizontal halo fits the workgroup.
 template <typename T, int K, int MODE, int NW>
 static int wt_launch_row_t(const StencilCtx &sc, ChainArgsT<T> a, int HX, const char *name)

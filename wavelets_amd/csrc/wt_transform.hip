@@ -229,24 +229,8 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     dim3 grid, block;
     const bool small = (1 << s) < 4, b3 = p->family == WT_B3SPLINE;
     if (g_opt_bilateral2) {                              // two pixels per thread: 4 waves per SIMD
-#ifdef WT_BILX_OLDGEO
-        WT_TRY(chain_geometry(p, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64));
-#else
-        // NW waves side by side on one chain: the chain items (phase x chunk) run over grid.y alone
-        static const int NW = getenv("WT_BIL_NW") ? std::max(1, std::min(4, atoi(getenv("WT_BIL_NW")))) : 4;   // (experiments; the LDS ring holds 256 threads)
-        const int wx = ((p->g.W + 1) / 2 + 63) / 64;            // waves across a row
-        WT_TRY(chain_geometry(p, s, a, grid, block, wx));
-        {
-            int64_t items = (int64_t)a.d * a.chunks;
-            while (items > 65528) {                               // grid.y limit
-                a.S *= 2;
-                a.chunks = ((p->g.nrows + a.d - 1) / a.d + a.S - 1) / a.S;
-                items = (int64_t)a.d * a.chunks;
-            }
-            grid = dim3((wx + NW - 1) / NW, (unsigned)((items + 7) / 8 * 8));
-            block = dim3(64, NW);
-        }
-#endif
+        // 4 waves side by side on one chain item (the LDS ring holds 256 threads)
+        WT_TRY(wt_march_geometry<float>(p->g, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64, 4));
         // WT_PROF_SCALES=1: one profiler entry per dilation (tools/bench_bil.py)
         static const bool by_scale = getenv("WT_PROF_SCALES") != nullptr;
         static char names[25][40];
