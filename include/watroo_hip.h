@@ -53,7 +53,8 @@ int wt_device_count(int *count);
 /* process-wide tuning / A-B switches (every setting produces the same bits).
  * "row_kernel" (default 1): single-scale operators use the LDS row kernel where the dilation
  *   allows, 0 forces the chain-march kernel;  "lattice_kernel" (1): lattice kernel for d >= 64;
- *   "bilateral2" (1): two-pixel-per-thread bilateral kernel (0: the four-pixel kernel).
+ *   "bilateral_paired" (1): the float32 bilateral march fetches an operand pair with one 8-byte load (0: two 4-byte loads:
+ *                  the generic path of polyphase borders; same bits).
  * "overlap" (1): multi-GPU strips run the halo exchange of the next pass beside the interior
  *   rows of the current one (second stream), 0 = every exchange between the passes;
  *   "overlap_reserve" (16): compute units the interior launch leaves to the RCCL kernels.

@@ -1076,23 +1076,26 @@ def test_coefficients_copy_and_pickle(W):
         np.testing.assert_array_equal(o.data, c.data)
 
 
-@pytest.mark.parametrize("fam_name,shape", [("b3spline", (300, 517)), ("triangle", (257, 300)), ("b3spline", (1100, 2050))])
-def test_two_pixel_bilateral_kernel_equals_four_pixel_kernel_bitwise(W, fam_name, shape):
-    """wt_bilateral2_kernel (2 pixels per thread, row filters of the variance cached in an LDS ring)
-    performs the per-pixel operations of wt_bilateral_kernel in the same order: every plane of a
-    bilateral transform is bit-identical whichever kernel runs (option "bilateral2")."""
+@pytest.mark.parametrize("fam_name,shape", [("b3spline", (300, 517)), ("triangle", (257, 300)), ("b3spline", (1100, 2050)),
+                                            ("b3spline", (40, 37)), ("triangle", (9, 6)), ("b3spline", (64, 1))])
+def test_bilateral_march_paired_loads_equal_the_generic_loads_bitwise(W, fam_name, shape):
+    """wt_bilateral2_kernel fetches an operand pair (x + j d, x + j d + 1) with ONE 8-byte buffer load at the lower of the
+    two reflected indices and swaps / duplicates by two selects in the waves that touch the image border (round 6);
+    the generic path (polyphase borders; option "bilateral_paired" = 0) loads the two pixels separately.  Same
+    arithmetic: every plane is bit-identical - including odd widths (unaligned pairs, a dead second pixel) and images
+    smaller than the dilated kernel (several bounces)."""
     from wavelets_amd import _lib as L
     fam = W.B3spline if fam_name == "b3spline" else W.Triangle
     a = rnd(shape, 31)
     out = {}
     try:
         for mode in (0, 1):
-            L.set_option("bilateral2", mode)
+            L.set_option("bilateral_paired", mode)
             c = W.AtrousTransform(fam, bilateral=1.0)(a, 6)
             out[mode] = c.data.copy()
             c2 = W.AtrousTransform(fam, bilateral=[1.0, 2.0, 0.5], bilateral_scaling=True)(a, 5)
             out[mode + 2] = c2.data.copy()
     finally:
-        L.set_option("bilateral2", 1)
+        L.set_option("bilateral_paired", 1)
     np.testing.assert_array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
     np.testing.assert_array_equal(out[2].view(np.uint32), out[3].view(np.uint32))

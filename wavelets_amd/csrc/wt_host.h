@@ -80,7 +80,7 @@ int rccl_load();
 
 // ------------------------------------------------------------------ options (wt_set_option, wt_transform.hip)
 extern int g_opt_tri4, g_opt_scatter, g_opt_scatter_strips;                  // wt_core.hip
-extern int g_opt_hist_window, g_opt_bilateral2, g_opt_overlap, g_opt_overlap_reserve, g_opt_split_dry, g_opt_host_pipeline;   // wt_transform.hip
+extern int g_opt_hist_window, g_opt_bilateral_paired, g_opt_overlap, g_opt_overlap_reserve, g_opt_split_dry, g_opt_host_pipeline;   // wt_transform.hip
 extern int g_opt_wow_overlap;                                                // wt_core.hip
 extern int g_opt_axis_filter;                                                // wt_apps.hip
 void wt_set_fused64(int on);                                                 // wt_f64.hip

@@ -15,149 +15,21 @@
 // K10  bilateral (range-weighted) dilated convolution - watroo/wavelets.py:74-105
 //   out = (k_c I + sum_t k_t e_t I_t) / (k_c + sum_t k_t e_t),
 //   e_t = exp(-((I - I_t)^2) / var / 2)                        (numexpr expression, :97)
-// Full K x K tap set (not separable), so this kernel is transcendental/VALU-bound, not
-// HBM-bound: K*K-1 exponentials per pixel.  A lane owns 4 adjacent pixels (16-byte row loads,
-// like every other kernel); per tap the weight is ONE v_exp_f32:
+// Full K x K tap set (not separable): K*K-1 exponentials per pixel.  Per tap the weight is ONE v_exp_f32:
 //   k_t * exp(-d^2/(2 var)) = 2^( d^2 * (-log2(e)/(2 var)) + log2(k_t) )
 // with the per-pixel factor -log2(e)/(2 var) formed once (one division per pixel instead of
 // one per tap).  fp32 rounding differs from the reference's exp()/divide sequence by a few
-// ulp of the weight - inside the stated bilateral tolerance (2e-5 * max|input|).
-// ---------------------------------------------------------------------------------------------
-// Work decomposition is the chain march of K1: a thread owns 4 columns and one polyphase row
-// chain, and keeps the K x K (dilated) neighbourhood rows in a register window that slides one
-// chain step per iteration - every input row is fetched once per chain (K coalesced 16-byte
+// ulp of the weight - inside the stated bilateral tolerance.
+// Work decomposition is the chain march of K1: a thread owns a group of columns and one polyphase row
+// chain, and keeps the K x K (dilated) neighbourhood rows in a register window that advances one
+// chain step per iteration - every input row is fetched once per chain (K coalesced
 // loads at x + j*d, L2-served) instead of once per output row, which is what makes the large
 // dilations of wow() (d up to 1024, where a tile has no spatial reuse) HBM-neutral.
-template <int K, bool SMALL_D>
-__global__ __launch_bounds__(256) void wt_bilateral_kernel(ChainArgs a)
-{
-    constexpr int hw = K / 2;
-    constexpr int NX = SMALL_D ? 3 : K;   // float4 per window row
-    const Geo g = a.g;
-    int bx, by;
-    wt_xcd_remap(bx, by);
-    const int x = (bx * 64 + threadIdx.x) * 4;
-    if (x >= g.W) return;
-    // one wave = one threadIdx.y: make the item (and with it the chain phase, the chunk, the row
-    // pointers and the loop counters) scalar - the compiler cannot prove threadIdx.y wave-uniform
-    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
-    const int d = a.d;
-    const int q = item % d;
-    const int c = item / d;
-    if (c >= a.chunks || q >= g.nrows) return;
-    const int n_q = (g.nrows - q + d - 1) / d;
-    const int r0 = c * a.S;
-    const int r1 = min(r0 + a.S, n_q);
-    if (r0 >= r1) return;
-    const int gy0 = g.row0 + q;
-    constexpr bool small_d = SMALL_D;    // d < 4: taps are sub-float4 shifts
-
-    // win[i][j]: row (r - hw + i) of the chain; j-th float4 of that row:
-    //   d >= 4: pixels x + (j - hw) d .. +3     (K float4 per row)
-    //   d <  4: pixels x - 4 + 4 j .. +3        (3 float4 per row: e[12] of wt_hrow)
-    float4 win[K][NX];
-    auto load_win_row = [&](int r, float4 (&dst)[NX]) {
-        const float *row = wt_row_b(a.in, g, gy0 + d * r, d);
-#pragma unroll
-        for (int j = 0; j < NX; ++j)
-            dst[j] = wt_load4_b(row, SMALL_D ? x - 4 + 4 * j : x + (j - hw) * d, g.W, d, g.border);
-    };
-#pragma unroll
-    for (int i = 0; i < K; ++i) load_win_row(r0 - hw + i, win[i]);
-    float4 nxt[NX];
-
-    const float kc = wt_tap<K>(hw) * wt_tap<K>(hw);
-    for (int r = r0; r < r1; ++r) {
-        // software prefetch of the row that enters the window in the next iteration
-        load_win_row(min(r + 1, r1 - 1) + hw, nxt);
-        const int64_t off = (int64_t)(q + d * r) * g.P + x;
-        const float4 Ic4 = win[hw][SMALL_D ? 1 : hw];
-        const float I[4] = {Ic4.x, Ic4.y, Ic4.z, Ic4.w};
-        float vv[4];
-        if (a.inline_var) {
-            // variance of watroo/wavelets.py:434-436 from the neighbourhood already in
-            // registers: same arithmetic (row filters, then column filter) as the MODE_VAR chain
-            // kernel, so the result is bit-identical to the separate variance pass
-            float4 m4, p4, h, h2, cdummy;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                wt_hrow_filter<float, K, MODE_VAR, SMALL_D>(win[i], d, h, h2, cdummy);
-                m4 = (i == 0) ? f4_scale(wt_tap<K>(0), h) : f4_fma(wt_tap<K>(i), h, m4);
-                p4 = (i == 0) ? f4_scale(wt_tap<K>(0), h2) : f4_fma(wt_tap<K>(i), h2, p4);
-            }
-            vv[0] = wt_var_point(p4.x, m4.x, a.f1, a.f2, 0);
-            vv[1] = wt_var_point(p4.y, m4.y, a.f1, a.f2, 0);
-            vv[2] = wt_var_point(p4.z, m4.z, a.f1, a.f2, 0);
-            vv[3] = wt_var_point(p4.w, m4.w, a.f1, a.f2, 0);
-        } else {
-            const float4 v4 = *reinterpret_cast<const float4 *>(a.aux + off);
-            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
-        }
-        float norm[4], acc[4], s2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            norm[k] = kc;
-            acc[k] = kc * I[k];
-            s2[k] = wt_div_nr(-0.72134752044448170368f, vv[k]);   // -log2(e) / (2 var)
-        }
-        // taps in the reference order (watroo/wavelets.py:89-91): kernel index (i, j) pairs with
-        // the shift (K-1-i-hw, K-1-j-hw) * d
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const float4 (&wr)[NX] = win[K - 1 - i];
-            float e[12] = {0.f};
-            if constexpr (small_d) {
-                e[0] = wr[0].x; e[1] = wr[0].y; e[2] = wr[0].z; e[3] = wr[0].w;
-                e[4] = wr[1].x; e[5] = wr[1].y; e[6] = wr[1].z; e[7] = wr[1].w;
-                e[8] = wr[2].x; e[9] = wr[2].y; e[10] = wr[2].z; e[11] = wr[2].w;
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                if (i == hw && j == hw) continue;
-                const float lk = wt_tap_log2<K>(i) + wt_tap_log2<K>(j);
-                float It[4];
-                if constexpr (small_d) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        It[k] = d == 1 ? e[4 + k + (K - 1 - j - hw)] : e[4 + k + 2 * (K - 1 - j - hw)];
-                } else {
-                    const float4 t = wr[SMALL_D ? 0 : K - 1 - j];
-                    It[0] = t.x; It[1] = t.y; It[2] = t.z; It[3] = t.w;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float diff = I[k] - It[k];
-                    const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, s2[k], lk));
-                    norm[k] += w;
-                    acc[k] = fmaf(It[k], w, acc[k]);
-                }
-            }
-        }
-        float o[4], ow[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o[k] = wt_div_nr(acc[k], norm[k]);
-            ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
-        }
-        const int64_t roff = (int64_t)(q + d * r) * g.P;
-        wt_store4(a.out_c + roff, x, g.P, make_float4(o[0], o[1], o[2], o[3]));
-        if (a.out_w) wt_store4(a.out_w + roff, x, g.P, make_float4(ow[0], ow[1], ow[2], ow[3]));
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-#pragma unroll
-            for (int i = 0; i < K - 1; ++i) win[i][j] = win[i + 1][j];
-            win[K - 1][j] = nxt[j];
-        }
-    }
-}
-
+// (Until round 5 a four-pixel-per-thread form of this kernel was kept beside the two-pixel one as its bitwise
+//  cross-check; it lost every timing since round 3 and went in round 6 - the cross-check is now the generic
+//  load path of the kernel below, option "bilateral_paired" = 0.)
 // ---------------------------------------------------------------------------------------------
-// K10b  the same bilateral convolution with TWO pixels per thread (any dilation).  The 4-pixel kernel
-// holds its K x K float4 neighbourhood in ~240 VGPRs: 2 waves per SIMD, and at that occupancy the
-// dependent chain of every tap (difference, square, scale, exp, accumulate) - not the instruction
-// count - sets the pace.  Half the pixels per thread halve the window (K x K float2) and allow
-// 4 waves per SIMD.  Per-pixel arithmetic is identical to wt_bilateral_kernel (same operations
-// in the same order, variance included), so the two kernels produce the same bits.
+// K10b  TWO pixels per thread (any dilation): a K x K float2 window, 92 VGPRs, 5 waves per SIMD.
 //
 // Round 6: the row that enters the window is fetched with raw BUFFER loads (SGPR descriptor of the row +
 // one 32-bit lane offset per operand, 2 K four-byte loads per row) instead of per-lane branches between one
@@ -175,35 +47,21 @@ typedef float wt_sf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void wt_store2(float *row, int x, int P, float2 v)
 {
     const wt_sf2 t = {v.x, v.y};
-#ifndef WT_BILX_STORE_AUX
-#define WT_BILX_STORE_AUX 0
-#endif
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), wt_row_rsrc(row, P), (unsigned)x * 4u, 0, WT_BILX_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wt_su2, t), wt_row_rsrc(row, P), (unsigned)x * 4u, 0, 0);
 }
-#ifdef WT_BILX_WAVES
-#define WT_BILX_ATTR __attribute__((amdgpu_waves_per_eu(WT_BILX_WAVES, WT_BILX_WAVES)))
-#else
-#define WT_BILX_ATTR
-#endif
 template <int K, bool INLINE_VAR, bool PAIRED>
-__global__ __launch_bounds__(256) WT_BILX_ATTR void wt_bilateral2_kernel(ChainArgs a)
+__global__ __launch_bounds__(256) void wt_bilateral2_kernel(ChainArgs a)
 {
     constexpr int hw = K / 2;
     const Geo g = a.g;
     int bx, by;
     wt_xcd_remap(bx, by);
-#ifdef WT_BILX_OLDGEO
-    const int x = (bx * 64 + threadIdx.x) * 2;
-    if (x >= g.W) return;
-    const int item = __builtin_amdgcn_readfirstlane(by * blockDim.y + threadIdx.y);
-#else
     // the waves of a workgroup sit SIDE BY SIDE on the same chain (round 6): a workgroup reads and writes
     // blockDim.y * 512 contiguous bytes of one row per step.  (Until round 5 each wave had a chain of its own and the
     // chip kept ~5 000 rows open with 512-byte accesses: HBM pages, not the VALU, set the kernel's pace.)
     const int x = ((bx * (int)blockDim.y + (int)threadIdx.y) * 64 + threadIdx.x) * 2;
     if (x >= g.W) return;
-    const int item = __builtin_amdgcn_readfirstlane(by);
-#endif
+    const int item = __builtin_amdgcn_readfirstlane(by);   // the chain item (phase, chunk) of this workgroup: scalar
     const int d = a.d;
     const int q = item % d;
     const int c = item / d;
@@ -311,19 +169,11 @@ __global__ __launch_bounds__(256) WT_BILX_ATTR void wt_bilateral2_kernel(ChainAr
     // Same operations in the same order in every phase: identical bits.
     auto step = [&](const int r, auto utag) {
         constexpr int U = decltype(utag)::value;
-#ifndef WT_BILX_NOLOAD
         load_win_row(min(r + 1, r1 - 1) + hw, nxt);      // software prefetch of the entering row
-#else
-        for (int j = 0; j < K; ++j) nxt[j] = win[U][j];
-#endif
         const int64_t roff = (int64_t)(q + d * r) * g.P;
         const float I[2] = {win[(hw + U) % K][hw].x, win[(hw + U) % K][hw].y};
         float vv[2];
-#ifdef WT_BILX_NOVAR
-        if constexpr (false) {
-#else
         if constexpr (INLINE_VAR) {
-#endif
             float2 hn, h2n;
             row_filters(win[(K - 1 + U) % K], hn, h2n);  // the row that entered the window
             hring[(K - 1 + U) % K][0][tid] = hn;
@@ -348,8 +198,6 @@ __global__ __launch_bounds__(256) WT_BILX_ATTR void wt_bilateral2_kernel(ChainAr
             }
             vv[0] = wt_var_point(p[0], m[0], a.f1, a.f2, 0);
             vv[1] = wt_var_point(p[1], m[1], a.f1, a.f2, 0);
-        } else if constexpr (INLINE_VAR) {
-            vv[0] = I[0] * I[0] + a.f1; vv[1] = I[1] * I[1] + a.f1;       // (WT_BILX_NOVAR timing experiment)
         } else {
             // variance plane: both pixels through the row's descriptor (the second column clamped into the
             // row: a lane whose second pixel is past the image stores nothing for it)
@@ -359,20 +207,16 @@ __global__ __launch_bounds__(256) WT_BILX_ATTR void wt_bilateral2_kernel(ChainAr
         }
         // The two pixels of a thread are a register PAIR throughout the tap loop: difference,
         // square, exponent (one v_pk_fma with the tap's log2 weight as the addend), and the two
-        // accumulations are packed-FP32 instructions; only the exponentials are per pixel.  Same
-        // operations in the same order as the four-pixel kernel: identical bits.
+        // accumulations are packed-FP32 instructions; only the exponentials are per pixel.
         typedef float wt_p2 __attribute__((ext_vector_type(2)));
         const wt_p2 Iv = {I[0], I[1]};
         wt_p2 norm = {kc, kc};
         wt_p2 acc = kc * Iv;
         const wt_p2 s2 = {wt_div_nr(-0.72134752044448170368f, vv[0]), wt_div_nr(-0.72134752044448170368f, vv[1])};   // -log2(e) / (2 var)
-        // taps in the reference order (watroo/wavelets.py:89-91), as in wt_bilateral_kernel
+        // taps in the reference order (watroo/wavelets.py:89-91): kernel index (i, j) pairs with the shift
+        // (K-1-i-hw, K-1-j-hw) * d
 #pragma unroll
-#ifdef WT_BILX_NOTAPS
-        for (int i = 0; i < 1; ++i) {
-#else
         for (int i = 0; i < K; ++i) {
-#endif
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 if (i == hw && j == hw) continue;
@@ -392,13 +236,8 @@ __global__ __launch_bounds__(256) WT_BILX_ATTR void wt_bilateral2_kernel(ChainAr
             o[k] = wt_div_nr(acc[k], norm[k]);
             ow[k] = I[k] - o[k];                           // detail plane, wavelets.py:442
         }
-#ifdef WT_BILX_NOSTORE
-        const int SP = 0;          // empty descriptor: the stores issue and are dropped by the range check
-#else
-        const int SP = g.P;
-#endif
-        wt_store2(a.out_c + roff, x, SP, make_float2(o[0], o[1]));
-        if (a.out_w) wt_store2(a.out_w + roff, x, SP, make_float2(ow[0], ow[1]));
+        wt_store2(a.out_c + roff, x, g.P, make_float2(o[0], o[1]));
+        if (a.out_w) wt_store2(a.out_w + roff, x, g.P, make_float2(ow[0], ow[1]));
         fix_row(nxt);
 #pragma unroll
         for (int j = 0; j < K; ++j) win[U][j] = nxt[j];    // slot of the row that left <- the row that entered

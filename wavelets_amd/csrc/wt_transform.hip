@@ -80,7 +80,7 @@ static int chain_geometry(const wt_plan *p, int s, ChainArgs &a, dim3 &grid, dim
 int g_opt_fused_fast = getenv("WT_FUSED_NO_FAST") ? 0 : 1;
 int g_opt_row_kernel = getenv("WT_NO_ROW_KERNEL") ? 0 : 1;      // (read by wt_stencil_launch.h in both units)
 int g_opt_lattice = getenv("WT_NO_LATTICE") ? 0 : 1;
-int g_opt_bilateral2 = getenv("WT_NO_BILATERAL2") ? 0 : 1;   // 2-pixel bilateral kernel
+int g_opt_bilateral_paired = 1;   // bilateral march: one 8-byte load per operand pair (0: the generic two-load path)
 // multi-GPU: run the halo exchange of pass i+1 beside the interior rows of pass i (0 = every
 // exchange on the compute stream, between the passes)
 int g_opt_overlap = getenv("WT_NO_OVERLAP") ? 0 : 1;
@@ -99,7 +99,7 @@ extern "C" int wt_set_option(const char *name, int value)
     if (!name) WT_FAIL("wt_set_option: null name");
     if (!strcmp(name, "row_kernel")) { g_opt_row_kernel = value != 0; return 0; }
     if (!strcmp(name, "lattice_kernel")) { g_opt_lattice = value != 0; return 0; }
-    if (!strcmp(name, "bilateral2")) { g_opt_bilateral2 = value != 0; return 0; }
+    if (!strcmp(name, "bilateral_paired")) { g_opt_bilateral_paired = value != 0; return 0; }
     if (!strcmp(name, "overlap")) { g_opt_overlap = value != 0; return 0; }
     if (!strcmp(name, "wow_overlap")) { g_opt_wow_overlap = value != 0; return 0; }
     if (!strcmp(name, "axis_filter")) { g_opt_axis_filter = value != 0; return 0; }
@@ -227,32 +227,22 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     a.in = in; a.out_c = out; a.out_w = out_w; a.aux = var;
     a.inline_var = var == nullptr; a.f1 = f1; a.f2 = f2;
     dim3 grid, block;
-    const bool small = (1 << s) < 4, b3 = p->family == WT_B3SPLINE;
-    if (g_opt_bilateral2) {                              // two pixels per thread: 4 waves per SIMD
-        // 4 waves side by side on one chain item (the LDS ring holds 256 threads)
-        WT_TRY(wt_march_geometry<float>(p->g, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64, 4));
-        // WT_PROF_SCALES=1: one profiler entry per dilation (tools/bench_bil.py)
-        static const bool by_scale = getenv("WT_PROF_SCALES") != nullptr;
-        static char names[25][40];
-        if (by_scale && !names[s][0]) snprintf(names[s], sizeof names[s], "wt_bilateral2_kernel d=%d", 1 << s);
-        ProfScope ps(p->ctx, by_scale ? names[s] : "wt_bilateral2_kernel");
-        static const int lds_pad = getenv("WT_BIL_LDS_PAD") ? atoi(getenv("WT_BIL_LDS_PAD")) : 0;   // experiments: dynamic LDS to cap the workgroups per CU
-        const bool paired = p->g.border == 0;      // one 8-byte load per operand pair (wt_kernels_transform.h)
+    const bool b3 = p->family == WT_B3SPLINE;
+    // 4 waves side by side on one chain item (the LDS ring holds 256 threads)
+    WT_TRY(wt_march_geometry<float>(p->g, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64, 4));
+    // WT_PROF_SCALES=1: one profiler entry per dilation (tools/bench_bil.py)
+    static const bool by_scale = getenv("WT_PROF_SCALES") != nullptr;
+    static char names[25][40];
+    if (by_scale && !names[s][0]) snprintf(names[s], sizeof names[s], "wt_bilateral2_kernel d=%d", 1 << s);
+    ProfScope ps(p->ctx, by_scale ? names[s] : "wt_bilateral2_kernel");
+    static const int lds_pad = getenv("WT_BIL_LDS_PAD") ? atoi(getenv("WT_BIL_LDS_PAD")) : 0;   // experiments: dynamic LDS to cap the workgroups per CU
+    const bool paired = p->g.border == 0 && g_opt_bilateral_paired;      // one 8-byte load per operand pair (wt_kernels_transform.h)
 #define WT_BIL2(KK, IV, PR) hipLaunchKernelGGL((wt_bilateral2_kernel<KK, IV, PR>), grid, block, lds_pad, p->ctx->stream, a)
-        if (b3 && a.inline_var) { if (paired) WT_BIL2(5, true, true); else WT_BIL2(5, true, false); }
-        else if (b3) { if (paired) WT_BIL2(5, false, true); else WT_BIL2(5, false, false); }
-        else if (a.inline_var) { if (paired) WT_BIL2(3, true, true); else WT_BIL2(3, true, false); }
-        else { if (paired) WT_BIL2(3, false, true); else WT_BIL2(3, false, false); }
+    if (b3 && a.inline_var) { if (paired) WT_BIL2(5, true, true); else WT_BIL2(5, true, false); }
+    else if (b3) { if (paired) WT_BIL2(5, false, true); else WT_BIL2(5, false, false); }
+    else if (a.inline_var) { if (paired) WT_BIL2(3, true, true); else WT_BIL2(3, true, false); }
+    else { if (paired) WT_BIL2(3, false, true); else WT_BIL2(3, false, false); }
 #undef WT_BIL2
-        WT_HIP(hipGetLastError());
-        return 0;
-    }
-    WT_TRY(chain_geometry(p, s, a, grid, block));
-    ProfScope ps(p->ctx, "wt_bilateral_kernel");
-    if (b3 && small) hipLaunchKernelGGL((wt_bilateral_kernel<5, true>), grid, block, 0, p->ctx->stream, a);
-    else if (b3) hipLaunchKernelGGL((wt_bilateral_kernel<5, false>), grid, block, 0, p->ctx->stream, a);
-    else if (small) hipLaunchKernelGGL((wt_bilateral_kernel<3, true>), grid, block, 0, p->ctx->stream, a);
-    else hipLaunchKernelGGL((wt_bilateral_kernel<3, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
     return 0;
 }
