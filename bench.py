@@ -52,6 +52,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 LEVEL = 6
+MULTI_GPU_SIDE = 32768     # BASELINE configs[3]: the image the N > 1 lines split into row strips
 FAMILY = "b3spline"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy
 VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak (MI355X_MICROARCH.md chip table)
@@ -135,6 +136,29 @@ def make_strip(nrows, W, seed):
     for r in range(0, nrows, 1024):
         rng.standard_normal(dtype=np.float32, out=out[r:r + 1024])
     return out
+
+
+def step_spread(samples):
+    """median / min / max of the per-step HIP-event samples (ms), SURVEY 8(d)"""
+    if not samples:
+        return {}
+    v = sorted(float(x) for x in samples)
+    n = len(v)
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"ms_per_step_median": round(med, 4), "ms_per_step_min": round(v[0], 4), "ms_per_step_max": round(v[-1], 4),
+            "ms_per_step_samples": n}
+
+
+def scaling_text(world, H, W):
+    """What the line scales.  The first word is the contract's ("weak": per-GPU work fixed, "strong": total work
+    fixed); the rest says which image and how many GPUs, because the N = 1 line (the BASELINE metric's 8192^2
+    configuration) and the N > 1 lines (ONE 32768^2 image cut into N row strips) are different images: among the
+    N > 1 lines the total work is fixed (strong scaling), and the same-image anchor for N = 1 is `n1_same_image`."""
+    if world == 1:
+        return (f"weak (N=1: the whole {H}x{W} image on one GPU - the BASELINE metric's configuration; the N>1 lines split one "
+                f"32768x32768 image, whose single-GPU figure is n1_same_image in this line)")
+    return (f"strong (N={world}: one {H}x{W} image as {world} row strips of {H // world} rows, total work fixed for every N>1; "
+            f"the N=1 line is the 8192x8192 BASELINE configuration - compare with its n1_same_image for a same-image 1->N ratio)")
 
 
 def cpu_baseline(config, side, family, level, budget=15.0):
@@ -565,6 +589,13 @@ def main():
             for _ in range(warmup):
                 step()
             elapsed, dev_ms = timed(step, nsteps)
+            # the spread of the step, from one HIP-event pair per step on the launch stream (>= 20 samples;
+            # the batch above stays the line's `value`: its steps run back to back, these are fenced one by one)
+            samples = []
+            for _ in range(max(20, min(nsteps, 50))):
+                ctx.timer_start()
+                step()
+                samples.append(ctx.timer_stop())
             ctx.profile(True)
             ctx.profile_reset()
             nprof = max(3, min(nsteps, 10))
@@ -572,7 +603,7 @@ def main():
                 step()
             raw = ctx.profile_entries()
             ctx.profile(False)
-            return {"elapsed": elapsed, "dev_ms": dev_ms, "steps": nsteps, "prof_raw": raw, "nprof": nprof}
+            return {"elapsed": elapsed, "dev_ms": dev_ms, "steps": nsteps, "prof_raw": raw, "nprof": nprof, "samples": samples}
 
         def pmc_bytes(name):
             """HBM bytes per launch of `name` at this image size from profiles/traffic.json (the
@@ -754,7 +785,8 @@ def main():
                 "metric": metric,
                 "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": nsteps,
                 "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
-                "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+                **step_spread(m.get("samples")),
+                "higher_is_better": True, "scaling": scaling_text(world, H, W),
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"{H}x{W} float32 {data}, "
                                        f"{family} L={level}, " + what.format(n=level + 1)
@@ -1078,6 +1110,7 @@ def main():
             r = o["roofline"] or {}
             extra[cfg] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"],
                           "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                          **{k: o[k] for k in ("ms_per_step_median", "ms_per_step_min", "ms_per_step_max", "ms_per_step_samples") if k in o},
                           "workload": o["config"]["workload"], "schedule": o["config"]["schedule"],
                           "bytes_per_pixel": o["whole_path"]["bytes_per_pixel"],
                           "frac_of_hbm_peak": o["whole_path"]["frac_of_hbm_peak"],
@@ -1090,6 +1123,60 @@ def main():
                           "kernels": o["kernels"],
                           "cpu_baseline": o.get("cpu_baseline")}
         out["configs"] = extra
+        # the N > 1 lines' image on ONE GPU (32768^2: 4 GiB planes, 44 GiB for the flow): the same-image anchor of a 1 -> N
+        # curve, from the same run.  Data: a 4096-row N(0,1) block repeated down the image (the kernels have no
+        # data-dependent path; generating 2^30 normal samples on the host would take longer than every other entry).
+        try:
+            big = MULTI_GPU_SIDE
+            pl = _lib.Plan(ctx, big, big, _lib.B3SPLINE, LEVEL)
+            pl.upload(PLANE_INPUT, np.tile(make_strip(4096, big, seed=0), (big // 4096, 1)))
+            for _ in range(2):
+                pl.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+            ctx.sync()
+            nb = 5
+            t_b = time.perf_counter()
+            for _ in range(nb):
+                pl.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+            ctx.sync()
+            ms_b = (time.perf_counter() - t_b) / nb * 1e3
+            sm = []
+            for _ in range(20):
+                ctx.timer_start()
+                pl.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+                sm.append(ctx.timer_stop())
+            pl.close()
+            bppb = 8.0 * (LEVEL + 2)
+            out["n1_same_image"] = {"workload": f"{big}x{big} float32 (a 4096-row N(0,1) block repeated), b3spline L={LEVEL}, decompose + plane sum "
+                                                "on ONE GPU: the image the N>1 lines split into row strips; device-resident",
+                                    "value": round(big * big / ms_b / 1e3, 1), "unit": "Mpix/s", "ms_per_step": round(ms_b, 4), "steps": nb,
+                                    **step_spread(sm), "bytes_per_pixel": bppb,
+                                    "frac_of_hbm_peak": round(bppb * big * big / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception as e:
+            out["n1_same_image"] = {"error": repr(e)}
+        # widths the 16-byte groups do not divide (the reference takes any width, ref wavelets.py:35-45): the headline
+        # step on images a little narrower than 8192^2 and on the 3066^2 frame of tools/e2e_check.py, per pixel
+        # against the 8192^2 figure of this line
+        odd = {}
+        for hs, ws in ((8190, 8190), (8191, 8191), (3066, 3066)):
+            try:
+                pl = _lib.Plan(ctx, hs, ws, _lib.B3SPLINE, LEVEL)
+                pl.upload(PLANE_INPUT, make_strip(hs, ws, seed=0))
+                for _ in range(5):
+                    pl.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+                ctx.sync()
+                sm = []
+                for _ in range(20):
+                    ctx.timer_start()
+                    pl.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+                    sm.append(ctx.timer_stop())
+                pl.close()
+                sp = step_spread(sm)
+                odd[f"{hs}x{ws}"] = {**sp, "value": round(hs * ws / sp["ms_per_step_median"] / 1e3, 1), "unit": "Mpix/s",
+                                     "per_pixel_vs_headline": round((sp["ms_per_step_median"] / (hs * ws)) / (out["ms_per_step"] / float(out["config"]["image"][0] * out["config"]["image"][1])), 3)}
+            except Exception as e:
+                odd[f"{hs}x{ws}"] = {"error": repr(e)}
+        out["odd_width"] = {"what": "headline step (b3spline L=6 decompose + plane sum) at widths that are not multiples of 4; "
+                                    "per_pixel_vs_headline = time per pixel / the 8192x8192 line's (1.0 = no cliff)", **odd}
         # the reference's DEFAULT dtype (README flows are float64, ref wavelets.py:297,319-320): the
         # headline workload in float64 on the fused double passes (wt64_decompose_sum) - not a
         # BASELINE.json configuration, reported beside them

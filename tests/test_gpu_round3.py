@@ -184,12 +184,27 @@ def test_bench_default_line_carries_every_config():
     # round 5: BASELINE configs[4] on the float64 engine (tuned float64 kernels: within 3.0 x the float32 flow of the
     # same run; 9.8 x on the generic kernels) and what the first call of a fresh process costs
     f5 = out["float64_cfg5"]
-    assert "error" not in f5 and f5["steps"] >= 3 and 0 < f5["vs_float32_cfg5"] < 3.0, f5       # (2.46-2.65 measured)
+    # (round 6, both marches re-worked: float64 14.9-15.9 ms against float32 5.5-5.65 across boxes = 2.5-2.65 x; the bar is what was
+    #  measured plus the box-to-box spread, not the 2.5 the round-4 review hoped for)
+    assert "error" not in f5 and f5["steps"] >= 3 and 0 < f5["vs_float32_cfg5"] < 2.8 and f5["ms_per_step"] < 16.5, f5
     assert any(k.startswith("wt64_bilateral") for k in f5["kernels_ms_per_step (overlapped kernels both count)"])
     fc = out["first_call"]
     # (100 ms before round 5; 14-15 ms behind an existing context - the review's bar is 30, the tree before the warm-up read 38-41 -, 32-35 straight after creating it)
     assert "error" not in fc and fc["steady_ms"] < fc["first_ms"] < 35.0, fc
     assert fc["first_ms"] < fc["one_shot"]["first_ms"] < 70.0 and fc["warmup_join_ms"] > 0, fc
+    # round 6: the line carries its own spread (>= 20 HIP-event samples), says what it scales, and holds the
+    # N > 1 image on one GPU and the odd-width cases
+    for c in [out] + list(out["configs"].values()):
+        assert c["ms_per_step_samples"] >= 20 and 0 < c["ms_per_step_min"] <= c["ms_per_step_median"] <= c["ms_per_step_max"], c
+        assert c["ms_per_step_median"] < 1.5 * c["ms_per_step"], c
+    assert out["scaling"].startswith("weak (N=1") and "8192x8192" in out["scaling"] and "n1_same_image" in out["scaling"]
+    n1 = out["n1_same_image"]
+    assert "error" not in n1 and "32768x32768" in n1["workload"] and n1["ms_per_step_samples"] >= 20, n1
+    assert 0.5 < (n1["ms_per_step"] / 16.0) / out["ms_per_step"] < 1.5, n1          # per pixel, the 8192^2 rate
+    ow = out["odd_width"]
+    assert {"8190x8190", "8191x8191", "3066x3066"} <= set(ow)
+    for k in ("8190x8190", "8191x8191", "3066x3066"):
+        assert "error" not in ow[k] and ow[k]["per_pixel_vs_headline"] > 0, ow[k]
     rf = out["roofline"]
     assert rf["kernel"] == "wt_fused_kernel" and 0 < rf["frac"] < 1.2
     if rf["traffic"] is not None:
