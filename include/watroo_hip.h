@@ -58,8 +58,8 @@ int wt_device_count(int *count);
  * "overlap" (1): multi-GPU strips run the halo exchange of the next pass beside the interior
  *   rows of the current one (second stream), 0 = every exchange between the passes;
  *   "overlap_reserve" (16): compute units the interior launch leaves to the RCCL kernels.
- * "fused_fast" (1): fused passes use the single-bounce / aligned-group addressing where the image
- *   allows (W % 4 == 0, halo <= image); 0 forces the generic (multi-bounce, gather) addressing.
+ * "fused_fast" (1): fused passes use the single-bounce / whole-group addressing where the image
+ *   allows (halo <= image; any width since round 6); 0 forces the generic (multi-bounce, gather) addressing.
  * "scatter" (4; env WT_SCATTER): planes >= 8 MiB of single-GPU plans created from now on are
  *   mapped over shuffled 2-MiB physical chunks created in groups worth this many planes
  *   (DESIGN.md section 2); 0 = one hipMalloc per plane (see wt_plane_ptr).

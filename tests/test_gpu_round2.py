@@ -64,7 +64,7 @@ def test_bench_step_8192_vs_c_oracle(L, C, fam, level):
 
 
 FAST_SHAPES = [
-    # (H, W, family, level)   W % 4 == 0 everywhere (fast path admissible)
+    # (H, W, family, level)
     (8, 32, "b3spline", 3),         # H below D*(LAT+1): generic anyway
     (15, 32, "b3spline", 3),        # H == LAT_IN + 1 (d1x3: 14 + 1), W == HX
     (16, 36, "b3spline", 3),
@@ -76,6 +76,11 @@ FAST_SHAPES = [
     (700, 964, "triangle", 8),      # d64x2 (triangle: 3 * 64 + 64 = 256 rows)
     (513, 260, "triangle", 5),
     (2048, 1024, "b3spline", 8),    # b3 d64x2: H >= 64 * 7 = 448, W >= 384
+    # round 6: widths the 16-byte groups do not divide take the fast addressing too (the group that straddles the
+    # right border is a swizzle of its own pixels; W % 4 = 1 loads the four pixels that end at the border)
+    (121, 131, "b3spline", 6), (300, 1001, "b3spline", 6), (300, 1002, "b3spline", 6), (300, 1003, "b3spline", 6),
+    (1100, 2098, "b3spline", 6), (700, 965, "triangle", 8), (513, 261, "triangle", 5), (2048, 1027, "b3spline", 8),
+    (16, 37, "b3spline", 3), (15, 33, "b3spline", 3),
 ]
 
 

@@ -133,6 +133,13 @@ template <> __device__ __forceinline__ double2 wt_vzero<double2>() { return make
 // the group read backwards (reflection of an aligned group that lies outside the image)
 __device__ __forceinline__ float4 wt_vrev(float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
 __device__ __forceinline__ double2 wt_vrev(double2 v) { return make_double2(v.y, v.x); }
+// the group that straddles the right image border (W % PX = r != 0): symmetric reflection of its own pixels; for
+// r == 1 the loaded group is the four pixels that END at the border
+__device__ __forceinline__ float4 wt_vstraddle(float4 v, int r)
+{
+    return r == 2 ? make_float4(v.x, v.y, v.y, v.x) : (r == 3 ? make_float4(v.x, v.y, v.z, v.z) : make_float4(v.w, v.w, v.z, v.y));
+}
+__device__ __forceinline__ double2 wt_vstraddle(double2 v, int) { return make_double2(v.x, v.x); }
 // scheduling fence on the components of a row (see the FAST path of the kernel)
 __device__ __forceinline__ void wt_vfence(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void wt_vfence(double2 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }

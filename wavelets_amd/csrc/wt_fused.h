@@ -373,9 +373,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     //   branch (border waves only); rows reflect any number of times.
     const bool lane_interior = (x >= 0) && (x + PX - 1 < g.W);
     const bool wave_has_edge = !__all(lane_interior);
-    const bool lane_rev = FAST && !lane_interior;
-    const int xg = x < 0 ? -PX - x : (x >= g.W ? 2 * g.W - PX - x : x);   // FAST: the group this lane loads
-    const int xc = FAST ? min(max(xg, 0), g.W - PX) : min(max(x, 0), g.P - PX);
+    // FAST with W % PX != 0 (round 6): ONE group per row straddles the right border.  Its reflected pixels lie inside
+    // the same four pixels - (g0, g1, g1, g0) for W % 4 == 2, (g0, g1, g2, g2) for 3, and for 1 the four pixels that
+    // END at the border read as (g3, g3, g2, g1); doubles: (g0, g0) - so it is one load and a swizzle like the
+    // reversed groups, which then start at 2W - PX - x: 8-byte aligned for odd W (a 16-byte load needs 4).
+    const int wrem = g.W % PX;                           // (wave-uniform)
+    const bool lane_str = FAST && x < g.W && x + PX > g.W;
+    const bool lane_rev = FAST && !lane_interior && !lane_str;
+    const int xg = x < 0 ? -PX - x : (x >= g.W ? 2 * g.W - PX - x : (lane_str && PX == 4 && wrem == 1 ? g.W - PX : x));   // FAST: the group this lane loads
+    const int xc = FAST ? min(max(xg, 0), g.P - PX) : min(max(x, 0), g.P - PX);
     const int xi0 = wt_refl(x, g.W), xi1 = wt_refl(x + 1, g.W), xi2 = wt_refl(x + (PX > 2 ? 2 : 0), g.W),
               xi3 = wt_refl(x + (PX > 2 ? 3 : 0), g.W);
     const int gy0 = g.row0 + q;                          // global row of chain element 0
@@ -534,6 +540,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
             wt_vfence(cur);
             if (wave_has_edge) {
                 if (lane_rev) cur = wt_vrev(cur);
+                if (wrem != 0) {
+                    if (lane_str) cur = wt_vstraddle(cur, wrem);
+                }
             }
         }
         V (*buf)[NL] = vbuf[kk & 1];
@@ -865,8 +874,11 @@ static int wt_fused_launch_t(PLAN *p, const FusedArgsT<T> &base, const char *nam
     //  exchange / interior / edge times of the multi-GPU schedule)
     const std::string pname = std::string(name) + (rows.part == 1 ? "/interior" : rows.part == 2 ? "/edge" : "");
     ProfScope ps(p->ctx, pname.c_str());
-    // fast addressing: aligned groups reflect onto aligned groups and no index reflects twice
-    const bool fast = g_opt_fused_fast && g.W % PX == 0 && g.W >= HX && g.H >= D * (hw * ((1 << NS) - 1) + 1);
+    // fast addressing: a group outside the image is a group inside it read backwards (any width since round 6: the one
+    // group that straddles the right border is a swizzle of its own four pixels) and no index reflects twice.  (The
+    // riding histogram counts whole groups: it keeps the generic addressing for widths the groups do not divide.)
+    const bool fast = g_opt_fused_fast && (g.W % PX == 0 || ACC != 3) && g.W >= HX && g.W >= 2 * PX &&
+                      g.H >= D * (hw * ((1 << NS) - 1) + 1);
     if (fast) hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, true>), grid, block, 0, p->ctx->stream, a);
     else hipLaunchKernelGGL((wt_fused_kernel<T, K, NS, D, NW, PD, ACC, false>), grid, block, 0, p->ctx->stream, a);
     WT_HIP(hipGetLastError());
