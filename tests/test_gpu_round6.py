@@ -47,3 +47,77 @@ def test_float64_fused_fast_addressing_at_odd_widths_is_bitwise_the_generic_one(
     for i, (x, y) in enumerate(zip(got[1], got[0])):
         np.testing.assert_array_equal(x.view(np.uint64), y.view(np.uint64), err_msg=f"output {i}")
     plan.close()
+
+
+# --------------------------------------------------------------------------- sequences of frames / channels
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _rnd(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape).astype(np.float32)
+
+
+def test_denoise_many_is_bitwise_the_per_call_api_and_keeps_the_order(L):
+    """16 frames (each different) through sequence.denoise_many on 3 lanes == denoise() frame by frame, bit for bit,
+    in input order; a generator as input; per-frame noise values; float64 and integer frames too."""
+    import wavelets_amd as W
+    frames = [_rnd((300, 517), 100 + i) * (1 + i) + i for i in range(16)]
+    ref = [W.denoise(f, [5, 3]) for f in frames]
+    got = W.denoise_many((f for f in frames), [5, 3])
+    assert len(got) == 16
+    for i in range(16):
+        np.testing.assert_array_equal(got[i].view(np.uint32), ref[i].view(np.uint32), err_msg=f"frame {i}")
+    noise = [0.5 + 0.1 * i for i in range(16)]
+    ref = [W.denoise(f, [4, 2, 1], W.Triangle, n, soft_threshold=False) for f, n in zip(frames, noise)]
+    got = W.denoise_many(frames, [4, 2, 1], W.Triangle, noise, soft_threshold=False, lanes=4)
+    for i in range(16):
+        np.testing.assert_array_equal(got[i].view(np.uint32), ref[i].view(np.uint32), err_msg=f"frame {i} (given noise)")
+    f64 = [f.astype(np.float64) * 10 + 1e3 for f in frames[:5]] + [(f * 50).astype(np.int16) for f in frames[5:8]]
+    ref = [W.denoise(f, [5, 3]) for f in f64]
+    got = W.denoise_many(f64, [5, 3], lanes=2)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a.dtype == b.dtype == np.float64
+        np.testing.assert_array_equal(a.view(np.uint64), b.view(np.uint64), err_msg=f"float64 frame {i}")
+    # a preallocated target, one lane (the plain loop), and an exception inside a lane
+    out = np.empty((16, 300, 517), np.float32)
+    assert W.denoise_many(frames, [5, 3], out=out, lanes=1) is out
+    np.testing.assert_array_equal(out[7].view(np.uint32), W.denoise(frames[7], [5, 3]).view(np.uint32))
+    with pytest.raises(ValueError, match="Unsupported number of dimensions"):
+        W.denoise_many(frames[:3] + [np.ones((2, 2, 2, 2), np.float32)] + frames[3:], [5, 3])
+
+
+def test_sequences_vs_reference_golden_g2_and_wow(L):
+    """the reference-generated denoise fixtures (g2) through denoise_many, wow through wow_many (g4's first case),
+    transform_many == AtrousTransform per frame (device-resident Coefficients from three lanes)."""
+    import wavelets_amd as W
+    g2 = np.load(os.path.join(GOLD, "g2_denoise.npz"))
+    img = g2["img"]
+    frames = [img, img[::-1].copy(), img[:, ::-1].copy(), img.T.copy()]
+    got = W.denoise_many(frames, [5, 3])
+    for a, f in zip(got, frames):
+        np.testing.assert_array_equal(a, W.denoise(f, [5, 3]))
+    assert float(np.abs(got[0] - g2["denoise_53_b3spline"]).max()) <= 4e-5 * float(np.abs(img).max())
+    w_ref = [W.wow(f, denoise_coefficients=[5, 2])[0] for f in frames]
+    w_got = W.wow_many(frames, denoise_coefficients=[5, 2])
+    for a, b in zip(w_got, w_ref):
+        np.testing.assert_array_equal(a[0], b)
+    cs = W.transform_many(frames, 4, W.Triangle)
+    for c, f in zip(cs, frames):
+        np.testing.assert_array_equal(c.data, W.AtrousTransform(W.Triangle)(f, 4).data)
+
+
+def test_enhance_channels_through_the_lanes_vs_golden_g10(L):
+    """enhance() on a (3, H, W) image runs its three channels on three lanes (ref utils.py:60-78 is a loop): the
+    reference-generated g10 fixtures hold, and each channel equals the 2-D call on that channel bit for bit."""
+    from wavelets_amd.utils import enhance
+    g = np.load(os.path.join(GOLD, "g10_enhance.npz"))
+    rgb = g["rgb"]
+    tol = 4e-5 * float(np.abs(g["img"]).max())
+    assert float(np.abs(enhance(rgb.copy(), weights=[[.5, 2], [1], [2, 2, 1]], denoise=[[3], [4, 2], None]) - g["enh_rgb"]).max()) <= tol
+    got = enhance(rgb, weights=[[1.5, 1.2, 1.0]] * 3, denoise=[[3, 2]] * 3)
+    for c in range(3):
+        np.testing.assert_array_equal(got[c], enhance(rgb[c], weights=[1.5, 1.2, 1.0], denoise=[3, 2]), err_msg=f"channel {c}")
+    # per-channel lists (ref:19-33) and a given noise per channel
+    got = enhance(rgb, [0.3, 0.2, 0.1], weights=[[1, 2], [1.5], [2, 1, 1]], denoise=[[3], [2, 1], []])
+    for c, (w, d) in enumerate(zip([[1, 2], [1.5], [2, 1, 1]], [[3], [2, 1], []])):
+        np.testing.assert_array_equal(got[c], enhance(rgb[c], [0.3, 0.2, 0.1][c], weights=list(w), denoise=list(d)), err_msg=f"channel {c}")

@@ -381,12 +381,50 @@ def _shutdown():
                 except Exception:           # (interpreter exit: report nothing, keep releasing)
                     pass
     _default_ctx.clear()
+    _lane_ctx.clear()
     del _pool[:]
 
 
-def default_context(device=None):
-    """Process-wide context (device from WATROO_HIP_DEVICE, default 0)."""
+_tls = threading.local()          # .ctx: the context the API calls of THIS thread run on (use_context)
+_lane_ctx = {}                    # device -> [Context]: the extra contexts of sequence.map_frames' worker lanes
+
+
+class use_context:
+    """`with use_context(ctx):` - the numpy-to-numpy calls of this thread (denoise, wow, AtrousTransform ...) run on
+    `ctx` (its stream, its scratch, plans pooled under it) instead of the process-wide default context.  What the
+    worker lanes of sequence.map_frames use: one context per lane, so that the upload of one frame, the passes of
+    another and the download of a third overlap."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "ctx", None)
+        _tls.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _tls.ctx = self.prev
+        return False
+
+
+def lane_contexts(n, device=None):
+    """`n` contexts of their own (HIP stream, scratch, warm-up) on `device`, created once per process and reused."""
     if device is None:
+        device = int(os.environ.get("WATROO_HIP_DEVICE", "0"))
+    with _pool_lock:
+        lanes = _lane_ctx.setdefault(device, [])
+        while len(lanes) < n:
+            lanes.append(Context(device))
+        return lanes[:n]
+
+
+def default_context(device=None):
+    """Process-wide context (device from WATROO_HIP_DEVICE, default 0); inside `use_context(ctx)`: that context."""
+    if device is None:
+        ctx = getattr(_tls, "ctx", None)
+        if ctx is not None and ctx._h:
+            return ctx
         device = int(os.environ.get("WATROO_HIP_DEVICE", "0"))
     ctx = _default_ctx.get(device)
     if ctx is None:

@@ -58,13 +58,18 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     weights = prepare_params(weights, img.ndim)
     denoise = prepare_params(denoise, img.ndim)
     atrous = AtrousTransform(**kwargs)
-    for c in channels:
+    plans = []
+    for c in channels:                                                    # the reference's list plumbing, in its order
         dns = denoise if c is Ellipsis else denoise[c]
         wgt = weights if c is Ellipsis else weights[c]
         if len(wgt) < len(dns):                                           # ref:65-68
             wgt.extend([1] * (len(dns) - len(wgt)))
         elif len(dns) < len(wgt):
             dns.extend([0] * (len(wgt) - len(dns)))
+        plans.append((c, dns, wgt))
+
+    def channel(item):
+        c, dns, wgt = item
         coeffs = atrous(img[c], len(wgt))                                 # ref:70
         if len(args) == 2:
             coeffs.noise = args[1] if c is Ellipsis else args[1][c]       # ref:71-72
@@ -72,7 +77,19 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
             coeffs.noise = coeffs.get_noise()
         plan = coeffs._denoise_sum(dns, weights=wgt, soft_threshold=soft_threshold,
                                    write_back=False)                       # ref:76-78
-        out[c] = plan.download(PLANE_OUT)
+        tgt = out[c]
+        want = np.float64 if isinstance(plan, _lib.Plan64) else np.float32
+        if (isinstance(tgt, np.ndarray) and tgt.ndim == 2 and tgt.dtype == want and tgt.shape == tuple(plan.shape)
+                and tgt.strides[1] == tgt.itemsize and tgt.flags.writeable):
+            plan.download(PLANE_OUT, out=tgt)                             # straight into the caller's rows
+        else:
+            out[c] = plan.download(PLANE_OUT)
+        return None
+
+    # the channels of a colour image are independent frames: one lane each, so that the upload of one
+    # channel, the passes of another and the download of a third overlap (sequence.map_frames; bit-identical)
+    from .sequence import map_frames
+    map_frames(channel, plans, lanes=len(plans) if len(plans) > 1 else 1)
     return out
 
 
