@@ -893,6 +893,37 @@ def main():
                 out["pcie_inclusive_serial_mpix_s"] = round(H * W / (time.perf_counter() - t) / 1e6, 1)
                 del recon
                 if config == "headline":
+                    # a SEQUENCE of frames, numpy to numpy (the reference's real use: image series, ref utils.py:83-102 per
+                    # frame): denoise(frame, [5, 3]) in a loop against sequence.denoise_many on three lanes - upload of one
+                    # frame, passes of another, download of a third side by side; bit-identical results
+                    try:
+                        import wavelets_amd as WA
+                        nseq = 16
+                        frames = [img + np.float32(i) for i in range(nseq)]
+                        loop_ms = many_ms = None
+                        for _ in range(2):                 # (first round: lanes, plans, page-locked result blocks)
+                            t = time.perf_counter()
+                            res = [WA.denoise(f, [5, 3]) for f in frames]
+                            loop_ms = (time.perf_counter() - t) / nseq * 1e3
+                            ref7 = res[7].copy()
+                            del res
+                        for _ in range(3):
+                            t = time.perf_counter()
+                            res = WA.denoise_many(frames, [5, 3])
+                            dt = (time.perf_counter() - t) / nseq * 1e3
+                            many_ms = dt if many_ms is None or _ > 0 and dt < many_ms else many_ms
+                            same = bool(np.array_equal(res[7], ref7))
+                            del res
+                        del frames
+                        out["pcie_inclusive_sequence_mpix_s"] = round(H * W / many_ms / 1e3, 1)
+                        out["sequence"] = {"what": f"{nseq} frames of {side}^2 float32, denoise(frame, [5, 3]) with the per-frame MAD noise "
+                                                   "estimate, numpy to numpy (pageable inputs, page-locked results)",
+                                           "loop_ms_per_frame": round(loop_ms, 3), "denoise_many_ms_per_frame": round(many_ms, 3),
+                                           "lanes": 3, "bitwise_equal_to_the_loop": same,
+                                           "loop_mpix_s": round(H * W / loop_ms / 1e3, 1)}
+                    except Exception as e:
+                        out["sequence"] = {"error": repr(e)}
+                if config == "headline":
                     # what a one-shot user sees: the FIRST denoise(img, [5, 3]) of a fresh process, numpy to numpy,
                     # next to its steady state (tools/first_call.py in a child process; ~3 s of wall time)
                     try:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 7
+#define WT_ABI_VERSION 8
 
 typedef struct wt_ctx wt_ctx;   /* device + stream (+ RCCL communicator) */
 typedef struct wt_plan wt_plan; /* geometry + device planes of one image strip */
@@ -127,6 +127,13 @@ int wt_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level,
 int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level,
                          int64_t row0, int64_t nrows, int64_t halo_rows, int rank,
                          int nranks, wt_plan **out);
+/* wt_plan_create with the placement of THIS plan's planes given instead of taken from the process-wide "scatter"
+ * option: scatter = 0 keeps every plane on plain hipMalloc, n > 0 maps planes >= 8 MiB over shuffled physical chunks
+ * created in groups worth n planes.  What the Python API's plan pool uses for its numpy-to-numpy calls
+ * (watroo/utils.py:83-102 crosses PCIe both ways: the mapping costs more than it earns there; no counterpart in the
+ * reference). */
+int wt_plan_create_placed(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level, int scatter,
+                          wt_plan **out);
 int wt_plan_destroy(wt_plan *plan);
 /* geometry query: out[0..7] = H, W, pitch, row0, nrows, halo, max_level, family */
 int wt_plan_info(wt_plan *plan, int64_t out[8]);

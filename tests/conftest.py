@@ -45,7 +45,9 @@ def measured_tol(what, got, ref, atol, rtol=0.0, allow=0):
     4 x what that log recorded on MI355X (ratio 0.25)."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     tol = atol + rtol * np.abs(ref)
-    ratio = np.abs(got - ref) / tol
+    err = np.abs(got - ref)
+    # (a zero tolerance - atol = 0 at a reference value of exactly 0 - admits only an exact match: ratio 0 or inf, never 0 / 0)
+    ratio = np.divide(err, tol, out=np.where(err == 0, 0.0, np.inf), where=tol > 0)
     order = np.sort(ratio, axis=None)
     worst = float(order[-1 - allow]) if order.size > allow else 0.0
     try:

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libwatroo_hip.so lacks {n}"
     assert sorted(_lib.SIGNATURES) == names       # python binding covers the whole header
-    assert _lib.load().wt_abi_version() == 7
+    assert _lib.load().wt_abi_version() == 8
 
 
 def test_schedule_host_logic():

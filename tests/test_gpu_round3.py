@@ -201,6 +201,9 @@ def test_bench_default_line_carries_every_config():
     n1 = out["n1_same_image"]
     assert "error" not in n1 and "32768x32768" in n1["workload"] and n1["ms_per_step_samples"] >= 20, n1
     assert 0.5 < (n1["ms_per_step"] / 16.0) / out["ms_per_step"] < 1.5, n1          # per pixel, the 8192^2 rate
+    sq = out["sequence"]                                     # 16 frames numpy to numpy: 9.9-10.0 ms per frame in a loop, 5.8-5.9 on three lanes
+    assert "error" not in sq and sq["bitwise_equal_to_the_loop"] is True and sq["denoise_many_ms_per_frame"] < 0.75 * sq["loop_ms_per_frame"], sq
+    assert out["pcie_inclusive_sequence_mpix_s"] > 1.3 * sq["loop_mpix_s"]
     ow = out["odd_width"]
     assert {"8190x8190", "8191x8191", "3066x3066"} <= set(ow)
     for k in ("8190x8190", "8191x8191", "3066x3066"):

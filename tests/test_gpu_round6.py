@@ -121,3 +121,22 @@ def test_enhance_channels_through_the_lanes_vs_golden_g10(L):
     got = enhance(rgb, [0.3, 0.2, 0.1], weights=[[1, 2], [1.5], [2, 1, 1]], denoise=[[3], [2, 1], []])
     for c, (w, d) in enumerate(zip([[1, 2], [1.5], [2, 1, 1]], [[3], [2, 1], []])):
         np.testing.assert_array_equal(got[c], enhance(rgb[c], [0.3, 0.2, 0.1][c], weights=list(w), denoise=list(d)), err_msg=f"channel {c}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_bilateral_transform_propagates_nan_like_the_reference(L, dtype):
+    """A NaN sample reaches every coefficient whose dilated neighbourhood (or local variance) holds it, exactly where the
+    numpy oracle's does (the float64 march clamps the exponent argument - weights never fall below k_t 2^-64 -, but a
+    NaN neighbour still enters through value x weight and a NaN centre through k_c I); everything else stays finite
+    and within the bilateral tolerance."""
+    from oracle import atrous_numpy as O
+    import wavelets_amd as W
+    a = (np.random.default_rng(3).standard_normal((96, 130)) * 2 + 10).astype(dtype)
+    a[40, 77] = np.nan
+    got = W.AtrousTransform(W.B3spline, bilateral=1)(a, 3).data
+    ref = O.atrous_standard(a, 3, "b3spline", bilateral=1)
+    assert got.dtype == dtype
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    tol = (1e-11 if dtype == np.float64 else 2e-5) * float(np.nanmax(np.abs(a)))
+    assert float(np.abs(got[ok] - ref[ok]).max()) <= tol

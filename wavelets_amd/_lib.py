@@ -62,6 +62,7 @@ SIGNATURES = {
     "wt_ctx_comm_info": (_c.c_int, [_vp, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "wt_comm_selftest": (_c.c_int, [_vp, _i64, _c.POINTER(_c.c_int)]),
     "wt_plan_create": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _c.POINTER(_vp)]),
+    "wt_plan_create_placed": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_vp)]),
     "wt_plan_create_strip": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _c.c_int, _i64, _i64, _i64,
                                         _c.c_int, _c.c_int, _c.POINTER(_vp)]),
     "wt_plan_destroy": (_c.c_int, [_vp]),
@@ -213,7 +214,7 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                 fn.restype, fn.argtypes = res, args
-            if L.wt_abi_version() != 7:
+            if L.wt_abi_version() != 8:
                 raise WatrooHipError("libwatroo_hip.so ABI version mismatch")
             _lib = L
     return _lib
@@ -571,16 +572,21 @@ class Plan:
     cold = False             # True: created by the pool (acquire_plan), planes on plain hipMalloc
 
     def __init__(self, ctx, H, W, family, max_level, row0=0, nrows=None, halo_rows=0,
-                 rank=0, nranks=1):
+                 rank=0, nranks=1, scatter=None):
         self._h = _vp()
         self.ctx = ctx
         nrows = H if nrows is None else nrows
         # `family` is TRIANGLE / B3SPLINE, or a tuple of 1-D taps for a user-defined scaling
         # function (wt_plan_set_taps); the tuple is kept as self.family (plan-pool key)
         taps = tuple(float(t) for t in family) if isinstance(family, (tuple, list)) else None
-        check(load().wt_plan_create_strip(ctx._h, H, W, B3SPLINE if taps else family, max_level,
-                                          row0, nrows, halo_rows, rank, nranks,
-                                          _c.byref(self._h)))
+        if scatter is not None and nranks == 1 and row0 == 0 and nrows == H:
+            # placement of THIS plan's planes (0: plain hipMalloc), whatever the process-wide "scatter" option says
+            check(load().wt_plan_create_placed(ctx._h, H, W, B3SPLINE if taps else family, max_level, int(scatter),
+                                               _c.byref(self._h)))
+        else:
+            check(load().wt_plan_create_strip(ctx._h, H, W, B3SPLINE if taps else family, max_level,
+                                              row0, nrows, halo_rows, rank, nranks,
+                                              _c.byref(self._h)))
         info = (_i64 * 8)()
         check(load().wt_plan_info(self._h, info))
         (self.H, self.W, self.pitch, self.row0, self.nrows, self.halo, self.max_level,
@@ -1135,14 +1141,9 @@ def acquire_plan(ctx, H, W, family, max_level):
                 plan = _pool.pop(i)[1]
                 plan.set_border(0)
                 return plan
-        if not _COLD_FIRST_USE or _option_values["scatter"] == 0:
-            return Plan(ctx, H, W, family, max_level)
-        keep = _option_values["scatter"]      # (the option is process-wide: changed and restored under the pool's lock)
-        set_option("scatter", 0)
-        try:
-            plan = Plan(ctx, H, W, family, max_level)
-        finally:
-            set_option("scatter", keep)
+    if not _COLD_FIRST_USE:
+        return Plan(ctx, H, W, family, max_level)
+    plan = Plan(ctx, H, W, family, max_level, scatter=0)      # (per plan: no process-wide option is touched)
     plan.cold = True
     return plan
 

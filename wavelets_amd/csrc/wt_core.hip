@@ -759,6 +759,8 @@ int plane_base(wt_plan *p, int id, float **base)
     return 0;
 }
 
+static thread_local int t_scatter_override = -1;      // wt_plan_create_placed: the placement of the plan being created
+
 extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level,
                                     int64_t row0, int64_t nrows, int64_t halo_rows, int rank,
                                     int nranks, wt_plan **out)
@@ -799,7 +801,7 @@ extern "C" int wt_plan_create_strip(wt_ctx *ctx, int64_t H, int64_t W, int famil
     p->rank = rank;
     p->nranks = nranks;
     p->plane_floats = (size_t)(nrows + 2 * halo) * (size_t)P;
-    p->scatter = g_opt_scatter;
+    p->scatter = t_scatter_override >= 0 ? t_scatter_override : g_opt_scatter;
     {
         // default skew: 4 KiB + 256 B per plane index (keeps 16-byte alignment); WT_PLANE_SKEW
         // (bytes, multiple of 16) overrides it for experiments
@@ -823,6 +825,15 @@ extern "C" int wt_plan_create(wt_ctx *ctx, int64_t H, int64_t W, int family, int
 {
     WtGuard guard_(ctx_of(ctx));
     return wt_plan_create_strip(ctx, H, W, family, max_level, 0, H, 0, 0, 1, out);
+}
+
+extern "C" int wt_plan_create_placed(wt_ctx *ctx, int64_t H, int64_t W, int family, int max_level, int scatter, wt_plan **out)
+{
+    WtGuard guard_(ctx_of(ctx));
+    t_scatter_override = scatter < 0 ? 0 : (scatter > 16 ? 16 : scatter);
+    const int rc = wt_plan_create_strip(ctx, H, W, family, max_level, 0, H, 0, 0, 1, out);
+    t_scatter_override = -1;
+    return rc;
 }
 
 void destroy_events(std::vector<hipEvent_t> &ev)

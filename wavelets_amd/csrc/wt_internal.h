@@ -98,6 +98,13 @@ struct wt_ctx {
     // side_pending: work has been queued here since the last join (every main-stream access to a plane joins
     // first: plane_base); in_side: an entry point is issuing its launches on the side stream right now
     // (`stream` IS the side stream for its duration, WtSideScope).  Created on first use.
+    // INVARIANT the overlap rests on: while side_pending, the main stream touches (a) planes only through plane_base()
+    // (which joins the side stream first and ends the overlap) and (b) none of the context scratch below (d_hist,
+    // d_partials, h_pinned) nor the planes the side work writes (SCRATCH(3), tmp[0], PLANE_OUT) - the bilateral
+    // kernels queued on the main stream read and write only the plane pointers they were launched with.  An entry
+    // point that reaches plane data or the context scratch some other way (cached pointers, FFT state) must call
+    // wt_side_join(ctx) first; wt_plane_sum_early additionally assumes that planes [0, count) were all updated on
+    // the side stream since the transform (overlap_ok && side_pending).
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side_done = nullptr;
     bool side_pending = false;
