@@ -1,7 +1,7 @@
 /* A stand-in for librccl.so with just the entry points libwatroo_hip.so binds (wt_core.hip, rccl_load), for
  * tests of the error paths: WATROO_HIP_RCCL_LIB=<this library>.  Nothing moves: Send / Recv / AllReduce return
  * success without touching their buffers.  RCCL_STUB_FAIL_SEND=<n> makes the n-th ncclSend of the process
- * (1-based) return ncclInternalError once.  The group depth and the call counts are exported so that a test
+ * (1-based) return ncclInternalError once, RCCL_STUB_FAIL_ALLREDUCE=<n> the n-th ncclAllReduce.  The group depth and the call counts are exported so that a test
  * can check that a failed exchange left no group open. */
 #include <stdlib.h>
 #include <string.h>
@@ -27,7 +27,16 @@ int ncclSend(const void *b, size_t n, int t, int peer, void *comm, void *st)
     return 0;
 }
 int ncclRecv(void *b, size_t n, int t, int peer, void *comm, void *st) { (void)b; (void)n; (void)t; (void)peer; (void)comm; (void)st; g_recvs++; return 0; }
-int ncclAllReduce(const void *s, void *r, size_t n, int t, int op, void *comm, void *st) { (void)s; (void)r; (void)n; (void)t; (void)op; (void)comm; (void)st; return 0; }
+static int g_allreduces;
+int ncclAllReduce(const void *s, void *r, size_t n, int t, int op, void *comm, void *st)
+{
+    (void)s; (void)r; (void)n; (void)t; (void)op; (void)comm; (void)st;
+    g_allreduces++;
+    const char *f = getenv("RCCL_STUB_FAIL_ALLREDUCE");     /* the n-th ncclAllReduce of the process (1-based) fails once */
+    if (f && atoi(f) == g_allreduces) return 3;
+    return 0;
+}
+int rccl_stub_allreduces(void) { return g_allreduces; }
 const char *ncclGetErrorString(int e) { return e == 3 ? "internal error (stub)" : (e == 5 ? "invalid usage (stub)" : "stub error"); }
 int ncclGetVersion(int *v) { *v = 29999; return 0; }
 /* {open groups, GroupStart calls, GroupEnd calls, Sends, Recvs, GroupStart calls made while a group was open} */

@@ -140,3 +140,60 @@ def test_bilateral_transform_propagates_nan_like_the_reference(L, dtype):
     ok = ~np.isnan(ref)
     tol = (1e-11 if dtype == np.float64 else 2e-5) * float(np.nanmax(np.abs(a)))
     assert float(np.abs(got[ok] - ref[ok]).max()) <= tol
+
+
+def test_failed_allreduce_surfaces_and_leaves_the_context_usable(tmp_path):
+    """The all-reduced scalars of a strip (wt_reduce's moments, the MAD median's histograms - Coefficients.get_noise and
+    wow's np.std / min / max on N GPUs) over the stand-in RCCL (tests/stubs/rccl_stub.c) with the n-th ncclAllReduce
+    failing: the call raises RCCL's error naming the entry point, nothing hangs, and the SAME calls succeed right
+    afterwards on the same context and plan (no marker, scratch buffer or side-stream state is left behind)."""
+    import subprocess
+    import textwrap
+    so = tmp_path / "librccl_stub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", str(so), os.path.join(ROOT, "tests", "stubs", "rccl_stub.c")])
+    script = textwrap.dedent(f'''
+        import ctypes, os, sys
+        import numpy as np
+        sys.path.insert(0, {ROOT!r})
+        from wavelets_amd import _lib as L
+        ctx = L.Context(0)
+        assert L.comm_version() == 29999
+        stub = ctypes.CDLL(os.environ["WATROO_HIP_RCCL_LIB"])
+        ctx.comm_init(0, 2, L.Context.unique_id())
+        plan = L.Plan(ctx, 256, 320, L.B3SPLINE, 2, row0=0, nrows=128, halo_rows=16, rank=0, nranks=2)
+        a = np.random.default_rng(0).standard_normal((128, 320), dtype=np.float32)
+        plan.upload(L.PLANE_INPUT, a)
+        def failing(call, what):
+            os.environ["RCCL_STUB_FAIL_ALLREDUCE"] = str(stub.rccl_stub_allreduces() + 1)
+            try:
+                call()
+            except L.WatrooHipError as e:
+                assert "RCCL error 3" in str(e) and "AllReduce" in str(e) and ("wt_" in str(e) or "select_pass" in str(e)), str(e)
+            else:
+                raise SystemExit(what + ": the failing all-reduce did not raise")
+            finally:
+                os.environ["RCCL_STUB_FAIL_ALLREDUCE"] = "0"
+        failing(lambda: plan.reduce(L.PLANE_INPUT), "wt_reduce")
+        s, s2, lo, hi = plan.reduce(L.PLANE_INPUT)              # the stub moves nothing: this rank's own moments
+        assert abs(s - float(a.astype(np.float64).sum())) < 1e-6 * a.size and lo == float(a.min()) and hi == float(a.max())
+        failing(lambda: plan.abs_median(L.PLANE_INPUT), "wt_abs_median")
+        # (the stub adds nobody's bins: a strip's median over the GLOBAL count cannot succeed with it - what must work
+        #  afterwards is everything that shares the context's select state and histogram words)
+        whole = L.Plan(ctx, 128, 320, L.B3SPLINE, 2)
+        whole.upload(L.PLANE_INPUT, a)
+        assert whole.abs_median(L.PLANE_INPUT) == float(np.median(np.abs(a)))
+        # a transform whose first pass rode the histogram, a median whose all-reduce fails, then the same on the
+        # unsharded plan: the riding-histogram marker of the failed call must not leak into it
+        plan.decompose(L.PLANE_INPUT, 2, L.FLAG_FUSED | L.FLAG_MEDIAN_HIST | L.FLAG_NO_EXCHANGE)
+        failing(lambda: plan.abs_median(0), "wt_abs_median")
+        whole.decompose(L.PLANE_INPUT, 2, L.FLAG_FUSED | L.FLAG_MEDIAN_HIST)
+        assert whole.abs_median(0) == float(np.median(np.abs(whole.download(0))))
+        s, s2, lo, hi = plan.reduce(L.PLANE_INPUT)
+        assert lo == float(a.min()) and hi == float(a.max())
+        whole.close()
+        plan.close()
+        print("OK", stub.rccl_stub_allreduces())
+    ''')
+    env = dict(os.environ, WATROO_HIP_RCCL_LIB=str(so), RCCL_STUB_NRANKS="2")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -191,6 +191,36 @@ def main():
             same(f"denoise_sum plane {s}", st.plane(s), c.data[s][r0:r0 + n])
         st.plan.close()
 
+    # placement of the strip planes chosen by measurement (StripTransform(planes="auto"), collective): a shape whose
+    # planes exceed 8 MiB, both placements timed and compared through the all-reduced moments; whatever wins, the
+    # result must be the unsharded one bit for bit, and every rank must have reached the same decision
+    from wavelets_amd import parallel as PAR
+    Hb, Wb = 2048 * world, 2304
+    big = np.random.default_rng(9).standard_normal((Hb, Wb), dtype=np.float32)
+    st = StripTransform(ctx, Hb, Wb, 6, B3spline, planes="auto")
+    meas = PAR._STRIP_PLANES.get((Hb, Wb, 6, L.B3SPLINE, world, True, "measured"))
+    checks.append(("auto placement measured both", bool(meas) and meas.get("hipmalloc") is not None))
+    votes = group.gather(st.planes)
+    checks.append(("auto placement agreed by every rank", rank != 0 or len(set(votes)) == 1))
+    r0, n = st.row0, st.nrows
+    st.upload(big[r0:r0 + n])
+    recon = st.decompose_sum()
+    whole = L.Plan(ctx, Hb, Wb, L.B3SPLINE, 6)
+    whole.upload(L.PLANE_INPUT, big)
+    whole.decompose_sum(L.PLANE_INPUT, 6, L.PLANE_OUT, L.FLAG_FUSED)
+    same(f"auto placement ({st.planes}) reconstruction", recon, whole.download(L.PLANE_OUT)[r0:r0 + n])
+    st.plan.close()
+    for forced in ("scattered", "hipmalloc"):
+        st = StripTransform(ctx, Hb, Wb, 6, B3spline, planes=forced)
+        st.upload(big[r0:r0 + n])
+        same(f"{forced} strip planes reconstruction", st.decompose_sum(), whole.download(L.PLANE_OUT)[r0:r0 + n])
+        mem = st.plan.memory()
+        checks.append((f"{forced} strip planes placement", (mem[1] > 0) == (forced == "scattered")))
+        st.plan.close()
+    whole.close()
+    if rank == 0:
+        print(f"check_rccl_ranks: strip planes chosen by measurement: {votes[0]} {meas}", flush=True)
+
     # a self-test between a transform whose first pass histogrammed |w_0| and the median that would
     # start from those bins: the self-test zeroes words of the same buffer, so the marker must go
     # (constant image: every |w_0| is exactly 0 and lives in the bins the self-test wipes)

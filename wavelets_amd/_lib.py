@@ -245,7 +245,8 @@ def fft_supported(H, W):
     return bool(ok.value)
 
 
-_option_values = {"scatter": int(os.environ.get("WT_SCATTER", "4"))}     # options the pool restores after a temporary change
+_option_values = {"scatter": int(os.environ.get("WT_SCATTER", "4")),      # options restored after a temporary change
+                  "scatter_strips": int(os.environ.get("WT_SCATTER_STRIPS", "0"))}
 
 
 def set_option(name, value):

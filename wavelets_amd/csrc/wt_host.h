@@ -70,7 +70,7 @@ int rccl_load();
     do {                                                                                      \
         int r_ = (expr);                                                                      \
         if (r_ != 0) {                                                                        \
-            wt_set_error("RCCL error %d (%s) at %s:%d: %s", r_,                               \
+            wt_set_error("%s: RCCL error %d (%s) at %s:%d: %s", __func__, r_,                 \
                          g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__,   \
                          __LINE__, #expr);                                                    \
             return 3;                                                                         \

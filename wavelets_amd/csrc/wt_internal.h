@@ -169,6 +169,7 @@ struct wt_plan {
     size_t skew_floats = 0;
     int n_allocs = 0;
     int scatter = 0;                        // the "scatter" option when the plan was created: its planes keep that placement
+    int scatter_strips = 0;                 // ... and the "scatter_strips" option (strip plans: mapped planes or plain hipMalloc)
     void *arena = nullptr;                  // WT_ARENA experiment: planes carved from one allocation
     int arena_left = 0;
     size_t arena_stride = 0;

@@ -52,6 +52,72 @@ def init_comm(ctx, rank, nranks, bcast):
     return ctx
 
 
+_STRIP_PLANES = {}       # (H, W, level, family, nranks, fused) -> "hipmalloc" | "scattered": what "auto" measured in this process
+
+
+def _make_strip_plan(ctx, H, W, family, level, row0, nrows, halo, rank, nranks, scattered):
+    """a strip plan whose planes >= 8 MiB are mapped over shuffled physical chunks (scattered) or plain hipMalloc"""
+    with _lib._pool_lock:                      # (the option is read when the plan is created and stays with the plan)
+        keep = _lib._option_values.get("scatter_strips", 0)
+        _lib.set_option("scatter_strips", int(bool(scattered)))
+        try:
+            return Plan(ctx, H, W, family, level, row0=row0, nrows=nrows, halo_rows=halo, rank=rank, nranks=nranks)
+        finally:
+            _lib.set_option("scatter_strips", keep)
+
+
+def choose_strip_planes(ctx, H, W, family, level, row0, nrows, halo, rank, nranks, fused=True, steps=3):
+    """Placement of a strip plan's planes, MEASURED over the real transport (collective: every rank calls it with the
+    same arguments).  Single-GPU plans are ~20 % faster with their planes mapped over shuffled chunks (DESIGN.md
+    section 2); whether RCCL's transport moves halo rows in and out of such planes as fast - and correctly - is a
+    property of the node, so: `steps` steps of decompose_sum on a synthetic strip with each placement (after one
+    warm-up step), the slowest rank's time all-reduced (wt_reduce of a filled plane), and the all-reduced moments of
+    the reconstruction and of w_0 compared between the two runs.  "scattered" only if it is correct and at least
+    3 % faster.  Cached per (shape, ranks) in the process; WATROO_HIP_STRIP_PLANES=hipmalloc|scattered skips the
+    measurement."""
+    import os
+    env = os.environ.get("WATROO_HIP_STRIP_PLANES", "auto").lower()
+    if env in ("hipmalloc", "scattered"):
+        return env
+    key = (H, W, level, family, nranks, bool(fused))
+    if key in _STRIP_PLANES:
+        return _STRIP_PLANES[key]
+    plane_bytes = (nrows + 2 * halo) * ((W + 3) // 4 * 4) * 4
+    if nranks == 1 or plane_bytes < (8 << 20) or isinstance(family, tuple):
+        _STRIP_PLANES[key] = "hipmalloc"       # (planes below 8 MiB are never mapped; nothing to choose)
+        return "hipmalloc"
+    strip = (np.arange(row0, row0 + nrows, dtype=np.float32)[:, None] * np.float32(0.25)
+             + (np.arange(W, dtype=np.float32) % 7)[None, :]).astype(np.float32)
+    flags = FLAG_FUSED if fused else 0
+    seen = {}
+    for name in ("hipmalloc", "scattered"):
+        try:
+            plan = _make_strip_plan(ctx, H, W, family, level, row0, nrows, halo, rank, nranks, name == "scattered")
+            plan.upload(PLANE_INPUT, strip)
+            plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(steps):
+                plan.decompose_sum(PLANE_INPUT, level, PLANE_OUT, flags)
+            ms = ctx.timer_stop() / steps
+            moments = plan.reduce(PLANE_OUT) + plan.reduce(0)
+            plan.fill(_lib.PLANE_SCRATCH(0), ms)
+            slowest = plan.reduce(_lib.PLANE_SCRATCH(0))[3]
+            plan.close()
+            seen[name] = (slowest, moments)
+        except _lib.WatrooHipError:
+            if name == "hipmalloc":
+                raise
+            seen[name] = None                  # mapped planes unavailable here: hipMalloc it is
+    best = "hipmalloc"
+    if seen.get("scattered") is not None and seen["scattered"][1] == seen["hipmalloc"][1] \
+            and seen["scattered"][0] < 0.97 * seen["hipmalloc"][0]:
+        best = "scattered"
+    _STRIP_PLANES[key] = best
+    _STRIP_PLANES[key + ("measured",)] = {k: (v[0] if v else None) for k, v in seen.items()}
+    return best
+
+
 class StripTransform:
     """The a-trous transform of one row strip of a global H x W image on this rank's GPU.
 
@@ -64,7 +130,7 @@ class StripTransform:
     fp64 moments inside wt_reduce)."""
 
     def __init__(self, ctx, H, W, level, scaling_function_class=B3spline, rank=None,
-                 nranks=None, fused=True):
+                 nranks=None, fused=True, planes="auto"):
         self.ctx = ctx
         self.rank = ctx.rank if rank is None else rank
         self.nranks = ctx.nranks if nranks is None else nranks
@@ -77,8 +143,16 @@ class StripTransform:
         if self.nranks > 1 and halo > min(n for _, n in partition_rows(H, self.nranks)):
             raise ValueError(f"strips of {H // self.nranks} rows are thinner than the "
                              f"{halo}-row halo of {level} scales: use fewer ranks")
-        self.plan = Plan(ctx, H, W, self.family, level, row0=self.row0, nrows=self.nrows,
-                         halo_rows=halo, rank=self.rank, nranks=self.nranks)
+        # planes: "hipmalloc", "scattered" (mapped over shuffled physical chunks, as single-GPU plans are) or "auto":
+        # measured once per (shape, ranks) over the real transport - choose_strip_planes; collective
+        if planes == "auto":
+            planes = choose_strip_planes(ctx, H, W, self.family, level, self.row0, self.nrows, halo, self.rank,
+                                         self.nranks, fused)
+        if planes not in ("hipmalloc", "scattered"):
+            raise ValueError("planes must be 'auto', 'hipmalloc' or 'scattered'")
+        self.planes = planes
+        self.plan = _make_strip_plan(ctx, H, W, self.family, level, self.row0, self.nrows, halo, self.rank,
+                                     self.nranks, planes == "scattered")
         self.noise = None
 
     def upload(self, strip):
