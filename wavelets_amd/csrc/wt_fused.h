@@ -335,6 +335,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
         }
         __syncthreads();
     }
+    // Keys below / above the window (bins 0 and WT_HIST_BINS - 1 of the clamped index) are ~90 % of a windowed
+    // histogram's samples - the window spans +-12 % around the predicted median - and as LDS atomics they all hit the
+    // same two words: 64 lanes serialise on one address.  They are counted in two registers per lane instead and
+    // added to their bins once, at the end of the chunk (round 6); only the in-window keys take the atomic.
+    int hist_out = 0, hist_below = 0;                    // samples outside the window / below it (this lane)
+    auto hist_count = [&](int rel) {                     // rel = key - first key of the window
+        if ((unsigned)(rel - 1) < (unsigned)(WT_HIST_BINS - 2)) atomicAdd(&lh[rel], 1u);
+        else ++hist_out;
+        hist_below += rel <= 0;
+    };
 
     const Geo g = a.g;
     const int gl = threadIdx.x;                          // lane index within the WG row
@@ -627,9 +637,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                                            __float_as_uint(d0.w)};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)       // (one v_bfe_u32 for the magnitude's top bits: the march is issue-bound)
-                        if (FAST || x + j < g.W)
-                            atomicAdd(&lh[min(max((int)__builtin_amdgcn_ubfe(b[j], (uint32_t)hist_shift, 31u - (uint32_t)hist_shift) - hist_lo, 0),
-                                              WT_HIST_BINS - 1)], 1u);
+                        if (FAST || x + j < g.W) hist_count((int)__builtin_amdgcn_ubfe(b[j], (uint32_t)hist_shift, 31u - (uint32_t)hist_shift) - hist_lo);
                 } else {
                     // double: the top 11 bits of the 63-bit magnitude are the exponent field (first level
                     // of wt64_abs_median's select)
@@ -637,8 +645,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
                                                      (unsigned long long)__double_as_longlong(d0.y)};
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        if (FAST || x + j < g.W)
-                            atomicAdd(&lh[min(max((int)((b[j] & 0x7fffffffffffffffull) >> hist_shift) - hist_lo, 0), WT_HIST_BINS - 1)], 1u);
+                        if (FAST || x + j < g.W) hist_count((int)((b[j] & 0x7fffffffffffffffull) >> hist_shift) - hist_lo);
                 }
             }
         }
@@ -770,6 +777,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? WT_FUSED_WG4_PER_CU(K, NS, ACC)
     }
 done:;
     if constexpr (HIST) {
+        if (hist_below) atomicAdd(&lh[0], (uint32_t)hist_below);
+        if (hist_out - hist_below) atomicAdd(&lh[WT_HIST_BINS - 1], (uint32_t)(hist_out - hist_below));
         __syncthreads();
         for (int i = threadIdx.x; i < WT_HIST_BINS; i += NL)
             if (lh[i]) atomicAdd(&a.hist[i], lh[i]);
