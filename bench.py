@@ -1066,11 +1066,46 @@ def main():
                                           "says how much of it the strip shape alone costs"}
         except Exception as e:
             model = {"error": repr(e)}
+        # (2c) replicas: the natural sharding of the reference's real workload (a SEQUENCE of frames, ref utils.py:83-102 per
+        # frame): every rank runs the N = 1 headline step on its own 8192^2 frame at the same time - no RCCL, no halo -
+        # between the same fences as the line; aggregate = N frames' pixels / the slowest rank's time.  A second,
+        # collective-free multi-process datum from the one run a node gives.
+        replicas = None
+        rep_ms, rep_err = None, None
+        rep_steps = max(10, min(steps, 30))
+        try:
+            rp = _lib.Plan(ctx, 8192, 8192, _lib.B3SPLINE, LEVEL)
+            try:
+                rp.upload(PLANE_INPUT, make_strip(8192, 8192, seed=100 + rank))
+                for _ in range(5):
+                    rp.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+                fence()
+                t_r = time.perf_counter()
+                for _ in range(rep_steps):
+                    rp.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+                fence()
+                rep_ms = (time.perf_counter() - t_r) / rep_steps * 1e3
+            finally:
+                rp.close()
+        except Exception as e:
+            rep_err = repr(e)
+            fence()
+            fence()
+        rep_all = group.gather(rep_ms if rep_err is None else {"error": rep_err})
+        if rank == 0:
+            if all(isinstance(v, float) for v in rep_all):
+                replicas = {"what": f"{world} independent 8192x8192 float32 frames, one per GPU, the N=1 headline step (b3spline L=6 decompose + "
+                                    "plane sum, device-resident) at the same time; no RCCL",
+                            "ms_per_step_per_rank": [round(v, 4) for v in rep_all], "steps": rep_steps,
+                            "value": round(world * 8192 * 8192 / (max(rep_all) * 1e-3) / 1e6, 1), "unit": "Mpix/s", "scaling": "weak"}
+            else:
+                replicas = {"error": rep_all}
         if out is not None:
             out["overlap"] = overlap
             out["halo_selfcheck"] = check
             out["strip_planes"] = planes_ab
             out["scaling_model"] = model
+            out["replicas"] = replicas
             state["result"] = out                     # from here on the time limit reports THIS line
         group.barrier()
         state["main_done"] = True

@@ -162,6 +162,10 @@ def test_bench_self_launches_four_ranks_on_the_shared_gpu():
     assert out["roofline"]["frac"] > 0
     # the ramp self-check of the halo exchange (every detail plane vanishes off the global border)
     assert out["halo_selfcheck"]["ok"], out["halo_selfcheck"]
+    # round 6: the line says what it scales, carries its spread, and the collective-free replica datum
+    assert out["scaling"].startswith(f"strong (N={MAX_RANK_PROCESSES}") and out["ms_per_step_samples"] >= 20
+    rep = out["replicas"]
+    assert "error" not in rep and len(rep["ms_per_step_per_rank"]) == MAX_RANK_PROCESSES and rep["value"] > 0, rep
 
 
 def test_bench_default_line_carries_every_config():

@@ -674,30 +674,12 @@ static int plan_alloc(wt_plan *p, float **slot)
     WT_HIP(hipSetDevice(p->ctx->device));
     const size_t skew_max = p->skew_floats * 16;
     const size_t need = (p->plane_floats + skew_max) * sizeof(float);
-    // WT_ARENA=n (experiment): the first n planes of a plan are carved from ONE allocation, so that
-    // their relative placement (and with it the HBM channel / bank relation between the planes a
-    // pass writes side by side) does not depend on what the allocator hands out per call
-    static const int arena_planes = getenv("WT_ARENA") ? atoi(getenv("WT_ARENA")) : 0;
     void *raw = nullptr;
-    if (arena_planes > 0) {
-        static const size_t arena_pad = getenv("WT_ARENA_PAD") ? (size_t)atoll(getenv("WT_ARENA_PAD")) / 16 * 16 : 0;
-        const size_t stride = (need + 4095) / 4096 * 4096 + arena_pad;
-        if (!p->arena) {
-            WT_HIP(hipMalloc(&p->arena, stride * (size_t)arena_planes));
-            p->raw_allocs.push_back(p->arena);
-            p->raw_bytes += stride * (size_t)arena_planes;
-            p->arena_left = arena_planes;
-            p->arena_stride = stride;
-        }
-        if (p->arena_left > 0) {
-            raw = (char *)p->arena + (size_t)(arena_planes - p->arena_left) * p->arena_stride;
-            p->arena_left--;
-        }
-    }
     // Planes whose physical memory is NOT one contiguous run (default; WT_SCATTER=0 restores plain
     // hipMalloc, WT_SCATTER=c sets the group size).  Measured on MI355X (profiles/r02_d): the same
     // binary runs the headline step in 0.61-0.66 ms when the planes' 2-MiB pages are scattered and in
-    // 0.76 ms when the planes lie physically back to back (one arena - or a freshly booted box, whose
+    // 0.76 ms when the planes lie physically back to back (one allocation carved into planes - the round-2
+    // WT_ARENA experiment, profiles/r02_d_arena_*.txt, removed in round 6 - or a freshly booted box, whose
     // allocator hands out consecutive blocks: the "slow hosts" of round 1).  The passes write the
     // same pixel of 5 planes side by side; with planes a power of two apart those addresses differ
     // only in bits the HBM channel / bank hash folds away, and the streams fight over the same banks.

@@ -170,9 +170,6 @@ struct wt_plan {
     int n_allocs = 0;
     int scatter = 0;                        // the "scatter" option when the plan was created: its planes keep that placement
     int scatter_strips = 0;                 // ... and the "scatter_strips" option (strip plans: mapped planes or plain hipMalloc)
-    void *arena = nullptr;                  // WT_ARENA experiment: planes carved from one allocation
-    int arena_left = 0;
-    size_t arena_stride = 0;
     // scattered planes (hipMem* virtual memory management): every plane is a contiguous VIRTUAL range
     // mapped onto physical chunks taken from a shuffled pool (see plan_alloc)
     struct VmmPlane {                       // one hipMemMap of vmm_gran bytes per chunk
@@ -184,7 +181,7 @@ struct wt_plan {
     std::vector<hipMemGenericAllocationHandle_t> vmm_pool;   // created, not yet mapped (idle HBM: wt_plan_trim)
     size_t vmm_gran = 0;
     uint64_t vmm_seed = 0x9e3779b97f4a7c15ull;   // shuffle stream (advances: every refill deals differently)
-    size_t raw_bytes = 0;                   // bytes behind raw_allocs (hipMalloc'ed planes, stage, arena)
+    size_t raw_bytes = 0;                   // bytes behind raw_allocs (hipMalloc'ed planes, stage)
     float *vmm_stage = nullptr;             // hipMalloc'ed bounce plane: hipMemcpy2D does not cross mapped chunks
     void *istage = nullptr;                 // integer / byte-swapped image on its way into a plane (wt_upload_int)
     size_t istage_cap = 0;

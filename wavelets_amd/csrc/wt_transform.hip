@@ -203,8 +203,9 @@ extern "C" int wt_local_variance(wt_plan *p, int src, int dst, int s, float f1, 
 }
 
 // var == nullptr: the kernel forms the variance itself (times f1, f2) from its register window
+// beside_side_work: the launch leaves room for the side stream's kernels (wt_decompose_bilateral with the overlap on)
 static int launch_bilateral(wt_plan *p, const float *in, const float *var, float *out, float *out_w, int s,
-                            float f1 = 1.f, float f2 = 1.f, int rev = 0)
+                            float f1 = 1.f, float f2 = 1.f, int rev = 0, bool beside_side_work = false)
 {
     if (p->g.border != 0 && p->g.border != 1) WT_FAIL("bilateral kernels implement the symmetric border (whole image or polyphase) only");
     if (p->ntaps) {      // user-defined scaling function: generic kernel, variance plane in scratch 12
@@ -235,7 +236,14 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     static char names[25][40];
     if (by_scale && !names[s][0]) snprintf(names[s], sizeof names[s], "wt_bilateral2_kernel d=%d", 1 << s);
     ProfScope ps(p->ctx, by_scale ? names[s] : "wt_bilateral2_kernel");
-    static const int lds_pad = getenv("WT_BIL_LDS_PAD") ? atoi(getenv("WT_BIL_LDS_PAD")) : 0;   // experiments: dynamic LDS to cap the workgroups per CU
+    // The march holds 20 KB of LDS and 4 x 96 VGPRs per workgroup: five fit a CU and take nearly every register of
+    // it, so the wow updates that run on the side stream beside the NEXT scales (memory-bound, 98-142 VGPRs per wave)
+    // find room only where a workgroup has just retired.  Beside side work the launch asks for 12 KB of dynamic LDS
+    // it never touches: four workgroups per CU (the march loses nothing alone: 4 and 5 waves per SIMD time the same),
+    // a quarter of the registers and 32 KB of LDS stay free.  cfg5 at 8192^2: 5.60-5.64 -> 5.45-5.46 ms
+    // (profiles/r06_b_cfg5_lds_cap.txt).  WT_BIL_LDS_PAD overrides (experiments).
+    static const int pad_env = getenv("WT_BIL_LDS_PAD") ? atoi(getenv("WT_BIL_LDS_PAD")) : -1;
+    const int lds_pad = pad_env >= 0 ? pad_env : (beside_side_work && a.inline_var && b3 ? 12288 : 0);
     const bool paired = p->g.border == 0 && g_opt_bilateral_paired;      // one 8-byte load per operand pair (wt_kernels_transform.h)
 #define WT_BIL2(KK, IV, PR) hipLaunchKernelGGL((wt_bilateral2_kernel<KK, IV, PR>), grid, block, lds_pad, p->ctx->stream, a)
     if (b3 && a.inline_var) { if (paired) WT_BIL2(5, true, true); else WT_BIL2(5, true, false); }
@@ -734,7 +742,7 @@ extern "C" int wt_decompose_bilateral(wt_plan *p, int src, int level, const doub
             WT_TRY(launch_chain<MODE_VAR>(p, in, var, nullptr, s, f1, f2, 0, "wt_chain_kernel<variance>"));
             WT_TRY(launch_bilateral(p, in, var, oc, ow, s, 1.f, 1.f, (flags & 8) != 0));
         } else {
-            WT_TRY(launch_bilateral(p, in, nullptr, oc, ow, s, f1, f2, (flags & 8) != 0));
+            WT_TRY(launch_bilateral(p, in, nullptr, oc, ow, s, f1, f2, (flags & 8) != 0, overlap));
         }
         if (overlap) WT_HIP(hipEventRecord(p->scale_ev[s], p->ctx->stream));     // w_s is written
         cur = nxt;
