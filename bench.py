@@ -1353,7 +1353,7 @@ def main():
                                    "frac_of_hbm_peak": round(bpp * 8192 * 8192 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "vs_float32_cfg5": round(ms64 / f32_ms, 3) if f32_ms else None,
                                    "bound": "VALU (float64 bilateral march: ~330 double-precision operations per pixel per scale, "
-                                            "0.91 of the issue rate at the 2.0 GHz the chip holds under it - profiles/r05_f_cfg5_clocks.csv)",
+                                            "0.93 of the issue rate at the 2.0 GHz the chip holds under it - profiles/r06_c_cfg5_clocks.csv)",
                                    "kernels_ms_per_step (overlapped kernels both count)": k64}
         except Exception as e:
             out["float64_cfg5"] = {"error": repr(e)}

@@ -188,9 +188,10 @@ def test_bench_default_line_carries_every_config():
     # round 5: BASELINE configs[4] on the float64 engine (tuned float64 kernels: within 3.0 x the float32 flow of the
     # same run; 9.8 x on the generic kernels) and what the first call of a fresh process costs
     f5 = out["float64_cfg5"]
-    # (round 6, both marches re-worked: float64 14.9-15.9 ms against float32 5.5-5.65 across boxes = 2.5-2.65 x; the bar is what was
-    #  measured plus the box-to-box spread, not the 2.5 the round-4 review hoped for)
-    assert "error" not in f5 and f5["steps"] >= 3 and 0 < f5["vs_float32_cfg5"] < 2.8 and f5["ms_per_step"] < 16.5, f5
+    # (round 6, both marches re-worked: float64 14.9-15.9 ms against float32 5.45-5.65 across boxes = 2.6-2.8 x - the float32
+    #  flow gained more (-6 %) than the float64 one (-3 %), so the RATIO rose from round 5's 2.46-2.66 while both times fell;
+    #  the bars are what was measured plus the box-to-box spread)
+    assert "error" not in f5 and f5["steps"] >= 3 and 0 < f5["vs_float32_cfg5"] < 3.0 and f5["ms_per_step"] < 16.5, f5
     assert any(k.startswith("wt64_bilateral") for k in f5["kernels_ms_per_step (overlapped kernels both count)"])
     fc = out["first_call"]
     # (100 ms before round 5; 14-15 ms behind an existing context - the review's bar is 30, the tree before the warm-up read 38-41 -, 32-35 straight after creating it)
