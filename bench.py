@@ -1066,6 +1066,12 @@ def main():
                                           "says how much of it the strip shape alone costs"}
         except Exception as e:
             model = {"error": repr(e)}
+        if out is not None:
+            out["overlap"] = overlap
+            out["halo_selfcheck"] = check
+            out["strip_planes"] = planes_ab
+            out["scaling_model"] = model
+            state["result"] = out                     # from here on the time limit reports THIS line
         # (2c) replicas: the natural sharding of the reference's real workload (a SEQUENCE of frames, ref utils.py:83-102 per
         # frame): every rank runs the N = 1 headline step on its own 8192^2 frame at the same time - no RCCL, no halo -
         # between the same fences as the line; aggregate = N frames' pixels / the slowest rank's time.  A second,
@@ -1073,24 +1079,30 @@ def main():
         replicas = None
         rep_ms, rep_err = None, None
         rep_steps = max(10, min(steps, 30))
-        try:
+        rp = None
+        try:                                       # (set-up: no collective inside, every rank reaches the fence below)
             rp = _lib.Plan(ctx, 8192, 8192, _lib.B3SPLINE, LEVEL)
+            rp.upload(PLANE_INPUT, make_strip(8192, 8192, seed=100 + rank))
+            for _ in range(5):
+                rp.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
+        except Exception as e:
+            rep_err = repr(e)
+        fence()                                    # all ranks start their steps together ...
+        if rep_err is None:
             try:
-                rp.upload(PLANE_INPUT, make_strip(8192, 8192, seed=100 + rank))
-                for _ in range(5):
-                    rp.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
-                fence()
                 t_r = time.perf_counter()
                 for _ in range(rep_steps):
                     rp.decompose_sum(PLANE_INPUT, LEVEL, PLANE_OUT, _lib.FLAG_FUSED)
-                fence()
+                ctx.sync()
                 rep_ms = (time.perf_counter() - t_r) / rep_steps * 1e3
-            finally:
+            except Exception as e:
+                rep_err = repr(e)
+        fence()                                    # ... and nobody leaves before the slowest has finished
+        if rp is not None:
+            try:
                 rp.close()
-        except Exception as e:
-            rep_err = repr(e)
-            fence()
-            fence()
+            except Exception:
+                pass
         rep_all = group.gather(rep_ms if rep_err is None else {"error": rep_err})
         if rank == 0:
             if all(isinstance(v, float) for v in rep_all):
@@ -1101,12 +1113,7 @@ def main():
             else:
                 replicas = {"error": rep_all}
         if out is not None:
-            out["overlap"] = overlap
-            out["halo_selfcheck"] = check
-            out["strip_planes"] = planes_ab
-            out["scaling_model"] = model
             out["replicas"] = replicas
-            state["result"] = out                     # from here on the time limit reports THIS line
         group.barrier()
         state["main_done"] = True
         release(plan, coefficients)
@@ -1146,6 +1153,7 @@ def main():
                                 out2["halo_selfcheck"] = check2
                                 out2["strip_planes"] = planes_ab
                                 out2["scaling_model"] = dict(model or {}, note="strip timed on hipMalloc'ed planes; the line on scattered ones")
+                                out2["replicas"] = replicas
                                 out = out2
                                 state["result"] = out
                     plan2.close()
