@@ -11,13 +11,13 @@
 // per pixel, and there is no double-precision exponential instruction - per tap
 //   k_t exp(-delta^2 / (2 var)) = 2^(delta^2 * (-log2(e) / (2 var)) + log2(k_t))
 // with the per-pixel factor formed once: u = fma(delta^2, s / 64, 1 + log2 k_t / 64) clamped to [0, 1] by the FMA's
-// own output modifier, the range reduction by the 1.5 * 2^40 trick, 2^(j / 64) from a 64-entry table in LDS, a degree-4
-// polynomial, the exponent added as an integer (wt_math64.h, table form).  13 double-precision operations (6 of them
-// FMAs) + 4 integer operations + 1 LDS read per tap, ~330 double-precision operations per pixel with the variance
+// own output modifier, the range reduction by the 1.5 * 2^37 trick, 2^(j / 512) from a 512-entry table in LDS, a degree-3
+// polynomial, the exponent added as an integer (wt_math64.h, table form).  12 double-precision operations (5 of them
+// FMAs) + 4 integer operations + 1 LDS read per tap, ~305 double-precision operations per pixel with the variance
 // and the two divisions.  The kernel is bound by its double-precision issue at the clock the chip holds under it
-// (0.92 VALU busy at 1.9 GHz): the first version (a degree-10 polynomial, 12 FMAs per tap at the
-// SAME instruction count) took 1.20 ms per scale of 8192^2, this one 1.08 - against 0.37 ms for the float kernel whose
-// taps are packed-FP32 pairs around a hardware v_exp_f32.
+// (DESIGN.md section 3.6): the first version (a degree-10 polynomial, 12 FMAs per tap at the SAME instruction count)
+// took 1.20 ms per scale of 8192^2, the 64-entry table 1.08, this one 1.05 (round 6: buffer loads, see below) -
+// against 0.34 ms for the float kernel whose taps are packed-FP32 pairs around a hardware v_exp_f32.
 // Differences from the reference's operation order (exp of a quotient; IEEE divisions) are a few ulp of
 // the weight: the float64 parity bound of the tests is 1e-12 * max|input|.
 #pragma once

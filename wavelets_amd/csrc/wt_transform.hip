@@ -233,7 +233,8 @@ static int launch_bilateral(wt_plan *p, const float *in, const float *var, float
     WT_TRY(wt_march_geometry<float>(p->g, s, a, grid, block, ((p->g.W + 1) / 2 + 63) / 64, 4));
     // WT_PROF_SCALES=1: one profiler entry per dilation (tools/bench_bil.py)
     static const bool by_scale = getenv("WT_PROF_SCALES") != nullptr;
-    static char names[25][40];
+    static char names[32][40];
+    if (s < 0 || s > 30) WT_FAIL("bilateral scale %d out of range", s);
     if (by_scale && !names[s][0]) snprintf(names[s], sizeof names[s], "wt_bilateral2_kernel d=%d", 1 << s);
     ProfScope ps(p->ctx, by_scale ? names[s] : "wt_bilateral2_kernel");
     // The march holds 20 KB of LDS and 4 x 96 VGPRs per workgroup: five fit a CU and take nearly every register of
