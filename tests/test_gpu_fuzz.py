@@ -17,7 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the generic tap-list operator; fuzz_lattice.py - lattice kernel vs row / chain kernels bitwise at dilations up to
 # 4096; fuzz_round4.py - denoise (float32 / float64), richardson_lucy, pad modes, generic taps, element types;
 # fuzz_round5.py - float64 stencils / bilateral / wow, side stream + early plane sum, mixed-radix FFT.
-FUZZERS = [("fuzz.py", 24, 5), ("fuzz_lattice.py", 40, 5), ("fuzz_round4.py", 48, 5), ("fuzz_round5.py", 50, 5)]
+# fuzz_round6.py - bilateral march's paired loads vs the generic ones (bitwise), fused passes' fast addressing at any
+# width in both precisions (bitwise), sequences on lanes vs the per-call loop (bitwise), the exact median behind the
+# riding histogram's register counters on hostile distributions.
+FUZZERS = [("fuzz.py", 24, 5), ("fuzz_lattice.py", 40, 5), ("fuzz_round4.py", 48, 5), ("fuzz_round5.py", 50, 5), ("fuzz_round6.py", 60, 5)]
 
 
 @pytest.mark.parametrize("script,cases,seed", FUZZERS)
