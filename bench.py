@@ -333,6 +333,10 @@ def load_traffic(path=None, digest=None, lib_overridden=None):
 
 
 def main():
+    # a rank that dies on a signal (SIGSEGV inside the runtime stack was seen once on the shared-GPU test rig) leaves
+    # its Python stack on stderr - children inherit the launcher's stderr - instead of just a signal number
+    import faulthandler
+    faulthandler.enable(all_threads=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

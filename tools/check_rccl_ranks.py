@@ -36,6 +36,8 @@ if ROOT not in sys.path:
 
 
 def main():
+    import faulthandler
+    faulthandler.enable(all_threads=True)          # a rank that dies on a signal leaves its Python stack on stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", type=int, nargs=2, default=[1536, 1100])
     ap.add_argument("--own-gpu", action="store_true")
