@@ -216,3 +216,27 @@ def test_float64_wow_bilateral_vs_oracle_at_a_megapixel(L):
     for s in range(9):
         assert float(np.abs(co.data[s] - cref.data[s]).max()) <= 1e-11 * float(np.abs(cref.data).max()), f"plane {s}"
     assert abs(co.noise - cref.noise) <= 1e-12 * abs(cref.noise)
+
+
+def test_denoise_many_downloads_straight_into_a_preallocated_cube(L):
+    """`out=` as an (N, H, W) array of the result dtype: every frame's download lands in its rows (no intermediate
+    block, no host copy) - also through the pipelined host call (noise given, image above its size threshold) - and a
+    cube of another dtype still gets the values by assignment."""
+    import wavelets_amd as W
+    frames = [_rnd((2304, 2048), 40 + i) for i in range(4)]
+    ref = [W.denoise(f, [5, 3]) for f in frames]
+    out = np.full((4, 2304, 2048), np.nan, np.float32)
+    assert W.denoise_many(frames, [5, 3], out=out) is out
+    for i in range(4):
+        np.testing.assert_array_equal(out[i].view(np.uint32), ref[i].view(np.uint32))
+    refn = [W.denoise(f, [5, 3], noise=1.0) for f in frames]            # 4.7 Mpixel: the pipelined host call
+    out[...] = np.nan
+    W.denoise_many(frames, [5, 3], noise=1.0, out=out, lanes=2)
+    for i in range(4):
+        np.testing.assert_array_equal(out[i].view(np.uint32), refn[i].view(np.uint32))
+    out64 = np.zeros((4, 2304, 2048), np.float64)
+    W.denoise_many(frames, [5, 3], out=out64)
+    np.testing.assert_array_equal(out64[2], ref[2].astype(np.float64))
+    view = np.zeros((4, 2304, 4096), np.float32)[:, :, ::2]            # rows not contiguous: falls back to assignment
+    W.denoise_many(frames, [5, 3], out=view)
+    np.testing.assert_array_equal(view[1], ref[1])

@@ -99,8 +99,18 @@ def denoise_many(frames, weights, scaling_function=None, noise=None, bilateral=N
 
     def one(item):
         i, f = item
-        return denoise(f, list(weights), sf, noise[i] if per_frame else noise, bilateral, soft_threshold, anscombe)
+        # (a preallocated array target receives the download directly where its rows allow it - no host copy)
+        tgt = out[i] if isinstance(out, np.ndarray) and out.ndim == 3 else None
+        res = denoise(f, list(weights), sf, noise[i] if per_frame else noise, bilateral, soft_threshold, anscombe, _out=tgt)
+        return None if (tgt is not None and res is tgt) else res
 
+    if isinstance(out, np.ndarray) and out.ndim == 3:
+        class _Skip:                               # map_frames' `out[i] = r` for frames that are already in place
+            def __setitem__(self, i, r):
+                if r is not None:
+                    out[i] = r
+        map_frames(one, enumerate(frames), lanes, _Skip())
+        return out
     return map_frames(one, enumerate(frames), lanes, out)
 
 

@@ -93,7 +93,7 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
     return out
 
 
-def _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe):
+def _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe, out=None):
     """denoise() with the noise level GIVEN as a scalar: every threshold is known before the first pixel
     arrives, so the whole call is one pipelined host-to-host pass (wt_denoise_sum_host: upload, passes,
     thresholds, passes, download over blocks of rows - about one PCIe leg instead of two).  Returns the
@@ -120,15 +120,29 @@ def _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_thr
             tau = -tau if soft_threshold else 0.0
         taus.append(tau)
     try:
-        return plan.denoise_sum_host(img, level, k, taus, [1.0] * covered, soft_threshold)
+        if not (isinstance(out, np.ndarray) and out.ndim == 2 and out.dtype == np.float32 and out.shape == tuple(plan.shape)
+                and out.strides[1] == 4 and out.flags.writeable):
+            out = None
+        return plan.denoise_sum_host(img, level, k, taus, [1.0] * covered, soft_threshold, out=out)
     except _lib.WatrooHipError as e:
         if "wt_denoise_sum_host: the threshold step" in str(e):     # no pipeline for this plan / size / option
             return None
         raise
 
 
+def _download_to(plan, target):
+    """PLANE_OUT of `plan` as a host array: straight into `target` when it is a writable 2-D array of the plan's
+    shape and element type with contiguous rows (sequence.denoise_many(out=...): no intermediate copy), else a fresh
+    page-locked block."""
+    want = np.float64 if isinstance(plan, _lib.Plan64) else np.float32
+    if (isinstance(target, np.ndarray) and target.ndim == 2 and target.dtype == want and target.shape == tuple(plan.shape)
+            and target.strides[1] == target.itemsize and target.flags.writeable):
+        return plan.download(PLANE_OUT, out=target)
+    return plan.download(PLANE_OUT)
+
+
 def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None,
-            soft_threshold=True, anscombe=False):
+            soft_threshold=True, anscombe=False, *, _out=None):
     """Denoise ``data``: transform over ``len(weights)`` scales, threshold each scale at
     ``weights[s]`` sigma, sum the planes (ref:83-102).  Optional Anscombe pre/post transform.
     Everything between the upload of ``data`` and the download of the result runs on the GPU.
@@ -152,7 +166,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
                                soft_threshold=soft_threshold, write_back=False)
         if anscombe:
             plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)             # ref:99-100
-        return plan.download(PLANE_OUT)
+        return _download_to(plan, _out)
     if np.ndim(data) in (1, 3) or (f64 and np.ndim(data) == 2) or _needs_generic(scaling_function):
         # signals, cubes and float64 images: the generic call sequence
         arr = np.asarray(data, np.float64 if f64 else np.float32)
@@ -171,7 +185,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
     plan = acquire_plan(default_context(), img.shape[0], img.shape[1], _family_of(sf), level)
     piped = None
     if img.dtype == np.float32:           # the pipelined host call takes float32 rows
-        piped = _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe)
+        piped = _denoise_pipelined(plan, img, level, sf, weights, noise, bilateral, soft_threshold, anscombe, out=_out)
     if piped is not None:
         release_plan(plan)
         return piped.astype(_result_dtype(data), copy=False)
@@ -187,7 +201,7 @@ def denoise(data, weights, scaling_function=B3spline, noise=None, bilateral=None
                            soft_threshold=soft_threshold, write_back=False)
     if anscombe:
         plan.anscombe(PLANE_OUT, PLANE_OUT, inverse=True)                 # ref:99-100
-    return plan.download(PLANE_OUT).astype(_result_dtype(data), copy=False)
+    return _download_to(plan, _out).astype(_result_dtype(data), copy=False)
 
 
 def _pad_list(values, n, fill):
