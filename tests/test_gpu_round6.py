@@ -240,3 +240,14 @@ def test_denoise_many_downloads_straight_into_a_preallocated_cube(L):
     view = np.zeros((4, 2304, 4096), np.float32)[:, :, ::2]            # rows not contiguous: falls back to assignment
     W.denoise_many(frames, [5, 3], out=view)
     np.testing.assert_array_equal(view[1], ref[1])
+
+
+def test_sequences_over_a_device_list(L):
+    """devices=[0] / "all" (one GPU here): the lanes of every listed GPU take frames from one queue; same bits, same order."""
+    import wavelets_amd as W
+    frames = [_rnd((200, 333), 70 + i) for i in range(9)]
+    ref = [W.denoise(f, [5, 3]) for f in frames]
+    for devs in ([0], "all"):
+        got = W.denoise_many(frames, [5, 3], lanes=2, devices=devs)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -15,13 +15,18 @@ class FakeCtx:
 
 @pytest.fixture()
 def fake_lanes(monkeypatch):
-    made = []
+    made, by_dev = [], {}
 
     def lane_contexts(n, device=None):
-        while len(made) < n:
-            made.append(FakeCtx())
-        return made[:n]
+        lst = by_dev.setdefault(device, [])
+        while len(lst) < n:
+            c = FakeCtx()
+            c.device = device
+            lst.append(c)
+            made.append(c)
+        return lst[:n]
     monkeypatch.setattr(_lib, "lane_contexts", lane_contexts)
+    monkeypatch.setattr(_lib, "device_count", lambda: 4)
     return made
 
 
@@ -80,3 +85,20 @@ def test_use_context_nests_and_restores():
             assert _lib.default_context() is b
         assert _lib.default_context() is a
     assert getattr(_lib._tls, "ctx", None) is None
+
+
+def test_lanes_on_several_devices(fake_lanes):
+    """devices=[...] / "all": `lanes` lanes on each GPU, frames dealt to whichever lane is free, order kept"""
+    used = set()
+
+    def fn(x):
+        time.sleep(0.002)
+        used.add(_lib.default_context().device)
+        return -x
+    assert sequence.map_frames(fn, range(60), lanes=2, devices=[2, 0, 2]) == [-x for x in range(60)]
+    assert used == {0, 2} and len(fake_lanes) == 4
+    used.clear()
+    assert sequence.map_frames(fn, range(60), lanes=1, devices="all") == [-x for x in range(60)]
+    assert used == {0, 1, 2, 3}
+    with pytest.raises(ValueError, match="no GPU"):
+        sequence.map_frames(fn, [1], devices=[])

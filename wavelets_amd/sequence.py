@@ -24,16 +24,25 @@ __all__ = ['map_frames', 'denoise_many', 'wow_many', 'transform_many']
 DEFAULT_LANES = 3        # one frame uploading, one in the passes, one downloading
 
 
-def map_frames(fn, frames, lanes=None, out=None, device=None):
+def map_frames(fn, frames, lanes=None, out=None, device=None, devices=None):
     """``[fn(frame) for frame in frames]`` with the calls spread over ``lanes`` worker lanes (threads; each runs
     its calls on a context of its own, `_lib.use_context`), results in input order.  ``frames`` may be any iterable
     (a generator is consumed as lanes become free: at most ``lanes`` frames are in flight).  ``out``: an optional
     sequence / array that receives ``out[i] = fn(frames[i])`` instead of the returned list.  The first exception
-    of any lane is re-raised after the lanes have stopped."""
+    of any lane is re-raised after the lanes have stopped.
+    ``devices``: a list of HIP ordinals, or "all" - ``lanes`` lanes on EACH of these GPUs, frames dealt to whichever
+    lane is free (independent frames need no exchange between GPUs: the replica form of multi-GPU work, one PCIe
+    link per GPU); default: the one device of ``device`` / WATROO_HIP_DEVICE."""
     lanes = DEFAULT_LANES if lanes is None else int(lanes)
     if lanes < 1:
         raise ValueError("lanes must be >= 1")
-    if lanes == 1:                                     # the plain loop (on the caller's thread and context)
+    if devices is not None:
+        devs = list(range(_lib.device_count())) if isinstance(devices, str) and devices == "all" else sorted({int(d) for d in devices})
+        if not devs:
+            raise ValueError("devices: no GPU given")
+    else:
+        devs = None
+    if lanes == 1 and devs is None:                    # the plain loop (on the caller's thread and context)
         res = []
         for i, f in enumerate(frames):
             r = fn(f)
@@ -42,8 +51,8 @@ def map_frames(fn, frames, lanes=None, out=None, device=None):
             else:
                 res.append(r)
         return out if out is not None else res
-    ctxs = _lib.lane_contexts(lanes, device)
-    todo = queue.Queue(maxsize=lanes)                  # (index, frame): bounded, so a generator is not run ahead
+    ctxs = _lib.lane_contexts(lanes, device) if devs is None else [c for d in devs for c in _lib.lane_contexts(lanes, d)]
+    todo = queue.Queue(maxsize=len(ctxs))              # (index, frame): bounded, so a generator is not run ahead
     results, errors = {}, []
     lock = threading.Lock()
 
@@ -88,7 +97,7 @@ def map_frames(fn, frames, lanes=None, out=None, device=None):
 
 
 def denoise_many(frames, weights, scaling_function=None, noise=None, bilateral=None, soft_threshold=True,
-                 anscombe=False, lanes=None, out=None):
+                 anscombe=False, lanes=None, out=None, devices=None):
     """``[denoise(f, weights, ...) for f in frames]`` (ref utils.py:83-102 per frame), double-buffered over PCIe.
     ``noise``: None (each frame's own MAD estimate), a scalar / map shared by all frames, or a list with one entry
     per frame."""
@@ -109,21 +118,21 @@ def denoise_many(frames, weights, scaling_function=None, noise=None, bilateral=N
             def __setitem__(self, i, r):
                 if r is not None:
                     out[i] = r
-        map_frames(one, enumerate(frames), lanes, _Skip())
+        map_frames(one, enumerate(frames), lanes, _Skip(), devices=devices)
         return out
-    return map_frames(one, enumerate(frames), lanes, out)
+    return map_frames(one, enumerate(frames), lanes, out, devices=devices)
 
 
-def wow_many(frames, lanes=None, out=None, **kwargs):
+def wow_many(frames, lanes=None, out=None, devices=None, **kwargs):
     """``[wow(f, **kwargs) for f in frames]`` (ref utils.py:105-219 per frame), double-buffered over PCIe; every
     element is what ``wow`` returns for that frame (the image, or ``(image, coefficients)``)."""
     from .utils import wow
-    return map_frames(lambda f: wow(f, **kwargs), frames, lanes, out)
+    return map_frames(lambda f: wow(f, **kwargs), frames, lanes, out, devices=devices)
 
 
-def transform_many(frames, level, scaling_function=None, lanes=None, **kwargs):
+def transform_many(frames, level, scaling_function=None, lanes=None, devices=None, **kwargs):
     """``[AtrousTransform(scaling_function, **kwargs)(f, level) for f in frames]`` (ref wavelets.py:290-328 per
     frame): a list of ``Coefficients`` whose planes stay on the device (each on the lane context that made it)."""
     from .wavelets import AtrousTransform, B3spline
     tr = AtrousTransform(B3spline if scaling_function is None else scaling_function, **kwargs)
-    return map_frames(lambda f: tr(f, level), frames, lanes)
+    return map_frames(lambda f: tr(f, level), frames, lanes, devices=devices)
