@@ -46,3 +46,4 @@ def test_ignore_lists_cover_unbundled_code_objects():
         assert pat in gi and pat in gp
     assert "*.so.*" in gi
     assert "oracle/_ref/" not in gp and "*.so" not in gp          # built libraries must travel to the GPU box
+    assert "wavelets_amd/csrc/_build*" in gp                      # ... their object files need not (13 MB per build directory)
