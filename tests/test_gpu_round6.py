@@ -117,6 +117,14 @@ def test_enhance_channels_through_the_lanes_vs_golden_g10(L):
     got = enhance(rgb, weights=[[1.5, 1.2, 1.0]] * 3, denoise=[[3, 2]] * 3)
     for c in range(3):
         np.testing.assert_array_equal(got[c], enhance(rgb[c], weights=[1.5, 1.2, 1.0], denoise=[3, 2]), err_msg=f"channel {c}")
+    # a colour image large enough for the lanes (>= 1 Mpixel per channel): three lanes, downloads straight into `out`
+    big = _rnd((3, 1100, 1024), 9) * 3 + 7
+    got = enhance(big, weights=[[1.5, 1.2, 1.0]] * 3, denoise=[[3, 2]] * 3)
+    for c in range(3):
+        np.testing.assert_array_equal(got[c], enhance(big[c], weights=[1.5, 1.2, 1.0], denoise=[3, 2]), err_msg=f"big channel {c}")
+    mine = np.full((3, 1100, 1024), np.nan, np.float32)
+    assert enhance(big, weights=[[1.5, 1.2, 1.0]] * 3, denoise=[[3, 2]] * 3, out=mine) is mine
+    np.testing.assert_array_equal(mine, got)
     # per-channel lists (ref:19-33) and a given noise per channel
     got = enhance(rgb, [0.3, 0.2, 0.1], weights=[[1, 2], [1.5], [2, 1, 1]], denoise=[[3], [2, 1], []])
     for c, (w, d) in enumerate(zip([[1, 2], [1.5], [2, 1, 1]], [[3], [2, 1], []])):

@@ -88,8 +88,11 @@ def enhance(*args, weights=None, denoise=None, soft_threshold=True, out=None, **
 
     # the channels of a colour image are independent frames: one lane each, so that the upload of one
     # channel, the passes of another and the download of a third overlap (sequence.map_frames; bit-identical)
+    # (from a megapixel per channel: below that the PCIe legs are microseconds, and the lanes' contexts - created on
+    #  their first use in a process, ~0.1 s each - would cost a one-shot call more than they can ever save it)
     from .sequence import map_frames
-    map_frames(channel, plans, lanes=len(plans) if len(plans) > 1 else 1)
+    big = len(plans) > 1 and img[0].size >= (1 << 20)
+    map_frames(channel, plans, lanes=len(plans) if big else 1)
     return out
 
 
