@@ -150,8 +150,9 @@ def step_spread(samples):
 
 
 def scaling_text(world, H, W):
-    """What the line scales.  The first word is the contract's ("weak": per-GPU work fixed, "strong": total work
-    fixed); the rest says which image and how many GPUs, because the N = 1 line (the BASELINE metric's 8192^2
+    """What the line scales (`scaling_detail`, next to the contract's one-word `scaling`).  The first word is the
+    contract's ("weak": per-GPU work fixed, "strong": total work fixed); the rest says which image and how many GPUs,
+    because the N = 1 line (the BASELINE metric's 8192^2
     configuration) and the N > 1 lines (ONE 32768^2 image cut into N row strips) are different images: among the
     N > 1 lines the total work is fixed (strong scaling), and the same-image anchor for N = 1 is `n1_same_image`."""
     if world == 1:
@@ -790,7 +791,8 @@ def main():
                 "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": nsteps,
                 "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
                 **step_spread(m.get("samples")),
-                "higher_is_better": True, "scaling": scaling_text(world, H, W),
+                "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",      # (the contract's two words)
+                "scaling_detail": scaling_text(world, H, W),
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"{H}x{W} float32 {data}, "
                                        f"{family} L={level}, " + what.format(n=level + 1)

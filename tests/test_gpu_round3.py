@@ -163,7 +163,7 @@ def test_bench_self_launches_four_ranks_on_the_shared_gpu():
     # the ramp self-check of the halo exchange (every detail plane vanishes off the global border)
     assert out["halo_selfcheck"]["ok"], out["halo_selfcheck"]
     # round 6: the line says what it scales, carries its spread, and the collective-free replica datum
-    assert out["scaling"].startswith(f"strong (N={MAX_RANK_PROCESSES}") and out["ms_per_step_samples"] >= 20
+    assert out["scaling"] == "strong" and out["scaling_detail"].startswith(f"strong (N={MAX_RANK_PROCESSES}") and out["ms_per_step_samples"] >= 20
     rep = out["replicas"]
     assert "error" not in rep and len(rep["ms_per_step_per_rank"]) == MAX_RANK_PROCESSES and rep["value"] > 0, rep
 
@@ -202,7 +202,8 @@ def test_bench_default_line_carries_every_config():
     for c in [out] + list(out["configs"].values()):
         assert c["ms_per_step_samples"] >= 20 and 0 < c["ms_per_step_min"] <= c["ms_per_step_median"] <= c["ms_per_step_max"], c
         assert c["ms_per_step_median"] < 1.5 * c["ms_per_step"], c
-    assert out["scaling"].startswith("weak (N=1") and "8192x8192" in out["scaling"] and "n1_same_image" in out["scaling"]
+    sd = out["scaling_detail"]
+    assert out["scaling"] == "weak" and sd.startswith("weak (N=1") and "8192x8192" in sd and "n1_same_image" in sd
     n1 = out["n1_same_image"]
     assert "error" not in n1 and "32768x32768" in n1["workload"] and n1["ms_per_step_samples"] >= 20, n1
     assert 0.5 < (n1["ms_per_step"] / 16.0) / out["ms_per_step"] < 1.5, n1          # per pixel, the 8192^2 rate
