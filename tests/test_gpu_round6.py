@@ -259,3 +259,41 @@ def test_sequences_over_a_device_list(L):
         got = W.denoise_many(frames, [5, 3], lanes=2, devices=devs)
         for a, b in zip(got, ref):
             np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_lanes_shared_by_concurrent_callers(L):
+    """Three host threads call denoise_many / wow_many / transform_many at the same time: they share the lanes' contexts
+    (calls on one context are serialised by its lock, plans are taken from the pool one caller at a time) - every result
+    still equals the per-call API bit for bit."""
+    import threading
+    import wavelets_amd as W
+    rng = np.random.default_rng(0)
+    frames = [rng.standard_normal((256, 300)).astype(np.float32) * (1 + i % 5) + i for i in range(60)]
+    ref_d = [W.denoise(f, [5, 3]) for f in frames]
+    ref_w = [W.wow(f, denoise_coefficients=[5, 2], bilateral=1)[0] for f in frames[:20]]
+    ref_t = [W.AtrousTransform(W.Triangle)(f, 4).data.copy() for f in frames[:20]]
+    bad = []
+
+    def t1():
+        for rep in range(2):
+            got = W.denoise_many(frames, [5, 3], lanes=4)
+            if any(not np.array_equal(a, b) for a, b in zip(got, ref_d)):
+                bad.append(("denoise", rep))
+
+    def t2():
+        for rep in range(2):
+            got = W.wow_many(frames[:20], lanes=3, denoise_coefficients=[5, 2], bilateral=1)
+            if any(not np.array_equal(a[0], b) for a, b in zip(got, ref_w)):
+                bad.append(("wow", rep))
+
+    def t3():
+        for rep in range(2):
+            cs = W.transform_many(frames[:20], 4, W.Triangle, lanes=2)
+            if any(not np.array_equal(c.data, r) for c, r in zip(cs, ref_t)):
+                bad.append(("transform", rep))
+    ts = [threading.Thread(target=f) for f in (t1, t2, t3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad
